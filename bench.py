@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Benchmark of the nunif hot path on MI355X: waifu2x swin_unet 2x, tile 256, synthetic 1080p frames.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A *step* is one full tiled render (gather -> 45 tiles through the net -> stitch) of one 1080p frame per rank, with
+the input frame already resident in HBM.  Frames are independent, so ranks shard frames with no data-path
+collective (weak scaling: every rank renders K frames).  ``value`` = input megapixels of all ranks / wall time
+(max over ranks), the metric BASELINE.json names ("MPix" = source-frame pixels).
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     — dominant kernel class (by HIP-event time): algorithmic FLOPs / measured duration vs the dense
+                 fp16 MFMA peak of MI355X (2.5 PFLOP/s, MI355X_MICROARCH.md)
+  cpu_baseline — the CPU oracle (oracle/, a torch-fp32 port of the reference path) timed on the host cores on a
+                 bounded sample of the same workload
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAME_H, FRAME_W = 1080, 1920
+TILE = 256
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_frame(seed, h, w):
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(1, 3, h // 16 + 1, w // 16 + 1, generator=g)
+    up = torch.nn.functional.interpolate(low, size=(h, w), mode="bilinear", align_corners=False)[0]
+    return torch.clamp(up * 0.8 + 0.2 * torch.rand(3, h, w, generator=g), 0, 1)
+
+
+def cpu_baseline(sd, frame, budget_s=20.0):
+    """Time the oracle's tiled_render on a crop of the same frame (bounded: ~10-30 s of CPU work)."""
+    from oracle import seam_blending as OS
+    from oracle import swin_unet as O
+    crop = frame[:, :480, :480].contiguous()        # 3x3 tiles of 256 (step 236) — same tile size as the GPU run
+    fn = lambda mb: O.model_forward(sd, mb)         # noqa: E731
+    t0 = time.perf_counter()
+    out = OS.tiled_render(crop, fn, 2, 16, 8, TILE, 4)
+    dt = time.perf_counter() - t0
+    return {"value": round(crop.shape[1] * crop.shape[2] / 1e6 / dt, 5), "unit": "MPix/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle tiled_render of a 480x480 crop (9 tiles of 256, batch 4), {dt:.1f} s"}, crop, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("NUNIF_BENCH_BATCH", "8")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    from nunif_amd import _hip
+    from nunif_amd.nunif.utils.render import tiled_render
+    from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x
+    from oracle import swin_unet as O      # weights generator + (rank 0) CPU baseline / parity check only
+
+    torch.set_grad_enabled(False)
+    sd = O.random_state_dict(102, 2)
+    model = SwinUNet2x().eval()
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    # a few distinct frames per rank, resident in HBM before the timed region
+    frames = [synth_frame(1234 + rank * 16 + i, FRAME_H, FRAME_W).to(dev) for i in range(4)]
+
+    def step(i):
+        return tiled_render(frames[i % len(frames)], model, tile_size=TILE, batch_size=args.batch_size)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel-class timing (HIP events on the launch stream), outside the timed region -------------------
+    roofline = None
+    classes = []
+    if rank == 0:
+        _hip.profile_enable(True)
+        n_prof = max(1, min(3, args.steps))
+        for i in range(n_prof):
+            step(i)
+        torch.cuda.synchronize(dev)
+        recs = _hip.profile_read(reset=True)
+        _hip.profile_enable(False)
+        total = sum(r["total_ms"] for r in recs) or 1.0
+        for r in sorted(recs, key=lambda r: -r["total_ms"]):
+            avg_us = 1e3 * r["total_ms"] / max(1, r["launches"])
+            classes.append({"kernel": r["name"], "share": round(r["total_ms"] / total, 4),
+                            "avg_us": round(avg_us, 2), "launches_per_frame": r["launches"] // n_prof,
+                            "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2) if r["total_ms"] else 0.0,
+                            "gbs": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1) if r["total_ms"] else 0.0})
+        dom = max(recs, key=lambda r: r["total_ms"])
+        ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(1e3 * dom["total_ms"] / max(1, dom["launches"]), 2),
+                    "algorithmic_flops_per_launch": dom["flops"] / max(1, dom["launches"])}
+
+    if rank == 0:
+        mpix_in = FRAME_H * FRAME_W / 1e6
+        value = mpix_in * args.steps * world / elapsed
+        result = {
+            "metric": "input MPix/s, waifu2x swin_unet 2x tiled render (tile 256) of 1080p frames",
+            "value": round(value, 2), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "waifu2x swin_unet 2x (art scale2x geometry), tile_size=256, 1080p frame, "
+                                   "random-init weights", "frame": [FRAME_H, FRAME_W], "tile_size": TILE,
+                       "tile_batch": args.batch_size, "tiles_per_frame": 45, "frames_per_step_per_gpu": 1,
+                       "parallelism": f"frame-sharded x{world}"},
+            "output_mpix_per_s": round(value * 4, 2),
+            "model_tflops": round(45 * 98e9 * args.steps * world / elapsed / 1e12, 2),
+            "roofline": roofline, "kernel_classes": classes,
+        }
+        if not args.no_cpu_baseline:
+            base, crop, ref = cpu_baseline(sd, frames[0].cpu())
+            got = tiled_render(crop, model, tile_size=TILE, batch_size=args.batch_size).cpu()
+            mse = torch.mean((got.double() - ref.double()) ** 2).item()
+            result["cpu_baseline"] = base
+            result["psnr_vs_oracle_db"] = round(10 * math.log10(1.0 / (mse + 1e-6)), 2)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

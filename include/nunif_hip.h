@@ -1,0 +1,118 @@
+/*
+ * nunif_hip.h — C ABI of libnunif_hip.so, the MI355X (gfx950) engine under nunif's tiled-inference hot path.
+ *
+ * The reference (nagadomi/nunif) is pure Python on PyTorch and has no FFI of its own: the
+ * drop-in boundary is a set of Python call signatures.  Each entry point below names the reference function
+ * (file:line under the reference tree) whose work it replaces; nunif_amd/ mirrors the Python signatures on top
+ * of these calls and INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no torch / C++ types.  `stream` is a hipStream_t passed as void* (NULL = the
+ *    null stream).  All device pointers are caller-owned (e.g. torch tensor.data_ptr()); the library owns only
+ *    the weights/workspace that live inside a model handle.
+ *  - every function returns 0 on success or a negative nunif_hip_status; nunif_hip_last_error() returns a
+ *    thread-local message for the last failure.  No function synchronises the device unless it says so.
+ *  - image tensors are planar CHW / NCHW float32 in [0,1] at the boundary, exactly like the reference.
+ */
+#ifndef NUNIF_HIP_H
+#define NUNIF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NUNIF_HIP_ABI_VERSION 1
+
+typedef enum {
+    NUNIF_HIP_OK = 0,
+    NUNIF_HIP_EINVAL = -1,   /* bad argument (the Python layer raises ValueError / AssertionError) */
+    NUNIF_HIP_ENOMEM = -2,   /* hipMalloc failed */
+    NUNIF_HIP_EHIP = -3,     /* a HIP runtime call or kernel launch failed */
+    NUNIF_HIP_EMISSING = -4, /* a required weight tensor is missing from the state dict */
+    NUNIF_HIP_EUNSUPPORTED = -5
+} nunif_hip_status;
+
+int nunif_hip_abi_version(void);
+const char *nunif_hip_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Tile grid + stitcher.  Replaces nunif/utils/seam_blending.py: create_config :109-143, create_blend_filter
+ * :146-153, the F.pad + tile slicing of tiled_render :82,:90, update :156-174 and get_output :39-40.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t x_h, x_w, scale, offset, tile_size, blend_size;                 /* inputs */
+    int32_t y_h, y_w, h_blocks, w_blocks;                                   /* create_config outputs */
+    int32_t pad_l, pad_r, pad_t, pad_b, y_buffer_h, y_buffer_w;
+    int32_t input_tile_step, output_tile_step;
+    int32_t out_tile_size;                                                  /* tile_size*scale - 2*offset */
+} nunif_tile_grid;
+
+/* Host-only integer math; bit-exact with create_config. */
+int nunif_hip_tile_grid_init(int32_t x_h, int32_t x_w, int32_t scale, int32_t offset, int32_t tile_size,
+                             int32_t blend_size, nunif_tile_grid *grid);
+
+/* Host-only: the 1-D edge ramp r[0..blend_size) (fp32) with filter F[y,x] = min(r'[y], r'[x]);
+ * values are the reference's Python-double `1 - (1/(b+1))*(i+1)` rounded to fp32. */
+int nunif_hip_blend_ramp(int32_t blend_size, float *ramp /* [blend_size] host */);
+
+/* tiles[k] = replicate-padded x[:, i:i+T, j:j+T] for tile indices tile_begin .. tile_begin+n_tiles (row-major
+ * over the grid).  x: [C,x_h,x_w] f32 device; tiles: [n_tiles,C,T,T] f32 device. */
+int nunif_hip_gather_tiles(const float *x, float *tiles, const nunif_tile_grid *grid, int32_t channels,
+                           int32_t tile_begin, int32_t n_tiles, void *stream);
+
+/* Single-pass stitch of ALL tile outputs of a frame: for each output pixel replay the reference's running-mean
+ * update over the (<=4) covering tiles in row-major tile order, crop to [y_h,y_w] and clamp to [0,1].
+ * tile_out: [h_blocks*w_blocks, C, To, To] f32 device; y: [C, y_h, y_w] f32 device. */
+int nunif_hip_stitch_tiles(const float *tile_out, float *y, const nunif_tile_grid *grid, int32_t channels,
+                           void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * waifu2x swin_unet.  Replaces waifu2x/models/swin_unet.py SwinUNetBase.forward :180-199 (+ the eval clamp of
+ * the SwinUNet/SwinUNet2x/SwinUNet4x wrappers :221-226,:244-249,:281-290) and torchvision's
+ * SwinTransformerBlock (imported at :9-12).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const char *name;      /* reference state_dict key, e.g. "unet.swin1.block.0.attn.qkv.weight" */
+    const float *data;     /* HOST pointer, contiguous fp32 */
+    int32_t ndim;
+    int64_t shape[4];
+} nunif_tensor_desc;
+
+typedef struct nunif_swin_unet nunif_swin_unet;
+
+/* Build a model from a reference-format state dict (host fp32).  Weights are repacked to MFMA-fragment-major
+ * fp16 in device memory owned by the handle.  scale_factor in {1,2,4}.  The current HIP device is bound. */
+int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int32_t n_tensors, int32_t scale_factor,
+                               nunif_swin_unet **handle);
+void nunif_hip_swin_unet_destroy(nunif_swin_unet *handle);
+
+/* z = clamp(unet(x), 0, 1).  x: [B,3,T,T] f32 device, z: [B,3,(T-16)*s,(T-16)*s] f32 device; T must satisfy the
+ * reference's tile_size_validator (swin_unet.py:202-205).  Workspace grows inside the handle as needed. */
+int nunif_hip_swin_unet_forward(nunif_swin_unet *handle, const float *x, float *z, int32_t batch,
+                                int32_t tile_size, void *stream);
+
+/* Whole-frame render = SeamBlending.tiled_render (seam_blending.py:48-106) with this model:
+ * x: [3,H,W] f32 device -> y: [3,H*s,W*s] f32 device.  The tile gather is fused into the first conv, tiles run
+ * in minibatches of `batch_size`, the stitch is the single-pass kernel above. */
+int nunif_hip_swin_unet_render(nunif_swin_unet *handle, const float *x, float *y, int32_t x_h, int32_t x_w,
+                               int32_t tile_size, int32_t batch_size, void *stream);
+
+/* Test hooks (tests/ only): snapshot every stage's NHWC fp16 output during the next forward calls, then read
+ * them back one by one (returns 1 past the last tap).  Names match oracle.swin_unet.unet_forward(taps=...). */
+int nunif_hip_swin_unet_debug_taps(nunif_swin_unet *handle, int32_t enable);
+int nunif_hip_swin_unet_get_tap(nunif_swin_unet *handle, int32_t index, char *name, int32_t name_cap,
+                                void *host_dst, int64_t cap_bytes, int64_t *nbytes);
+
+/* Timing hooks for bench.py: per-kernel-class HIP-event accumulation on the launch stream. */
+int nunif_hip_profile_enable(int32_t on);
+/* Writes up to `cap` (name,total_ms,launches) records; returns the count. Synchronises the events. */
+typedef struct { char name[48]; double total_ms; int64_t launches; double flops; double bytes; } nunif_prof_record;
+int nunif_hip_profile_read(nunif_prof_record *out, int32_t cap, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUNIF_HIP_H */

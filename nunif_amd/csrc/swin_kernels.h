@@ -1,0 +1,47 @@
+// Launch wrappers of the swin_unet device kernels (swin_kernels.hip) used by the host model (swin_unet.cpp).
+#pragma once
+#include "common.h"
+
+namespace nunif {
+
+// ---- implicit-GEMM linear / conv:  D[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]) (+ res) -------------------
+// X is gathered from an NHWC fp16 map: output token m=(b,y,x) over [B,Ho,Wo]; K = taps*Cin where tap t=(dy,dx),
+// dy=t/kw, dx=t%kw reads pixel (y*stride+oy+dy, x*stride+ox+dx).  A plain Linear is taps=1, stride=1.
+struct GemmArgs {
+    const f16 *a; int B, Hi, Wi, Cin;
+    int Ho, Wo, stride, oy, ox, kw;
+    int K;                    // taps*Cin, multiple of 32
+    const f16 *w;             // packed [N/16][K/32][64 lanes][8] (see pack_weight_frag in swin_unet.cpp)
+    const float *bias;        // [N] (padded)
+    int N;                    // padded to a multiple of 16
+    int mode;                 // 0: NHWC fp16 [M][ldo]   1: 2x2 pixel-shuffle NHWC fp16   2: to_image NCHW f32 clamp
+    int act;                  // 0 none, 1 GELU(erf), 2 LeakyReLU(slope)
+    float slope;
+    const f16 *res;           // optional residual, indexed like out (modes 0,1)
+    void *out;
+    int ldo;                  // channels per output pixel (mode 0: N_real, mode 1: N/4)
+    int n_real;               // number of valid output columns
+    int ps;                   // mode 2: pixel-shuffle factor s (out channels = n_real/(s*s))
+};
+int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag);
+
+// ---- first conv of the stem (3 -> C1 real channels, stored padded to C1P), VALU ----------------------------------
+struct Stem1Args {
+    const float *x;           // tile mode: [B,3,T,T]; frame mode: [3,H,W]
+    int frame_mode, H, W, wb, istep, pad_t, pad_l, tile_begin;   // frame-mode tile origin (seam_blending.py:82,90)
+    int B, T;
+    const float *w;           // [C1][3][3][3] fp32 (reference layout)
+    const float *bias;        // [C1]
+    int C1, C1P;
+    f16 *out;                 // [B, T-14, T-14, C1P]  (conv1 coordinates [6, T-8), the part conv2+crop consumes)
+    float slope;
+};
+int launch_stem1(const Stem1Args &a, hipStream_t s);
+
+// ---- (shifted) 6x6 window attention on a fused qkv map ----------------------------------------------------------
+// qkv: [B,H,W,3C] fp16 (q | k | v, each heads x hd), out: [B,H,W,C]; bias: [heads][36][48] fp32 with the
+// relative-position bias gathered per (q,key) and -1e30 in the 12 padding key columns.
+int launch_window_attn(const f16 *qkv, f16 *out, const float *bias, int B, int H, int W, int heads, int hd,
+                       int shift, hipStream_t s);
+
+}  // namespace nunif

@@ -1,0 +1,391 @@
+// Device kernels of the waifu2x swin_unet forward for gfx950 (CDNA4, wave64, MFMA).
+//
+// Reference ops replaced: waifu2x/models/swin_unet.py patch :132-137, PatchDown :45-62,
+// PatchUp :65-82, ToImage :85-116, and torchvision SwinTransformerBlock (qkv/proj/MLP Linear, window attention).
+//
+// Layout: every feature map is NHWC fp16 in HBM; accumulation is fp32 in MFMA accumulators.
+// All GEMM-shaped work runs on v_mfma_f32_16x16x32_f16 with the *weights* as the A operand (rows = output
+// channel n) and the *activations* as the B operand (cols = token m).  The accumulator of a lane then holds 4
+// consecutive output channels of ONE token (D[n = 4*(lane>>4)+r][m = lane&15]) so the epilogue stores 8 bytes of
+// contiguous NHWC per lane and bias/residual are plain 4-wide loads — no LDS transpose anywhere.
+#include "swin_kernels.h"
+
+namespace nunif {
+
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// =================================================================================================================
+// Implicit-GEMM linear / conv.  One wave owns MF x 16 tokens and keeps their whole K extent in registers (the
+// activations are the streaming operand: read once from HBM); it then sweeps all N/16 output-channel tiles,
+// pulling each 1-KiB weight fragment (64 lanes x 16 B, fragment-major => one coalesced load) from L2.
+// =================================================================================================================
+template <int KS, int MF>
+__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r16 = lane & 15;
+    const int grp = lane >> 4;
+    const long M = (long)g.B * g.Ho * g.Wo;
+    const long m_base = ((long)blockIdx.x * 4 + wave) * (MF * 16);
+    if (m_base >= M) return;
+
+    f16x8 xf[MF][KS];
+    int tb[MF], ty[MF], tx[MF];
+    bool valid[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        long m = m_base + f * 16 + r16;
+        valid[f] = m < M;
+        if (m >= M) m = M - 1;
+        const int x = (int)(m % g.Wo);
+        const long t = m / g.Wo;
+        const int y = (int)(t % g.Ho);
+        const int b = (int)(t / g.Ho);
+        tb[f] = b; ty[f] = y; tx[f] = x;
+        const long pix0 = ((long)b * g.Hi + (long)y * g.stride + g.oy) * g.Wi + (long)x * g.stride + g.ox;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = ks * 32;
+            const int tap = k0 / g.Cin;
+            const int c0 = k0 - tap * g.Cin;
+            const int dy = tap / g.kw;
+            const int dx = tap - dy * g.kw;
+            const f16 *p = g.a + (pix0 + (long)dy * g.Wi + dx) * g.Cin + c0 + grp * 8;
+            xf[f][ks] = *reinterpret_cast<const f16x8 *>(p);
+        }
+    }
+
+    const int NT = g.N >> 4;
+    const f16x8 *wbase = reinterpret_cast<const f16x8 *>(g.w) + lane;
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 acc[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f16x8 *wp = wbase + (long)nt * KS * 64;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 wv = wp[ks * 64];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc[f] = MFMA_16x16x32(wv, xf[f][ks], acc[f]);
+        }
+        const int n0 = nt * 16 + grp * 4;
+        const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            if (!valid[f]) continue;
+            float v[4] = {acc[f][0] + bv.x, acc[f][1] + bv.y, acc[f][2] + bv.z, acc[f][3] + bv.w};
+            if (g.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            } else if (g.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * g.slope;
+            }
+            if (g.mode == 2) {
+                // ToImage: column n = c*s*s + i*s + j -> out[b][c][y*s+i][x*s+j], clamp(0,1)  (swin_unet.py:110-116)
+                const int s = g.ps, s2 = s * s;
+                const int OC = g.n_real / s2;
+                float *o = reinterpret_cast<float *>(g.out);
+                const long OH = (long)g.Ho * s, OW = (long)g.Wo * s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + r;
+                    if (n < g.n_real) {
+                        const int c = n / s2, rem = n - c * s2;
+                        const int i = rem / s, j = rem - i * s;
+                        o[(((long)tb[f] * OC + c) * OH + (long)ty[f] * s + i) * OW + (long)tx[f] * s + j] =
+                            fminf(fmaxf(v[r], 0.f), 1.f);
+                    }
+                }
+            } else {
+                if (n0 >= g.n_real) continue;
+                long off;
+                if (g.mode == 0) {
+                    off = (((long)tb[f] * g.Ho + ty[f]) * g.Wo + tx[f]) * g.ldo + n0;
+                } else {
+                    // PatchUp: column n = q*Cq + c (repacked), q=(i,j) -> pixel (2y+i, 2x+j)  (swin_unet.py:76-82)
+                    const int q = n0 / g.ldo, c = n0 - q * g.ldo;
+                    off = (((long)tb[f] * (2 * g.Ho) + 2 * ty[f] + (q >> 1)) * (2 * g.Wo) + 2 * tx[f] + (q & 1)) * g.ldo + c;
+                }
+                if (g.res) {
+                    const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
+                f16x4 ov = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(g.out) + off) = ov;
+            }
+        }
+    }
+}
+
+template <int KS, int MF>
+static int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
+    const long M = (long)g.B * g.Ho * g.Wo;
+    const long rows_per_block = 4 * MF * 16;
+    const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
+    gemm_kernel<KS, MF><<<blocks, 256, 0, s>>>(g);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
+    NUNIF_REQUIRE(g.K % 32 == 0 && g.N % 16 == 0 && g.Cin % 32 == 0, "gemm %s: K=%d N=%d Cin=%d not aligned", tag,
+                  g.K, g.N, g.Cin);
+    const long M = (long)g.B * g.Ho * g.Wo;
+    if (M == 0) return NUNIF_HIP_OK;
+    const double flops = 2.0 * (double)M * g.K * g.n_real;
+    const double bytes = (double)M * (g.Cin * 2.0 * (g.K / g.Cin > 1 ? 1.0 : 1.0) + g.n_real * (g.mode == 2 ? 4.0 : 2.0) +
+                                      (g.res ? g.n_real * 2.0 : 0.0));
+    ProfScope ps(tag, s, flops, bytes);
+    switch (g.K / 32) {
+        case 3: return launch_gemm_t<3, 4>(g, s);
+        case 6: return launch_gemm_t<6, 4>(g, s);
+        case 12: return launch_gemm_t<12, 2>(g, s);
+        case 18: return launch_gemm_t<18, 2>(g, s);
+        case 24: return launch_gemm_t<24, 1>(g, s);
+        default:
+            set_error("gemm %s: unsupported K=%d", tag, g.K);
+            return NUNIF_HIP_EUNSUPPORTED;
+    }
+}
+
+// =================================================================================================================
+// Stem conv1: 3 -> C1 3x3 VALID + LeakyReLU on the VALU (K = 27 is too thin for MFMA; 0.15 % of the FLOPs).
+// Fuses the reference's replicate-pad + tile slicing (seam_blending.py:82,90) when reading from the frame.
+// One thread = one output pixel, all channels; weights broadcast from LDS.
+// =================================================================================================================
+__global__ void __launch_bounds__(256) stem1_kernel(Stem1Args a) {
+    extern __shared__ float sw[];   // [27][C1] then bias[C1]
+    const int C1 = a.C1;
+    for (int i = threadIdx.x; i < 27 * C1 + C1; i += blockDim.x) {
+        if (i < 27 * C1) {
+            const int co = i % C1, t = i / C1;        // t = ci*9 + ky*3 + kx
+            sw[i] = a.w[co * 27 + t];
+        } else {
+            sw[i] = a.bias[i - 27 * C1];
+        }
+    }
+    __syncthreads();
+    const int S = a.T - 14;
+    const long total = (long)a.B * S * S;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % S);
+    const long t = idx / S;
+    const int y = (int)(t % S);
+    const int b = (int)(t / S);
+
+    float in[27];
+    if (a.frame_mode) {
+        const int k = a.tile_begin + b;
+        const int ti = k / a.wb, tj = k - ti * a.wb;
+        const int y0 = ti * a.istep - a.pad_t + y + 6, x0 = tj * a.istep - a.pad_l + x + 6;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int sy = min(max(y0 + ky, 0), a.H - 1), sx = min(max(x0 + kx, 0), a.W - 1);
+                    in[ci * 9 + ky * 3 + kx] = a.x[((long)ci * a.H + sy) * a.W + sx];
+                }
+    } else {
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    in[ci * 9 + ky * 3 + kx] = a.x[(((long)b * 3 + ci) * a.T + (y + 6 + ky)) * a.T + (x + 6 + kx)];
+    }
+    f16 *o = a.out + idx * a.C1P;
+    for (int c0 = 0; c0 < a.C1P; c0 += 8) {
+        f16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int co = c0 + j;
+            float acc = 0.f;
+            if (co < C1) {
+                acc = sw[27 * C1 + co];
+#pragma unroll
+                for (int t2 = 0; t2 < 27; ++t2) acc = fmaf(in[t2], sw[t2 * C1 + co], acc);
+                acc = acc >= 0.f ? acc : acc * a.slope;
+            }
+            ov[j] = (f16)acc;
+        }
+        *reinterpret_cast<f16x8 *>(o + c0) = ov;
+    }
+}
+
+int launch_stem1(const Stem1Args &a, hipStream_t s) {
+    NUNIF_REQUIRE(a.C1P % 8 == 0 && a.C1 <= a.C1P && a.T > 14, "stem1: bad shape");
+    const int S = a.T - 14;
+    const long total = (long)a.B * S * S;
+    ProfScope ps("stem_conv1", s, 2.0 * 27 * a.C1 * (double)total, (double)total * (a.C1P * 2.0 + 12.0));
+    const size_t smem = (size_t)(28 * a.C1) * sizeof(float);
+    stem1_kernel<<<(unsigned)((total + 255) / 256), 256, smem, s>>>(a);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+// =================================================================================================================
+// Window attention, one wave per (window, head).  36 tokens are padded to 48 = 3 MFMA tiles.
+//   S^T[key][q] = K Q^T          (A = K rows, B = Q rows)         -> lane holds (q = lane&15, 4 keys)
+//   softmax over keys            = over the 12 in-lane values and the 4 lane groups (2 xor-shuffles)
+//   O^T[d][q]  = V^T P^T         (A = V^T gathered, B = P^T)      -> P^T is already in B-operand layout
+// The cyclic shift (torch.roll) and the window partition are folded into the token addressing; the shift mask is
+// computed from coordinates (torchvision shifted_window_attention).
+// =================================================================================================================
+template <int HD>
+__global__ void __launch_bounds__(256)
+window_attn_kernel(const f16 *__restrict__ qkv, f16 *__restrict__ out, const float *__restrict__ bias, int B, int H,
+                   int W, int heads, int shift, float scale) {
+    typedef typename std::conditional<HD == 32, f16x8, f16x4>::type frag_t;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r16 = lane & 15;
+    const int grp = lane >> 4;
+    const int C = heads * HD, C3 = 3 * C;
+    const int nwx = W / 6, nwy = H / 6;
+    const long total = (long)B * nwy * nwx * heads;
+    const long gid = (long)blockIdx.x * 4 + wave;
+    if (gid >= total) return;
+    const int head = (int)(gid % heads);
+    long wi = gid / heads;
+    const int wx = (int)(wi % nwx);
+    wi /= nwx;
+    const int wy = (int)(wi % nwy);
+    const int b = (int)(wi / nwy);
+
+    auto pix = [&](int t) -> long {   // window-local token -> pixel index in the un-rolled map
+        t = min(t, 35);
+        const int iy = t / 6, ix = t - iy * 6;
+        int yy = wy * 6 + iy + shift, xx = wx * 6 + ix + shift;
+        if (yy >= H) yy -= H;
+        if (xx >= W) xx -= W;
+        return ((long)b * H + yy) * W + xx;
+    };
+    auto region = [&](int t) -> int {  // 9-region id of the rolled position (slices (0,-6),(-6,-3),(-3,None))
+        t = min(t, 35);
+        const int iy = t / 6, ix = t - iy * 6;
+        const int py = wy * 6 + iy, px = wx * 6 + ix;
+        const int ry = py < H - 6 ? 0 : (py < H - 3 ? 1 : 2);
+        const int rx = px < W - 6 ? 0 : (px < W - 3 ? 1 : 2);
+        return ry * 3 + rx;
+    };
+
+    long pq[3];
+    frag_t qf[3], kf[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        pq[t] = pix(t * 16 + r16);
+        const f16 *p = qkv + pq[t] * C3 + head * HD + grp * (HD / 4);
+        qf[t] = *reinterpret_cast<const frag_t *>(p);
+        kf[t] = *reinterpret_cast<const frag_t *>(p + C);
+    }
+
+    // scores: sc[kt][qt][r] is S[q = qt*16 + r16][key = kt*16 + grp*4 + r]
+    float sc[3][3][4];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 3; ++qt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (HD == 32) acc = MFMA_16x16x32(kf[kt], qf[qt], acc);
+            else acc = MFMA_16x16x16(kf[kt], qf[qt], acc);
+            const int qi = min(qt * 16 + r16, 35);
+            const float4 bv = *reinterpret_cast<const float4 *>(bias + ((long)head * 36 + qi) * 48 + kt * 16 + grp * 4);
+            sc[kt][qt][0] = acc[0] * scale + bv.x;
+            sc[kt][qt][1] = acc[1] * scale + bv.y;
+            sc[kt][qt][2] = acc[2] * scale + bv.z;
+            sc[kt][qt][3] = acc[3] * scale + bv.w;
+        }
+    if (shift > 0) {
+        int idq[3], idk[3][4];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            idq[t] = region(t * 16 + r16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) idk[t][r] = region(t * 16 + grp * 4 + r);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (idq[qt] != idk[kt][r]) sc[kt][qt][r] += -100.0f;
+    }
+
+    // softmax over keys (un-normalised p in fp16 feeds the MFMA; 1/sum is applied to the fp32 output)
+    float inv_sum[3];
+    f16x4 pf[3][3];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][qt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[kt][qt][r] - mx);
+                sum += p;
+                pf[kt][qt][r] = (f16)p;
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        inv_sum[qt] = 1.0f / sum;
+    }
+
+    // O^T = V^T P^T
+    const f16 *vbase = qkv + 2 * C + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+        f16x4 vf[3];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vf[kt][j] = vbase[pix(kt * 16 + grp * 4 + j) * C3 + dt * 16 + r16];
+#pragma unroll
+        for (int qt = 0; qt < 3; ++qt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) acc = MFMA_16x16x16(vf[kt], pf[kt][qt], acc);
+            if (qt * 16 + r16 < 36) {
+                const float s = inv_sum[qt];
+                f16x4 ov = {(f16)(acc[0] * s), (f16)(acc[1] * s), (f16)(acc[2] * s), (f16)(acc[3] * s)};
+                *reinterpret_cast<f16x4 *>(out + pq[qt] * C + head * HD + dt * 16 + grp * 4) = ov;
+            }
+        }
+    }
+}
+
+int launch_window_attn(const f16 *qkv, f16 *out, const float *bias, int B, int H, int W, int heads, int hd,
+                       int shift, hipStream_t s) {
+    NUNIF_REQUIRE(H % 6 == 0 && W % 6 == 0, "window_attn: %dx%d not a multiple of the 6x6 window", H, W);
+    NUNIF_REQUIRE(hd == 16 || hd == 32, "window_attn: head_dim %d unsupported", hd);
+    // torchvision disables the shift on an axis whose size is <= the window; both axes are equal here
+    if (H <= 6) shift = 0;
+    const long total = (long)B * (H / 6) * (W / 6) * heads;
+    const double tok = (double)B * H * W;
+    ProfScope ps("window_attn", s, 4.0 * tok * 36.0 * heads * hd, tok * heads * hd * 2.0 * 4.0);
+    const unsigned blocks = (unsigned)((total + 3) / 4);
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (hd == 16) window_attn_kernel<16><<<blocks, 256, 0, s>>>(qkv, out, bias, B, H, W, heads, shift, scale);
+    else window_attn_kernel<32><<<blocks, 256, 0, s>>>(qkv, out, bias, B, H, W, heads, shift, scale);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+}  // namespace nunif

@@ -1,0 +1,442 @@
+// Host side of the waifu2x swin_unet engine: weight repacking, workspace, launch sequence, whole-frame render.
+//
+// Reference: waifu2x/models/swin_unet.py SwinUNetBase.__init__/forward :119-199 (layer inventory and data flow),
+// nunif/utils/seam_blending.py tiled_render :48-106 (frame loop).  State-dict keys are the reference's.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "swin_kernels.h"
+
+namespace nunif {
+
+int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int C, hipStream_t s);
+
+namespace {
+
+struct HostTensor { const float *data; std::vector<int64_t> shape; int64_t numel; };
+
+struct Linear {          // fragment-packed fp16 weight + fp32 bias, device memory
+    f16 *w = nullptr;
+    float *bias = nullptr;
+    int N = 0, n_real = 0, K = 0;
+};
+
+struct Block {
+    Linear qkv, proj, mlp0, mlp3;
+    float *attn_bias = nullptr;   // [heads][36][48]
+};
+
+struct DeviceBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return NUNIF_HIP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            set_error("hipMalloc(%zu) failed", bytes);
+            return NUNIF_HIP_ENOMEM;
+        }
+        cap = bytes;
+        return NUNIF_HIP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+}  // namespace nunif
+
+using namespace nunif;
+
+struct nunif_swin_unet {
+    int scale_factor = 2;
+    int C = 96, heads = 6;
+    int C1 = 48, C1P = 64;            // stem conv1 channels (real / padded to a multiple of 32)
+    int top_dim = 96;                 // channels of level 1 on the decoder side (C for 1x/2x, 2C for 4x)
+    float *stem1_w = nullptr, *stem1_b = nullptr;
+    Linear stem2, down1, down2, up2, up1, proj2, to_image;
+    bool has_proj2 = false;
+    std::vector<Block> swin[5];
+    std::vector<void *> owned;        // every device allocation made at create time
+    DeviceBuf s1, f1, f2, f3, g1, qkv, att, hid, tile_out;
+    int device = 0;
+    // debug taps (tests only): when on, every stage's fp16 output is snapshotted device-side
+    struct Tap { std::string name; void *dev; size_t bytes; };
+    bool taps_on = false;
+    std::vector<Tap> taps;
+    void clear_taps() { for (auto &t : taps) (void)hipFree(t.dev); taps.clear(); }
+};
+
+namespace nunif {
+namespace {
+
+typedef std::map<std::string, HostTensor> TensorMap;
+
+int find(const TensorMap &m, const std::string &key, const HostTensor **out) {
+    auto it = m.find(key);
+    if (it == m.end()) {
+        set_error("state_dict is missing '%s'", key.c_str());
+        return NUNIF_HIP_EMISSING;
+    }
+    *out = &it->second;
+    return NUNIF_HIP_OK;
+}
+
+template <typename T>
+int upload(nunif_swin_unet *h, const std::vector<T> &host, T **dev) {
+    void *p = nullptr;
+    if (hipMalloc(&p, host.size() * sizeof(T)) != hipSuccess) {
+        set_error("hipMalloc(%zu) failed", host.size() * sizeof(T));
+        return NUNIF_HIP_ENOMEM;
+    }
+    h->owned.push_back(p);
+    NUNIF_HIP_CHECK(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = reinterpret_cast<T *>(p);
+    return NUNIF_HIP_OK;
+}
+
+// Fragment-major packing for the MFMA A operand (v_mfma_f32_16x16x32_f16): fragment (nt, ks) is 64 lanes x 8 halfs,
+// lane l holds W[nt*16 + (l&15)][ks*32 + (l>>4)*8 + 0..7]; rows beyond n_real are zero.  `wt(n,k)` returns fp32.
+template <typename F>
+int make_linear(nunif_swin_unet *h, int n_real, int K, F wt, const float *bias, Linear *L) {
+    const int N = (n_real + 15) / 16 * 16;
+    std::vector<f16> packed((size_t)N * K);
+    const int KS = K / 32;
+    for (int nt = 0; nt < N / 16; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = nt * 16 + (l & 15), k = ks * 32 + (l >> 4) * 8 + j;
+                    packed[(((size_t)nt * KS + ks) * 64 + l) * 8 + j] = (f16)(n < n_real ? wt(n, k) : 0.0f);
+                }
+    std::vector<float> b(N, 0.0f);
+    for (int n = 0; n < n_real; ++n) b[n] = bias[n];
+    L->N = N; L->n_real = n_real; L->K = K;
+    int rc = upload(h, packed, &L->w);
+    if (rc) return rc;
+    return upload(h, b, &L->bias);
+}
+
+int make_plain_linear(nunif_swin_unet *h, const TensorMap &m, const std::string &key, int n_real, int K, Linear *L) {
+    const HostTensor *w, *b;
+    int rc;
+    if ((rc = find(m, key + ".weight", &w)) || (rc = find(m, key + ".bias", &b))) return rc;
+    NUNIF_REQUIRE(w->numel == (int64_t)n_real * K && b->numel == n_real, "%s: unexpected shape", key.c_str());
+    const float *wd = w->data;
+    return make_linear(h, n_real, K, [=](int n, int k) { return wd[(size_t)n * K + k]; }, b->data, L);
+}
+
+int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, int dim, int layers,
+               std::vector<Block> *blocks) {
+    blocks->resize(layers);
+    const int heads = h->heads;
+    for (int i = 0; i < layers; ++i) {
+        const std::string p = key + ".block." + std::to_string(i) + ".";
+        Block &bl = (*blocks)[i];
+        int rc;
+        if ((rc = make_plain_linear(h, m, p + "attn.qkv", 3 * dim, dim, &bl.qkv))) return rc;
+        if ((rc = make_plain_linear(h, m, p + "attn.proj", dim, dim, &bl.proj))) return rc;
+        if ((rc = make_plain_linear(h, m, p + "mlp.0", 2 * dim, dim, &bl.mlp0))) return rc;
+        if ((rc = make_plain_linear(h, m, p + "mlp.3", dim, 2 * dim, &bl.mlp3))) return rc;
+        NUNIF_REQUIRE(m.find(p + "norm1.weight") == m.end(), "%s: LayerNorm variants (swin_unet_4xl) unsupported",
+                      p.c_str());
+        const HostTensor *tab;
+        if ((rc = find(m, p + "attn.relative_position_bias_table", &tab))) return rc;
+        NUNIF_REQUIRE(tab->numel == 121 * heads, "%s: bias table shape", p.c_str());
+        // bias[h][q][key] = table[(yq-yk+5)*11 + (xq-xk+5)][h]  (torchvision relative_position_index, window 6x6);
+        // the 12 padding key columns get -1e30 so that exp() makes them exactly 0.
+        std::vector<float> bias((size_t)heads * 36 * 48);
+        for (int hh = 0; hh < heads; ++hh)
+            for (int q = 0; q < 36; ++q)
+                for (int k = 0; k < 48; ++k) {
+                    float v = -1.0e30f;
+                    if (k < 36) {
+                        const int idx = (q / 6 - k / 6 + 5) * 11 + (q % 6 - k % 6 + 5);
+                        v = tab->data[(size_t)idx * heads + hh];
+                    }
+                    bias[((size_t)hh * 36 + q) * 48 + k] = v;
+                }
+        if ((rc = upload(h, bias, &bl.attn_bias))) return rc;
+    }
+    return NUNIF_HIP_OK;
+}
+
+int run_gemm(const Linear &L, const f16 *a, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int stride, int oy,
+             int ox, int kw, int mode, int act, float slope, const f16 *res, void *out, int ldo, int ps,
+             hipStream_t s, const char *tag) {
+    GemmArgs g;
+    g.a = a; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin;
+    g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.oy = oy; g.ox = ox; g.kw = kw;
+    g.K = L.K; g.w = L.w; g.bias = L.bias; g.N = L.N;
+    g.mode = mode; g.act = act; g.slope = slope; g.res = res; g.out = out; g.ldo = ldo;
+    g.n_real = L.n_real; g.ps = ps;
+    return launch_gemm(g, s, tag);
+}
+
+int run_linear(const Linear &L, const f16 *a, int B, int H, int W, int act, const f16 *res, f16 *out,
+               hipStream_t s, const char *tag) {
+    return run_gemm(L, a, B, H, W, L.K, H, W, 1, 0, 0, 1, 0, act, 0.f, res, out, L.n_real, 1, s, tag);
+}
+
+int tap(nunif_swin_unet *h, const std::string &name, const void *src, size_t bytes, hipStream_t s) {
+    if (!h->taps_on) return NUNIF_HIP_OK;
+    void *p = nullptr;
+    NUNIF_HIP_CHECK(hipMalloc(&p, bytes));
+    NUNIF_HIP_CHECK(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToDevice, s));
+    h->taps.push_back({name, p, bytes});
+    return NUNIF_HIP_OK;
+}
+
+int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int S, int dim, hipStream_t s,
+              const char *name) {
+    f16 *qkv = (f16 *)h->qkv.p, *att = (f16 *)h->att.p, *hid = (f16 *)h->hid.p;
+    const size_t tok = (size_t)B * S * S;
+    int rc;
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        Block &bl = blocks[i];
+        const int shift = (i % 2 == 1) ? 3 : 0;      // swin_unet.py:30
+        const std::string tn = std::string(name) + ".b" + std::to_string(i);
+        if ((rc = run_linear(bl.qkv, x, B, S, S, 0, nullptr, qkv, s, "gemm_qkv"))) return rc;
+        if ((rc = tap(h, tn + ".qkv", qkv, tok * 3 * dim * 2, s))) return rc;
+        if ((rc = launch_window_attn(qkv, att, bl.attn_bias, B, S, S, h->heads, dim / h->heads, shift, s))) return rc;
+        if ((rc = tap(h, tn + ".attn", att, tok * dim * 2, s))) return rc;
+        if ((rc = run_linear(bl.proj, att, B, S, S, 0, x, x, s, "gemm_proj"))) return rc;       // x += proj(attn)
+        if ((rc = run_linear(bl.mlp0, x, B, S, S, 1, nullptr, hid, s, "gemm_mlp0"))) return rc;  // GELU
+        if ((rc = run_linear(bl.mlp3, hid, B, S, S, 0, x, x, s, "gemm_mlp3"))) return rc;        // x += mlp(x)
+        if ((rc = tap(h, tn + ".out", x, tok * dim * 2, s))) return rc;
+    }
+    return NUNIF_HIP_OK;
+}
+
+int ensure_workspace(nunif_swin_unet *h, int B, int T) {
+    const size_t S = T - 16, S2 = S / 2, S4 = S / 4, C = h->C;
+    const size_t t1 = (size_t)B * S * S, t2 = (size_t)B * S2 * S2, t3 = (size_t)B * S4 * S4;
+    const size_t top = h->top_dim;
+    int rc;
+    if ((rc = h->s1.ensure((size_t)B * (T - 14) * (T - 14) * h->C1P * 2))) return rc;
+    if ((rc = h->f1.ensure(t1 * C * 2))) return rc;
+    if ((rc = h->f2.ensure(t2 * 2 * C * 2))) return rc;
+    if ((rc = h->f3.ensure(t3 * 2 * C * 2))) return rc;
+    if (h->has_proj2 && (rc = h->g1.ensure(t1 * top * 2))) return rc;
+    const size_t qkv_elems = std::max(t1 * 3 * std::max(C, top), t2 * 6 * C);
+    if ((rc = h->qkv.ensure(qkv_elems * 2))) return rc;
+    if ((rc = h->att.ensure(std::max(t1 * std::max(C, top), t2 * 2 * C) * 2))) return rc;
+    if ((rc = h->hid.ensure(std::max(t1 * 2 * std::max(C, top), t2 * 4 * C) * 2))) return rc;
+    return NUNIF_HIP_OK;
+}
+
+// x: tile mode [B,3,T,T] or (frame != NULL) the frame + grid; z: [B,3,S*s,S*s]
+int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const nunif_tile_grid *grid,
+                 int tile_begin, float *z, int B, int T, hipStream_t s) {
+    const int S = T - 16, C = h->C;
+    NUNIF_REQUIRE(T > 16 && S % 12 == 0 && S % 16 == 0, "tile_size %d is not valid for swin_unet", T);
+    int rc;
+    if ((rc = ensure_workspace(h, B, T))) return rc;
+    f16 *s1 = (f16 *)h->s1.p, *f1 = (f16 *)h->f1.p, *f2 = (f16 *)h->f2.p, *f3 = (f16 *)h->f3.p;
+
+    Stem1Args a1;
+    memset(&a1, 0, sizeof(a1));
+    if (frame) {
+        a1.x = frame; a1.frame_mode = 1; a1.H = grid->x_h; a1.W = grid->x_w; a1.wb = grid->w_blocks;
+        a1.istep = grid->input_tile_step; a1.pad_t = grid->pad_t; a1.pad_l = grid->pad_l; a1.tile_begin = tile_begin;
+    } else {
+        a1.x = x;
+    }
+    a1.B = B; a1.T = T; a1.w = h->stem1_w; a1.bias = h->stem1_b; a1.C1 = h->C1; a1.C1P = h->C1P; a1.out = s1;
+    a1.slope = 0.1f;
+    if ((rc = launch_stem1(a1, s))) return rc;
+    // conv2 3x3 VALID + LeakyReLU(0.1) + crop 6 (swin_unet.py:135-137,182): s1 already starts at conv1 row/col 6
+    if ((rc = run_gemm(h->stem2, s1, B, T - 14, T - 14, h->C1P, S, S, 1, 0, 0, 3, 0, 2, 0.1f, nullptr, f1, C, 1, s,
+                       "gemm_stem2")))
+        return rc;
+    if ((rc = tap(h, "stem", f1, (size_t)B * S * S * C * 2, s))) return rc;
+    if ((rc = run_stage(h, h->swin[0], f1, B, S, C, s, "swin1"))) return rc;                          // swin1 -> x3
+    if ((rc = run_gemm(h->down1, f1, B, S, S, C, S / 2, S / 2, 2, 0, 0, 2, 0, 0, 0.f, nullptr, f2, 2 * C, 1, s,
+                       "gemm_down")))
+        return rc;
+    if ((rc = tap(h, "down1", f2, (size_t)B * (S / 2) * (S / 2) * 2 * C * 2, s))) return rc;
+    if ((rc = run_stage(h, h->swin[1], f2, B, S / 2, 2 * C, s, "swin2"))) return rc;                  // swin2 -> x4
+    if ((rc = run_gemm(h->down2, f2, B, S / 2, S / 2, 2 * C, S / 4, S / 4, 2, 0, 0, 2, 0, 0, 0.f, nullptr, f3,
+                       2 * C, 1, s, "gemm_down")))
+        return rc;
+    if ((rc = tap(h, "down2", f3, (size_t)B * (S / 4) * (S / 4) * 2 * C * 2, s))) return rc;
+    if ((rc = run_stage(h, h->swin[2], f3, B, S / 4, 2 * C, s, "swin3"))) return rc;                  // swin3
+    // x = up2(x5) + x4, written in place over x4 (each lane reads then writes its own 8 bytes)
+    if ((rc = run_gemm(h->up2, f3, B, S / 4, S / 4, 2 * C, S / 4, S / 4, 1, 0, 0, 1, 1, 0, 0.f, f2, f2, 2 * C, 1, s,
+                       "gemm_up")))
+        return rc;
+    if ((rc = tap(h, "up2", f2, (size_t)B * (S / 2) * (S / 2) * 2 * C * 2, s))) return rc;
+    if ((rc = run_stage(h, h->swin[3], f2, B, S / 2, 2 * C, s, "swin4"))) return rc;                  // swin4
+    f16 *top = f1;
+    if (h->has_proj2) {
+        // 4x: x = up1(x) + proj2(x3)   (swin_unet.py:166,195-196)
+        top = (f16 *)h->g1.p;
+        if ((rc = run_linear(h->proj2, f1, B, S, S, 0, nullptr, top, s, "gemm_proj2"))) return rc;
+    }
+    if ((rc = run_gemm(h->up1, f2, B, S / 2, S / 2, 2 * C, S / 2, S / 2, 1, 0, 0, 1, 1, 0, 0.f, top, top,
+                       h->top_dim, 1, s, "gemm_up")))
+        return rc;
+    if ((rc = tap(h, "up1", top, (size_t)B * S * S * h->top_dim * 2, s))) return rc;
+    if ((rc = run_stage(h, h->swin[4], top, B, S, h->top_dim, s, "swin5"))) return rc;                // swin5
+    // to_image + pixel_shuffle + clamp(0,1) (ToImage.forward :110-116, wrapper eval clamp :225-226)
+    if ((rc = run_gemm(h->to_image, top, B, S, S, h->top_dim, S, S, 1, 0, 0, 1, 2, 0, 0.f, nullptr, z, 0,
+                       h->scale_factor, s, "gemm_to_image")))
+        return rc;
+    return NUNIF_HIP_OK;
+}
+
+}  // namespace
+}  // namespace nunif
+
+extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int32_t n_tensors,
+                                          int32_t scale_factor, nunif_swin_unet **handle) {
+    NUNIF_REQUIRE(tensors && handle && n_tensors > 0, "swin_unet_create: NULL argument");
+    NUNIF_REQUIRE(scale_factor == 1 || scale_factor == 2 || scale_factor == 4,
+                  "swin_unet_create: scale_factor %d unsupported (1, 2, 4)", scale_factor);
+    TensorMap m;
+    for (int i = 0; i < n_tensors; ++i) {
+        HostTensor t;
+        t.data = tensors[i].data;
+        t.numel = 1;
+        for (int d = 0; d < tensors[i].ndim; ++d) {
+            t.shape.push_back(tensors[i].shape[d]);
+            t.numel *= tensors[i].shape[d];
+        }
+        m[tensors[i].name] = t;
+    }
+    nunif_swin_unet *h = new nunif_swin_unet();
+    (void)hipGetDevice(&h->device);
+    h->scale_factor = scale_factor;
+    const std::string P = "unet.";
+    int rc = NUNIF_HIP_OK;
+    do {
+        const HostTensor *w0, *b0, *w2, *b2;
+        if ((rc = find(m, P + "patch.0.weight", &w0)) || (rc = find(m, P + "patch.0.bias", &b0)) ||
+            (rc = find(m, P + "patch.2.weight", &w2)) || (rc = find(m, P + "patch.2.bias", &b2)))
+            break;
+        if (w2->shape.size() != 4 || w0->shape.size() != 4 || w0->shape[1] != 3) {
+            set_error("patch conv: unexpected shape"); rc = NUNIF_HIP_EINVAL; break;
+        }
+        const int C = (int)w2->shape[0];
+        const int C1 = (int)w0->shape[0];
+        if (C % 96 != 0 || C1 * 2 != C) { set_error("base_dim %d unsupported", C); rc = NUNIF_HIP_EUNSUPPORTED; break; }
+        h->C = C; h->heads = C / 16; h->C1 = C1; h->C1P = (C1 + 31) / 32 * 32;
+        h->has_proj2 = scale_factor == 4;
+        h->top_dim = h->has_proj2 ? 2 * C : C;
+        {
+            std::vector<float> w(w0->data, w0->data + w0->numel), b(b0->data, b0->data + b0->numel);
+            if ((rc = upload(h, w, &h->stem1_w)) || (rc = upload(h, b, &h->stem1_b))) break;
+        }
+        {   // conv2 [C][C1][3][3] -> W[n][k = (dy*3+dx)*C1P + ci], zero for the padded input channels
+            const float *wd = w2->data;
+            const int C1P = h->C1P;
+            rc = make_linear(h, C, 9 * C1P, [=](int n, int k) {
+                const int tap = k / C1P, ci = k % C1P;
+                return ci < C1 ? wd[((size_t)n * C1 + ci) * 9 + tap] : 0.0f;
+            }, b2->data, &h->stem2);
+            if (rc) break;
+        }
+        if ((rc = make_stage(h, m, P + "swin1", C, 2, &h->swin[0]))) break;
+        if ((rc = make_stage(h, m, P + "swin2", 2 * C, 2, &h->swin[1]))) break;
+        if ((rc = make_stage(h, m, P + "swin3", 2 * C, 6, &h->swin[2]))) break;
+        if ((rc = make_stage(h, m, P + "swin4", 2 * C, 2, &h->swin[3]))) break;
+        if ((rc = make_stage(h, m, P + "swin5", h->top_dim, 2, &h->swin[4]))) break;
+        auto make_down = [&](const std::string &key, int cin, int cout, Linear *L) -> int {
+            const HostTensor *w, *b;
+            int r;
+            if ((r = find(m, key + ".conv.weight", &w)) || (r = find(m, key + ".conv.bias", &b))) return r;
+            NUNIF_REQUIRE(w->numel == (int64_t)cout * cin * 4, "%s: shape", key.c_str());
+            const float *wd = w->data;   // [cout][cin][2][2] -> k = (i*2+j)*cin + ci
+            return make_linear(h, cout, 4 * cin, [=](int n, int k) {
+                const int tap = k / cin, ci = k % cin;
+                return wd[((size_t)n * cin + ci) * 4 + tap];
+            }, b->data, L);
+        };
+        auto make_up = [&](const std::string &key, int cin, int cq, Linear *L) -> int {
+            const HostTensor *w, *b;
+            int r;
+            if ((r = find(m, key + ".proj.weight", &w)) || (r = find(m, key + ".proj.bias", &b))) return r;
+            NUNIF_REQUIRE(w->numel == (int64_t)4 * cq * cin, "%s: shape", key.c_str());
+            const float *wd = w->data;   // rows c*4 + q  ->  q*cq + c   (pixel_shuffle(2) channel order)
+            std::vector<float> bb(4 * cq);
+            for (int n = 0; n < 4 * cq; ++n) bb[n] = b->data[(n % cq) * 4 + n / cq];
+            return make_linear(h, 4 * cq, cin, [=](int n, int k) {
+                const int q = n / cq, c = n % cq;
+                return wd[((size_t)(c * 4 + q)) * cin + k];
+            }, bb.data(), L);
+        };
+        if ((rc = make_down(P + "down1", C, 2 * C, &h->down1))) break;
+        if ((rc = make_down(P + "down2", 2 * C, 2 * C, &h->down2))) break;
+        if ((rc = make_up(P + "up2", 2 * C, 2 * C, &h->up2))) break;
+        if ((rc = make_up(P + "up1", 2 * C, h->top_dim, &h->up1))) break;
+        if (h->has_proj2 && (rc = make_plain_linear(h, m, P + "proj2", 2 * C, C, &h->proj2))) break;
+        if ((rc = make_plain_linear(h, m, P + "to_image.proj", 3 * scale_factor * scale_factor, h->top_dim,
+                                    &h->to_image)))
+            break;
+    } while (0);
+    if (rc) {
+        nunif_hip_swin_unet_destroy(h);
+        return rc;
+    }
+    *handle = h;
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_swin_unet_debug_taps(nunif_swin_unet *h, int32_t enable) {
+    NUNIF_REQUIRE(h, "debug_taps: NULL handle");
+    h->clear_taps();
+    h->taps_on = enable != 0;
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_swin_unet_get_tap(nunif_swin_unet *h, int32_t index, char *name, int32_t name_cap,
+                                           void *host_dst, int64_t cap_bytes, int64_t *nbytes) {
+    NUNIF_REQUIRE(h && nbytes, "get_tap: NULL argument");
+    if (index < 0 || index >= (int)h->taps.size()) return 1;   // end of list
+    const auto &t = h->taps[index];
+    if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    *nbytes = (int64_t)t.bytes;
+    if (host_dst) {
+        NUNIF_REQUIRE(cap_bytes >= (int64_t)t.bytes, "get_tap: buffer too small");
+        NUNIF_HIP_CHECK(hipDeviceSynchronize());
+        NUNIF_HIP_CHECK(hipMemcpy(host_dst, t.dev, t.bytes, hipMemcpyDeviceToHost));
+    }
+    return NUNIF_HIP_OK;
+}
+
+extern "C" void nunif_hip_swin_unet_destroy(nunif_swin_unet *h) {
+    if (!h) return;
+    h->clear_taps();
+    for (void *p : h->owned) (void)hipFree(p);
+    for (DeviceBuf *b : {&h->s1, &h->f1, &h->f2, &h->f3, &h->g1, &h->qkv, &h->att, &h->hid, &h->tile_out}) b->release();
+    delete h;
+}
+
+extern "C" int nunif_hip_swin_unet_forward(nunif_swin_unet *h, const float *x, float *z, int32_t batch,
+                                           int32_t tile_size, void *stream) {
+    NUNIF_REQUIRE(h && x && z && batch > 0, "swin_unet_forward: bad argument");
+    return forward_impl(h, x, nullptr, nullptr, 0, z, batch, tile_size, (hipStream_t)stream);
+}
+
+extern "C" int nunif_hip_swin_unet_render(nunif_swin_unet *h, const float *x, float *y, int32_t x_h, int32_t x_w,
+                                          int32_t tile_size, int32_t batch_size, void *stream) {
+    NUNIF_REQUIRE(h && x && y && batch_size > 0, "swin_unet_render: bad argument");
+    const int s = h->scale_factor;
+    nunif_tile_grid g;
+    int rc = nunif_hip_tile_grid_init(x_h, x_w, s, 8 * s, tile_size, 4 * s, &g);   // offsets/blend: swin_unet.py:213,234,267
+    if (rc) return rc;
+    const int n_tiles = g.h_blocks * g.w_blocks;
+    const size_t To = g.out_tile_size;
+    if ((rc = h->tile_out.ensure((size_t)n_tiles * 3 * To * To * sizeof(float)))) return rc;
+    float *tile_out = (float *)h->tile_out.p;
+    hipStream_t st = (hipStream_t)stream;
+    for (int t0 = 0; t0 < n_tiles; t0 += batch_size) {
+        const int nb = std::min(batch_size, n_tiles - t0);
+        if ((rc = forward_impl(h, nullptr, x, &g, t0, tile_out + (size_t)t0 * 3 * To * To, nb, tile_size, st)))
+            return rc;
+    }
+    return launch_stitch(tile_out, y, &g, 3, st);
+}

@@ -1,0 +1,281 @@
+"""waifu2x swin_unet on the HIP engine.
+
+Mirrors the model classes of ``waifu2x/models/swin_unet.py`` (reference): ``SwinUNet`` :208-226, ``SwinUNet2x``
+:229-249, ``SwinUNet4x`` :261-306, ``SwinUNetDownscaled`` :339-387 and ``tile_size_validator`` :202-205 — same
+registry names, constructor kwargs, ``i2i_*`` geometry and ``state_dict`` keys, so reference ``.pth`` files load
+unchanged.  The forward pass is ``nunif_hip_swin_unet_forward`` (nunif_amd/csrc/swin_unet.cpp); Python only holds
+the fp32 master weights and hands their pointers to the C ABI.
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+from ...nunif.models import I2IBaseModel, register_model
+from ... import _hip
+
+WINDOW = 6
+
+
+def tile_size_validator(size):
+    return size > 16 and (size - 16) % 12 == 0 and (size - 16) % 16 == 0
+
+
+def _relative_position_index():
+    ys, xs = torch.meshgrid(torch.arange(WINDOW), torch.arange(WINDOW), indexing="ij")
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    return ((ys[:, None] - ys[None, :] + WINDOW - 1) * (2 * WINDOW - 1) + xs[:, None] - xs[None, :] + WINDOW - 1).reshape(-1)
+
+
+def _init_weights(scale_factor, base_dim, in_channels, out_channels):
+    """Fresh weights in the reference's key layout (SwinUNetBase.__init__ :119-178; torchvision block init)."""
+    sd = OrderedDict()
+    C = base_dim
+
+    def conv(key, cin, cout, k):
+        w = torch.empty(cout, cin, k, k)
+        torch.nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
+        sd[key + ".weight"], sd[key + ".bias"] = w, torch.zeros(cout)
+
+    def linear(key, cin, cout, bias_std=0.0):
+        w = torch.empty(cout, cin)
+        torch.nn.init.xavier_uniform_(w)
+        sd[key + ".weight"] = w
+        sd[key + ".bias"] = torch.randn(cout) * bias_std if bias_std else torch.zeros(cout)
+
+    def stage(key, dim, layers):
+        for i in range(layers):
+            p = f"{key}.block.{i}."
+            for name, cout in (("attn.qkv", dim * 3), ("attn.proj", dim)):
+                w = torch.empty(cout, dim)
+                torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+                sd[p + name + ".weight"] = w
+                sd[p + name + ".bias"] = (torch.rand(cout) * 2 - 1) / math.sqrt(dim)
+            sd[p + "attn.relative_position_bias_table"] = torch.nn.init.trunc_normal_(
+                torch.empty((2 * WINDOW - 1) ** 2, C // 16), std=0.02)
+            sd[p + "attn.relative_position_index"] = _relative_position_index()
+            linear(p + "mlp.0", dim, dim * 2, 1e-6)
+            linear(p + "mlp.3", dim * 2, dim, 1e-6)
+
+    P = "unet."
+    conv(P + "patch.0", in_channels, C // 2, 3)
+    conv(P + "patch.2", C // 2, C, 3)
+    stage(P + "swin1", C, 2)
+    conv(P + "down1.conv", C, C * 2, 2)
+    stage(P + "swin2", C * 2, 2)
+    conv(P + "down2.conv", C * 2, C * 2, 2)
+    stage(P + "swin3", C * 2, 6)
+    linear(P + "up2.proj", C * 2, C * 2 * 4)
+    if scale_factor in (4, 8):
+        linear(P + "proj2", C, C * 2)
+    stage(P + "swin4", C * 2, 2)
+    top = C if scale_factor in (1, 2) else C * 2
+    linear(P + "up1.proj", C * 2, top * 4)
+    stage(P + "swin5", top, 2)
+    linear(P + "to_image.proj", top, out_channels * scale_factor ** 2)
+    return sd
+
+
+class HipSwinUNetEngine:
+    """Owns one ``nunif_swin_unet*`` handle (device weights + workspace) for one device."""
+
+    def __init__(self, state_dict, scale_factor, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the swin_unet HIP engine needs a ROCm device (model.to('cuda:N')); no CPU fallback")
+        self.scale_factor = scale_factor
+        keep = []
+        descs = []
+        for name, t in state_dict.items():
+            if not t.is_floating_point():
+                continue   # relative_position_index is recomputed from the window geometry
+            t = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+            keep.append(t)
+            d = _hip.TensorDesc()
+            d.name = name.encode()
+            d.data = t.data_ptr()
+            d.ndim = t.dim()
+            for i, s in enumerate(t.shape):
+                d.shape[i] = s
+            descs.append(d)
+        arr = (_hip.TensorDesc * len(descs))(*descs)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _hip.check(_hip.lib().nunif_hip_swin_unet_create(arr, len(descs), scale_factor, ctypes.byref(handle)))
+        self.handle = handle
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                _hip.lib().nunif_hip_swin_unet_destroy(h)
+            except Exception:
+                pass
+
+    def forward(self, x):
+        B, C, T, T2 = x.shape
+        assert C == 3 and T == T2
+        s = self.scale_factor
+        z = torch.empty((B, 3, (T - 16) * s, (T - 16) * s), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _hip.check(_hip.lib().nunif_hip_swin_unet_forward(
+                self.handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(z.data_ptr()), B, T,
+                _hip.current_stream_ptr(self.device)))
+        return z
+
+    def render(self, x, tile_size, batch_size):
+        C, H, W = x.shape
+        assert C == 3
+        s = self.scale_factor
+        y = torch.empty((3, H * s, W * s), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _hip.check(_hip.lib().nunif_hip_swin_unet_render(
+                self.handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), H, W, tile_size,
+                batch_size, _hip.current_stream_ptr(self.device)))
+        return y
+
+
+class _HipSwinUNetModel(I2IBaseModel):
+    """Common machinery: flat fp32 master weights under the reference's keys + a lazily built HIP engine."""
+    unet_scale_factor = 1
+
+    def _setup(self, in_channels, out_channels, base_dim=96, layer_norm=False):
+        if in_channels != 3 or out_channels != 3:
+            raise ValueError("the HIP swin_unet engine supports in_channels = out_channels = 3")
+        if base_dim != 96 or layer_norm:
+            raise ValueError("the HIP swin_unet engine supports base_dim=96 without LayerNorm (not swin_unet_4xl)")
+        self.register_tile_size_validator(tile_size_validator)
+        self.register_buffer("_device_probe", torch.empty(0), persistent=False)
+        self._weights = _init_weights(self.unet_scale_factor, base_dim, in_channels, out_channels)
+        self._engine = None
+
+    # -- nn.Module surface ------------------------------------------------------------------------------------
+    def get_device(self):
+        return self._device_probe.device
+
+    def state_dict(self, *args, **kwargs):
+        return OrderedDict((k, v.clone()) for k, v in self._weights.items())
+
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        missing = [k for k in self._weights if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._weights]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: "
+                               f"missing {missing[:4]}{'...' if len(missing) > 4 else ''}, "
+                               f"unexpected {unexpected[:4]}{'...' if len(unexpected) > 4 else ''}")
+        for k in self._weights:
+            if k in state_dict:
+                v = state_dict[k].detach().to("cpu")
+                if v.shape != self._weights[k].shape:
+                    raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(self._weights[k].shape)}")
+                self._weights[k] = v.to(self._weights[k].dtype).clone()
+        self._engine = None
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def parameters(self, recurse=True):
+        return iter(v for v in self._weights.values() if v.is_floating_point())
+
+    def half(self):      # storage precision is the engine's business (fp16 maps, fp32 accumulate)
+        return self
+
+    def float(self):
+        return self
+
+    def engine(self):
+        dev = self.get_device()
+        if self._engine is None or self._engine.device != dev:
+            self._engine = HipSwinUNetEngine(self._weights, self.unet_scale_factor, dev)
+        return self._engine
+
+    def _prepare(self, x):
+        return x.to(device=self.get_device(), dtype=torch.float32).contiguous()
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("the HIP engine is inference-only; call .eval()")
+        dtype = x.dtype
+        return self.engine().forward(self._prepare(x)).to(dtype)
+
+    def render_frame(self, x, tile_size, batch_size):
+        """Whole-frame tiled render in one C call (used by SeamBlending.tiled_render)."""
+        return self.engine().render(self._prepare(x), tile_size, batch_size)
+
+
+@register_model
+class SwinUNet(_HipSwinUNetModel):
+    name = "waifu2x.swin_unet_1x"
+    unet_scale_factor = 1
+
+    def __init__(self, in_channels=3, out_channels=3):
+        super().__init__(dict(in_channels=in_channels, out_channels=out_channels),
+                         scale=1, offset=8, in_channels=in_channels, blend_size=4)
+        self._setup(in_channels, out_channels)
+
+
+@register_model
+class SwinUNet2x(_HipSwinUNetModel):
+    name = "waifu2x.swin_unet_2x"
+    unet_scale_factor = 2
+
+    def __init__(self, in_channels=3, out_channels=3, base_dim=96, layer_norm=False):
+        super().__init__(dict(in_channels=in_channels, out_channels=out_channels, base_dim=base_dim,
+                              layer_norm=layer_norm),
+                         scale=2, offset=16, in_channels=in_channels, blend_size=8)
+        self._setup(in_channels, out_channels, base_dim, layer_norm)
+
+
+@register_model
+class SwinUNet4x(_HipSwinUNetModel):
+    name = "waifu2x.swin_unet_4x"
+    unet_scale_factor = 4
+
+    def __init__(self, in_channels=3, out_channels=3, pre_antialias=False, base_dim=96, layer_norm=False):
+        super().__init__(dict(in_channels=in_channels, out_channels=out_channels, pre_antialias=pre_antialias,
+                              base_dim=base_dim, layer_norm=layer_norm),
+                         scale=4, offset=32, in_channels=in_channels, blend_size=16)
+        if pre_antialias:
+            raise ValueError("pre_antialias=True is not supported by the HIP engine yet")
+        self.out_channels = out_channels
+        self._setup(in_channels, out_channels, base_dim, layer_norm)
+
+    def to_2x(self, shared=True):
+        return SwinUNetDownscaled(in_channels=self.i2i_in_channels, out_channels=self.out_channels,
+                                  downscale_factor=2, unet=self)
+
+    def to_1x(self, shared=True):
+        return SwinUNetDownscaled(in_channels=self.i2i_in_channels, out_channels=self.out_channels,
+                                  downscale_factor=4, unet=self)
+
+
+@register_model
+class SwinUNetDownscaled(I2IBaseModel):
+    """4x net followed by bicubic-antialias /f and clamp (reference :339-379)."""
+    name = "waifu2x.swin_unet_downscaled"
+
+    def __init__(self, in_channels=3, out_channels=3, downscale_factor=2, unet=None, pre_antialias=False):
+        assert downscale_factor in {2, 4}
+        super().__init__(dict(in_channels=in_channels, out_channels=out_channels, downscale_factor=downscale_factor),
+                         scale=4 // downscale_factor, offset=32 // downscale_factor, in_channels=in_channels,
+                         blend_size=4 * downscale_factor)
+        self.register_tile_size_validator(tile_size_validator)
+        self.net4x = unet if unet is not None else SwinUNet4x(in_channels, out_channels)
+        self.downscale_factor = downscale_factor
+
+    def get_device(self):
+        return self.net4x.get_device()
+
+    def state_dict(self, *args, **kwargs):
+        return self.net4x.state_dict()
+
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        return self.net4x.load_state_dict(state_dict, strict=strict)
+
+    def forward(self, x):
+        z = self.net4x(x)           # already clamped to [0,1]
+        f = self.downscale_factor
+        # TODO(next): HIP antialiased-bicubic kernel; ATen on the ROCm device for now
+        z = F.interpolate(z, size=(z.shape[-2] // f, z.shape[-1] // f), mode="bicubic", align_corners=False,
+                          antialias=True)
+        return torch.clamp(z, 0.0, 1.0)

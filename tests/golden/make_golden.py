@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE itself (``/root/reference``) on CPU.
+
+Run in the build container only (the reference is not present on the GPU box):
+
+    python tests/golden/make_golden.py [group ...]
+
+Each group writes ``tests/golden/<group>.npz`` (+ ``seam_configs.json``).  Inputs and weights are seeded and
+re-creatable (``oracle.*.random_state_dict(seed)``), so only reference *outputs* (and small inputs) are stored.
+The fixtures pin the oracle (``tests/test_oracle_golden.py``) and, through it, the HIP path.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import refstub  # noqa: E402
+
+refstub.install()
+torch.set_grad_enabled(False)
+
+
+def sd_checksum(sd):
+    return float(sum(v.double().sum().item() for v in sd.values() if v.is_floating_point()))
+
+
+def synth_image(seed, c, h, w):
+    """Smooth + noise image in [0,1] (SURVEY.md §8d synthetic input recipe)."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(1, c, max(2, h // 16 + 1), max(2, w // 16 + 1), generator=g)
+    up = torch.nn.functional.interpolate(low, size=(h, w), mode="bilinear", align_corners=False)[0]
+    return torch.clamp(up * 0.8 + 0.2 * torch.rand(c, h, w, generator=g), 0, 1)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def gen_seam():
+    from nunif.utils.seam_blending import SeamBlending
+    cases = []
+    for (h, w, s, o, t, b) in [(512, 512, 1, 28, 256, 0), (1080, 1920, 2, 16, 256, 8), (2160, 3840, 4, 32, 256, 16),
+                               (1080, 1920, 2, 16, 640, 8), (100, 130, 2, 16, 64, 8), (1, 1, 2, 16, 64, 8),
+                               (17, 300, 1, 8, 64, 4), (720, 1280, 4, 32, 112, 16), (333, 777, 2, 36, 256, 0),
+                               (64, 64, 2, 16, 64, 8), (49, 48, 1, 8, 64, 4), (1080, 1920, 2, 8, 256, 8)]:
+        cfg = SeamBlending.create_config((h, w), s, o, t, b)
+        case = {"args": [h, w, s, o, t, b], "config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}}
+        if b > 0:
+            f = SeamBlending.create_blend_filter(s, o, t, b, 1)[0]
+            mid = f.shape[0] // 2
+            case["ramp_bits"] = [int(v) for v in f[mid, :b + 1].view(torch.int32)]  # fp32 bit patterns of the edge ramp
+            case["filter_sum"] = float(f.double().sum())
+            case["corner"] = [float(v) for v in f[:b + 1, :b + 1].reshape(-1)]
+        cases.append(case)
+    with open(os.path.join(HERE, "seam_configs.json"), "w") as fh:
+        json.dump(cases, fh, indent=1)
+    print("wrote seam_configs.json", len(cases), "cases")
+
+
+def gen_swin():
+    from waifu2x.models.swin_unet import SwinUNet, SwinUNet2x, SwinUNet4x
+    from nunif.utils.render import tiled_render
+    from oracle import swin_unet as O
+    out = {}
+    x = synth_image(11, 3, 64, 64).unsqueeze(0)
+    out["x"] = x
+    for cls, sf, tag in ((SwinUNet, 1, "1x"), (SwinUNet2x, 2, "2x"), (SwinUNet4x, 4, "4x")):
+        sd = O.random_state_dict(100 + sf, sf)
+        m = cls().eval()
+        m.load_state_dict(sd, strict=True)
+        out["y_" + tag] = m(x)
+        out["sdsum_" + tag] = sd_checksum(sd)
+        if sf == 4:
+            out["y_4x_to2x"] = m.to_2x().eval()(x)
+            out["y_4x_to1x"] = m.to_1x().eval()(x)
+    # shift-mask edge case: a 28x28 tile gives a 12x12 level-1 map, 6x6 at level 2 (shift disabled), 3x3 would
+    # break the %6 assumption -> the smallest legal tile is 64; use a second, different image instead
+    x2 = synth_image(12, 3, 112, 112).unsqueeze(0)
+    sd = O.random_state_dict(102, 2)
+    m = SwinUNet2x().eval()
+    m.load_state_dict(sd, strict=True)
+    out["x_112"] = x2
+    out["y_2x_112"] = m(x2)
+    # tiled render through the reference stitcher (ragged size; 2x3 tiles of 64)
+    img = synth_image(13, 3, 100, 130)
+    out["img"] = img
+    out["render_2x_t64_b4"] = tiled_render(img, m, tile_size=64, batch_size=4)
+    save("swin_unet", **out)
+
+
+GROUPS = {"seam": gen_seam, "swin": gen_swin}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(GROUPS)
+    for n in names:
+        GROUPS[n]()

@@ -1,0 +1,182 @@
+"""swin_unet HIP engine against the oracle and the reference-generated golden fixtures.
+
+Tolerance: float PSNR 10*log10(1/(mse+1e-6)) >= 50 dB on the [0,1] output (BASELINE.json north_star); the engine
+stores activations in fp16 and accumulates in fp32, the oracle is fp32 end to end.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import psnr, synth_image
+from oracle import seam_blending as OS
+from oracle import swin_unet as O
+
+pytestmark = pytest.mark.gpu
+PSNR_MIN = 50.0
+NAMES = {1: "waifu2x.swin_unet_1x", 2: "waifu2x.swin_unet_2x", 4: "waifu2x.swin_unet_4x"}
+
+
+def make_model(sf, seed):
+    from nunif_amd.waifu2x.models import swin_unet as M
+    cls = {1: M.SwinUNet, 2: M.SwinUNet2x, 4: M.SwinUNet4x}[sf]
+    sd = O.random_state_dict(seed, sf)
+    m = cls().eval()
+    m.load_state_dict(sd, strict=True)
+    return m.to("cuda:0"), sd
+
+
+def read_taps(engine):
+    from nunif_amd import _hip
+    lib = _hip.lib()
+    taps = {}
+    i = 0
+    while True:
+        name = ctypes.create_string_buffer(64)
+        nbytes = ctypes.c_int64(0)
+        rc = lib.nunif_hip_swin_unet_get_tap(engine.handle, i, name, 64, None, 0, ctypes.byref(nbytes))
+        if rc == 1:
+            break
+        _hip.check(rc)
+        buf = np.empty(nbytes.value // 2, dtype=np.float16)
+        _hip.check(lib.nunif_hip_swin_unet_get_tap(engine.handle, i, name, 64, buf.ctypes.data_as(ctypes.c_void_p),
+                                                   nbytes.value, ctypes.byref(nbytes)))
+        taps[name.value.decode()] = torch.from_numpy(buf.astype(np.float32))
+        i += 1
+    return taps
+
+
+def test_stagewise_taps_2x(hiplib, capsys):
+    """Every intermediate of the 2x net against the oracle (relative RMS error per stage) — localises a wrong
+    kernel to its stage.  Tile 64: level maps 48 / 24 / 12 (the 12x12 map has 2x2 windows: shift + mask active)."""
+    from nunif_amd import _hip
+    m, sd = make_model(2, 102)
+    x = torch.stack([synth_image(21, 3, 64, 64), synth_image(22, 3, 64, 64)])
+    ref_taps = {}
+    y_ref = torch.clamp(O.unet_forward(sd, x, 2, taps=ref_taps), 0, 1)
+    eng = m.engine()
+    _hip.check(hiplib.nunif_hip_swin_unet_debug_taps(eng.handle, 1))
+    y = m(x.to("cuda:0")).cpu()
+    taps = read_taps(eng)
+    _hip.check(hiplib.nunif_hip_swin_unet_debug_taps(eng.handle, 0))
+    assert len(taps) == len(ref_taps) and len(taps) > 40
+    report, worst = [], 0.0
+    for name, ref in ref_taps.items():
+        got = taps[name].reshape(ref.shape)
+        rel = ((got - ref).pow(2).mean().sqrt() / (ref.pow(2).mean().sqrt() + 1e-12)).item()
+        report.append(f"{name:18s} rel_rms={rel:.2e} ref_rms={ref.pow(2).mean().sqrt().item():.3f}")
+        worst = max(worst, rel)
+    with capsys.disabled():
+        print("\n" + "\n".join(report))
+        print(f"final PSNR {psnr(y, y_ref):.2f} dB")
+    assert worst < 2e-2, "a stage deviates by more than fp16 noise:\n" + "\n".join(report)
+    assert psnr(y, y_ref) >= PSNR_MIN
+
+
+@pytest.mark.parametrize("sf,tag", [(1, "1x"), (2, "2x"), (4, "4x")])
+def test_forward_matches_golden_and_oracle(hiplib, golden_swin, sf, tag):
+    m, sd = make_model(sf, 100 + sf)
+    x = torch.from_numpy(golden_swin["x"])
+    y = m(x.to("cuda:0")).cpu()
+    ref = torch.from_numpy(golden_swin["y_" + tag])          # the reference's own output
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    assert float(y.min()) >= 0.0 and float(y.max()) <= 1.0
+    assert psnr(y, ref) >= PSNR_MIN, f"PSNR vs reference fixture {psnr(y, ref):.2f} dB"
+    assert psnr(y, O.model_forward(sd, x, NAMES[sf])) >= PSNR_MIN
+
+
+def test_forward_112_batch3_and_half_input(hiplib, golden_swin):
+    m, sd = make_model(2, 102)
+    x = torch.from_numpy(golden_swin["x_112"])
+    ref = torch.from_numpy(golden_swin["y_2x_112"])
+    xb = torch.cat([x, x.flip(-1), x.flip(-2)])
+    y = m(xb.to("cuda:0")).cpu()
+    assert psnr(y[0], ref[0]) >= PSNR_MIN
+    assert psnr(y[1], O.model_forward(sd, xb[1:2])[0]) >= PSNR_MIN
+    assert psnr(y[2], O.model_forward(sd, xb[2:3])[0]) >= PSNR_MIN
+    yh = m(x.to("cuda:0").half())
+    assert yh.dtype == torch.float16 and psnr(yh.float().cpu(), ref) >= 48.0   # fp16 I/O quantisation on top
+
+
+def test_batch_invariance_and_determinism(hiplib):
+    m, _ = make_model(2, 5)
+    x = torch.rand(5, 3, 64, 64, generator=torch.Generator().manual_seed(9)).to("cuda:0")
+    y = m(x)
+    assert torch.equal(y, m(x)), "non-deterministic"
+    assert torch.equal(y[3:4], m(x[3:4])), "result depends on the minibatch size"
+
+
+def test_tiled_render_matches_reference_fixture(hiplib, golden_swin):
+    from nunif_amd.nunif.utils.render import tiled_render
+    m, sd = make_model(2, 102)
+    img = torch.from_numpy(golden_swin["img"])
+    ref = torch.from_numpy(golden_swin["render_2x_t64_b4"])    # reference tiled_render output
+    out = tiled_render(img, m, tile_size=64, batch_size=4)
+    assert out.shape == ref.shape and out.device.type == "cuda"
+    assert psnr(out.cpu(), ref) >= PSNR_MIN
+    # minibatch size must not matter; the generic (non-fused) path must agree with the fused frame path
+    out2 = tiled_render(img, m, tile_size=64, batch_size=1)
+    assert torch.equal(out, out2)
+    gen = tiled_render(img, _NoFrame(m), tile_size=64, batch_size=4)
+    assert torch.equal(gen, out), "fused gather+conv1 frame path != gather_tiles + forward + stitch"
+
+
+class _NoFrame(torch.nn.Module):
+    """Hide render_frame so that tiled_render takes the generic gather -> model -> stitch path."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+        for k in ("i2i_scale", "i2i_offset", "i2i_blend_size", "i2i_default_tile_size", "i2i_default_batch_size"):
+            setattr(self, k, getattr(m, k))
+
+    def get_device(self):
+        return self.m.get_device()
+
+    def find_valid_tile_size(self, t):
+        return self.m.find_valid_tile_size(t)
+
+    def forward(self, x):
+        return self.m(x)
+
+
+def test_full_size_1080p_properties(hiplib):
+    """BASELINE config 2 (1080p, tile 256) — too slow for the CPU oracle as a whole frame, so check
+    size-independent properties: a cropped window of the frame rendered alone must reproduce the same pixels away
+    from its border (tiling/stitch invariance up to fp16 noise), flip equivariance of the grid, determinism, and
+    oracle parity on one interior 256-tile."""
+    from nunif_amd.nunif.utils.render import tiled_render
+    m, sd = make_model(2, 102)
+    img = synth_image(77, 3, 1080, 1920)
+    out = tiled_render(img, m, tile_size=256, batch_size=8)
+    assert out.shape == (3, 2160, 3840)
+    assert torch.equal(out, tiled_render(img, m, tile_size=256, batch_size=5))
+    # one tile through the oracle: tile (1,1) of the grid covers input [228:484) (pad 8, step 236)
+    cfg = OS.create_config(1080, 1920, 2, 16, 256, 8)
+    xp = torch.nn.functional.pad(img[None], cfg["pad"], mode="replicate")[0]
+    t = xp[:, 236:236 + 256, 236:236 + 256][None]
+    z = O.model_forward(sd, t)[0]                       # [3,480,480] covers output [472:952)
+    inner = out[:, 472 + 8:952 - 8, 472 + 8:952 - 8].cpu()   # exclude the blended ramps
+    assert psnr(inner, z[:, 8:-8, 8:-8]) >= PSNR_MIN
+    # a different tiling (tile 208) of the same frame agrees away from nothing in particular: the net is not
+    # translation invariant at tile borders, so only require closeness in PSNR terms
+    out208 = tiled_render(img, m, tile_size=208, batch_size=8)
+    assert psnr(out208.cpu(), out.cpu()) >= 30.0
+
+
+def test_load_save_roundtrip_and_errors(hiplib, tmp_path):
+    from nunif_amd.nunif.models import load_model, save_model, create_model
+    m, sd = make_model(2, 102)
+    p = str(tmp_path / "scale2x.pth")
+    save_model(m, p)
+    m2, meta = load_model(p, device_ids=[0], weights_only=True)
+    assert meta["name"] == "waifu2x.swin_unet_2x" and m2.get_device().type == "cuda"
+    x = torch.rand(1, 3, 64, 64).to("cuda:0")
+    assert torch.equal(m(x), m2(x))
+    with pytest.raises(RuntimeError):
+        create_model("waifu2x.swin_unet_2x").load_state_dict({"bogus": torch.zeros(1)})
+    with pytest.raises(Exception):
+        m(torch.rand(1, 3, 100, 100).to("cuda:0"))      # 100 is not a valid tile size
+    with pytest.raises(RuntimeError):
+        create_model("waifu2x.swin_unet_2x").eval()(torch.rand(1, 3, 64, 64))   # model on CPU: no fallback
