@@ -69,6 +69,10 @@ def lib():
     """Load (once) and return the ctypes library.  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  It must be in the process BEFORE this
+        # library is dlopen'ed so that both bind to ONE HIP runtime (streams and pointers are shared); loading
+        # /opt/rocm's copy first gives two runtimes and hipMalloc fails.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP engine is not built. Run `python -m nunif_amd.build` "

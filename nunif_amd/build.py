@@ -18,6 +18,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip", "-
          "-fno-gpu-rdc"]
 
 
+# the stitcher replays the reference's fp32 recurrence bit-exactly: no FMA contraction in that file
+EXTRA_FLAGS = {"stitch.hip": ["-ffp-contract=off"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -40,7 +44,7 @@ def _compile(src, force):
     newest = max(os.path.getmtime(p) for p in [src] + headers())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
-    cmd = [hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [hipcc()] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

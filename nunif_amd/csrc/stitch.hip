@@ -45,6 +45,9 @@ __device__ __forceinline__ float ramp_at(const StitchParams &p, int t) {
 template <int VEC>
 __global__ void __launch_bounds__(256)
 stitch_kernel(const float *__restrict__ tiles, float *__restrict__ y, StitchParams p) {
+    // HIP's __fmul_rn/__fadd_rn are plain operators: without this the compiler contracts P*a + t*b into an FMA
+    // and the result is 1 ulp off the reference's separately rounded mul/mul/add (seen on gfx950).
+#pragma clang fp contract(off)
     const int xg = blockIdx.x * blockDim.x + threadIdx.x;   // group of VEC pixels along x
     const int Y = blockIdx.y;
     const int X0 = xg * VEC;
@@ -77,10 +80,14 @@ stitch_kernel(const float *__restrict__ tiles, float *__restrict__ y, StitchPara
                     for (int v = 0; v < VEC; ++v) {
                         // seam_blending.py:163-168, same operation order, no FMA contraction
                         const float F = fminf(ry, ramp_at(p, tx + v));
-                        const float w_new = __fadd_rn(Wt[v], F);
-                        const float a = __fdiv_rn(Wt[v], w_new);
-                        const float b = __fsub_rn(1.0f, a);
-                        P[v] = __fadd_rn(__fmul_rn(P[v], a), __fmul_rn(t[v], b));
+                        // plain operators on purpose: they are compiled under contract(off) above, whereas the
+                        // __fmul_rn/__fadd_rn header wrappers carry their own 'contract' flag and still fuse
+                        const float w_new = Wt[v] + F;
+                        const float a = Wt[v] / w_new;
+                        const float b = 1.0f - a;
+                        const float pa = P[v] * a;
+                        const float tb = t[v] * b;
+                        P[v] = pa + tb;
                         Wt[v] = w_new;
                     }
                 }

@@ -168,10 +168,14 @@ def find_valid_tile_size(base):
     raise ValueError(f"Could not find valid tile size: tile_size={base}")
 
 
-# The residual stream of a random-init net reaches rms ~10 at the head; a trained net's head maps it into
-# [0,1].  Scale the head so the un-clamped output sits around 0.5 +- 0.25 like a real image — otherwise the
-# final clamp saturates most pixels and PSNR stops measuring anything.
-HEAD_GAIN = 0.02
+# Conditioning of the seeded test weights.  With plain xavier/kaiming init the residual stream of this 14-block
+# net doubles every two blocks (rms 0.1 -> 13), attention logits reach +-60 and the softmax becomes a hard argmax:
+# a regime no trained net is in, where fp16 storage (the reference's own GPU mode) flips winners and PSNR measures
+# chaos instead of kernel correctness (measured: rel. error 1e-2 in the last attention).  So the two residual
+# branch outputs (attn.proj, mlp.3) are scaled by BRANCH_GAIN (stream rms ends ~1.3, logits O(1)), and the head is
+# scaled so the un-clamped image sits around 0.5 +- 0.2 like a real picture instead of saturating the clamp.
+BRANCH_GAIN = 0.8
+HEAD_GAIN = 0.12
 
 
 def random_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_channels=3):
@@ -202,11 +206,11 @@ def random_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_chan
         for i in range(layers):
             p = f"{key}.block.{i}."
             lin(p + "attn.qkv", dim, dim * 3)
-            lin(p + "attn.proj", dim, dim)
+            lin(p + "attn.proj", dim, dim, BRANCH_GAIN)
             sd[p + "attn.relative_position_bias_table"] = normal((121, heads), 0.02)
             sd[p + "attn.relative_position_index"] = relative_position_index(*WINDOW)
             lin(p + "mlp.0", dim, dim * 2)
-            lin(p + "mlp.3", dim * 2, dim)
+            lin(p + "mlp.3", dim * 2, dim, BRANCH_GAIN)
 
     c, h = base_dim, base_dim // 16
     P = "unet."
