@@ -1,0 +1,216 @@
+// Tail of a swin block on gfx950: three GEMMs chained through registers, weights streamed through an LDS ring.
+//
+//     y  = x + Wp att + bp                     (attn.proj + residual)
+//     x' = y + W3 gelu(W0 y + b0) + b3         (mlp.0, GELU(erf), mlp.3 + residual)      in place on x
+//
+// Replaces, per block, torchvision SwinTransformerBlock's `x = x + proj(...)` and `x = x + mlp(norm2(x))`
+// (norm = Identity for the waifu2x nets, waifu2x/models/swin_unet.py:16-17,26-36).
+//
+// Register chaining.  The weights are the MFMA A operand (rows = output channel), the activations the B operand
+// (cols = token).  A 16x16 accumulator tile then holds, in lane l, channels 4*(l>>4)+r of token l&15 — which is
+// exactly a B-operand fragment of the NEXT GEMM once two tiles are paired into 8 k-slots.  The k-slot permutation
+// that implies is baked into the "chained" weight packing on the host (make_linear in swin_unet.cpp), so y and the
+// 2C-wide hidden activation never leave registers: no LDS transpose, no HBM round trip.
+//
+// Weight ring.  All 4 waves of a workgroup walk the SAME fragment sequence (each wave owns MF x 16 other tokens),
+// so the host lays the three weight matrices out as ONE stream of 1-KiB fragments in consumption order.  The
+// workgroup pulls it in 8-KiB chunks: global -> registers is issued one chunk ahead (in flight during a whole
+// chunk of MFMAs), registers -> LDS happens at the chunk boundary, one __syncthreads per chunk, two LDS buffers.
+// Fragments are read back with lane-linear ds_read_b128 (conflict free).  L2 weight traffic drops 4x and the
+// ~500-cycle L2 latency that v1 exposed on every fragment is hidden.
+//
+// HBM traffic per token: read att (2C B) + read x (2C B) + write x (2C B).
+#include "swin_kernels.h"
+
+namespace nunif {
+
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+// GELU(erf) with erf from Abramowitz & Stegun 7.1.26 (|err| <= 1.5e-7, far below the fp16 store that follows):
+// 1 rcp + 1 exp + 6 fma instead of libm erff's ~40 instructions; the VALU work of GELU is otherwise comparable to
+// the MFMA time of the whole block.
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-z * z);     // erf(|v|/sqrt2)
+    return 0.5f * v + 0.5f * fabsf(v) * e;              // 0.5 v (1 + sign(v) e)
+}
+
+constexpr int kChunkFrags = 8;   // 8 KiB per chunk: 256 threads x 2 x 16 B
+
+template <int C, int MF>
+__global__ void __launch_bounds__(256, 2)
+proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wstream, int n_chunks,
+                const float *__restrict__ bp, const float *__restrict__ b0, const float *__restrict__ b3, long M) {
+    constexpr int KS = C / 32;       // K chunks of the C-wide GEMMs (proj, mlp.0)
+    constexpr int NT = C / 16;       // 16-channel output tiles of a C-wide result
+    constexpr int SH = 2 * C / 32;   // K chunks of the hidden (2C) dimension
+    constexpr int CH = kChunkFrags;
+    __shared__ f16x8 ring[2][CH * 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r16 = lane & 15;
+    const int grp = lane >> 4;
+    const long m_base = ((long)blockIdx.x * 4 + wave) * (MF * 16);
+    // NOTE: no early exit — every wave takes part in every chunk barrier; out-of-range rows are clamped + masked.
+
+    const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(wstream) + tid;
+    f16x8 st0 = gsrc[0], st1 = gsrc[256];       // chunk 0 in flight
+
+    // fragment `fi` of the stream (fi is a compile-time constant at every call site after unrolling, and call
+    // sites are in increasing fi order)
+    auto wfrag = [&](int fi) -> f16x8 {
+        const int c = fi / CH;
+        if (fi % CH == 0) {
+            ring[c & 1][tid] = st0;
+            ring[c & 1][tid + 256] = st1;
+            __syncthreads();
+            if (c + 1 < n_chunks) {
+                st0 = gsrc[(long)(c + 1) * (CH * 64)];
+                st1 = gsrc[(long)(c + 1) * (CH * 64) + 256];
+            }
+        }
+        return ring[c & 1][(fi % CH) * 64 + lane];
+    };
+
+    long row[MF];
+    bool valid[MF];
+    f16x8 yf[MF][KS];        // y (fp16) as B-operand fragments: slots 0-3 = tile 2s, slots 4-7 = tile 2s+1
+    {
+        f16x8 of[MF][KS];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const long m = m_base + f * 16 + r16;
+            valid[f] = m < M;
+            row[f] = m < M ? m : M - 1;
+            const f16 *p = att + row[f] * C + grp * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) of[f][ks] = *reinterpret_cast<const f16x8 *>(p + ks * 32);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {           // output-tile pair (2s, 2s+1) -> yf[.][s]
+            f32x4 a0[MF], a1[MF];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) { a0[f] = (f32x4){0.f, 0.f, 0.f, 0.f}; a1[f] = a0[f]; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 wa = wfrag((s * KS + ks) * 2);
+                const f16x8 wb = wfrag((s * KS + ks) * 2 + 1);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    a0[f] = MFMA_16x16x32(wa, of[f][ks], a0[f]);
+                    a1[f] = MFMA_16x16x32(wb, of[f][ks], a1[f]);
+                }
+            }
+            const int n0 = 32 * s + 4 * grp;
+            const float4 ba = *reinterpret_cast<const float4 *>(bp + n0);
+            const float4 bb = *reinterpret_cast<const float4 *>(bp + n0 + 16);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const f16x4 xa = *reinterpret_cast<const f16x4 *>(x + row[f] * C + n0);
+                const f16x4 xb = *reinterpret_cast<const f16x4 *>(x + row[f] * C + n0 + 16);
+                yf[f][s] = (f16x8){(f16)(a0[f][0] + ba.x + (float)xa[0]), (f16)(a0[f][1] + ba.y + (float)xa[1]),
+                                   (f16)(a0[f][2] + ba.z + (float)xa[2]), (f16)(a0[f][3] + ba.w + (float)xa[3]),
+                                   (f16)(a1[f][0] + bb.x + (float)xb[0]), (f16)(a1[f][1] + bb.y + (float)xb[1]),
+                                   (f16)(a1[f][2] + bb.z + (float)xb[2]), (f16)(a1[f][3] + bb.w + (float)xb[3])};
+            }
+        }
+    }
+    // mlp.3 accumulators start from the residual y (+ b3): y needs no second copy
+    f32x4 acc[NT][MF];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int n0 = 32 * s + 4 * grp;
+        const float4 ca = *reinterpret_cast<const float4 *>(b3 + n0);
+        const float4 cb = *reinterpret_cast<const float4 *>(b3 + n0 + 16);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            acc[2 * s][f] = (f32x4){(float)yf[f][s][0] + ca.x, (float)yf[f][s][1] + ca.y,
+                                    (float)yf[f][s][2] + ca.z, (float)yf[f][s][3] + ca.w};
+            acc[2 * s + 1][f] = (f32x4){(float)yf[f][s][4] + cb.x, (float)yf[f][s][5] + cb.y,
+                                        (float)yf[f][s][6] + cb.z, (float)yf[f][s][7] + cb.w};
+        }
+    }
+
+    constexpr int F_MLP = 2 * KS * KS;            // first fragment of the mlp part of the stream
+    constexpr int F_STEP = 2 * KS + NT;           // fragments per 32 hidden channels
+    // a real loop (not unrolled): full unrolling lets the scheduler hoist ~100 loads and spill; the chunk-boundary
+    // test inside wfrag() is wave-uniform, so a run-time fragment index costs one scalar branch
+#pragma unroll 1
+    for (int s = 0; s < SH; ++s) {               // 32 hidden channels at a time
+        f32x4 h0[MF], h1[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) { h0[f] = (f32x4){0.f, 0.f, 0.f, 0.f}; h1[f] = h0[f]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 wa = wfrag(F_MLP + s * F_STEP + ks * 2);
+            const f16x8 wb = wfrag(F_MLP + s * F_STEP + ks * 2 + 1);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                h0[f] = MFMA_16x16x32(wa, yf[f][ks], h0[f]);
+                h1[f] = MFMA_16x16x32(wb, yf[f][ks], h1[f]);
+            }
+        }
+        const int n0 = 32 * s + 4 * grp;
+        const float4 ba = *reinterpret_cast<const float4 *>(b0 + n0);
+        const float4 bb = *reinterpret_cast<const float4 *>(b0 + n0 + 16);
+        f16x8 hf[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            hf[f] = (f16x8){(f16)gelu_fast(h0[f][0] + ba.x), (f16)gelu_fast(h0[f][1] + ba.y),
+                            (f16)gelu_fast(h0[f][2] + ba.z), (f16)gelu_fast(h0[f][3] + ba.w),
+                            (f16)gelu_fast(h1[f][0] + bb.x), (f16)gelu_fast(h1[f][1] + bb.y),
+                            (f16)gelu_fast(h1[f][2] + bb.z), (f16)gelu_fast(h1[f][3] + bb.w)};
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f16x8 wv = wfrag(F_MLP + s * F_STEP + 2 * KS + nt);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(wv, hf[f], acc[nt][f]);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = 16 * nt + 4 * grp;
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            if (!valid[f]) continue;
+            const f16x4 o = {(f16)acc[nt][f][0], (f16)acc[nt][f][1], (f16)acc[nt][f][2], (f16)acc[nt][f][3]};
+            *reinterpret_cast<f16x4 *>(x + row[f] * C + n0) = o;
+        }
+    }
+}
+
+int proj_mlp_stream_frags(int C) {
+    const int KS = C / 32, NT = C / 16, SH = 2 * C / 32;
+    return 2 * KS * KS + SH * (2 * KS + NT);
+}
+
+int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
+                    long M, int C, hipStream_t s) {
+    if (M == 0) return NUNIF_HIP_OK;
+    ProfScope ps("proj_mlp", s, 2.0 * (double)M * C * C * 5.0, (double)M * C * 2.0 * 3.0);
+    const int n_chunks = (proj_mlp_stream_frags(C) + kChunkFrags - 1) / kChunkFrags;
+    if (C == 96) {
+        constexpr int MF = 4;
+        const unsigned blocks = (unsigned)((M + 4 * MF * 16 - 1) / (4 * MF * 16));
+        proj_mlp_kernel<96, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M);
+    } else if (C == 192) {
+        constexpr int MF = 2;
+        const unsigned blocks = (unsigned)((M + 4 * MF * 16 - 1) / (4 * MF * 16));
+        proj_mlp_kernel<192, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M);
+    } else {
+        set_error("proj_mlp: channel count %d unsupported (96, 192)", C);
+        return NUNIF_HIP_EUNSUPPORTED;
+    }
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+}  // namespace nunif

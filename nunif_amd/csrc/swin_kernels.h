@@ -38,6 +38,18 @@ struct Stem1Args {
 };
 int launch_stem1(const Stem1Args &a, hipStream_t s);
 
+// ---- tail of a swin block: x = y + W3 gelu(W0 y + b0) + b3 with y = x + Wp att + bp, in place on x ------------------
+// wstream: proj (plain packed) | mlp.0 | mlp.3 ("chained" packed) fragments in consumption order, padded to a
+// multiple of 8 fragments (swin_block_tail.hip; assembled in make_stage, swin_unet.cpp).
+int proj_mlp_stream_frags(int C);
+int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
+                    long M, int C, hipStream_t s);
+
+// ---- fused qkv Linear + (shifted) window attention, C = 96 / 6 heads of 16 (swin_qkv_attn.hip) ---------------------
+// x: [B,H,W,C] -> att: [B,H,W,C] (pre-projection attention output at the un-rolled positions)
+int launch_qkv_attn(const f16 *x, f16 *att, const f16 *wqkv, const float *bqkv, const float *bias, int B, int H,
+                    int W, int C, int heads, int shift, hipStream_t s);
+
 // ---- (shifted) 6x6 window attention on a fused qkv map ----------------------------------------------------------
 // qkv: [B,H,W,3C] fp16 (q | k | v, each heads x hd), out: [B,H,W,C]; bias: [heads][36][48] fp32 with the
 // relative-position bias gathered per (q,key) and -1e30 in the 12 padding key columns.

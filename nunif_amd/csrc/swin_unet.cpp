@@ -2,6 +2,7 @@
 //
 // Reference: waifu2x/models/swin_unet.py SwinUNetBase.__init__/forward :119-199 (layer inventory and data flow),
 // nunif/utils/seam_blending.py tiled_render :48-106 (frame loop).  State-dict keys are the reference's.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -27,6 +28,7 @@ struct Linear {          // fragment-packed fp16 weight + fp32 bias, device memo
 struct Block {
     Linear qkv, proj, mlp0, mlp3;
     float *attn_bias = nullptr;   // [heads][36][48]
+    f16 *tail_stream = nullptr;   // proj | mlp.0 | mlp.3 fragments in proj_mlp_kernel's consumption order
 };
 
 struct DeviceBuf {
@@ -100,8 +102,15 @@ int upload(nunif_swin_unet *h, const std::vector<T> &host, T **dev) {
 
 // Fragment-major packing for the MFMA A operand (v_mfma_f32_16x16x32_f16): fragment (nt, ks) is 64 lanes x 8 halfs,
 // lane l holds W[nt*16 + (l&15)][ks*32 + (l>>4)*8 + 0..7]; rows beyond n_real are zero.  `wt(n,k)` returns fp32.
+//
+// `chained` packing is for a GEMM whose B operand is not loaded from memory but taken straight from the fp32
+// accumulators of the previous GEMM (proj -> mlp.0 -> mlp.3 in proj_mlp_kernel): a lane of a 16x16 accumulator
+// tile holds channels 4*(l>>4)+r, so the 8 k-slots of lane group g in K-chunk ks are the channels
+// {32ks + 4g + 0..3} (tile 2ks) and {32ks + 16 + 4g + 0..3} (tile 2ks+1).  The reduction order over k is free, so
+// the permutation is absorbed here at zero run-time cost.
 template <typename F>
-int make_linear(nunif_swin_unet *h, int n_real, int K, F wt, const float *bias, Linear *L) {
+int make_linear(nunif_swin_unet *h, int n_real, int K, F wt, const float *bias, Linear *L, bool chained = false,
+                std::vector<f16> *keep = nullptr) {
     const int N = (n_real + 15) / 16 * 16;
     std::vector<f16> packed((size_t)N * K);
     const int KS = K / 32;
@@ -109,24 +118,28 @@ int make_linear(nunif_swin_unet *h, int n_real, int K, F wt, const float *bias, 
         for (int ks = 0; ks < KS; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
-                    const int n = nt * 16 + (l & 15), k = ks * 32 + (l >> 4) * 8 + j;
+                    const int g = l >> 4;
+                    const int n = nt * 16 + (l & 15);
+                    const int k = chained ? ks * 32 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : ks * 32 + g * 8 + j;
                     packed[(((size_t)nt * KS + ks) * 64 + l) * 8 + j] = (f16)(n < n_real ? wt(n, k) : 0.0f);
                 }
     std::vector<float> b(N, 0.0f);
     for (int n = 0; n < n_real; ++n) b[n] = bias[n];
     L->N = N; L->n_real = n_real; L->K = K;
+    if (keep) *keep = packed;
     int rc = upload(h, packed, &L->w);
     if (rc) return rc;
     return upload(h, b, &L->bias);
 }
 
-int make_plain_linear(nunif_swin_unet *h, const TensorMap &m, const std::string &key, int n_real, int K, Linear *L) {
+int make_plain_linear(nunif_swin_unet *h, const TensorMap &m, const std::string &key, int n_real, int K, Linear *L,
+                      bool chained = false, std::vector<f16> *keep = nullptr) {
     const HostTensor *w, *b;
     int rc;
     if ((rc = find(m, key + ".weight", &w)) || (rc = find(m, key + ".bias", &b))) return rc;
     NUNIF_REQUIRE(w->numel == (int64_t)n_real * K && b->numel == n_real, "%s: unexpected shape", key.c_str());
     const float *wd = w->data;
-    return make_linear(h, n_real, K, [=](int n, int k) { return wd[(size_t)n * K + k]; }, b->data, L);
+    return make_linear(h, n_real, K, [=](int n, int k) { return wd[(size_t)n * K + k]; }, b->data, L, chained, keep);
 }
 
 int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, int dim, int layers,
@@ -138,9 +151,29 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
         Block &bl = (*blocks)[i];
         int rc;
         if ((rc = make_plain_linear(h, m, p + "attn.qkv", 3 * dim, dim, &bl.qkv))) return rc;
-        if ((rc = make_plain_linear(h, m, p + "attn.proj", dim, dim, &bl.proj))) return rc;
-        if ((rc = make_plain_linear(h, m, p + "mlp.0", 2 * dim, dim, &bl.mlp0))) return rc;
-        if ((rc = make_plain_linear(h, m, p + "mlp.3", dim, 2 * dim, &bl.mlp3))) return rc;
+        std::vector<f16> hp, h0, h3;
+        if ((rc = make_plain_linear(h, m, p + "attn.proj", dim, dim, &bl.proj, false, &hp))) return rc;
+        if ((rc = make_plain_linear(h, m, p + "mlp.0", 2 * dim, dim, &bl.mlp0, true, &h0))) return rc;   // chained
+        if ((rc = make_plain_linear(h, m, p + "mlp.3", dim, 2 * dim, &bl.mlp3, true, &h3))) return rc;   // chained
+        {   // one linear stream of 1-KiB fragments in the order proj_mlp_kernel consumes them (swin_block_tail.hip)
+            const int KS = dim / 32, NT = dim / 16, SH = 2 * dim / 32;
+            const int nf = proj_mlp_stream_frags(dim);
+            std::vector<f16> stream((size_t)(nf + 7) / 8 * 8 * 512, (f16)0.0f);
+            size_t fi = 0;
+            auto put = [&](const std::vector<f16> &src, int frag) {
+                std::copy(src.begin() + (size_t)frag * 512, src.begin() + (size_t)(frag + 1) * 512,
+                          stream.begin() + fi * 512);
+                ++fi;
+            };
+            for (int sx = 0; sx < KS; ++sx)
+                for (int ks = 0; ks < KS; ++ks) { put(hp, (2 * sx) * KS + ks); put(hp, (2 * sx + 1) * KS + ks); }
+            for (int sx = 0; sx < SH; ++sx) {
+                for (int ks = 0; ks < KS; ++ks) { put(h0, (2 * sx) * KS + ks); put(h0, (2 * sx + 1) * KS + ks); }
+                for (int nt = 0; nt < NT; ++nt) put(h3, nt * SH + sx);
+            }
+            NUNIF_REQUIRE((int)fi == nf, "internal: tail stream has %zu fragments, expected %d", fi, nf);
+            if ((rc = upload(h, stream, &bl.tail_stream))) return rc;
+        }
         NUNIF_REQUIRE(m.find(p + "norm1.weight") == m.end(), "%s: LayerNorm variants (swin_unet_4xl) unsupported",
                       p.c_str());
         const HostTensor *tab;
@@ -192,20 +225,27 @@ int tap(nunif_swin_unet *h, const std::string &name, const void *src, size_t byt
 
 int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int S, int dim, hipStream_t s,
               const char *name) {
-    f16 *qkv = (f16 *)h->qkv.p, *att = (f16 *)h->att.p, *hid = (f16 *)h->hid.p;
+    f16 *qkv = (f16 *)h->qkv.p, *att = (f16 *)h->att.p;
     const size_t tok = (size_t)B * S * S;
     int rc;
     for (size_t i = 0; i < blocks.size(); ++i) {
         Block &bl = blocks[i];
         const int shift = (i % 2 == 1) ? 3 : 0;      // swin_unet.py:30
         const std::string tn = std::string(name) + ".b" + std::to_string(i);
-        if ((rc = run_linear(bl.qkv, x, B, S, S, 0, nullptr, qkv, s, "gemm_qkv"))) return rc;
-        if ((rc = tap(h, tn + ".qkv", qkv, tok * 3 * dim * 2, s))) return rc;
-        if ((rc = launch_window_attn(qkv, att, bl.attn_bias, B, S, S, h->heads, dim / h->heads, shift, s))) return rc;
+        if (dim == 96 && h->heads == 6) {
+            // qkv Linear + attention in one kernel; the 3C-wide qkv map never exists in HBM
+            if ((rc = launch_qkv_attn(x, att, bl.qkv.w, bl.qkv.bias, bl.attn_bias, B, S, S, dim, h->heads, shift, s)))
+                return rc;
+        } else {
+            if ((rc = run_linear(bl.qkv, x, B, S, S, 0, nullptr, qkv, s, "gemm_qkv"))) return rc;
+            if ((rc = tap(h, tn + ".qkv", qkv, tok * 3 * dim * 2, s))) return rc;
+            if ((rc = launch_window_attn(qkv, att, bl.attn_bias, B, S, S, h->heads, dim / h->heads, shift, s)))
+                return rc;
+        }
         if ((rc = tap(h, tn + ".attn", att, tok * dim * 2, s))) return rc;
-        if ((rc = run_linear(bl.proj, att, B, S, S, 0, x, x, s, "gemm_proj"))) return rc;       // x += proj(attn)
-        if ((rc = run_linear(bl.mlp0, x, B, S, S, 1, nullptr, hid, s, "gemm_mlp0"))) return rc;  // GELU
-        if ((rc = run_linear(bl.mlp3, hid, B, S, S, 0, x, x, s, "gemm_mlp3"))) return rc;        // x += mlp(x)
+        // x = y + mlp(y), y = x + proj(attn): three GEMMs chained through registers, one read + one write of x
+        if ((rc = launch_proj_mlp(att, x, bl.tail_stream, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, dim, s)))
+            return rc;
         if ((rc = tap(h, tn + ".out", x, tok * dim * 2, s))) return rc;
     }
     return NUNIF_HIP_OK;
