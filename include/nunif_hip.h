@@ -100,6 +100,47 @@ int nunif_hip_swin_unet_forward(nunif_swin_unet *handle, const float *x, float *
 int nunif_hip_swin_unet_render(nunif_swin_unet *handle, const float *x, float *y, int32_t x_h, int32_t x_w,
                                int32_t tile_size, int32_t batch_size, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * iw3 stereo synthesis + depth post-processing.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, H, W;          /* c: [B,3,H,W], depth: [B,1,H,W] (already at image resolution) */
+    double divergence;        /* percent of the base size, as in the reference (doubles: host math is done in double) */
+    double convergence;
+    int32_t fill;             /* 1 = method "forward_fill" (shift_fill inpaint), 0 = "forward" (clamp) */
+    int32_t synthetic_view;   /* 0 both, 1 left, 2 right */
+    int32_t width_base;       /* base_size = W if 1 else max(H,W) */
+} nunif_forward_warp_params;
+
+/* Replaces iw3/forward_warp.py apply_divergence_forward_warp :246-256 -> depth_order_bilinear_forward_warp
+ * :140-243 (inconsistent_shift=False).  left/right: [B,3,H,W]; lmask/rmask: optional [B,1,H,W] (gen_mask2).
+ * For a single-eye view the other output pointer is ignored (the caller returns the source image). */
+int nunif_hip_forward_warp(const float *c, const float *depth, float *left, float *right, float *lmask,
+                           float *rmask, const nunif_forward_warp_params *params, void *stream);
+
+/* Replaces iw3/backward_warp.py apply_divergence_grid_sample :96-121 (make_grid + backward_warp + grid_sample
+ * bilinear/border/align_corners=True + clamp).  c: [B,C,H,W]; depth: [B,1,dh,dw] (grid is built at depth
+ * resolution and bilinearly resized, as the reference does). */
+int nunif_hip_backward_warp(const float *c, const float *depth, float *left, float *right, int32_t B, int32_t C,
+                            int32_t H, int32_t W, int32_t dh, int32_t dw, double divergence, double convergence,
+                            int32_t synthetic_view, void *stream);
+
+/* F.interpolate(..., antialias=True) for planar fp32 maps: bilinear (bicubic=0) or bicubic a=-0.5 (bicubic=1),
+ * with ATen's coordinate rules (align_corners changes only the scale when antialias is on — SURVEY.md App. C).
+ * Optional fused clamp to [0,1] and (x-mean[c])/std[c] over 3-channel groups (iw3/depth_anything_model.py
+ * batch_preprocess :103-109; mean3/std3 are HOST pointers or NULL).  tmp: [planes,h_in,w_out] floats. */
+int nunif_hip_resize_aa(const float *x, float *y, float *tmp, int64_t planes, int32_t h_in, int32_t w_in,
+                        int32_t h_out, int32_t w_out, int32_t bicubic, int32_t align_corners, int32_t clamp01,
+                        const float *mean3, const float *std3, void *stream);
+
+/* Replaces iw3/dilation.py dilate_edge :116-142.  x,y: [B,1,H,W]; work: B*H*W + 16*B + 8 floats of scratch. */
+int nunif_hip_dilate_edge(const float *x, float *y, float *work, int32_t B, int32_t H, int32_t W, int32_t n_x,
+                          int32_t n_y, void *stream);
+
+/* Per-image (x-min)/(max-min) clamped to [0,1] (iw3/depth_scaler.py minmax_normalize :4-17 with the frame's own
+ * min/max, i.e. EMA off).  minmax: [B,2] device scratch that receives the order-keyed min/max. */
+int nunif_hip_minmax_normalize(const float *x, float *y, float *minmax, int32_t B, int64_t n_per, void *stream);
+
 /* Test hooks (tests/ only): snapshot every stage's NHWC fp16 output during the next forward calls, then read
  * them back one by one (returns 1 past the last tap).  Names match oracle.swin_unet.unet_forward(taps=...). */
 int nunif_hip_swin_unet_debug_taps(nunif_swin_unet *handle, int32_t enable);

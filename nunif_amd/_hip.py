@@ -38,6 +38,11 @@ class TensorDesc(ctypes.Structure):
     _fields_ = [("name", c_char_p), ("data", c_void_p), ("ndim", c_int32), ("shape", c_int64 * 4)]
 
 
+class ForwardWarpParams(ctypes.Structure):
+    _fields_ = [("B", c_int32), ("H", c_int32), ("W", c_int32), ("divergence", c_double), ("convergence", c_double),
+                ("fill", c_int32), ("synthetic_view", c_int32), ("width_base", c_int32)]
+
+
 class ProfRecord(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("total_ms", c_double), ("launches", c_int64),
                 ("flops", c_double), ("bytes", c_double)]
@@ -55,6 +60,14 @@ SIGNATURES = {
     "nunif_hip_swin_unet_destroy": (None, [c_void_p]),
     "nunif_hip_swin_unet_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "nunif_hip_swin_unet_render": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_forward_warp": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         ctypes.POINTER(ForwardWarpParams), c_void_p]),
+    "nunif_hip_backward_warp": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 6 +
+                                [c_double, c_double, c_int32, c_void_p]),
+    "nunif_hip_resize_aa": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64] + [c_int32] * 7 +
+                            [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
+    "nunif_hip_dilate_edge": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
+    "nunif_hip_minmax_normalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
     "nunif_hip_swin_unet_debug_taps": (c_int32, [c_void_p, c_int32]),
     "nunif_hip_swin_unet_get_tap": (c_int32, [c_void_p, c_int32, c_char_p, c_int32, c_void_p, c_int64,
                                               ctypes.POINTER(c_int64)]),

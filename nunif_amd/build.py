@@ -19,7 +19,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip", "-
 
 
 # the stitcher replays the reference's fp32 recurrence bit-exactly: no FMA contraction in that file
-EXTRA_FLAGS = {"stitch.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"stitch.hip": ["-ffp-contract=off"], "iw3_warp.hip": ["-ffp-contract=off"],
+               "iw3_depth.hip": ["-ffp-contract=off"]}
 
 
 def sources():

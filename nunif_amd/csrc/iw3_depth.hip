@@ -1,0 +1,288 @@
+// iw3 depth-side kernels for gfx950: antialiased separable resize, edge-weighted depth dilation, min-max normalise.
+//
+// Reference: iw3/dilation.py — dilate_edge :116-142, edge_weight :101-113, gaussian_blur :30-38, dilate :41-46;
+// iw3/depth_anything_model.py batch_preprocess :69-110 (bilinear antialias resize + clamp + ImageNet normalise);
+// iw3/forward_warp.py:147-148 (depth -> frame size, bilinear + align_corners + antialias);
+// iw3/depth_scaler.py minmax_normalize :4-17;  ATen upsample_bilinear2d_aa / upsample_bicubic2d_aa
+// (UpSampleKernel.cpp, _compute_indices_min_size_weights_aa) for the resampling semantics.
+//
+// All HBM-bound.  dilate_edge: the reference runs ~12 full-frame ATen ops per iteration; here an iteration is one
+// statistics pass (range mean / variance / min / max per image, fp64 block-reduced atomics) and one apply pass that
+// recomputes the 3x3 range, the Gaussian and the max-pool from a 5x5 neighbourhood in registers.
+#include "common.h"
+
+namespace nunif {
+
+// ---- antialiased separable resize -----------------------------------------------------------------------------------
+__device__ __forceinline__ float aa_filter(float x, int bicubic) {
+    if (x < 0.f) x = -x;
+    if (!bicubic) return x < 1.f ? 1.f - x : 0.f;
+    const float a = -0.5f;                                   // antialiased bicubic uses a = -0.5 (non-aa: -0.75)
+    if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+    if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * a;
+    return 0.f;
+}
+
+// one axis: out[n][o][i] = sum_j w_j in[n][xmin+j][i]  (stride_in/stride_out select row- or column-wise)
+__global__ void __launch_bounds__(256)
+resize_aa_axis_kernel(const float *__restrict__ in, float *__restrict__ out, long planes, int len_in, int len_out,
+                      int other, int axis_is_x, float scale, int bicubic, int do_clamp, int norm_channels,
+                      float m0, float m1, float m2, float s0, float s1, float s2) {
+    // thread = one output element; index layout [plane][y][x]
+    const long total = planes * (long)len_out * other;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    int o, q;           // o = output index along the resized axis, q = index along the other axis
+    long plane;
+    if (axis_is_x) { o = (int)(id % len_out); const long t = id / len_out; q = (int)(t % other); plane = t / other; }
+    else { q = (int)(id % other); const long t = id / other; o = (int)(t % len_out); plane = t / len_out; }
+    const float interp = bicubic ? 4.f : 2.f;
+    const float support = scale >= 1.f ? (interp * 0.5f) * scale : interp * 0.5f;
+    const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    const float center = scale * ((float)o + 0.5f);          // align_corners_delta = 0 whenever antialias is on
+    int xmin = (int)(center - support + 0.5f);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5f);
+    if (xmax > len_in) xmax = len_in;
+    const int xsize = xmax - xmin;
+    float total_w = 0.f;
+    for (int j = 0; j < xsize; ++j) total_w += aa_filter(((float)(j + xmin) - center + 0.5f) * invscale, bicubic);
+    const float norm = total_w != 0.f ? 1.f / total_w : 0.f;
+    const float *src = in + plane * (long)len_in * other;
+    float acc = 0.f;
+    for (int j = 0; j < xsize; ++j) {
+        const float w = aa_filter(((float)(j + xmin) - center + 0.5f) * invscale, bicubic) * norm;
+        const long off = axis_is_x ? (long)q * len_in + (xmin + j) : (long)(xmin + j) * other + q;
+        acc += w * src[off];
+    }
+    if (do_clamp) acc = fminf(fmaxf(acc, 0.f), 1.f);
+    if (norm_channels > 0) {    // x.sub_(mean).div_(std), depth_anything_model.py:107-109
+        const int c = (int)(plane % norm_channels);
+        acc = (acc - (c == 0 ? m0 : (c == 1 ? m1 : m2))) / (c == 0 ? s0 : (c == 1 ? s1 : s2));
+    }
+    out[id] = acc;
+}
+
+// ---- dilate_edge ------------------------------------------------------------------------------------------------------
+struct RangeStats { double sum, sumsq; unsigned int rmin, rmax; };   // range >= 0: float bits order as unsigned
+
+__device__ __forceinline__ float range3x3(const float *__restrict__ img, int H, int W, int y, int x) {
+    float mx = -3.0e38f, mn = 3.0e38f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {       // max_pool2d pads with -inf: outside is ignored
+                const float v = img[(long)yy * W + xx];
+                mx = fmaxf(mx, v);
+                mn = fminf(mn, v);
+            }
+        }
+    return mx - mn;
+}
+
+__global__ void __launch_bounds__(256)
+range_stats_kernel(const float *__restrict__ x, RangeStats *stats, int H, int W) {
+    const int b = blockIdx.y;
+    const float *img = x + (long)b * H * W;
+    double s = 0.0, s2 = 0.0;
+    float mn = 3.0e38f, mx = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)H * W; i += (long)gridDim.x * 256) {
+        const float r = range3x3(img, H, W, (int)(i / W), (int)(i % W));
+        s += r; s2 += (double)r * r;
+        mn = fminf(mn, r); mx = fmaxf(mx, r);
+    }
+    __shared__ double sh_s[256], sh_s2[256];
+    __shared__ float sh_mn[256], sh_mx[256];
+    sh_s[threadIdx.x] = s; sh_s2[threadIdx.x] = s2; sh_mn[threadIdx.x] = mn; sh_mx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            sh_s[threadIdx.x] += sh_s[threadIdx.x + st];
+            sh_s2[threadIdx.x] += sh_s2[threadIdx.x + st];
+            sh_mn[threadIdx.x] = fminf(sh_mn[threadIdx.x], sh_mn[threadIdx.x + st]);
+            sh_mx[threadIdx.x] = fmaxf(sh_mx[threadIdx.x], sh_mx[threadIdx.x + st]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[b].sum, sh_s[0]);
+        atomicAdd(&stats[b].sumsq, sh_s2[0]);
+        atomicMin(&stats[b].rmin, __float_as_uint(sh_mn[0]));
+        atomicMax(&stats[b].rmax, __float_as_uint(sh_mx[0]));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+dilate_apply_kernel(const float *__restrict__ x, float *__restrict__ y, const RangeStats *stats, int H, int W,
+                    int ky, int kx) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)H * W) return;
+    const int py = (int)(i / W), px = (int)(i % W);
+    const float *img = x + (long)b * H * W;
+    const double n = (double)H * W;
+    const double meand = stats[b].sum / n;
+    const float mean = (float)meand;
+    double var = stats[b].sumsq / n - meand * meand;
+    if (var < 0.0) var = 0.0;
+    const float denom = (float)sqrt(var) + 1e-6f;                                     // dilation.py:107-108
+    const float r = range3x3(img, H, W, py, px);
+    auto weight = [&](float rv) { return fminf(fmaxf((rv - mean) / denom, -3.f), 3.f); };
+    const float w_min = weight(__uint_as_float(stats[b].rmin)), w_max = weight(__uint_as_float(stats[b].rmax));
+    const float w = (weight(r) - w_min) / ((w_max - w_min) + 1e-6f);                   // :109-110
+    // x2 = max_pool(gaussian_blur(x)) over a ky x kx window (blur: replicate pad; pool: -inf pad)
+    float x2 = -3.0e38f;
+    for (int dy = -(ky / 2); dy <= ky / 2; ++dy)
+        for (int dx = -(kx / 2); dx <= kx / 2; ++dx) {
+            const int cy = py + dy, cx = px + dx;
+            if (cy < 0 || cy >= H || cx < 0 || cx >= W) continue;
+            float g = 0.f;
+#pragma unroll
+            for (int gy = -1; gy <= 1; ++gy)
+#pragma unroll
+                for (int gx = -1; gx <= 1; ++gx) {
+                    const int yy = min(max(cy + gy, 0), H - 1), xx = min(max(cx + gx, 0), W - 1);
+                    const float kw = (gy == 0 && gx == 0) ? 48.f / 256.f
+                                     : ((gy == 0 || gx == 0) ? 31.f / 256.f : 21.f / 256.f);
+                    g += kw * img[(long)yy * W + xx];
+                }
+            x2 = fmaxf(x2, g);
+        }
+    const float v = img[i];
+    y[(long)b * H * W + i] = (v * (1.f - w)) + (x2 * w);                                // :121
+}
+
+// ---- per-image min-max normalise (depth_scaler.py:4-17, reset path: ema disabled) ----------------------------------------
+__global__ void __launch_bounds__(256) minmax_stats_kernel(const float *__restrict__ x, float *mm, long n_per) {
+    const int b = blockIdx.y;
+    const float *img = x + (long)b * n_per;
+    float mn = 3.0e38f, mx = -3.0e38f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_per; i += (long)gridDim.x * 256) {
+        const float v = img[i];
+        mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
+    __shared__ float sh_mn[256], sh_mx[256];
+    sh_mn[threadIdx.x] = mn; sh_mx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            sh_mn[threadIdx.x] = fminf(sh_mn[threadIdx.x], sh_mn[threadIdx.x + st]);
+            sh_mx[threadIdx.x] = fmaxf(sh_mx[threadIdx.x], sh_mx[threadIdx.x + st]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // order-preserving float -> uint so that atomicMin/Max work for negative values too
+        auto key = [](float v) { unsigned int u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+        atomicMin(reinterpret_cast<unsigned int *>(mm) + 2 * b, key(sh_mn[0]));
+        atomicMax(reinterpret_cast<unsigned int *>(mm) + 2 * b + 1, key(sh_mx[0]));
+    }
+}
+
+__global__ void __launch_bounds__(256) minmax_apply_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                           const float *mm, long n_per) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_per) return;
+    auto unkey = [](unsigned int k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); };
+    const unsigned int *u = reinterpret_cast<const unsigned int *>(mm);
+    const float mn = unkey(u[2 * b]), mx = unkey(u[2 * b + 1]);
+    const float v = x[(long)b * n_per + i];
+    // depth_scaler.py minmax_normalize: (x - min) / (max - min) with a guard for a flat map, clamped to [0,1]
+    const float range = mx - mn;
+    const float o = range > 0.f ? (v - mn) / range : v;
+    y[(long)b * n_per + i] = fminf(fmaxf(o, 0.f), 1.f);
+}
+
+}  // namespace nunif
+
+using namespace nunif;
+
+extern "C" int nunif_hip_resize_aa(const float *x, float *y, float *tmp, int64_t planes, int32_t h_in, int32_t w_in,
+                                   int32_t h_out, int32_t w_out, int32_t bicubic, int32_t align_corners,
+                                   int32_t clamp01, const float *mean3, const float *std3, void *stream) {
+    NUNIF_REQUIRE(x && y && tmp && planes > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0, "resize_aa: bad argument");
+    // area_pixel_compute_scale: align_corners -> (in-1)/(out-1) (0 when out == 1), else in/out
+    auto scale_of = [&](int in, int out) -> float {
+        if (align_corners) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+        return (float)in / (float)out;
+    };
+    hipStream_t s = (hipStream_t)stream;
+    const double bytes = (double)planes * 4.0 * ((double)h_in * w_in + 2.0 * h_in * w_out + (double)h_out * w_out);
+    ProfScope ps("resize_aa", s, 0.0, bytes);
+    {   // width first: [planes][h_in][w_in] -> tmp [planes][h_in][w_out]
+        const long total = planes * (long)h_in * w_out;
+        resize_aa_axis_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(
+            x, tmp, planes, w_in, w_out, h_in, 1, scale_of(w_in, w_out), bicubic, 0, 0, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
+        NUNIF_LAUNCH_CHECK();
+    }
+    {   // then height: tmp -> y [planes][h_out][w_out]
+        const long total = planes * (long)h_out * w_out;
+        resize_aa_axis_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(
+            tmp, y, planes, h_in, h_out, w_out, 0, scale_of(h_in, h_out), bicubic, clamp01, mean3 ? 3 : 0,
+            mean3 ? mean3[0] : 0.f, mean3 ? mean3[1] : 0.f, mean3 ? mean3[2] : 0.f, std3 ? std3[0] : 1.f,
+            std3 ? std3[1] : 1.f, std3 ? std3[2] : 1.f);
+        NUNIF_LAUNCH_CHECK();
+    }
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_dilate_edge(const float *x, float *y, float *work, int32_t B, int32_t H, int32_t W,
+                                     int32_t n_x, int32_t n_y, void *stream) {
+    NUNIF_REQUIRE(x && y && work && B > 0 && H > 0 && W > 0 && n_x >= 0 && n_y >= 0, "dilate_edge: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)B * H * W;
+    // work: [n floats ping-pong][B RangeStats]
+    float *bufs[2] = {y, work};
+    RangeStats *stats = reinterpret_cast<RangeStats *>(work + ((n + 3) / 4) * 4 + 4);
+    const int xy = n_x < n_y ? n_x : n_y;                       // dilation.py:118-120
+    const int total_iters = xy + (n_y - xy) + (n_x - xy);
+    if (total_iters == 0) {
+        if (x != y) NUNIF_HIP_CHECK(hipMemcpyAsync(y, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return NUNIF_HIP_OK;
+    }
+    ProfScope ps("dilate_edge", s, 0.0, (double)n * 16.0 * total_iters);
+    const float *src = x;
+    int it = 0;
+    // the last iteration must land in y: choose the starting buffer by parity
+    int dst_i = (total_iters % 2 == 1) ? 0 : 1;
+    auto run = [&](int ky, int kx) -> int {
+        NUNIF_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(RangeStats) * B, s));
+        // rmin must start at +max: set via a tiny memset pattern (0xFF.. is NaN-ish as float but compared as uint)
+        for (int b = 0; b < B; ++b)
+            NUNIF_HIP_CHECK(hipMemsetAsync(&stats[b].rmin, 0xFF, sizeof(unsigned int), s));
+        dim3 g1((unsigned)std::min<long>(((long)H * W + 255) / 256, 512), B);
+        range_stats_kernel<<<g1, 256, 0, s>>>(src, stats, H, W);
+        dim3 g2((unsigned)(((long)H * W + 255) / 256), B);
+        dilate_apply_kernel<<<g2, 256, 0, s>>>(src, bufs[dst_i], stats, H, W, ky, kx);
+        src = bufs[dst_i];
+        dst_i ^= 1;
+        ++it;
+        return NUNIF_HIP_OK;
+    };
+    int rc;
+    for (int i = 0; i < xy; ++i) if ((rc = run(3, 3))) return rc;
+    for (int i = 0; i < n_y - xy; ++i) if ((rc = run(3, 1))) return rc;       // kernel_size=(3,1): rows
+    for (int i = 0; i < n_x - xy; ++i) if ((rc = run(1, 3))) return rc;
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_minmax_normalize(const float *x, float *y, float *minmax, int32_t B, int64_t n_per,
+                                          void *stream) {
+    NUNIF_REQUIRE(x && y && minmax && B > 0 && n_per > 0, "minmax_normalize: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("minmax_normalize", s, 0.0, (double)B * n_per * 12.0);
+    for (int b = 0; b < B; ++b) {
+        NUNIF_HIP_CHECK(hipMemsetAsync(reinterpret_cast<unsigned int *>(minmax) + 2 * b, 0xFF, 4, s));
+        NUNIF_HIP_CHECK(hipMemsetAsync(reinterpret_cast<unsigned int *>(minmax) + 2 * b + 1, 0x00, 4, s));
+    }
+    dim3 g1((unsigned)std::min<long>((n_per + 255) / 256, 512), B);
+    minmax_stats_kernel<<<g1, 256, 0, s>>>(x, minmax, n_per);
+    dim3 g2((unsigned)((n_per + 255) / 256), B);
+    minmax_apply_kernel<<<g2, 256, 0, s>>>(x, y, minmax, n_per);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}

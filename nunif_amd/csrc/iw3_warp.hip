@@ -1,0 +1,311 @@
+// iw3 stereo warps for gfx950: depth-ordered bilinear forward warp (splat) and grid-sample backward warp.
+//
+// Reference: iw3/forward_warp.py — depth_order_bilinear_forward_warp :140-243 with warp :113-132,
+// make_bilinear_data :75-85, ordered_index_copy :88-110, shift_fill(_pack) :18-42, fix_layered_holes :45-59,
+// gen_mask2 :135-137;  iw3/backward_warp.py — apply_divergence_grid_sample :96-121, backward_warp :67-83,
+// make_grid :86-93.
+//
+// Forward warp, MI355X design.  The reference argsorts every pixel of the batch by depth and runs two
+// deterministic index_copy_ scatters per eye, then up to 200 host-synchronised fill iterations.  All shifts are
+// horizontal, so the whole algorithm is ROW-LOCAL: one workgroup owns one image row in LDS.
+//   * depth order == per-destination z-test: a 64-bit LDS atomicMax of (order-preserving depth bits << 32 | src x)
+//     for the floor and for the ceil target picks exactly the source the sorted overwrite would leave behind
+//     (ties cannot collide inside the un-padded region);
+//   * shift_fill / fix_layered_holes are capped row scans (closed forms verified bit-exact against the reference
+//     on CPU, oracle/forward_warp.py), no iteration, no host sync;
+//   * replicate padding is a clamp on the source column, nothing is materialised.
+// HBM traffic: read rgb + depth once, write each eye once (40 B / pixel for both eyes).
+// This file is compiled with -ffp-contract=off: the arithmetic below mirrors the reference's separately rounded
+// fp32 operations so that indices, masks and pixels are bit-identical for identical inputs.
+#include "common.h"
+
+namespace nunif {
+
+struct FwdWarpArgs {
+    const float *c;        // [B,3,H,W]
+    const float *depth;    // [B,1,H,W]
+    float *out[2];         // left, right  [B,3,H,W] (NULL = skip that eye)
+    float *mask[2];        // optional [B,1,H,W]
+    int B, H, W, pad, fill;
+    float shift_size;      // fp32(divergence*0.01*base*0.5)
+    float shift_conv;      // fp32(shift_size*convergence) computed in double on the host
+};
+
+__device__ __forceinline__ unsigned int order_key(float v) {
+    const unsigned int b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// weights / targets of source column xs (padded coordinates) for eye sign sgn (+1 left, -1 right)
+__device__ __forceinline__ void bilinear_target(float depth, float sgn, float shift_size, float shift_conv, int xs,
+                                                int Wp, int &fl, int &ce, float &fw, float &cw) {
+    const float shift = depth * shift_size - shift_conv;           // forward_warp.py:166
+    const float fidx = fminf(fmaxf((float)xs + sgn * shift, 0.f), (float)(Wp - 1));
+    const float f0 = fminf(fmaxf(floorf(fidx), 0.f), (float)(Wp - 1));
+    const float c0 = fminf(fmaxf(ceilf(fidx), 0.f), (float)(Wp - 1));
+    cw = fminf(fmaxf(fidx - f0, 1e-5f), (float)(1.0 - 1e-5));      // :79-80
+    fw = 1.0f - cw;
+    fl = (int)f0;
+    ce = (int)c0;
+}
+
+constexpr int kMaxTries = 100;
+
+__global__ void __launch_bounds__(256) forward_warp_kernel(FwdWarpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = a.W, pad = a.pad, Wp = W + 2 * pad;
+    unsigned long long *kf = reinterpret_cast<unsigned long long *>(smem);   // [Wp] floor winners
+    unsigned long long *kc = kf + Wp;                                        // [Wp] ceil winners
+    float *img = reinterpret_cast<float *>(kc + Wp);                         // [3][W]
+    float *idx = img + 3 * W;                                                // [W] warped x index
+    float *idx2 = idx + W;                                                   // [W] after shift_fill
+    const int row = blockIdx.x;                  // b*H + y
+    const int b = row / a.H, y = row - b * a.H;
+    const float *drow = a.depth + (long)row * W;
+    const float *crow = a.c + ((long)b * 3 * a.H + y) * W;
+    const long cplane = (long)a.H * W;
+    const int tid = threadIdx.x;
+
+    for (int eye = 0; eye < 2; ++eye) {
+        if (a.out[eye] == nullptr) continue;
+        const float sgn = eye == 0 ? 1.0f : -1.0f;
+        for (int x = tid; x < Wp; x += 256) { kf[x] = 0ull; kc[x] = 0ull; }
+        __syncthreads();
+        // ---- splat: z-test per destination ---------------------------------------------------------------------------
+        for (int xs = tid; xs < Wp; xs += 256) {
+            const float d = drow[min(max(xs - pad, 0), W - 1)];
+            int fl, ce; float fw, cw;
+            bilinear_target(d, sgn, a.shift_size, a.shift_conv, xs, Wp, fl, ce, fw, cw);
+            const unsigned long long key = ((unsigned long long)order_key(d) << 32) | (unsigned int)(xs + 1);
+            atomicMax(&kf[fl], key);
+            atomicMax(&kc[ce], key);
+        }
+        __syncthreads();
+        // ---- combine the two winners of every destination inside the un-padded region -----------------------------------
+        for (int j = tid; j < W; j += 256) {
+            const int xd = j + pad;
+            const int sf = (int)(unsigned int)(kf[xd] & 0xffffffffull) - 1;
+            const int sc = (int)(unsigned int)(kc[xd] & 0xffffffffull) - 1;
+            float fwt = 0.f, cwt = 0.f, fv[4] = {-1.f, -1.f, -1.f, -1.f}, cv[4] = {-1.f, -1.f, -1.f, -1.f};
+            if (sf >= 0) {
+                const int sx = min(max(sf - pad, 0), W - 1);
+                int fl, ce; float fw, cw;
+                bilinear_target(drow[sx], sgn, a.shift_size, a.shift_conv, sf, Wp, fl, ce, fw, cw);
+                fwt = fw;
+                fv[0] = crow[sx]; fv[1] = crow[cplane + sx]; fv[2] = crow[2 * cplane + sx]; fv[3] = (float)sf;
+            }
+            if (sc >= 0) {
+                const int sx = min(max(sc - pad, 0), W - 1);
+                int fl, ce; float fw, cw;
+                bilinear_target(drow[sx], sgn, a.shift_size, a.shift_conv, sc, Wp, fl, ce, fw, cw);
+                cwt = cw;
+                cv[0] = crow[sx]; cv[1] = crow[cplane + sx]; cv[2] = crow[2 * cplane + sx]; cv[3] = (float)sc;
+            }
+            const float wsum = fwt + cwt;
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float num = fv[k] * fwt + cv[k] * cwt;        // :129, separately rounded
+                const float v = num / wsum;
+                o[k] = (v != v) ? -1.0f : v;                        // nan_to_num(out, -1) :130
+            }
+            img[j] = o[0]; img[W + j] = o[1]; img[2 * W + j] = o[2]; idx[j] = o[3];
+        }
+        __syncthreads();
+        // ---- shift_fill on the index row: left eye takes from the left, right eye from the right ---------------------------
+        const int dir = eye == 0 ? -1 : 1;
+        for (int j = tid; j < W; j += 256) {
+            float v = idx[j];
+            if (v < 0.f) {
+                for (int k = 1; k <= kMaxTries; ++k) {
+                    const int q = j + dir * k;
+                    const float cand = (q >= 0 && q < W) ? idx[q] : 0.0f;     // zero inflow at the border
+                    if (cand >= 0.f || k == kMaxTries) { v = cand; break; }
+                }
+            }
+            idx2[j] = v;
+        }
+        __syncthreads();
+        // ---- fix_layered_holes: windowed running min (left) / max (right) of the index; changed pixels become -2 ------------
+        for (int j = tid; j < W; j += 256) {
+            const float v0 = idx2[j];
+            float m = v0;
+            if (eye == 0) {
+                const int hi = min(j + kMaxTries, W - 1);
+                for (int q = j + 1; q <= hi; ++q) m = fminf(m, idx2[q]);
+            } else {
+                const int lo = max(j - kMaxTries, 0);
+                for (int q = j - 1; q >= lo; --q) m = fmaxf(m, idx2[q]);
+            }
+            if (m != v0) { img[j] = -2.f; img[W + j] = -2.f; img[2 * W + j] = -2.f; }
+        }
+        __syncthreads();
+        // ---- mask, then fill or clamp, straight to HBM -------------------------------------------------------------------------
+        float *orow = a.out[eye] + ((long)b * 3 * a.H + y) * W;
+        float *mrow = a.mask[eye] ? a.mask[eye] + (long)row * W : nullptr;
+        for (int j = tid; j < W; j += 256) {
+            if (mrow) {
+                const float v = img[j];
+                mrow[j] = v == -1.f ? 1.0f : (v == -2.f ? 0.5f : 0.0f);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float *r = img + ch * W;
+                float v = r[j];
+                if (a.fill) {
+                    if (v < 0.f) {
+                        for (int k = 1; k <= kMaxTries; ++k) {
+                            const int q = j + dir * k;
+                            const float cand = (q >= 0 && q < W) ? r[q] : 0.0f;
+                            if (cand >= 0.f || k == kMaxTries) { v = cand; break; }
+                        }
+                    }
+                } else {
+                    v = fminf(fmaxf(v, 0.f), 1.f);
+                }
+                orow[ch * cplane + j] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- backward warp: grid_sample(bilinear, border, align_corners=True) of a horizontally displaced identity grid -----
+struct BwdWarpArgs {
+    const float *c;        // [B,C,H,W]
+    const float *depth;    // [B,1,h,w]
+    float *out[2];         // left (uses -delta), right (+delta); NULL = skip
+    int B, C, H, W, h, w;
+    float shift_size;      // fp32(divergence*0.01)
+    float shift_conv;      // fp32(shift_size*convergence)
+    float delta_scale;     // fp32(max(h,w)/w)
+};
+
+// torch.linspace(-1, 1, n)[i] in fp32 (ATen: step = 2/(n-1); first half from the start, second half from the end)
+__device__ __forceinline__ float linspace_pm1(int i, int n) {
+    if (n == 1) return -1.0f;
+    const float step = (1.0f - (-1.0f)) / (float)(n - 1);
+    return i < n / 2 ? -1.0f + step * (float)i : 1.0f - step * (float)(n - 1 - i);
+}
+
+__global__ void __launch_bounds__(256) backward_warp_kernel(BwdWarpArgs a) {
+    const long total = (long)a.B * a.H * a.W;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int X = (int)(id % a.W);
+    const long t = id / a.W;
+    const int Y = (int)(t % a.H);
+    const int b = (int)(t / a.H);
+    const bool same = (a.h == a.H && a.w == a.W);
+    const float *dmap = a.depth + (long)b * a.h * a.w;
+    for (int eye = 0; eye < 2; ++eye) {
+        if (!a.out[eye]) continue;
+        const float sgn = eye == 0 ? -1.0f : 1.0f;      // left = backward_warp(c, grid, -delta)
+        // grid value at a (y, x) node of the depth-resolution grid: linspace + delta*delta_scale (backward_warp.py:68)
+        auto gx_at = [&](int yy, int xx) -> float {
+            const float sh = dmap[(long)yy * a.w + xx] * a.shift_size - a.shift_conv;
+            return linspace_pm1(xx, a.w) + (sgn * sh) * a.delta_scale;
+        };
+        float gx, gy;
+        if (same) {
+            gx = gx_at(Y, X);
+            gy = linspace_pm1(Y, a.h);
+        } else {
+            // F.interpolate(grid, size=(H,W), bilinear, align_corners=True) :69-71 (ATen upsample_bilinear2d)
+            const float ry = a.H > 1 ? (float)(a.h - 1) / (float)(a.H - 1) : 0.f;
+            const float rx = a.W > 1 ? (float)(a.w - 1) / (float)(a.W - 1) : 0.f;
+            const float sy = ry * (float)Y, sx = rx * (float)X;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < a.h - 1 ? 1 : 0), x1 = x0 + (x0 < a.w - 1 ? 1 : 0);
+            const float ly = sy - (float)y0, lx = sx - (float)x0;
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            gx = hy * (hx * gx_at(y0, x0) + lx * gx_at(y0, x1)) + ly * (hx * gx_at(y1, x0) + lx * gx_at(y1, x1));
+            const float g0 = linspace_pm1(y0, a.h), g1 = linspace_pm1(y1, a.h);
+            gy = hy * (hx * g0 + lx * g0) + ly * (hx * g1 + lx * g1);
+        }
+        // grid_sampler_2d, align_corners=True, padding_mode=border
+        float ix = ((gx + 1.f) / 2.f) * (float)(a.W - 1);
+        float iy = ((gy + 1.f) / 2.f) * (float)(a.H - 1);
+        ix = fminf(fmaxf(ix, 0.f), (float)(a.W - 1));
+        iy = fminf(fmaxf(iy, 0.f), (float)(a.H - 1));
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+        const float tx = ix - fx, ty = iy - fy;
+        const float w_nw = (1.f - tx) * (1.f - ty), w_ne = tx * (1.f - ty), w_sw = (1.f - tx) * ty, w_se = tx * ty;
+        const bool xin = x1 <= a.W - 1, yin = y1 <= a.H - 1;
+        for (int ch = 0; ch < a.C; ++ch) {
+            const float *p = a.c + ((long)b * a.C + ch) * a.H * a.W;
+            float v = p[(long)y0 * a.W + x0] * w_nw;
+            if (xin) v += p[(long)y0 * a.W + x1] * w_ne;
+            if (yin) v += p[(long)y1 * a.W + x0] * w_sw;
+            if (xin && yin) v += p[(long)y1 * a.W + x1] * w_se;
+            a.out[eye][(((long)b * a.C + ch) * a.H + Y) * a.W + X] = fminf(fmaxf(v, 0.f), 1.f);
+        }
+    }
+}
+
+}  // namespace nunif
+
+using namespace nunif;
+
+extern "C" int nunif_hip_forward_warp(const float *c, const float *depth, float *left, float *right, float *lmask,
+                                      float *rmask, const nunif_forward_warp_params *p, void *stream) {
+    NUNIF_REQUIRE(c && depth && p, "forward_warp: NULL argument");
+    NUNIF_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0, "forward_warp: bad shape");
+    NUNIF_REQUIRE(p->synthetic_view >= 0 && p->synthetic_view <= 2, "forward_warp: synthetic_view must be 0/1/2");
+    double divergence = p->divergence;
+    if (p->synthetic_view != 0) divergence *= 2.0;                                   // :150-151
+    const int base = p->width_base ? p->W : (p->H > p->W ? p->H : p->W);             // :154-157
+    const int pad = (int)((double)base * divergence * 0.01 + 2.0);                   // :159
+    const double shift_size = divergence * 0.01 * (double)base * 0.5;                // :166
+    FwdWarpArgs a;
+    a.c = c; a.depth = depth;
+    a.out[0] = p->synthetic_view == 2 ? nullptr : left;
+    a.out[1] = p->synthetic_view == 1 ? nullptr : right;
+    a.mask[0] = lmask; a.mask[1] = rmask;
+    NUNIF_REQUIRE((p->synthetic_view == 2 || left) && (p->synthetic_view == 1 || right), "forward_warp: output NULL");
+    a.B = p->B; a.H = p->H; a.W = p->W; a.pad = pad; a.fill = p->fill;
+    a.shift_size = (float)shift_size;
+    a.shift_conv = (float)(shift_size * p->convergence);
+    const long Wp = (long)p->W + 2 * pad;
+    const size_t smem = (size_t)Wp * 16 + (size_t)p->W * 5 * sizeof(float);
+    NUNIF_REQUIRE(smem <= 160 * 1024, "forward_warp: row of %d (+2*%d pad) does not fit LDS", p->W, pad);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)forward_warp_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const double px = (double)p->B * p->H * p->W;
+    const int eyes = (a.out[0] ? 1 : 0) + (a.out[1] ? 1 : 0);
+    ProfScope ps("forward_warp", s, 0.0, px * (16.0 + 12.0 * eyes));
+    forward_warp_kernel<<<p->B * p->H, 256, smem, s>>>(a);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_backward_warp(const float *c, const float *depth, float *left, float *right, int32_t B,
+                                       int32_t C, int32_t H, int32_t W, int32_t dh, int32_t dw, double divergence,
+                                       double convergence, int32_t synthetic_view, void *stream) {
+    NUNIF_REQUIRE(c && depth && B > 0 && C > 0 && H > 0 && W > 0 && dh > 0 && dw > 0, "backward_warp: bad argument");
+    NUNIF_REQUIRE(synthetic_view >= 0 && synthetic_view <= 2, "backward_warp: synthetic_view must be 0/1/2");
+    double div = divergence;
+    if (synthetic_view != 0) div *= 2.0;                                             // backward_warp.py:101-102
+    const double shift_size = div * 0.01;
+    BwdWarpArgs a;
+    a.c = c; a.depth = depth;
+    a.out[0] = synthetic_view == 2 ? nullptr : left;
+    a.out[1] = synthetic_view == 1 ? nullptr : right;
+    NUNIF_REQUIRE((synthetic_view == 2 || left) && (synthetic_view == 1 || right), "backward_warp: output NULL");
+    a.B = B; a.C = C; a.H = H; a.W = W; a.h = dh; a.w = dw;
+    a.shift_size = (float)shift_size;
+    a.shift_conv = (float)(shift_size * convergence);
+    a.delta_scale = (float)((double)(dh > dw ? dh : dw) / (double)dw);
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * H * W;
+    ProfScope ps("backward_warp", s, 0.0, (double)total * (4.0 + 4.0 * C * 3));
+    backward_warp_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(a);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}

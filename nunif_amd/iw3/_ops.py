@@ -1,0 +1,95 @@
+"""Thin tensor-level wrappers over the iw3 entry points of libnunif_hip.so (no fallbacks)."""
+import ctypes
+
+import torch
+
+from .. import _hip
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _cuda_f32(t, name):
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{name}: tensor must live on a ROCm device (got {t.device}); there is no CPU fallback")
+    return t.to(torch.float32).contiguous()
+
+
+def resize_aa(x, size, mode="bilinear", align_corners=False, clamp01=False, mean=None, std=None):
+    """F.interpolate(x, size, mode, align_corners, antialias=True) for [B,C,H,W] (+ optional fused clamp/normalise)."""
+    assert mode in ("bilinear", "bicubic")
+    x = _cuda_f32(x, "resize_aa")
+    b, c, h, w = x.shape
+    oh, ow = int(size[0]), int(size[1])
+    y = torch.empty((b, c, oh, ow), dtype=torch.float32, device=x.device)
+    tmp = torch.empty((b, c, h, ow), dtype=torch.float32, device=x.device)
+    m = (ctypes.c_float * 3)(*mean) if mean is not None else None
+    s = (ctypes.c_float * 3)(*std) if std is not None else None
+    if mean is not None:
+        assert c == 3
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_resize_aa(_p(x), _p(y), _p(tmp), b * c, h, w, oh, ow,
+                                                  1 if mode == "bicubic" else 0, 1 if align_corners else 0,
+                                                  1 if clamp01 else 0, m, s, _hip.current_stream_ptr(x.device)))
+    return y
+
+
+def dilate_edge(x, n_x, n_y):
+    x = _cuda_f32(x, "dilate_edge")
+    b, c, h, w = x.shape
+    assert c == 1
+    y = torch.empty_like(x)
+    work = torch.empty(b * h * w + 16 * b + 8, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_dilate_edge(_p(x), _p(y), _p(work), b, h, w, n_x, n_y,
+                                                    _hip.current_stream_ptr(x.device)))
+    return y
+
+
+def minmax_normalize(x):
+    """Per-item (x-min)/(max-min), clamp [0,1]; x: [B,...]."""
+    x = _cuda_f32(x, "minmax_normalize")
+    b = x.shape[0]
+    y = torch.empty_like(x)
+    mm = torch.empty((b, 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_minmax_normalize(_p(x), _p(y), _p(mm), b, x[0].numel(),
+                                                         _hip.current_stream_ptr(x.device)))
+    return y
+
+
+VIEW = {"both": 0, "left": 1, "right": 2}
+
+
+def forward_warp(c, depth, divergence, convergence, fill, synthetic_view, return_mask, width_base):
+    c = _cuda_f32(c, "forward_warp")
+    depth = _cuda_f32(depth, "forward_warp").to(c.device)
+    b, ch, h, w = c.shape
+    assert ch == 3 and depth.shape == (b, 1, h, w)
+    view = VIEW[synthetic_view]
+    left = torch.empty_like(c) if view != 2 else None
+    right = torch.empty_like(c) if view != 1 else None
+    lm = torch.empty((b, 1, h, w), dtype=torch.float32, device=c.device) if (return_mask and view != 2) else None
+    rm = torch.empty((b, 1, h, w), dtype=torch.float32, device=c.device) if (return_mask and view != 1) else None
+    p = _hip.ForwardWarpParams(b, h, w, float(divergence), float(convergence), 1 if fill else 0, view,
+                               1 if width_base else 0)
+    with torch.cuda.device(c.device):
+        _hip.check(_hip.lib().nunif_hip_forward_warp(_p(c), _p(depth), _p(left), _p(right), _p(lm), _p(rm),
+                                                     ctypes.byref(p), _hip.current_stream_ptr(c.device)))
+    return left, right, lm, rm
+
+
+def backward_warp(c, depth, divergence, convergence, synthetic_view):
+    c = _cuda_f32(c, "backward_warp")
+    depth = _cuda_f32(depth, "backward_warp").to(c.device)
+    b, ch, h, w = c.shape
+    dh, dw = depth.shape[2:]
+    view = VIEW[synthetic_view]
+    left = torch.empty_like(c) if view != 2 else None
+    right = torch.empty_like(c) if view != 1 else None
+    with torch.cuda.device(c.device):
+        _hip.check(_hip.lib().nunif_hip_backward_warp(_p(c), _p(depth), _p(left), _p(right), b, ch, h, w, dh, dw,
+                                                      float(divergence), float(convergence), view,
+                                                      _hip.current_stream_ptr(c.device)))
+    return left, right

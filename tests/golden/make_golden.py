@@ -95,7 +95,41 @@ def gen_swin():
     save("swin_unet", **out)
 
 
-GROUPS = {"seam": gen_seam, "swin": gen_swin}
+def gen_iw3():
+    from iw3.forward_warp import apply_divergence_forward_warp
+    from iw3.backward_warp import apply_divergence_grid_sample
+    from iw3.dilation import dilate_edge
+    from iw3.depth_anything_model import batch_preprocess
+    from oracle.forward_warp import synth_depth
+    out = {}
+    c = synth_image(31, 3, 64, 160).unsqueeze(0)
+    d = synth_depth(32, 1, 64, 160, "edges")
+    d_small = synth_depth(33, 1, 32, 80, "smooth_edges")
+    out["c"], out["depth"], out["depth_small"] = c, d, d_small
+    for tag, depth in (("full", d), ("small", d_small)):
+        le, ri, lm, rm = apply_divergence_forward_warp(c.clone(), depth.clone(), 40.0, 0.5, method="forward_fill",
+                                                       synthetic_view="both", return_mask=True, width_base=False)
+        out[f"fw_{tag}_left"], out[f"fw_{tag}_right"], out[f"fw_{tag}_lmask"], out[f"fw_{tag}_rmask"] = le, ri, lm, rm
+    le, ri = apply_divergence_forward_warp(c.clone(), d.clone(), 12.0, 0.2, method="forward", synthetic_view="both")
+    out["fw_nofill_left"], out["fw_nofill_right"] = le, ri
+    _, ri = apply_divergence_forward_warp(c.clone(), d.clone(), 8.0, 0.5, method="forward_fill", synthetic_view="right")
+    out["fw_right_only"] = ri
+    le, ri = apply_divergence_grid_sample(c, d, 2.5, 0.3, "both")
+    out["gs_left"], out["gs_right"] = le, ri
+    le, ri = apply_divergence_grid_sample(c, d_small, 2.5, 0.3, "both")
+    out["gs_small_left"], out["gs_small_right"] = le, ri
+    raw = synth_depth(34, 2, 56, 98, "smooth_edges") * 7.0 + 0.5      # un-normalised network-like output
+    out["raw_depth"] = raw
+    out["dilate_2_1"] = dilate_edge(raw.clone(), [2, 1])
+    out["dilate_1_3"] = dilate_edge(raw.clone(), [1, 3])
+    out["dilate_2"] = dilate_edge(raw.clone(), 2)
+    img = torch.stack([synth_image(35, 3, 90, 160), synth_image(36, 3, 90, 160)])
+    out["pre_in"] = img
+    out["pre_out"] = batch_preprocess(img.clone(), lower_bound=56)
+    save("iw3", **out)
+
+
+GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -1,0 +1,147 @@
+"""iw3 HIP kernels against the oracle / the reference-generated fixtures, through the C ABI.
+
+Forward warp: bit-exact (indices, hole masks and pixels) for identical inputs.  Resize / dilate / grid-sample are
+float pipelines whose summation order differs from ATen's: PSNR >= 50 dB (10*log10(1/(mse+1e-6))) plus a tight
+max-abs bound, both written in the tests.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, psnr, synth_image
+from oracle import backward_warp as OB
+from oracle import depth_pre as OP
+from oracle import dilation as OD
+from oracle import forward_warp as OF
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def g():
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "iw3.npz")).items()}
+
+
+def test_forward_warp_matches_reference_fixture_bit_exact(hiplib, g):
+    from nunif_amd.iw3.forward_warp import apply_divergence_forward_warp
+    c, d = g["c"].to(DEV), g["depth"].to(DEV)
+    out = apply_divergence_forward_warp(c, d, 40.0, 0.5, method="forward_fill", synthetic_view="both",
+                                        return_mask=True, width_base=False)
+    for got, key in zip(out, ("left", "right", "lmask", "rmask")):
+        ref = g[f"fw_full_{key}"]
+        assert torch.equal(got.cpu(), ref), f"{key}: {(got.cpu() != ref).sum().item()} elements differ, " \
+                                            f"max {(got.cpu() - ref).abs().max().item():.3e}"
+    le, ri = apply_divergence_forward_warp(c, d, 12.0, 0.2, method="forward", synthetic_view="both")
+    assert torch.equal(le.cpu(), g["fw_nofill_left"]) and torch.equal(ri.cpu(), g["fw_nofill_right"])
+    le, ri = apply_divergence_forward_warp(c, d, 8.0, 0.5, method="forward_fill", synthetic_view="right")
+    assert le is c and torch.equal(ri.cpu(), g["fw_right_only"])
+
+
+CASES = [(2, 64, 96, "edges", 2.0, 0.5, True, "both", True), (1, 80, 120, "edges", 10.0, 0.5, True, "both", False),
+         (1, 80, 120, "smooth_edges", 5.0, 0.3, False, "both", True), (1, 60, 100, "ramp", 4.0, 0.0, True, "both", True),
+         (1, 60, 100, "const", 4.0, 1.0, True, "both", True), (1, 64, 96, "edges", 3.0, 0.5, True, "right", True),
+         (1, 64, 96, "edges", 3.0, 0.5, False, "left", True), (1, 40, 400, "edges", 40.0, 0.5, True, "both", True),
+         (1, 3, 7, "edges", 30.0, 0.5, True, "both", True)]
+
+
+@pytest.mark.parametrize("b,h,w,kind,div,conv,fill,view,wb", CASES)
+def test_forward_warp_vs_oracle_bit_exact(hiplib, b, h, w, kind, div, conv, fill, view, wb):
+    from nunif_amd.iw3.forward_warp import depth_order_bilinear_forward_warp
+    c = torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(h * w))
+    d = OF.synth_depth(5, b, h, w, kind)
+    ref = OF.forward_warp(c, d, div, conv, fill=fill, synthetic_view=view, return_mask=True, width_base=wb)
+    got = depth_order_bilinear_forward_warp(c.to(DEV), d.to(DEV), div, conv, fill=fill, synthetic_view=view,
+                                            return_mask=True, width_base=wb)
+    for r, o in zip(ref, got):
+        if r is None:
+            assert o is None
+            continue
+        assert torch.equal(o.cpu(), r), f"{(o.cpu() != r).sum().item()} differ, max {(o.cpu() - r).abs().max():.3e}"
+
+
+def test_forward_warp_1080p_properties(hiplib):
+    """BASELINE config 4 size (1080p, divergence 2.0, depth at 392x686): mirror symmetry (warping the flipped frame
+    gives the flipped opposite eye), determinism, and oracle equality on a band of rows."""
+    from nunif_amd.iw3.forward_warp import apply_divergence_forward_warp
+    from nunif_amd.iw3 import _ops
+    c = synth_image(41, 3, 1080, 1920).unsqueeze(0)
+    d_small = OF.synth_depth(42, 1, 392, 686, "smooth_edges")
+    cd, dd = c.to(DEV), d_small.to(DEV)
+    le, ri, lm, rm = apply_divergence_forward_warp(cd, dd, 2.0, 0.5, method="forward_fill", return_mask=True,
+                                                   width_base=False)
+    le2, ri2, _, _ = apply_divergence_forward_warp(cd, dd, 2.0, 0.5, method="forward_fill", return_mask=True,
+                                                   width_base=False)
+    assert torch.equal(le, le2) and torch.equal(ri, ri2)
+    assert le.shape == (1, 3, 1080, 1920) and float(le.min()) >= 0.0 and float(le.max()) <= 1.0
+    # oracle on the SAME up-sampled depth (so the comparison isolates the warp): rows 500..531
+    d_full = _ops.resize_aa(dd, (1080, 1920), mode="bilinear", align_corners=True)
+    ref = OF.forward_warp(c[:, :, 500:532], d_full.cpu()[:, :, 500:532], 2.0 * 1920 / 1920, 0.5, fill=True,
+                          return_mask=True, width_base=True)
+    assert torch.equal(le.cpu()[:, :, 500:532], ref[0]) and torch.equal(rm.cpu()[:, :, 500:532], ref[3])
+    # mirror symmetry: flip(x) with the same depth flipped -> left/right swap
+    le_f, ri_f = apply_divergence_forward_warp(cd.flip(-1), d_full.flip(-1), 2.0, 0.5, method="forward_fill",
+                                               width_base=False)
+    le_d, ri_d = apply_divergence_forward_warp(cd, d_full, 2.0, 0.5, method="forward_fill", width_base=False)
+    assert psnr(le_f.flip(-1).cpu(), ri_d.cpu()) >= 50.0 and psnr(ri_f.flip(-1).cpu(), le_d.cpu()) >= 50.0
+
+
+def test_resize_aa_matches_aten(hiplib):
+    from nunif_amd.iw3 import _ops
+    F = torch.nn.functional
+    x = torch.rand(2, 3, 90, 160, generator=torch.Generator().manual_seed(1))
+    for mode, size, ac in [("bilinear", (56, 98), False), ("bilinear", (200, 333), True), ("bilinear", (30, 31), True),
+                           ("bicubic", (45, 80), False), ("bicubic", (22, 40), False), ("bicubic", (123, 77), True)]:
+        ref = F.interpolate(x, size=size, mode=mode, align_corners=ac, antialias=True)
+        got = _ops.resize_aa(x.to(DEV), size, mode=mode, align_corners=ac).cpu()
+        assert (got - ref).abs().max().item() < 2e-6, (mode, size, ac, (got - ref).abs().max().item())
+    d = torch.rand(1, 1, 392, 686, generator=torch.Generator().manual_seed(2))
+    ref = F.interpolate(d, size=(1080, 1920), mode="bilinear", align_corners=True, antialias=True)
+    got = _ops.resize_aa(d.to(DEV), (1080, 1920), mode="bilinear", align_corners=True).cpu()
+    assert (got - ref).abs().max().item() < 2e-6
+
+
+def test_preprocess_dilate_normalize_vs_reference_fixture(hiplib, g):
+    from nunif_amd.iw3.depth_anything_model import batch_preprocess, preprocess_size, batch_infer
+    from nunif_amd.iw3.dilation import dilate_edge
+    from nunif_amd.iw3.depth_scaler import minmax_normalize
+    got = batch_preprocess(g["pre_in"].to(DEV), lower_bound=56).cpu()
+    assert got.shape == g["pre_out"].shape and (got - g["pre_out"]).abs().max().item() < 1e-5
+    assert preprocess_size(1080, 1920) == (392, 686)
+    raw = g["raw_depth"].to(DEV)
+    for n, key in (([2, 1], "dilate_2_1"), ([1, 3], "dilate_1_3"), (2, "dilate_2")):
+        out = dilate_edge(raw, n).cpu()
+        ref = g[key]
+        rng = float(ref.max() - ref.min())
+        assert (out - ref).abs().max().item() < 2e-5 * rng + 1e-5, (key, (out - ref).abs().max().item())
+        assert psnr(out / rng, ref / rng) >= 50.0
+    assert torch.equal(dilate_edge(raw, 0).cpu(), g["raw_depth"])
+    nm = minmax_normalize(raw).cpu()
+    for i in range(raw.shape[0]):
+        assert (nm[i] - OP.minmax_normalize(g["raw_depth"][i])).abs().max().item() < 1e-6
+    flat = torch.full((1, 1, 8, 8), 0.7, device=DEV)
+    assert torch.equal(minmax_normalize(flat).cpu(), torch.full((1, 1, 8, 8), 0.7))
+    # pre -> (stand-in network) -> dilate -> flip merge plumbing
+    net = lambda t: t.mean(1)                                        # noqa: E731
+    dep = batch_infer(net, g["pre_in"].to(DEV), flip_aug=True, edge_dilation=[2, 1], lower_bound=56)
+    assert dep.shape == (2, 1, 56, 98) and torch.isfinite(dep).all()
+
+
+def test_backward_warp_vs_reference_fixture(hiplib, g):
+    from nunif_amd.iw3.backward_warp import apply_divergence_grid_sample
+    c = g["c"].to(DEV)
+    for depth_key, lk, rk in (("depth", "gs_left", "gs_right"), ("depth_small", "gs_small_left", "gs_small_right")):
+        le, ri = apply_divergence_grid_sample(c, g[depth_key].to(DEV), 2.5, 0.3, "both")
+        for got, key in ((le, lk), (ri, rk)):
+            assert (got.cpu() - g[key]).abs().max().item() < 1e-5, (key, (got.cpu() - g[key]).abs().max().item())
+            assert psnr(got.cpu(), g[key]) >= 50.0
+    le, ri = apply_divergence_grid_sample(c, g["depth"].to(DEV), 2.5, 0.3, "left")
+    assert ri is c and psnr(le.cpu(), OB.grid_sample_warp(g["c"], g["depth"], 2.5, 0.3, "left")[0]) >= 50.0
+
+
+def test_iw3_ops_reject_cpu_tensors(hiplib):
+    from nunif_amd.iw3.dilation import dilate_edge
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dilate_edge(torch.rand(1, 1, 8, 8), 2)
