@@ -11,7 +11,6 @@ import math
 from collections import OrderedDict
 
 import torch
-import torch.nn.functional as F
 
 from ...nunif.models import I2IBaseModel, register_model
 from ... import _hip
@@ -273,9 +272,9 @@ class SwinUNetDownscaled(I2IBaseModel):
         return self.net4x.load_state_dict(state_dict, strict=strict)
 
     def forward(self, x):
+        from ...iw3 import _ops
         z = self.net4x(x)           # already clamped to [0,1]
         f = self.downscale_factor
-        # TODO(next): HIP antialiased-bicubic kernel; ATen on the ROCm device for now
-        z = F.interpolate(z, size=(z.shape[-2] // f, z.shape[-1] // f), mode="bicubic", align_corners=False,
-                          antialias=True)
-        return torch.clamp(z, 0.0, 1.0)
+        # bicubic (a=-0.5) antialiased /f + clamp, fused in nunif_hip_resize_aa (reference :366-379)
+        return _ops.resize_aa(z, (z.shape[-2] // f, z.shape[-1] // f), mode="bicubic", align_corners=False,
+                              clamp01=True).to(x.dtype)

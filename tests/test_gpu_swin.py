@@ -88,6 +88,17 @@ def test_forward_matches_golden_and_oracle(hiplib, golden_swin, sf, tag):
     assert psnr(y, O.model_forward(sd, x, NAMES[sf])) >= PSNR_MIN
 
 
+def test_downscaled_4x_to_2x_and_1x(hiplib, golden_swin):
+    """SwinUNet4x.to_2x()/to_1x() (the fallback when scale2x.pth is absent, waifu2x/utils.py:139-144)."""
+    m, _ = make_model(4, 104)
+    x = torch.from_numpy(golden_swin["x"]).to("cuda:0")
+    for net, key, scale, offset, blend in ((m.to_2x().eval(), "y_4x_to2x", 2, 16, 8), (m.to_1x().eval(), "y_4x_to1x", 1, 8, 16)):
+        assert (net.i2i_scale, net.i2i_offset, net.i2i_blend_size) == (scale, offset, blend)
+        y = net(x).cpu()
+        ref = torch.from_numpy(golden_swin[key])
+        assert y.shape == ref.shape and psnr(y, ref) >= PSNR_MIN, psnr(y, ref)
+
+
 def test_forward_112_batch3_and_half_input(hiplib, golden_swin):
     m, sd = make_model(2, 102)
     x = torch.from_numpy(golden_swin["x_112"])
