@@ -50,6 +50,12 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
 int launch_qkv_attn(const f16 *x, f16 *att, const f16 *wqkv, const float *bqkv, const float *bias, int B, int H,
                     int W, int C, int heads, int shift, hipStream_t s);
 
+// ---- fused qkv Linear + window attention, one window per wave, C = 96 or 192 (swin_qkv_attn_w.hip) ----------------
+// wstream: per head Wq | Wk | Wv fragments in consumption order (assembled in make_stage, swin_unet.cpp)
+int qkv_attn_w_stream_frags(int C);
+int launch_qkv_attn_w(const f16 *x, f16 *att, const f16 *wstream, const float *bqkv, const float *bias, int B, int H,
+                      int W, int C, int heads, int shift, hipStream_t s);
+
 // ---- (shifted) 6x6 window attention on a fused qkv map ----------------------------------------------------------
 // qkv: [B,H,W,3C] fp16 (q | k | v, each heads x hd), out: [B,H,W,C]; bias: [heads][36][48] fp32 with the
 // relative-position bias gathered per (q,key) and -1e30 in the 12 padding key columns.

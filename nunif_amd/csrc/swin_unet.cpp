@@ -4,6 +4,7 @@
 // nunif/utils/seam_blending.py tiled_render :48-106 (frame loop).  State-dict keys are the reference's.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -29,6 +30,7 @@ struct Block {
     Linear qkv, proj, mlp0, mlp3;
     float *attn_bias = nullptr;   // [heads][36][48]
     f16 *tail_stream = nullptr;   // proj | mlp.0 | mlp.3 fragments in proj_mlp_kernel's consumption order
+    f16 *qkv_stream = nullptr;    // per-head Wq | Wk | Wv fragments in qkv_attn_w_kernel's consumption order
 };
 
 struct DeviceBuf {
@@ -67,6 +69,7 @@ struct nunif_swin_unet {
     int device = 0;
     // debug taps (tests only): when on, every stage's fp16 output is snapshotted device-side
     struct Tap { std::string name; void *dev; size_t bytes; };
+    int attn_variant = 2;             // see run_stage(); NUNIF_QKV_ATTN=0|1|2 overrides (A/B measurements)
     bool taps_on = false;
     std::vector<Tap> taps;
     void clear_taps() { for (auto &t : taps) (void)hipFree(t.dev); taps.clear(); }
@@ -150,7 +153,23 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
         const std::string p = key + ".block." + std::to_string(i) + ".";
         Block &bl = (*blocks)[i];
         int rc;
-        if ((rc = make_plain_linear(h, m, p + "attn.qkv", 3 * dim, dim, &bl.qkv))) return rc;
+        std::vector<f16> hq;
+        if ((rc = make_plain_linear(h, m, p + "attn.qkv", 3 * dim, dim, &bl.qkv, false, &hq))) return rc;
+        {   // qkv weights in the order qkv_attn_w_kernel consumes them: per head Wq tiles, Wk tiles, Wv tiles
+            const int KS = dim / 32, NTH = (dim / heads) / 16, nf = qkv_attn_w_stream_frags(dim);
+            std::vector<f16> stream((size_t)(nf + 7) / 8 * 8 * 512, (f16)0.0f);
+            size_t fi = 0;
+            for (int hh = 0; hh < heads; ++hh)
+                for (int part = 0; part < 3; ++part)
+                    for (int nt = 0; nt < NTH; ++nt)
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const size_t frag = (size_t)(part * (dim / 16) + hh * NTH + nt) * KS + ks;
+                            std::copy(hq.begin() + frag * 512, hq.begin() + (frag + 1) * 512, stream.begin() + fi * 512);
+                            ++fi;
+                        }
+            NUNIF_REQUIRE((int)fi == nf, "internal: qkv stream has %zu fragments, expected %d", fi, nf);
+            if ((rc = upload(h, stream, &bl.qkv_stream))) return rc;
+        }
         std::vector<f16> hp, h0, h3;
         if ((rc = make_plain_linear(h, m, p + "attn.proj", dim, dim, &bl.proj, false, &hp))) return rc;
         if ((rc = make_plain_linear(h, m, p + "mlp.0", 2 * dim, dim, &bl.mlp0, true, &h0))) return rc;   // chained
@@ -232,8 +251,13 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         Block &bl = blocks[i];
         const int shift = (i % 2 == 1) ? 3 : 0;      // swin_unet.py:30
         const std::string tn = std::string(name) + ".b" + std::to_string(i);
-        if (dim == 96 && h->heads == 6) {
-            // qkv Linear + attention in one kernel; the 3C-wide qkv map never exists in HBM
+        // qkv Linear + attention in one kernel; the 3C-wide qkv map never exists in HBM.
+        // variant 2 (default): one window per wave, weights through the LDS ring (both widths);
+        // variant 1: one wave per head, 4 windows per workgroup (C = 96 only); variant 0: unfused GEMM + attention.
+        if (h->attn_variant == 2 && h->heads == 6 && (dim == 96 || dim == 192)) {
+            if ((rc = launch_qkv_attn_w(x, att, bl.qkv_stream, bl.qkv.bias, bl.attn_bias, B, S, S, dim, h->heads, shift, s)))
+                return rc;
+        } else if (h->attn_variant >= 1 && dim == 96 && h->heads == 6) {
             if ((rc = launch_qkv_attn(x, att, bl.qkv.w, bl.qkv.bias, bl.attn_bias, B, S, S, dim, h->heads, shift, s)))
                 return rc;
         } else {
@@ -349,6 +373,7 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
     }
     nunif_swin_unet *h = new nunif_swin_unet();
     (void)hipGetDevice(&h->device);
+    if (const char *v = getenv("NUNIF_QKV_ATTN")) h->attn_variant = atoi(v);
     h->scale_factor = scale_factor;
     const std::string P = "unet.";
     int rc = NUNIF_HIP_OK;
