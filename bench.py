@@ -11,8 +11,10 @@ collective (weak scaling: every rank renders K frames).  ``value`` = input megap
 (max over ranks), the metric BASELINE.json names ("MPix" = source-frame pixels).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     — dominant kernel class (by HIP-event time): algorithmic FLOPs / measured duration vs the dense
-                 fp16 MFMA peak of MI355X (2.5 PFLOP/s, MI355X_MICROARCH.md)
+  roofline     — the dominant kernel (largest share of HIP-event time, classes are kernel symbols): algorithmic
+                 FLOPs or bytes per launch / measured average launch duration, against the MI355X peak that bounds
+                 it (arithmetic intensity vs the 2.5 PFLOP/s / 8 TB/s ridge); ``traffic`` = HBM bytes per launch
+                 from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE, KiB units)
   cpu_baseline — the CPU oracle (oracle/, a torch-fp32 port of the reference path) timed on the host cores on a
                  bounded sample of the same workload
 """
@@ -20,6 +22,7 @@ import argparse
 import json
 import math
 import os
+import re
 import sys
 import time
 
@@ -31,7 +34,7 @@ sys.path.insert(0, ROOT)
 FRAME_H, FRAME_W = 1080, 1920
 TILE = 256
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0       # spec (≈6.3 TB/s achievable)
 
 
 def synth_frame(seed, h, w):
@@ -41,7 +44,7 @@ def synth_frame(seed, h, w):
     return torch.clamp(up * 0.8 + 0.2 * torch.rand(3, h, w, generator=g), 0, 1)
 
 
-def cpu_baseline(sd, frame, budget_s=20.0):
+def cpu_baseline(sd, frame):
     """Time the oracle's tiled_render on a crop of the same frame (bounded: ~10-30 s of CPU work)."""
     from oracle import seam_blending as OS
     from oracle import swin_unet as O
@@ -55,12 +58,37 @@ def cpu_baseline(sd, frame, budget_s=20.0):
             "sample": f"oracle tiled_render of a 480x480 crop (9 tiles of 256, batch 4), {dt:.1f} s"}, crop, out
 
 
+def pmc_traffic_bytes(symbol):
+    """HBM bytes per launch of ``symbol`` from the newest committed PMC summaries (profiles/rNN_pmc_*.txt)."""
+    def per_launch(path):
+        key = re.sub(r"[^A-Za-z0-9]", "", symbol.split("<")[0])
+        args = re.findall(r"\d+", symbol.split("<", 1)[1]) if "<" in symbol else []
+        for line in open(path):
+            name = line.split(" launches=")[0]
+            flat = re.sub(r"[^A-Za-z0-9]", "", name)
+            # demangled "ns::kernel<6, 4>(…)" or mangled "_ZN5nunif15proj_mlp_kernelILi96ELi4EEE…"
+            if key in flat and all((f"Li{a}E" in name) or re.search(rf"[<,]\s*{a}\s*[,>]", name) for a in args):
+                m = re.search(r"per_launch=([0-9.]+)", line)
+                if m:
+                    return float(m.group(1)) * 1024.0
+        return None
+    pdir = os.path.join(ROOT, "profiles")
+    rounds = sorted({f[:3] for f in os.listdir(pdir) if re.match(r"r\d\d_pmc_FETCH_SIZE", f)}) if os.path.isdir(pdir) else []
+    for r in reversed(rounds):
+        fetch = per_launch(os.path.join(pdir, f"{r}_pmc_FETCH_SIZE.txt"))
+        write = per_launch(os.path.join(pdir, f"{r}_pmc_WRITE_SIZE.txt"))
+        if fetch is not None and write is not None:
+            return 2.0 * fetch + write, r      # FETCH_SIZE reports half of a wide coalesced read on gfx950
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("NUNIF_BENCH_BATCH", "8")))
+    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("NUNIF_BENCH_BATCH", "45")),
+                    help="tiles per model launch (the reference's tile minibatch; results do not depend on it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -80,7 +108,7 @@ def main():
     from nunif_amd import _hip
     from nunif_amd.nunif.utils.render import tiled_render
     from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x
-    from oracle import swin_unet as O      # weights generator + (rank 0) CPU baseline / parity check only
+    from oracle import swin_unet as O      # seeded weight generator + (rank 0) CPU baseline / parity check only
 
     torch.set_grad_enabled(False)
     sd = O.random_state_dict(102, 2)
@@ -104,7 +132,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(i)
+        step(i)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -112,9 +140,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-kernel-class timing (HIP events on the launch stream), outside the timed region -------------------
-    roofline = None
-    classes = []
+    # ---- per-kernel timing with HIP events on the launch stream (library hooks), outside the timed region ----------
+    roofline, classes = None, []
     if rank == 0:
         _hip.profile_enable(True)
         n_prof = max(1, min(3, args.steps))
@@ -125,17 +152,32 @@ def main():
         _hip.profile_enable(False)
         total = sum(r["total_ms"] for r in recs) or 1.0
         for r in sorted(recs, key=lambda r: -r["total_ms"]):
-            avg_us = 1e3 * r["total_ms"] / max(1, r["launches"])
+            sec = r["total_ms"] * 1e-3
             classes.append({"kernel": r["name"], "share": round(r["total_ms"] / total, 4),
-                            "avg_us": round(avg_us, 2), "launches_per_frame": r["launches"] // n_prof,
-                            "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2) if r["total_ms"] else 0.0,
-                            "gbs": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1) if r["total_ms"] else 0.0})
+                            "avg_us": round(1e3 * r["total_ms"] / max(1, r["launches"]), 2),
+                            "launches_per_frame": r["launches"] // n_prof,
+                            "tflops": round(r["flops"] / sec / 1e12, 2) if sec else 0.0,
+                            "gbs": round(r["bytes"] / sec / 1e9, 1) if sec else 0.0})
         dom = max(recs, key=lambda r: r["total_ms"])
-        ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "avg_launch_us": round(1e3 * dom["total_ms"] / max(1, dom["launches"]), 2),
-                    "algorithmic_flops_per_launch": dom["flops"] / max(1, dom["launches"])}
+        n = max(1, dom["launches"])
+        avg_s = dom["total_ms"] * 1e-3 / n
+        flops_l, bytes_l = dom["flops"] / n, dom["bytes"] / n
+        intensity = flops_l / bytes_l if bytes_l else float("inf")
+        ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        traffic, src = pmc_traffic_bytes(dom["name"])
+        if intensity >= ridge:
+            ach = flops_l / avg_s / 1e12
+            roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
+        else:
+            ach = bytes_l / avg_s / 1e9
+            roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+        roofline.update({"traffic": traffic, "traffic_source": f"profiles/{src}_pmc_*" if src else None,
+                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_flops_per_launch": flops_l,
+                         "algorithmic_bytes_per_launch": bytes_l, "flop_per_byte": round(intensity, 1),
+                         "achieved_tflops": round(flops_l / avg_s / 1e12, 2),
+                         "mfma_frac": round(flops_l / avg_s / 1e12 / MFMA_PEAK_TFLOPS, 4)})
 
     if rank == 0:
         mpix_in = FRAME_H * FRAME_W / 1e6
@@ -151,6 +193,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}"},
             "output_mpix_per_s": round(value * 4, 2),
             "model_tflops": round(45 * 98e9 * args.steps * world / elapsed / 1e12, 2),
+            "model_mfma_frac": round(45 * 98e9 * args.steps * world / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
             "roofline": roofline, "kernel_classes": classes,
         }
         if not args.no_cpu_baseline:

@@ -127,7 +127,7 @@ int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int
     const bool vec = (p.To % 4 == 0) && (p.ostep % 4 == 0) && (p.y_w % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(tile_out) | reinterpret_cast<uintptr_t>(y)) % 16 == 0);
     const double bytes = (double)C * p.y_h * p.y_w * 4.0 * 2.0;
-    ProfScope ps("stitch", s, 0.0, bytes);
+    ProfScope ps(vec ? "stitch_kernel<4>" : "stitch_kernel<1>", s, 0.0, bytes);
     if (vec) {
         dim3 grid(cdiv(p.y_w / 4, 256), p.y_h);
         stitch_kernel<4><<<grid, 256, 0, s>>>(tile_out, y, p);
@@ -187,7 +187,7 @@ extern "C" int nunif_hip_gather_tiles(const float *x, float *tiles, const nunif_
     const int T = g->tile_size;
     const long total = (long)n_tiles * C * T * T;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope ps("gather_tiles", s, 0.0, (double)total * 8.0);
+    ProfScope ps("gather_tiles_kernel", s, 0.0, (double)total * 8.0);
     gather_tiles_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(
         x, tiles, C, g->x_h, g->x_w, T, g->w_blocks, g->input_tile_step, g->pad_t, g->pad_l, tile_begin, total);
     NUNIF_LAUNCH_CHECK();

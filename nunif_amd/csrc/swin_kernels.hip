@@ -19,18 +19,39 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 
 // =================================================================================================================
 // Implicit-GEMM linear / conv.  One wave owns MF x 16 tokens and keeps their whole K extent in registers (the
-// activations are the streaming operand: read once from HBM); it then sweeps all N/16 output-channel tiles,
-// pulling each 1-KiB weight fragment (64 lanes x 16 B, fragment-major => one coalesced load) from L2.
+// activations are the streaming operand: read once from HBM); it then sweeps all N/16 output-channel tiles.
+// The packed weight array [nt][ks] is already the consumption order, so the 4 waves of a workgroup pull it through
+// the same 2 x 8 KiB LDS ring as the block kernels (global -> registers one chunk ahead, registers -> LDS at the
+// chunk boundary, one __syncthreads per chunk).  v1 loaded every fragment straight from L2 and exposed its latency.
 // =================================================================================================================
 template <int KS, int MF>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
+    constexpr int CH = 8;
+    __shared__ __attribute__((aligned(16))) f16x8 ring[2][CH * 64];
+    const int tid = threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r16 = lane & 15;
     const int grp = lane >> 4;
     const long M = (long)g.B * g.Ho * g.Wo;
     const long m_base = ((long)blockIdx.x * 4 + wave) * (MF * 16);
-    if (m_base >= M) return;
+    // no early exit: every wave joins every chunk barrier; rows beyond M are clamped on load and masked on store
+    // (the host pads every packed weight array with 16 KiB of zeros, so the one-chunk-ahead prefetch never
+    //  leaves the allocation — make_linear in swin_unet.cpp)
+    const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.w);
+    auto fetch = [&](int e) -> f16x8 { return gsrc[e]; };
+    f16x8 st0 = fetch(tid), st1 = fetch(tid + 256);
+    auto wfrag = [&](int fi) -> f16x8 {
+        const int c = fi / CH;
+        if (fi % CH == 0) {
+            ring[c & 1][tid] = st0;
+            ring[c & 1][tid + 256] = st1;
+            __syncthreads();
+            st0 = fetch((c + 1) * (CH * 64) + tid);
+            st1 = fetch((c + 1) * (CH * 64) + tid + 256);
+        }
+        return ring[c & 1][(fi % CH) * 64 + lane];
+    };
 
     f16x8 xf[MF][KS];
     int tb[MF], ty[MF], tx[MF];
@@ -59,15 +80,14 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     }
 
     const int NT = g.N >> 4;
-    const f16x8 *wbase = reinterpret_cast<const f16x8 *>(g.w) + lane;
+#pragma unroll 1
     for (int nt = 0; nt < NT; ++nt) {
         f32x4 acc[MF];
 #pragma unroll
         for (int f = 0; f < MF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f16x8 *wp = wbase + (long)nt * KS * 64;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const f16x8 wv = wp[ks * 64];
+            const f16x8 wv = wfrag(nt * KS + ks);
 #pragma unroll
             for (int f = 0; f < MF; ++f) acc[f] = MFMA_16x16x32(wv, xf[f][ks], acc[f]);
         }
@@ -140,7 +160,10 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
     const double flops = 2.0 * (double)M * g.K * g.n_real;
     const double bytes = (double)M * (g.Cin * 2.0 * (g.K / g.Cin > 1 ? 1.0 : 1.0) + g.n_real * (g.mode == 2 ? 4.0 : 2.0) +
                                       (g.res ? g.n_real * 2.0 : 0.0));
-    ProfScope ps(tag, s, flops, bytes);
+    // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
+    const char *sym = g.K == 96 ? "gemm_kernel<3,4>" : g.K == 192 ? "gemm_kernel<6,4>" : g.K == 384 ? "gemm_kernel<12,2>"
+                    : g.K == 576 ? "gemm_kernel<18,2>" : "gemm_kernel<24,1>";
+    ProfScope ps(sym, s, flops, bytes);
     switch (g.K / 32) {
         case 3: return launch_gemm_t<3, 4>(g, s);
         case 6: return launch_gemm_t<6, 4>(g, s);
@@ -225,7 +248,7 @@ int launch_stem1(const Stem1Args &a, hipStream_t s) {
     NUNIF_REQUIRE(a.C1P % 8 == 0 && a.C1 <= a.C1P && a.T > 14, "stem1: bad shape");
     const int S = a.T - 14;
     const long total = (long)a.B * S * S;
-    ProfScope ps("stem_conv1", s, 2.0 * 27 * a.C1 * (double)total, (double)total * (a.C1P * 2.0 + 12.0));
+    ProfScope ps("stem1_kernel", s, 2.0 * 27 * a.C1 * (double)total, (double)total * (a.C1P * 2.0 + 12.0));
     const size_t smem = (size_t)(28 * a.C1) * sizeof(float);
     stem1_kernel<<<(unsigned)((total + 255) / 256), 256, smem, s>>>(a);
     NUNIF_LAUNCH_CHECK();
@@ -379,7 +402,7 @@ int launch_window_attn(const f16 *qkv, f16 *out, const float *bias, int B, int H
     if (H <= 6) shift = 0;
     const long total = (long)B * (H / 6) * (W / 6) * heads;
     const double tok = (double)B * H * W;
-    ProfScope ps("window_attn", s, 4.0 * tok * 36.0 * heads * hd, tok * heads * hd * 2.0 * 4.0);
+    ProfScope ps(hd == 16 ? "window_attn_kernel<16>" : "window_attn_kernel<32>", s, 4.0 * tok * 36.0 * heads * hd, tok * heads * hd * 2.0 * 4.0);
     const unsigned blocks = (unsigned)((total + 3) / 4);
     const float scale = 1.0f / sqrtf((float)hd);
     if (hd == 16) window_attn_kernel<16><<<blocks, 256, 0, s>>>(qkv, out, bias, B, H, W, heads, shift, scale);

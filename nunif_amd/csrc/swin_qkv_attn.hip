@@ -267,7 +267,7 @@ int launch_qkv_attn(const f16 *x, f16 *att, const f16 *wqkv, const float *bqkv, 
     a.n_groups = (a.n_windows + 3) / 4;
     a.scale = 1.0f / sqrtf((float)(C / heads));
     const double tok = (double)B * H * W;
-    ProfScope ps("qkv_attn", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 2.0 * 2.0);
+    ProfScope ps("qkv_attn_hd16_kernel<96>", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 2.0 * 2.0);
     const int grid = a.n_groups < 512 ? a.n_groups : 512;     // persistent: 2 workgroups per CU
     qkv_attn_hd16_kernel<96><<<grid, 384, 0, s>>>(a);
     NUNIF_LAUNCH_CHECK();

@@ -115,7 +115,8 @@ template <typename F>
 int make_linear(nunif_swin_unet *h, int n_real, int K, F wt, const float *bias, Linear *L, bool chained = false,
                 std::vector<f16> *keep = nullptr) {
     const int N = (n_real + 15) / 16 * 16;
-    std::vector<f16> packed((size_t)N * K);
+    // + 16 KiB of zeros: the LDS-ring kernels prefetch one 8-KiB chunk past the last fragment they consume
+    std::vector<f16> packed((size_t)N * K + 8192, (f16)0.0f);
     const int KS = K / 32;
     for (int nt = 0; nt < N / 16; ++nt)
         for (int ks = 0; ks < KS; ++ks)
