@@ -101,6 +101,20 @@ int nunif_hip_swin_unet_render(nunif_swin_unet *handle, const float *x, float *y
                                int32_t tile_size, int32_t batch_size, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * waifu2x CUNet.  Replaces waifu2x/models/cunet.py CUNet.forward :183-196 (UNet1 :52-67, UNet2 :99-121, SEBlock
+ * nunif/modules/attention.py:29-44).  Geometry: scale 1, offset 28, no blending (cunet.py:177).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct nunif_cunet nunif_cunet;
+int nunif_hip_cunet_create(const nunif_tensor_desc *tensors, int32_t n_tensors, int32_t no_clip, nunif_cunet **handle);
+void nunif_hip_cunet_destroy(nunif_cunet *handle);
+/* z = clamp(crop(z1,20) + unet2(z1), 0, 1), z1 = clamp(unet1(x)).  x: [B,3,T,T] f32, z: [B,3,T-56,T-56] f32; T % 4 == 0. */
+int nunif_hip_cunet_forward(nunif_cunet *handle, const float *x, float *z, int32_t batch, int32_t tile_size,
+                            void *stream);
+/* Whole-frame tiled render (x: [3,H,W] -> y: [3,H,W]); tile gather fused into the first conv, overwrite stitch. */
+int nunif_hip_cunet_render(nunif_cunet *handle, const float *x, float *y, int32_t x_h, int32_t x_w,
+                           int32_t tile_size, int32_t batch_size, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * iw3 stereo synthesis + depth post-processing.
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct {

@@ -60,6 +60,10 @@ SIGNATURES = {
     "nunif_hip_swin_unet_destroy": (None, [c_void_p]),
     "nunif_hip_swin_unet_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "nunif_hip_swin_unet_render": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_cunet_create": (c_int32, [ctypes.POINTER(TensorDesc), c_int32, c_int32, ctypes.POINTER(c_void_p)]),
+    "nunif_hip_cunet_destroy": (None, [c_void_p]),
+    "nunif_hip_cunet_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "nunif_hip_cunet_render": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "nunif_hip_forward_warp": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          ctypes.POINTER(ForwardWarpParams), c_void_p]),
     "nunif_hip_backward_warp": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 6 +

@@ -1,0 +1,338 @@
+// Host side of the waifu2x CUNet engine: weight repacking, workspace, launch sequence, whole-frame render.
+//
+// Reference: waifu2x/models/cunet.py — UNet1 :31-67, UNet2 :70-121, CUNet :172-203 (layer inventory, crops, the
+// cascade z = crop(z1, 20) + unet2(z1)); nunif/utils/seam_blending.py tiled_render :48-106 (frame loop; CUNet has
+// blend_size None -> plain overwrite).  State-dict keys are the reference's.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "swin_kernels.h"
+
+namespace nunif {
+int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int C, hipStream_t s);
+}
+
+using namespace nunif;
+
+namespace {
+
+struct HostT { const float *data; std::vector<int64_t> shape; int64_t numel; };
+typedef std::map<std::string, HostT> TMap;
+
+struct Buf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return NUNIF_HIP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) { set_error("hipMalloc(%zu) failed", bytes); return NUNIF_HIP_ENOMEM; }
+        cap = bytes;
+        return NUNIF_HIP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ConvW { f16 *stream = nullptr; float *bias = nullptr; int N = 0, n_real = 0, Cin = 0, k = 3, stride = 1; };
+struct UpW { f16 *w = nullptr; float *bias = nullptr; int N = 0, K = 0, cq = 0; };       // ConvTranspose2d 2x2 s2
+struct SEW { float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr; int C = 0; };
+struct C3W { float *w = nullptr, *b = nullptr; int C = 0; };
+
+}  // namespace
+
+struct nunif_cunet {
+    int no_clip = 0;
+    std::vector<void *> owned;
+    // unet1
+    C3W u1c1a; ConvW u1c1b, u1down, u1c2a, u1c2b, u1c3, u1bottom; SEW u1se2; UpW u1up;
+    // unet2
+    C3W u2c1a; ConvW u2c1b, u2down1, u2c2a, u2c2b, u2down2, u2c3a, u2c3b, u2c4a, u2c4b, u2c5, u2bottom;
+    SEW u2se2, u2se3, u2se4; UpW u2up3, u2up4;
+    Buf t[12], z1, sums, scale, tile_out;
+};
+
+namespace {
+
+int find(const TMap &m, const std::string &key, const HostT **out) {
+    auto it = m.find(key);
+    if (it == m.end()) { set_error("state_dict is missing '%s'", key.c_str()); return NUNIF_HIP_EMISSING; }
+    *out = &it->second;
+    return NUNIF_HIP_OK;
+}
+
+template <typename T>
+int upload(nunif_cunet *h, const std::vector<T> &host, T **dev) {
+    void *p = nullptr;
+    if (hipMalloc(&p, host.size() * sizeof(T)) != hipSuccess) { set_error("hipMalloc failed"); return NUNIF_HIP_ENOMEM; }
+    h->owned.push_back(p);
+    NUNIF_HIP_CHECK(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = reinterpret_cast<T *>(p);
+    return NUNIF_HIP_OK;
+}
+
+int upload_f32(nunif_cunet *h, const HostT *t, float **dev) {
+    std::vector<float> v(t->data, t->data + t->numel);
+    return upload(h, v, dev);
+}
+
+// Conv2d weight [Cout][Cin][k][k] -> MFMA A fragments in [k-step][n-tile] order, reduction index = tap*Cin + ci
+int make_conv(nunif_cunet *h, const TMap &m, const std::string &key, int cin, int cout, int k, int stride, ConvW *c) {
+    const HostT *w, *b;
+    int rc;
+    if ((rc = find(m, key + ".weight", &w)) || (rc = find(m, key + ".bias", &b))) return rc;
+    NUNIF_REQUIRE(w->numel == (int64_t)cout * cin * k * k && b->numel == cout, "%s: unexpected shape", key.c_str());
+    NUNIF_REQUIRE(cin % 32 == 0, "%s: Cin=%d must be a multiple of 32", key.c_str(), cin);
+    const int N = (cout + 15) / 16 * 16, NT = N / 16, KS = k * k * cin / 32;
+    std::vector<f16> stream((size_t)KS * NT * 512 + 8192, (f16)0.0f);
+    for (int ks = 0; ks < KS; ++ks)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = nt * 16 + (l & 15), kk = ks * 32 + (l >> 4) * 8 + j;
+                    const int tap = kk / cin, ci = kk % cin;
+                    const float v = n < cout ? w->data[((size_t)n * cin + ci) * k * k + tap] : 0.0f;
+                    stream[(((size_t)ks * NT + nt) * 64 + l) * 8 + j] = (f16)v;
+                }
+    std::vector<float> bias(N, 0.0f);
+    for (int n = 0; n < cout; ++n) bias[n] = b->data[n];
+    c->N = N; c->n_real = cout; c->Cin = cin; c->k = k; c->stride = stride;
+    if ((rc = upload(h, stream, &c->stream))) return rc;
+    return upload(h, bias, &c->bias);
+}
+
+// ConvTranspose2d(cin, cout, 2, 2) weight [cin][cout][2][2] -> Linear cin -> 4*cout with pixel-shuffle column order
+// n = q*cout + co, q = i*2 + j  (gemm_kernel mode 1), fragments in [n-tile][k-step] order
+int make_up(nunif_cunet *h, const TMap &m, const std::string &key, int cin, int cout, UpW *u) {
+    const HostT *w, *b;
+    int rc;
+    if ((rc = find(m, key + ".weight", &w)) || (rc = find(m, key + ".bias", &b))) return rc;
+    NUNIF_REQUIRE(w->numel == (int64_t)cin * cout * 4 && b->numel == cout, "%s: unexpected shape", key.c_str());
+    const int N = 4 * cout, NT = N / 16, KS = cin / 32;
+    std::vector<f16> packed((size_t)N * cin + 8192, (f16)0.0f);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = nt * 16 + (l & 15), ci = ks * 32 + (l >> 4) * 8 + j;
+                    const int q = n / cout, co = n % cout;
+                    packed[(((size_t)nt * KS + ks) * 64 + l) * 8 + j] = (f16)w->data[((size_t)ci * cout + co) * 4 + q];
+                }
+    std::vector<float> bias(N);
+    for (int n = 0; n < N; ++n) bias[n] = b->data[n % cout];
+    u->N = N; u->K = cin; u->cq = cout;
+    if ((rc = upload(h, packed, &u->w))) return rc;
+    return upload(h, bias, &u->bias);
+}
+
+int make_c3(nunif_cunet *h, const TMap &m, const std::string &key, int cout, C3W *c) {
+    const HostT *w, *b;
+    int rc;
+    if ((rc = find(m, key + ".weight", &w)) || (rc = find(m, key + ".bias", &b))) return rc;
+    NUNIF_REQUIRE(w->numel == (int64_t)cout * 27 && b->numel == cout, "%s: unexpected shape (3 input channels)", key.c_str());
+    c->C = cout;
+    if ((rc = upload_f32(h, w, &c->w))) return rc;
+    return upload_f32(h, b, &c->b);
+}
+
+int make_se(nunif_cunet *h, const TMap &m, const std::string &key, int C, SEW *s) {
+    const HostT *w1, *b1, *w2, *b2;
+    int rc;
+    if ((rc = find(m, key + ".conv1.weight", &w1)) || (rc = find(m, key + ".conv1.bias", &b1)) ||
+        (rc = find(m, key + ".conv2.weight", &w2)) || (rc = find(m, key + ".conv2.bias", &b2)))
+        return rc;
+    NUNIF_REQUIRE(w1->numel == (int64_t)C * C / 8 && w2->numel == (int64_t)C * C / 8, "%s: unexpected shape", key.c_str());
+    s->C = C;
+    if ((rc = upload_f32(h, w1, &s->w1)) || (rc = upload_f32(h, b1, &s->b1)) || (rc = upload_f32(h, w2, &s->w2)) ||
+        (rc = upload_f32(h, b2, &s->b2)))
+        return rc;
+    return NUNIF_HIP_OK;
+}
+
+int run_conv(const ConvW &c, const f16 *a, const f16 *a2, int H2, int crop2, int B, int Hi, f16 *out, float *out32,
+             const float *add32, int addH, int add_crop, int clamp01, int act, hipStream_t s) {
+    ConvArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = a; g.a2 = a2; g.H2 = H2; g.W2 = H2; g.crop2 = crop2;
+    g.B = B; g.Hi = Hi; g.Wi = Hi; g.Cin = c.Cin; g.stride = c.stride; g.kh = c.k; g.kw = c.k;
+    g.Ho = (Hi - c.k) / c.stride + 1; g.Wo = g.Ho;
+    g.wstream = c.stream; g.bias = c.bias; g.N = c.N; g.n_real = c.n_real;
+    g.act = act; g.slope = 0.1f;
+    g.out = out; g.out32 = out32; g.add32 = add32; g.addH = addH; g.addW = addH; g.add_crop = add_crop;
+    g.clamp01 = clamp01;
+    return launch_conv(g, s);
+}
+
+int run_up(const UpW &u, const f16 *a, int B, int Hi, f16 *out, hipStream_t s) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = a; g.B = B; g.Hi = Hi; g.Wi = Hi; g.Cin = u.K; g.Ho = Hi; g.Wo = Hi; g.stride = 1; g.kw = 1;
+    g.K = u.K; g.w = u.w; g.bias = u.bias; g.N = u.N; g.mode = 1; g.act = 2; g.slope = 0.1f;
+    g.out = out; g.ldo = u.cq; g.n_real = u.N; g.ps = 1;
+    return launch_gemm(g, s, "cunet_up");
+}
+
+// x: tile mode [B,3,T,T] or (frame != NULL) frame + grid; z: [B,3,T-56,T-56]
+int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif_tile_grid *grid, int tile_begin,
+                 float *z, int B, int T, hipStream_t s) {
+    NUNIF_REQUIRE(T % 4 == 0 && T >= 64, "tile_size %d is not valid for cunet (multiple of 4, >= 64)", T);
+    const size_t b = B;
+    const int a1 = T - 2, x1 = T - 4, d1 = x1 / 2, e1 = d1 - 2, f1 = d1 - 4, g1 = 2 * f1, h1 = g1 - 2, T2 = g1 - 4;
+    const int a2 = T2 - 2, y1 = T2 - 4, d2 = y1 / 2, e2 = d2 - 2, y2 = d2 - 4, d3 = y2 / 2, e3 = d3 - 2, f3 = d3 - 4;
+    const int g3 = 2 * f3, e4 = g3 - 2, f4 = g3 - 4, g4 = 2 * f4, h5 = g4 - 2, To = g4 - 4;
+    NUNIF_REQUIRE(g1 == x1 - 8 && g3 == y2 - 8 && g4 == y1 - 32 && To == T - 56, "internal: cunet geometry");
+    auto sz = [&](int side, int ch) { return b * side * side * ch * sizeof(f16); };
+    int rc;
+    // live-range packing of the fp16 maps onto 12 buffers
+    enum { A = 0, X1, D, E, F, G, H, Y1, X2, U3, P, Q };
+    if ((rc = h->t[A].ensure(std::max(sz(a1, 32), sz(a2, 32)))) || (rc = h->t[X1].ensure(sz(x1, 64))) ||
+        (rc = h->t[D].ensure(std::max({sz(d1, 64), sz(d2, 64), sz(d3, 128)}))) ||
+        (rc = h->t[E].ensure(std::max({sz(e1, 128), sz(e2, 64), sz(e3, 256), sz(e4, 64)}))) ||
+        (rc = h->t[F].ensure(std::max({sz(f1, 64), sz(f3, 128), sz(f4, 64)}))) ||
+        (rc = h->t[G].ensure(std::max({sz(g1, 64), sz(g3, 128), sz(g4, 64)}))) ||
+        (rc = h->t[H].ensure(std::max(sz(h1, 64), sz(h5, 64)))) || (rc = h->t[Y1].ensure(sz(y1, 64))) ||
+        (rc = h->t[X2].ensure(sz(y2, 128))) || (rc = h->z1.ensure(b * 3 * T2 * T2 * sizeof(float))) ||
+        (rc = h->sums.ensure(b * 128 * 256 * sizeof(float))) || (rc = h->scale.ensure(b * 256 * sizeof(float))))
+        return rc;
+    f16 *tA = (f16 *)h->t[A].p, *tX1 = (f16 *)h->t[X1].p, *tD = (f16 *)h->t[D].p, *tE = (f16 *)h->t[E].p;
+    f16 *tF = (f16 *)h->t[F].p, *tG = (f16 *)h->t[G].p, *tH = (f16 *)h->t[H].p, *tY1 = (f16 *)h->t[Y1].p;
+    f16 *tX2 = (f16 *)h->t[X2].p;
+    float *z1 = (float *)h->z1.p, *sums = (float *)h->sums.p, *scale = (float *)h->scale.p;
+
+    // ---------------- unet1 (cunet.py:52-67) ----------------
+    C3ConvArgs c3;
+    memset(&c3, 0, sizeof(c3));
+    if (frame) {
+        c3.x = frame; c3.frame_mode = 1; c3.H = grid->x_h; c3.W = grid->x_w; c3.wb = grid->w_blocks;
+        c3.istep = grid->input_tile_step; c3.pad_t = grid->pad_t; c3.pad_l = grid->pad_l; c3.tile_begin = tile_begin;
+    } else {
+        c3.x = x;
+    }
+    c3.B = B; c3.T = T; c3.w = h->u1c1a.w; c3.bias = h->u1c1a.b; c3.C = h->u1c1a.C; c3.out = tA; c3.slope = 0.1f;
+    if ((rc = launch_c3_conv(c3, s))) return rc;
+    if ((rc = run_conv(h->u1c1b, tA, nullptr, 0, 0, B, a1, tX1, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;       // x1
+    if ((rc = run_conv(h->u1down, tX1, nullptr, 0, 0, B, x1, tD, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_conv(h->u1c2a, tD, nullptr, 0, 0, B, d1, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_conv(h->u1c2b, tE, nullptr, 0, 0, B, e1, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = launch_se(tF, sums, scale, h->u1se2.w1, h->u1se2.b1, h->u1se2.w2, h->u1se2.b2, B, (long)f1 * f1, 64, s))) return rc;
+    if ((rc = run_up(h->u1up, tF, B, f1, tG, s))) return rc;
+    // conv3(crop(x1, 4) + x2)
+    if ((rc = run_conv(h->u1c3, tG, tX1, x1, 4, B, g1, tH, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    // conv_bottom -> z1 (clamped unless no_clip, cunet.py:185-186)
+    if ((rc = run_conv(h->u1bottom, tH, nullptr, 0, 0, B, h1, nullptr, z1, nullptr, 0, 0, h->no_clip ? 0 : 1, 0, s))) return rc;
+
+    // ---------------- unet2 (cunet.py:99-121) ----------------
+    memset(&c3, 0, sizeof(c3));
+    c3.x = z1; c3.B = B; c3.T = T2; c3.w = h->u2c1a.w; c3.bias = h->u2c1a.b; c3.C = h->u2c1a.C; c3.out = tA; c3.slope = 0.1f;
+    if ((rc = launch_c3_conv(c3, s))) return rc;
+    if ((rc = run_conv(h->u2c1b, tA, nullptr, 0, 0, B, a2, tY1, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;       // x1
+    if ((rc = run_conv(h->u2down1, tY1, nullptr, 0, 0, B, y1, tD, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_conv(h->u2c2a, tD, nullptr, 0, 0, B, d2, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_conv(h->u2c2b, tE, nullptr, 0, 0, B, e2, tX2, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;       // x2
+    if ((rc = launch_se(tX2, sums, scale, h->u2se2.w1, h->u2se2.b1, h->u2se2.w2, h->u2se2.b2, B, (long)y2 * y2, 128, s))) return rc;
+    if ((rc = run_conv(h->u2down2, tX2, nullptr, 0, 0, B, y2, tD, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_conv(h->u2c3a, tD, nullptr, 0, 0, B, d3, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_conv(h->u2c3b, tE, nullptr, 0, 0, B, e3, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = launch_se(tF, sums, scale, h->u2se3.w1, h->u2se3.b1, h->u2se3.w2, h->u2se3.b2, B, (long)f3 * f3, 128, s))) return rc;
+    if ((rc = run_up(h->u2up3, tF, B, f3, tG, s))) return rc;
+    // conv4(crop(x2, 4) + x3)
+    if ((rc = run_conv(h->u2c4a, tG, tX2, y2, 4, B, g3, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_conv(h->u2c4b, tE, nullptr, 0, 0, B, e4, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = launch_se(tF, sums, scale, h->u2se4.w1, h->u2se4.b1, h->u2se4.w2, h->u2se4.b2, B, (long)f4 * f4, 64, s))) return rc;
+    if ((rc = run_up(h->u2up4, tF, B, f4, tG, s))) return rc;
+    // conv5(crop(x1, 16) + x4)
+    if ((rc = run_conv(h->u2c5, tG, tY1, y1, 16, B, g4, tH, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    // z = clamp(crop(z1, 20) + conv_bottom(x5), 0, 1)
+    if ((rc = run_conv(h->u2bottom, tH, nullptr, 0, 0, B, h5, nullptr, z, z1, T2, 20, 1, 0, s))) return rc;
+    return NUNIF_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" int nunif_hip_cunet_create(const nunif_tensor_desc *tensors, int32_t n_tensors, int32_t no_clip,
+                                      nunif_cunet **handle) {
+    NUNIF_REQUIRE(tensors && handle && n_tensors > 0, "cunet_create: NULL argument");
+    TMap m;
+    for (int i = 0; i < n_tensors; ++i) {
+        HostT t;
+        t.data = tensors[i].data;
+        t.numel = 1;
+        for (int d = 0; d < tensors[i].ndim; ++d) { t.shape.push_back(tensors[i].shape[d]); t.numel *= tensors[i].shape[d]; }
+        m[tensors[i].name] = t;
+    }
+    nunif_cunet *h = new nunif_cunet();
+    h->no_clip = no_clip;
+    int rc = NUNIF_HIP_OK;
+    do {
+        const HostT *bw;
+        if ((rc = find(m, "unet1.conv_bottom.weight", &bw))) break;
+        if (bw->shape.size() == 4 && bw->shape[2] == 4) {
+            set_error("UpCUNet (ConvTranspose2d 4x4 head) is not supported by the HIP engine yet");
+            rc = NUNIF_HIP_EUNSUPPORTED;
+            break;
+        }
+        const std::string a = "unet1.", b = "unet2.";
+        if ((rc = make_c3(h, m, a + "conv1.conv.0", 32, &h->u1c1a))) break;
+        if ((rc = make_conv(h, m, a + "conv1.conv.2", 32, 64, 3, 1, &h->u1c1b))) break;
+        if ((rc = make_conv(h, m, a + "conv1_down", 64, 64, 2, 2, &h->u1down))) break;
+        if ((rc = make_conv(h, m, a + "conv2.conv.0", 64, 128, 3, 1, &h->u1c2a))) break;
+        if ((rc = make_conv(h, m, a + "conv2.conv.2", 128, 64, 3, 1, &h->u1c2b))) break;
+        if ((rc = make_se(h, m, a + "conv2.seblock", 64, &h->u1se2))) break;
+        if ((rc = make_up(h, m, a + "conv2_up", 64, 64, &h->u1up))) break;
+        if ((rc = make_conv(h, m, a + "conv3", 64, 64, 3, 1, &h->u1c3))) break;
+        if ((rc = make_conv(h, m, a + "conv_bottom", 64, 3, 3, 1, &h->u1bottom))) break;
+        if ((rc = make_c3(h, m, b + "conv1.conv.0", 32, &h->u2c1a))) break;
+        if ((rc = make_conv(h, m, b + "conv1.conv.2", 32, 64, 3, 1, &h->u2c1b))) break;
+        if ((rc = make_conv(h, m, b + "conv1_down", 64, 64, 2, 2, &h->u2down1))) break;
+        if ((rc = make_conv(h, m, b + "conv2.conv.0", 64, 64, 3, 1, &h->u2c2a))) break;
+        if ((rc = make_conv(h, m, b + "conv2.conv.2", 64, 128, 3, 1, &h->u2c2b))) break;
+        if ((rc = make_se(h, m, b + "conv2.seblock", 128, &h->u2se2))) break;
+        if ((rc = make_conv(h, m, b + "conv2_down", 128, 128, 2, 2, &h->u2down2))) break;
+        if ((rc = make_conv(h, m, b + "conv3.conv.0", 128, 256, 3, 1, &h->u2c3a))) break;
+        if ((rc = make_conv(h, m, b + "conv3.conv.2", 256, 128, 3, 1, &h->u2c3b))) break;
+        if ((rc = make_se(h, m, b + "conv3.seblock", 128, &h->u2se3))) break;
+        if ((rc = make_up(h, m, b + "conv3_up", 128, 128, &h->u2up3))) break;
+        if ((rc = make_conv(h, m, b + "conv4.conv.0", 128, 64, 3, 1, &h->u2c4a))) break;
+        if ((rc = make_conv(h, m, b + "conv4.conv.2", 64, 64, 3, 1, &h->u2c4b))) break;
+        if ((rc = make_se(h, m, b + "conv4.seblock", 64, &h->u2se4))) break;
+        if ((rc = make_up(h, m, b + "conv4_up", 64, 64, &h->u2up4))) break;
+        if ((rc = make_conv(h, m, b + "conv5", 64, 64, 3, 1, &h->u2c5))) break;
+        if ((rc = make_conv(h, m, b + "conv_bottom", 64, 3, 3, 1, &h->u2bottom))) break;
+    } while (0);
+    if (rc) { nunif_hip_cunet_destroy(h); return rc; }
+    *handle = h;
+    return NUNIF_HIP_OK;
+}
+
+extern "C" void nunif_hip_cunet_destroy(nunif_cunet *h) {
+    if (!h) return;
+    for (void *p : h->owned) (void)hipFree(p);
+    for (auto &b : h->t) b.release();
+    h->z1.release(); h->sums.release(); h->scale.release(); h->tile_out.release();
+    delete h;
+}
+
+extern "C" int nunif_hip_cunet_forward(nunif_cunet *h, const float *x, float *z, int32_t batch, int32_t tile_size,
+                                       void *stream) {
+    NUNIF_REQUIRE(h && x && z && batch > 0, "cunet_forward: bad argument");
+    return forward_impl(h, x, nullptr, nullptr, 0, z, batch, tile_size, (hipStream_t)stream);
+}
+
+extern "C" int nunif_hip_cunet_render(nunif_cunet *h, const float *x, float *y, int32_t x_h, int32_t x_w,
+                                      int32_t tile_size, int32_t batch_size, void *stream) {
+    NUNIF_REQUIRE(h && x && y && batch_size > 0, "cunet_render: bad argument");
+    nunif_tile_grid g;
+    int rc = nunif_hip_tile_grid_init(x_h, x_w, 1, 28, tile_size, 0, &g);      // scale 1, offset 28, no blending
+    if (rc) return rc;
+    const int n_tiles = g.h_blocks * g.w_blocks;
+    const size_t To = g.out_tile_size;
+    if ((rc = h->tile_out.ensure((size_t)n_tiles * 3 * To * To * sizeof(float)))) return rc;
+    float *tile_out = (float *)h->tile_out.p;
+    hipStream_t st = (hipStream_t)stream;
+    for (int t0 = 0; t0 < n_tiles; t0 += batch_size) {
+        const int nb = std::min(batch_size, n_tiles - t0);
+        if ((rc = forward_impl(h, nullptr, x, &g, t0, tile_out + (size_t)t0 * 3 * To * To, nb, tile_size, st))) return rc;
+    }
+    return launch_stitch(tile_out, y, &g, 3, st);
+}

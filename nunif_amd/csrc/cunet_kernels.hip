@@ -1,0 +1,300 @@
+// Device kernels of the waifu2x CUNet forward for gfx950.
+//
+// Reference ops replaced: waifu2x/models/cunet.py — UNetConv :10-28 (3x3 VALID conv +
+// LeakyReLU(0.1) x2), conv 2x2 stride 2 :34,:76,:78, the cropped skip additions :63,:111,:116, conv_bottom + the
+// cascade sum `crop(z1,20) + unet2(z1)` + clamp :183-196; nunif/modules/attention.py SEBlock :29-44.
+// (ConvTranspose2d 2x2 stride 2 runs on gemm_kernel's pixel-shuffle mode, swin_kernels.hip.)
+//
+// conv_kernel<NT,MF>: implicit-GEMM conv on v_mfma_f32_16x16x32_f16, NHWC fp16 maps, fp32 accumulation.  Same operand
+// orientation as the swin kernels (weights = A, activations = B => a lane's accumulator is 4 consecutive output
+// channels of one pixel).  Cout <= 256, so ALL output-channel tiles of a pixel group stay in accumulators while the
+// kernel walks K = taps x Cin: activations stream from HBM exactly once (next k-step prefetched into registers),
+// weights stream [k-step][n-tile] through the 2 x 8 KiB LDS ring shared by the 4 waves.
+#include "swin_kernels.h"
+
+namespace nunif {
+
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+template <int NT, int MF>
+__global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
+    constexpr int CH = 8;
+    __shared__ __attribute__((aligned(16))) f16x8 ring[2][CH * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r16 = lane & 15;
+    const int grp = lane >> 4;
+    const long M = (long)g.B * g.Ho * g.Wo;
+    const long m_base = ((long)blockIdx.x * 4 + wave) * (MF * 16);
+
+    const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.wstream);      // zero-padded by 16 KiB on the host
+    f16x8 st0 = gsrc[tid], st1 = gsrc[tid + 256];
+    auto wfrag = [&](int fi) -> f16x8 {
+        const int c = fi / CH;
+        if (fi % CH == 0) {
+            ring[c & 1][tid] = st0;
+            ring[c & 1][tid + 256] = st1;
+            __syncthreads();
+            st0 = gsrc[(c + 1) * (CH * 64) + tid];
+            st1 = gsrc[(c + 1) * (CH * 64) + tid + 256];
+        }
+        return ring[c & 1][(fi % CH) * 64 + lane];
+    };
+
+    // per-lane pixel bases (element offsets) of the MF tiles
+    long base[MF], base2[MF];
+    int pb[MF], py[MF], px[MF];
+    bool valid[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        long m = m_base + f * 16 + r16;
+        valid[f] = m < M;
+        if (m >= M) m = M - 1;
+        px[f] = (int)(m % g.Wo);
+        const long t = m / g.Wo;
+        py[f] = (int)(t % g.Ho);
+        pb[f] = (int)(t / g.Ho);
+        base[f] = (((long)pb[f] * g.Hi + (long)py[f] * g.stride) * g.Wi + (long)px[f] * g.stride) * g.Cin + 8 * grp;
+        base2[f] = g.a2 ? (((long)pb[f] * g.H2 + (long)py[f] * g.stride + g.crop2) * g.W2 + (long)px[f] * g.stride +
+                           g.crop2) * g.Cin + 8 * grp : 0;
+    }
+    const int cpt = g.Cin >> 5;                     // 32-channel chunks per tap
+    const int ksteps = g.kh * g.kw * cpt;
+    auto load_x = [&](int ks, f16x8 (&dst)[MF]) {
+        const int tap = ks / cpt, c0 = (ks - tap * cpt) << 5;
+        const int dy = tap / g.kw, dx = tap - dy * g.kw;
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            f16x8 v = *reinterpret_cast<const f16x8 *>(g.a + base[f] + ((long)dy * g.Wi + dx) * g.Cin + c0);
+            if (g.a2) v += *reinterpret_cast<const f16x8 *>(g.a2 + base2[f] + ((long)dy * g.W2 + dx) * g.Cin + c0);
+            dst[f] = v;
+        }
+    };
+
+    f32x4 acc[NT][MF];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int f = 0; f < MF; ++f) acc[nt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f16x8 xa[MF], xb[MF];
+    load_x(0, xa);
+#pragma unroll 1
+    for (int ks = 0; ks < ksteps; ks += 2) {         // two k-steps per trip: statically named register buffers
+        if (ks + 1 < ksteps) load_x(ks + 1, xb);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f16x8 w = wfrag(ks * NT + nt);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(w, xa[f], acc[nt][f]);
+        }
+        if (ks + 1 < ksteps) {
+            if (ks + 2 < ksteps) load_x(ks + 2, xa);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f16x8 w = wfrag((ks + 1) * NT + nt);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(w, xb[f], acc[nt][f]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = nt * 16 + grp * 4;
+        const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            if (!valid[f]) continue;
+            float v[4] = {acc[nt][f][0] + bv.x, acc[nt][f][1] + bv.y, acc[nt][f][2] + bv.z, acc[nt][f][3] + bv.w};
+            if (g.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * g.slope;
+            }
+            if (g.out32) {
+                // image head: planar fp32, optional `+ crop(add32)` and clamp  (cunet.py:183-196)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + r;
+                    if (n >= g.n_real) continue;
+                    float o = v[r];
+                    if (g.add32)
+                        o += g.add32[(((long)pb[f] * g.n_real + n) * g.addH + py[f] + g.add_crop) * g.addW + px[f] + g.add_crop];
+                    if (g.clamp01) o = fminf(fmaxf(o, 0.f), 1.f);
+                    g.out32[(((long)pb[f] * g.n_real + n) * g.Ho + py[f]) * g.Wo + px[f]] = o;
+                }
+            } else if (n0 < g.n_real) {
+                const f16x4 ov = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *reinterpret_cast<f16x4 *>(g.out + (((long)pb[f] * g.Ho + py[f]) * g.Wo + px[f]) * g.n_real + n0) = ov;
+            }
+        }
+    }
+}
+
+template <int NT, int MF>
+static int launch_conv_t(const ConvArgs &g, hipStream_t s) {
+    const long M = (long)g.B * g.Ho * g.Wo;
+    const long rows = 4 * MF * 16;
+    conv_kernel<NT, MF><<<(unsigned)((M + rows - 1) / rows), 256, 0, s>>>(g);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+int launch_conv(const ConvArgs &g, hipStream_t s) {
+    NUNIF_REQUIRE(g.Cin % 32 == 0 && g.N % 16 == 0, "conv: Cin=%d N=%d not aligned", g.Cin, g.N);
+    const long M = (long)g.B * g.Ho * g.Wo;
+    if (M == 0) return NUNIF_HIP_OK;
+    const double K = (double)g.kh * g.kw * g.Cin;
+    const double flops = 2.0 * (double)M * K * g.n_real;
+    const double bytes = (double)g.B * g.Hi * g.Wi * g.Cin * 2.0 * (g.a2 ? 2.0 : 1.0) +
+                         (double)M * g.n_real * (g.out32 ? 4.0 : 2.0);
+    switch (g.N / 16) {
+        case 1: { ProfScope ps("conv_kernel<1,4>", s, flops, bytes); return launch_conv_t<1, 4>(g, s); }
+        case 2: { ProfScope ps("conv_kernel<2,4>", s, flops, bytes); return launch_conv_t<2, 4>(g, s); }
+        case 4: { ProfScope ps("conv_kernel<4,4>", s, flops, bytes); return launch_conv_t<4, 4>(g, s); }
+        case 8: { ProfScope ps("conv_kernel<8,4>", s, flops, bytes); return launch_conv_t<8, 4>(g, s); }
+        case 16: { ProfScope ps("conv_kernel<16,2>", s, flops, bytes); return launch_conv_t<16, 2>(g, s); }
+        default:
+            set_error("conv: unsupported Cout=%d", g.N);
+            return NUNIF_HIP_EUNSUPPORTED;
+    }
+}
+
+// ---- first conv of a UNet: 3 -> Cout (<= 64) 3x3 VALID + LeakyReLU on the VALU (K = 27) ---------------------------------
+// in: tile mode [B,3,T,T] fp32 or, frame mode, the frame [3,H,W] with replicate-pad + tile slicing folded in.
+__global__ void __launch_bounds__(256) c3_conv_kernel(C3ConvArgs a) {
+    extern __shared__ float sw[];   // [27][C] then bias[C]
+    const int C = a.C;
+    for (int i = threadIdx.x; i < 28 * C; i += blockDim.x) {
+        if (i < 27 * C) { const int co = i % C, t = i / C; sw[i] = a.w[co * 27 + t]; }
+        else sw[i] = a.bias[i - 27 * C];
+    }
+    __syncthreads();
+    const int S = a.T - 2;
+    const long total = (long)a.B * S * S;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % S);
+    const long t = idx / S;
+    const int y = (int)(t % S);
+    const int b = (int)(t / S);
+    float in[27];
+    if (a.frame_mode) {
+        const int k = a.tile_begin + b;
+        const int ti = k / a.wb, tj = k - ti * a.wb;
+        const int y0 = ti * a.istep - a.pad_t + y, x0 = tj * a.istep - a.pad_l + x;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int sy = min(max(y0 + ky, 0), a.H - 1), sx = min(max(x0 + kx, 0), a.W - 1);
+                    in[ci * 9 + ky * 3 + kx] = a.x[((long)ci * a.H + sy) * a.W + sx];
+                }
+    } else {
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    in[ci * 9 + ky * 3 + kx] = a.x[(((long)b * 3 + ci) * a.T + (y + ky)) * a.T + (x + kx)];
+    }
+    f16 *o = a.out + idx * C;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        f16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float acc = sw[27 * C + c0 + j];
+#pragma unroll
+            for (int t2 = 0; t2 < 27; ++t2) acc = fmaf(in[t2], sw[t2 * C + c0 + j], acc);
+            ov[j] = (f16)(acc >= 0.f ? acc : acc * a.slope);
+        }
+        *reinterpret_cast<f16x8 *>(o + c0) = ov;
+    }
+}
+
+int launch_c3_conv(const C3ConvArgs &a, hipStream_t s) {
+    NUNIF_REQUIRE(a.C % 8 == 0 && a.C <= 64 && a.T > 2, "c3_conv: bad shape");
+    const int S = a.T - 2;
+    const long total = (long)a.B * S * S;
+    ProfScope ps("c3_conv_kernel", s, 2.0 * 27 * a.C * (double)total, (double)total * (a.C * 2.0 + 12.0));
+    c3_conv_kernel<<<(unsigned)((total + 255) / 256), 256, (size_t)(28 * a.C) * sizeof(float), s>>>(a);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+// ---- squeeze-excitation: global average pool -> 1x1 -> ReLU -> 1x1 -> sigmoid -> channel scale ------------------------------
+constexpr int kSePoolBlocks = 128;
+
+// Deterministic two-stage pooling (no float atomics: the result must not depend on launch order or tile batch).
+__global__ void __launch_bounds__(256) se_pool_kernel(const f16 *__restrict__ x, float *partial, long hw, int C) {
+    // thread = (pixel lane, channel): consecutive threads read consecutive channels of one pixel (coalesced NHWC)
+    const int b = blockIdx.y;
+    const int c = threadIdx.x % C, pl = threadIdx.x / C, ppb = 256 / C;
+    const f16 *img = x + (long)b * hw * C;
+    float s = 0.f;
+    for (long p = (long)blockIdx.x * ppb + pl; p < hw; p += (long)gridDim.x * ppb) s += (float)img[p * C + c];
+    __shared__ float sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < ppb; ++k) s += sh[k * C + c];
+        partial[((long)b * kSePoolBlocks + blockIdx.x) * C + c] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+se_mlp_kernel(const float *__restrict__ partial, float *scale, const float *__restrict__ w1,
+              const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2, float inv_hw,
+              int C) {
+    __shared__ float mean[256], hid[32];
+    const int b = blockIdx.x, t = threadIdx.x, R = C / 8;
+    if (t < C) {
+        float s = 0.f;
+        for (int k = 0; k < kSePoolBlocks; ++k) s += partial[((long)b * kSePoolBlocks + k) * C + t];
+        mean[t] = s * inv_hw;
+    }
+    __syncthreads();
+    if (t < R) {
+        float a = b1[t];
+        for (int c = 0; c < C; ++c) a += w1[t * C + c] * mean[c];
+        hid[t] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    if (t < C) {
+        float a = b2[t];
+        for (int j = 0; j < R; ++j) a += w2[t * R + j] * hid[j];
+        scale[b * C + t] = 1.0f / (1.0f + __expf(-a));
+    }
+}
+
+__global__ void __launch_bounds__(256) se_scale_kernel(f16 *x, const float *__restrict__ scale, long hw, int C, long total8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;      // one f16x8 per thread
+    if (i >= total8) return;
+    const long e = i * 8;
+    const int c = (int)(e % C);
+    const int b = (int)(e / (hw * C));
+    f16x8 v = *reinterpret_cast<f16x8 *>(x + e);
+    const float *sc = scale + b * C + c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (f16)((float)v[j] * sc[j]);
+    *reinterpret_cast<f16x8 *>(x + e) = v;
+}
+
+int launch_se(f16 *x, float *sums, float *scale, const float *w1, const float *b1, const float *w2, const float *b2,
+              int B, long hw, int C, hipStream_t s) {
+    NUNIF_REQUIRE(C % 8 == 0 && C <= 256 && 256 % C == 0, "se: C=%d unsupported", C);
+    ProfScope ps("se_block", s, 0.0, (double)B * hw * C * 2.0 * 3.0);
+    dim3 g1(kSePoolBlocks, B);                    // sums: [B][kSePoolBlocks][C] partials
+    se_pool_kernel<<<g1, 256, 0, s>>>(x, sums, hw, C);
+    se_mlp_kernel<<<B, 256, 0, s>>>(sums, scale, w1, b1, w2, b2, 1.0f / (float)hw, C);
+    const long total8 = (long)B * hw * C / 8;
+    se_scale_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, s>>>(x, scale, hw, C, total8);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+}  // namespace nunif

@@ -62,4 +62,36 @@ int launch_qkv_attn_w(const f16 *x, f16 *att, const f16 *wstream, const float *b
 int launch_window_attn(const f16 *qkv, f16 *out, const float *bias, int B, int H, int W, int heads, int hd,
                        int shift, hipStream_t s);
 
+// ---- CUNet kernels (cunet_kernels.hip) ---------------------------------------------------------------------------------
+// K-looped implicit-GEMM conv, NHWC fp16.  Output pixel (y,x), tap (dy,dx) reads a[(y*stride+dy), (x*stride+dx)];
+// optional second input a2 is added element-wise at (y*stride+dy+crop2, x*stride+dx+crop2) (the cropped U-Net skip).
+struct ConvArgs {
+    const f16 *a; const f16 *a2;
+    int H2, W2, crop2;
+    int B, Hi, Wi, Cin, Ho, Wo, stride, kh, kw;
+    const f16 *wstream;       // fragments in [k-step][n-tile] order, k = tap*Cin + ci, zero-padded by 16 KiB
+    const float *bias;        // [N]
+    int N, n_real;
+    int act; float slope;     // 0 none, 2 LeakyReLU
+    f16 *out;                 // NHWC [B,Ho,Wo,n_real] (when out32 == NULL)
+    float *out32;             // image head: planar fp32 [B,n_real,Ho,Wo]
+    const float *add32; int addH, addW, add_crop;   // optional + add32[b][n][y+add_crop][x+add_crop]
+    int clamp01;
+};
+int launch_conv(const ConvArgs &g, hipStream_t s);
+
+struct C3ConvArgs {
+    const float *x; int frame_mode, H, W, wb, istep, pad_t, pad_l, tile_begin;
+    int B, T;                 // tile mode input [B,3,T,T]; output [B,T-2,T-2,C]
+    const float *w, *bias;    // [C][3][3][3], [C]
+    int C;
+    f16 *out;
+    float slope;
+};
+int launch_c3_conv(const C3ConvArgs &a, hipStream_t s);
+
+// x[b,:,:,c] *= sigmoid(W2 relu(W1 mean_hw(x[b]) + b1) + b2)   (nunif/modules/attention.py SEBlock :29-44)
+int launch_se(f16 *x, float *sums, float *scale, const float *w1, const float *b1, const float *w2, const float *b2,
+              int B, long hw, int C, hipStream_t s);
+
 }  // namespace nunif

@@ -161,10 +161,13 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
     const double bytes = (double)M * (g.Cin * 2.0 * (g.K / g.Cin > 1 ? 1.0 : 1.0) + g.n_real * (g.mode == 2 ? 4.0 : 2.0) +
                                       (g.res ? g.n_real * 2.0 : 0.0));
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
-    const char *sym = g.K == 96 ? "gemm_kernel<3,4>" : g.K == 192 ? "gemm_kernel<6,4>" : g.K == 384 ? "gemm_kernel<12,2>"
+    const char *sym = g.K == 64 ? "gemm_kernel<2,4>" : g.K == 128 ? "gemm_kernel<4,4>" : g.K == 96 ? "gemm_kernel<3,4>"
+                    : g.K == 192 ? "gemm_kernel<6,4>" : g.K == 384 ? "gemm_kernel<12,2>"
                     : g.K == 576 ? "gemm_kernel<18,2>" : "gemm_kernel<24,1>";
     ProfScope ps(sym, s, flops, bytes);
     switch (g.K / 32) {
+        case 2: return launch_gemm_t<2, 4>(g, s);
+        case 4: return launch_gemm_t<4, 4>(g, s);
         case 3: return launch_gemm_t<3, 4>(g, s);
         case 6: return launch_gemm_t<6, 4>(g, s);
         case 12: return launch_gemm_t<12, 2>(g, s);

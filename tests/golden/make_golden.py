@@ -129,7 +129,26 @@ def gen_iw3():
     save("iw3", **out)
 
 
-GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3}
+def gen_cunet():
+    from waifu2x.models.cunet import CUNet
+    from nunif.utils.render import tiled_render
+    from oracle import cunet as OC
+    out = {}
+    sd = OC.random_state_dict(201, up=False)
+    m = CUNet().eval()
+    m.load_state_dict(sd, strict=True)
+    x = torch.stack([synth_image(51, 3, 96, 96), synth_image(52, 3, 96, 96)])
+    out["x"], out["y"], out["sdsum"] = x, m(x), sd_checksum(sd)
+    m2 = CUNet(no_clip=True).eval()
+    m2.load_state_dict(sd, strict=True)
+    out["y_no_clip"] = m2(x[:1])
+    img = synth_image(53, 3, 150, 170)          # 3x3 tiles of 96 (step 40), plain-overwrite stitch
+    out["img"] = img
+    out["render_t96_b4"] = tiled_render(img, m, tile_size=96, batch_size=4)
+    save("cunet", **out)
+
+
+GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -1,0 +1,76 @@
+"""CUNet: oracle vs the reference fixture (CPU) and HIP engine vs oracle / fixture (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, psnr, sd_checksum, synth_image
+from oracle import cunet as OC
+from oracle import seam_blending as OS
+
+
+@pytest.fixture(scope="module")
+def g():
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "cunet.npz")).items()}
+
+
+def test_oracle_matches_reference_fixture(g):
+    sd = OC.random_state_dict(201)
+    assert sd_checksum(sd) == pytest.approx(float(g["sdsum"]), rel=1e-12)
+    y = OC.model_forward(sd, g["x"])
+    assert y.shape == g["y"].shape == (2, 3, 40, 40) and (y - g["y"]).abs().max().item() < 1e-5
+    assert (OC.model_forward(sd, g["x"][:1], no_clip=True) - g["y_no_clip"]).abs().max().item() < 1e-5
+    out = OS.tiled_render(g["img"], lambda mb: OC.model_forward(sd, mb), 1, 28, 0, 96, 4)
+    assert out.shape == g["render_t96_b4"].shape and (out - g["render_t96_b4"]).abs().max().item() < 1e-5
+    assert 0.05 < g["y"].std().item() < 0.4 and float((g["y"] <= 0).float().mean()) < 0.15
+
+
+def test_geometry():
+    assert OC.GEOMETRY["waifu2x.cunet"] == (1, 28, 0)
+    assert [t for t in range(60, 80) if OC.valid_tile_size(t)] == [60, 64, 68, 72, 76]
+    cfg = OS.create_config(512, 512, 1, 28, 256, 0)
+    assert (cfg["h_blocks"], cfg["w_blocks"], cfg["input_tile_step"], cfg["pad"]) == (3, 3, 200, (28, 116, 28, 116))
+
+
+@pytest.mark.gpu
+def test_hip_forward_and_render(hiplib, g):
+    from nunif_amd.waifu2x.models.cunet import CUNet
+    from nunif_amd.nunif.utils.render import tiled_render
+    sd = OC.random_state_dict(201)
+    m = CUNet().eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda:0")
+    assert (m.i2i_scale, m.i2i_offset, m.i2i_blend_size) == (1, 28, None)
+    y = m(g["x"].to("cuda:0")).cpu()
+    assert y.shape == g["y"].shape and float(y.min()) >= 0 and float(y.max()) <= 1
+    assert psnr(y, g["y"]) >= 50.0, psnr(y, g["y"])            # vs the reference's own output
+    y1 = m(g["x"][1:2].to("cuda:0")).cpu()
+    assert torch.equal(y1, y[1:2]), "result depends on the minibatch (SE pooling must stay per tile)"
+    out = tiled_render(g["img"], m, tile_size=96, batch_size=4)
+    assert psnr(out.cpu(), g["render_t96_b4"]) >= 50.0
+    assert torch.equal(out, tiled_render(g["img"], m, tile_size=96, batch_size=9))
+    m2 = CUNet(no_clip=True).eval()
+    m2.load_state_dict(sd)
+    assert psnr(m2.to("cuda:0")(g["x"][:1].to("cuda:0")).cpu(), g["y_no_clip"]) >= 50.0
+
+
+@pytest.mark.gpu
+def test_hip_config1_512_tile256(hiplib):
+    """BASELINE config 1 geometry: cunet on a 512x512 image, tile 256 (9 tiles); oracle on the full image is ~10 s
+    of CPU, so compare one tile's interior and check determinism / range / shape for the frame."""
+    from nunif_amd.waifu2x.models.cunet import CUNet
+    from nunif_amd.nunif.utils.render import tiled_render
+    sd = OC.random_state_dict(202)
+    m = CUNet().eval()
+    m.load_state_dict(sd)
+    m = m.to("cuda:0")
+    img = synth_image(61, 3, 512, 512)
+    out = tiled_render(img, m, tile_size=256, batch_size=4)
+    assert out.shape == (3, 512, 512) and torch.equal(out, tiled_render(img, m, tile_size=256, batch_size=9))
+    cfg = OS.create_config(512, 512, 1, 28, 256, 0)
+    xp = torch.nn.functional.pad(img[None], cfg["pad"], mode="replicate")[0]
+    z = OC.model_forward(sd, xp[:, 200:456, 200:456][None])[0]        # tile (1,1) -> output [200:400)
+    assert psnr(out[:, 200:400, 200:400].cpu(), z) >= 50.0
+    with pytest.raises(Exception):
+        m(torch.rand(1, 3, 62, 62).to("cuda:0"))                     # not a multiple of 4
