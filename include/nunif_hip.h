@@ -155,6 +155,22 @@ int nunif_hip_dilate_edge(const float *x, float *y, float *work, int32_t B, int3
  * min/max, i.e. EMA off).  minmax: [B,2] device scratch that receives the order-keyed min/max. */
 int nunif_hip_minmax_normalize(const float *x, float *y, float *minmax, int32_t B, int64_t n_per, void *stream);
 
+/* Frame edge.  frame: HWC [H,W,3] uint8 (bits=8) or uint16 (bits=16) device memory.
+ * frame_to_tensor replaces nunif/utils/video.py to_tensor :218-223 (x.permute(2,0,1) / iinfo.max).
+ * stereo_to_frame fuses iw3/utils.py postprocess_image :468-479 (cat + clamp) with video.py from_tensor :236-245
+ * ((x*max).round().to(uint)); layout 0 = left|right, 1 = right|left (cross-eyed), 2 = left over right (top-bottom).
+ * stereo_compose is the same composition with a planar fp32 result [3,Ho,Wo]. */
+int nunif_hip_frame_to_tensor(const void *frame, float *chw, int32_t H, int32_t W, int32_t bits, void *stream);
+int nunif_hip_stereo_to_frame(const float *left, const float *right, void *frame, int32_t H, int32_t W,
+                              int32_t layout, int32_t bits, void *stream);
+int nunif_hip_stereo_compose(const float *left, const float *right, float *out, int32_t H, int32_t W,
+                             int32_t layout, void *stream);
+
+/* Pointwise depth -> disparity mappers of iw3/mapper.py :7-118.  kind: 0 identity, 1 pow2, 2 softplus01_legacy(c=p0),
+ * 3 softplus01(bias=p0, scale=p1), 4 inv_softplus01(bias=p0, scale=p1), 5 distance_to_disparity(c=p0),
+ * 6 shift_relative_depth(min_distance=p0, max_distance=p1). */
+int nunif_hip_map_depth(const float *x, float *y, int64_t n, int32_t kind, double p0, double p1, void *stream);
+
 /* Test hooks (tests/ only): snapshot every stage's NHWC fp16 output during the next forward calls, then read
  * them back one by one (returns 1 past the last tap).  Names match oracle.swin_unet.unet_forward(taps=...). */
 int nunif_hip_swin_unet_debug_taps(nunif_swin_unet *handle, int32_t enable);

@@ -72,6 +72,10 @@ SIGNATURES = {
                             [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
     "nunif_hip_dilate_edge": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
     "nunif_hip_minmax_normalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "nunif_hip_frame_to_tensor": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_stereo_to_frame": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_stereo_compose": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_map_depth": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_double, c_double, c_void_p]),
     "nunif_hip_swin_unet_debug_taps": (c_int32, [c_void_p, c_int32]),
     "nunif_hip_swin_unet_get_tap": (c_int32, [c_void_p, c_int32, c_char_p, c_int32, c_void_p, c_int64,
                                               ctypes.POINTER(c_int64)]),

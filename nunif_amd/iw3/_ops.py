@@ -93,3 +93,56 @@ def backward_warp(c, depth, divergence, convergence, synthetic_view):
                                                       float(divergence), float(convergence), view,
                                                       _hip.current_stream_ptr(c.device)))
     return left, right
+
+
+def frame_to_tensor(frame_hwc):
+    """uint8 / int32-held-uint16 HWC [H,W,3] on the device -> CHW float (VU.to_tensor, video.py:218-223)."""
+    if frame_hwc.device.type != "cuda":
+        raise RuntimeError("frame_to_tensor: tensor must live on a ROCm device; there is no CPU fallback")
+    assert frame_hwc.dim() == 3 and frame_hwc.shape[2] == 3
+    if frame_hwc.dtype == torch.uint8:
+        bits, src = 8, frame_hwc.contiguous()
+    elif frame_hwc.dtype in (torch.int16, torch.uint16):
+        bits, src = 16, frame_hwc.contiguous()
+    else:
+        raise ValueError(f"unsupported frame dtype {frame_hwc.dtype}")
+    h, w, _ = src.shape
+    out = torch.empty((3, h, w), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _hip.check(_hip.lib().nunif_hip_frame_to_tensor(_p(src), _p(out), h, w, bits, _hip.current_stream_ptr(src.device)))
+    return out
+
+
+LAYOUT = {"sbs": 0, "cross_eyed": 1, "tb": 2}
+
+
+def stereo_to_frame(left, right, layout="sbs", bits=8):
+    """clamp(cat(left,right)) quantised to HWC uint8 (or uint16 stored as int16 bit pattern) in one pass."""
+    left, right = _cuda_f32(left, "stereo_to_frame"), _cuda_f32(right, "stereo_to_frame")
+    _, h, w = left.shape
+    ho, wo = (2 * h, w) if layout == "tb" else (h, 2 * w)
+    out = torch.empty((ho, wo, 3), dtype=torch.uint8 if bits == 8 else torch.int16, device=left.device)
+    with torch.cuda.device(left.device):
+        _hip.check(_hip.lib().nunif_hip_stereo_to_frame(_p(left), _p(right), _p(out), h, w, LAYOUT[layout], bits,
+                                                        _hip.current_stream_ptr(left.device)))
+    return out
+
+
+def stereo_compose(left, right, layout="sbs"):
+    left, right = _cuda_f32(left, "stereo_compose"), _cuda_f32(right, "stereo_compose")
+    _, h, w = left.shape
+    ho, wo = (2 * h, w) if layout == "tb" else (h, 2 * w)
+    out = torch.empty((3, ho, wo), dtype=torch.float32, device=left.device)
+    with torch.cuda.device(left.device):
+        _hip.check(_hip.lib().nunif_hip_stereo_compose(_p(left), _p(right), _p(out), h, w, LAYOUT[layout],
+                                                       _hip.current_stream_ptr(left.device)))
+    return out
+
+
+def map_depth(x, kind, p0=0.0, p1=0.0):
+    x = _cuda_f32(x, "map_depth")
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_map_depth(_p(x), _p(y), x.numel(), kind, float(p0), float(p1),
+                                                  _hip.current_stream_ptr(x.device)))
+    return y

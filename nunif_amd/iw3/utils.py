@@ -1,0 +1,97 @@
+"""Per-frame stereo glue on the HIP engine.  Mirrors the hot-path functions of ``iw3/utils.py`` (reference):
+``apply_divergence`` :292-391 (mapper + method dispatch; forward / forward_fill / grid_sample / backward / NULL),
+``postprocess_image`` :430-487 (IPD pad, half-SBS / half-TB bicubic-antialias resize, SBS / TB / cross-eyed compose,
+max-output resize) and ``nunif/utils/video.py`` ``to_tensor`` / ``to_frame`` :218-269 (``to_frame_tensor`` here returns
+the quantised HWC tensor; wrapping it into an ``av.VideoFrame`` is the caller's codec business).
+NN side-model methods (row_flow / mlbw / inpaint), anaglyph and VR180 projection are "next" rows."""
+import torch
+import torch.nn.functional as F
+
+from . import _ops
+from .backward_warp import apply_divergence_grid_sample
+from .forward_warp import apply_divergence_forward_warp
+from .mapper import get_mapper
+
+
+def apply_divergence(depth, im, args, side_model=None, reset_pts=None):
+    batch = depth.ndim == 4
+    if not batch:
+        depth, im = depth.unsqueeze(0), im.unsqueeze(0)
+    depth = get_mapper(args.mapper)(depth)
+    convergence = args.convergence
+    if args.method == "NULL":
+        left, right = im.clone(), im.clone()
+    elif args.method in {"grid_sample", "backward"}:
+        left, right = apply_divergence_grid_sample(im, depth, args.divergence, convergence=convergence,
+                                                   synthetic_view=args.synthetic_view)
+    elif args.method in {"forward", "forward_fill"}:
+        left, right = apply_divergence_forward_warp(im, depth, args.divergence, convergence=convergence,
+                                                    method=args.method, synthetic_view=args.synthetic_view,
+                                                    width_base=False)
+    else:
+        raise NotImplementedError(f"method={args.method}: NN side models are not on the HIP engine yet")
+    if not batch:
+        left, right = left.squeeze(0), right.squeeze(0)
+    return left, right
+
+
+def _zero_pad(x, left, top, right, bottom):
+    return F.pad(x, (left, right, top, bottom), mode="constant", value=0.0)
+
+
+def postprocess_image(left_eye, right_eye, args):
+    """CHW, CHW -> CHW float in [0,1]."""
+    g = lambda k, d=None: getattr(args, k, d)     # noqa: E731
+    for unsupported in ("vr180", "anaglyph", "rgbd", "half_rgbd"):
+        if g(unsupported):
+            raise NotImplementedError(f"--{unsupported} is not on the HIP engine yet")
+    ipd_pad = int(abs(g("ipd_offset", 0)) * 0.01 * max(left_eye.shape[-2:]))
+    ipd_pad -= ipd_pad % 2
+    if ipd_pad > 0:
+        pad_o, pad_i = (ipd_pad * 2, ipd_pad) if g("ipd_offset", 0) > 0 else (ipd_pad, ipd_pad * 2)
+        left_eye = _zero_pad(left_eye, pad_o, 0, pad_i, 0)
+        right_eye = _zero_pad(right_eye, pad_i, 0, pad_o, 0)
+    if g("pad") is not None or g("pad_mode") == "16:9":
+        raise NotImplementedError("--pad / --pad-mode is not on the HIP engine yet")
+    if g("half_sbs"):
+        size = (left_eye.shape[1], left_eye.shape[2] // 2)
+        left_eye, right_eye = (_ops.resize_aa(e.unsqueeze(0), size, mode="bicubic")[0] for e in (left_eye, right_eye))
+    elif g("half_tb"):
+        size = (left_eye.shape[1] // 2, left_eye.shape[2])
+        left_eye, right_eye = (_ops.resize_aa(e.unsqueeze(0), size, mode="bicubic")[0] for e in (left_eye, right_eye))
+    layout = "tb" if (g("tb") or g("half_tb")) else ("cross_eyed" if g("cross_eyed") else "sbs")
+    sbs = _ops.stereo_compose(left_eye, right_eye, layout)
+    h, w = sbs.shape[1:]
+    new_w, new_h = w, h
+    if g("max_output_height") is not None and new_h > args.max_output_height:
+        if g("keep_aspect_ratio"):
+            new_w = int(args.max_output_height / new_h * new_w)
+        new_h = args.max_output_height
+    if g("max_output_width") is not None and new_w > args.max_output_width:
+        if g("keep_aspect_ratio"):
+            new_h = int(args.max_output_width / new_w * new_h)
+        new_w = args.max_output_width
+    if new_w != w or new_h != h:
+        new_h -= new_h % 2
+        new_w -= new_w % 2
+        sbs = _ops.resize_aa(sbs.unsqueeze(0), (new_h, new_w), mode="bicubic", clamp01=True)[0]
+    return sbs
+
+
+def to_tensor(frame_hwc, device=None):
+    """uint8/uint16 HWC (numpy array or tensor) -> CHW float on the device (video.py:218-223)."""
+    if not torch.is_tensor(frame_hwc):
+        import numpy as np
+        arr = np.ascontiguousarray(frame_hwc)
+        frame_hwc = torch.from_numpy(arr.view(np.int16) if arr.dtype == np.uint16 else arr)
+    if device is not None:
+        frame_hwc = frame_hwc.to(device)
+    return _ops.frame_to_tensor(frame_hwc)
+
+
+def to_frame_tensor(x, use_16bit=False):
+    """CHW float -> HWC uint8 (or uint16 bit pattern in int16), (x*max).round() like video.py:236-245."""
+    # the stereo kernel with the top half of a top-bottom layout == clamp + quantise of `x` (video frames normally
+    # leave through stereo_to_frame directly, which fuses the SBS compose as well)
+    h = x.shape[1]
+    return _ops.stereo_to_frame(x, x, "tb", 16 if use_16bit else 8)[:h]
