@@ -50,8 +50,13 @@ __device__ __forceinline__ void bilinear_target(float depth, float sgn, float sh
 }
 
 constexpr int kMaxTries = 100;
+// 1024 threads per row: the winner gathers in the combine phase are dependent global loads (depth, then colour of
+// the winning source); with 256 threads each lane ran ~8 of those round trips back to back (measured 472 us for two
+// 1080p frames = 4 % of HBM; 238 us with 1024).  Staging the source row in LDS instead was measured SLOWER (314 us):
+// 101 KiB of LDS per row halves the resident workgroups.
+constexpr int kWarpThreads = 1024;
 
-__global__ void __launch_bounds__(256) forward_warp_kernel(FwdWarpArgs a) {
+__global__ void __launch_bounds__(1024) forward_warp_kernel(FwdWarpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = a.W, pad = a.pad, Wp = W + 2 * pad;
     unsigned long long *kf = reinterpret_cast<unsigned long long *>(smem);   // [Wp] floor winners
@@ -69,10 +74,10 @@ __global__ void __launch_bounds__(256) forward_warp_kernel(FwdWarpArgs a) {
     for (int eye = 0; eye < 2; ++eye) {
         if (a.out[eye] == nullptr) continue;
         const float sgn = eye == 0 ? 1.0f : -1.0f;
-        for (int x = tid; x < Wp; x += 256) { kf[x] = 0ull; kc[x] = 0ull; }
+        for (int x = tid; x < Wp; x += kWarpThreads) { kf[x] = 0ull; kc[x] = 0ull; }
         __syncthreads();
         // ---- splat: z-test per destination ---------------------------------------------------------------------------
-        for (int xs = tid; xs < Wp; xs += 256) {
+        for (int xs = tid; xs < Wp; xs += kWarpThreads) {
             const float d = drow[min(max(xs - pad, 0), W - 1)];
             int fl, ce; float fw, cw;
             bilinear_target(d, sgn, a.shift_size, a.shift_conv, xs, Wp, fl, ce, fw, cw);
@@ -82,7 +87,7 @@ __global__ void __launch_bounds__(256) forward_warp_kernel(FwdWarpArgs a) {
         }
         __syncthreads();
         // ---- combine the two winners of every destination inside the un-padded region -----------------------------------
-        for (int j = tid; j < W; j += 256) {
+        for (int j = tid; j < W; j += kWarpThreads) {
             const int xd = j + pad;
             const int sf = (int)(unsigned int)(kf[xd] & 0xffffffffull) - 1;
             const int sc = (int)(unsigned int)(kc[xd] & 0xffffffffull) - 1;
@@ -114,7 +119,7 @@ __global__ void __launch_bounds__(256) forward_warp_kernel(FwdWarpArgs a) {
         __syncthreads();
         // ---- shift_fill on the index row: left eye takes from the left, right eye from the right ---------------------------
         const int dir = eye == 0 ? -1 : 1;
-        for (int j = tid; j < W; j += 256) {
+        for (int j = tid; j < W; j += kWarpThreads) {
             float v = idx[j];
             if (v < 0.f) {
                 for (int k = 1; k <= kMaxTries; ++k) {
@@ -127,7 +132,7 @@ __global__ void __launch_bounds__(256) forward_warp_kernel(FwdWarpArgs a) {
         }
         __syncthreads();
         // ---- fix_layered_holes: windowed running min (left) / max (right) of the index; changed pixels become -2 ------------
-        for (int j = tid; j < W; j += 256) {
+        for (int j = tid; j < W; j += kWarpThreads) {
             const float v0 = idx2[j];
             float m = v0;
             if (eye == 0) {
@@ -143,7 +148,7 @@ __global__ void __launch_bounds__(256) forward_warp_kernel(FwdWarpArgs a) {
         // ---- mask, then fill or clamp, straight to HBM -------------------------------------------------------------------------
         float *orow = a.out[eye] + ((long)b * 3 * a.H + y) * W;
         float *mrow = a.mask[eye] ? a.mask[eye] + (long)row * W : nullptr;
-        for (int j = tid; j < W; j += 256) {
+        for (int j = tid; j < W; j += kWarpThreads) {
             if (mrow) {
                 const float v = img[j];
                 mrow[j] = v == -1.f ? 1.0f : (v == -2.f ? 0.5f : 0.0f);
@@ -280,7 +285,7 @@ extern "C" int nunif_hip_forward_warp(const float *c, const float *depth, float 
     const double px = (double)p->B * p->H * p->W;
     const int eyes = (a.out[0] ? 1 : 0) + (a.out[1] ? 1 : 0);
     ProfScope ps("forward_warp", s, 0.0, px * (16.0 + 12.0 * eyes));
-    forward_warp_kernel<<<p->B * p->H, 256, smem, s>>>(a);
+    forward_warp_kernel<<<p->B * p->H, kWarpThreads, smem, s>>>(a);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
