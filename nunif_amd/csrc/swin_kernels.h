@@ -53,6 +53,9 @@ int launch_qkv_attn(const f16 *x, f16 *att, const f16 *wqkv, const float *bqkv, 
 // ---- fused qkv Linear + window attention, one window per wave, C = 96 or 192 (swin_qkv_attn_w.hip) ----------------
 // wstream: per head Wq | Wk | Wv fragments in consumption order (assembled in make_stage, swin_unet.cpp)
 int qkv_attn_w_stream_frags(int C);
+// ---- same, qkv weights resident in LDS, no barrier in the window loop (swin_qkv_attn_r.hip) -------------------------
+int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, int B, int H, int W,
+                      int C, int heads, int shift, hipStream_t s);
 int launch_qkv_attn_w(const f16 *x, f16 *att, const f16 *wstream, const float *bqkv, const float *bias, int B, int H,
                       int W, int C, int heads, int shift, hipStream_t s);
 

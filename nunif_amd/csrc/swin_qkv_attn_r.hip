@@ -1,0 +1,288 @@
+// Fused qkv projection + (shifted) 6x6 window attention with the qkv weights RESIDENT in LDS, for gfx950.
+//
+// Replaces torchvision shifted_window_attention steps 2-7 (roll, window partition, qkv Linear,
+// q*scale, QK^T + relative-position bias + shift mask, softmax, PV), called from waifu2x/models/swin_unet.py:26-36.
+//
+// Same math and register dataflow as swin_qkv_attn_w.hip (one window per wave, everything after the GEMM in registers,
+// bias / padding / shift-region masks folded into the score MFMA).  What changed, and why (measured):
+// the ring version needs one workgroup barrier per 8 weight fragments, which keeps the two waves of a SIMD in lock
+// step — both in their MFMA phase or both in their softmax (VALU) phase — and 40 % of the wave cycles were waits.
+// 160 KB of LDS per CU holds the whole packed Wqkv of C = 96 (54 KiB) and half of the heads of C = 192 (108 KiB), so
+// here a persistent 8-wave workgroup copies the weights once (per pass of HPP heads), and the window loop has NO
+// barrier: waves drift apart and one wave's exp/convert work overlaps the other's MFMAs.
+//   * q weights / bias are pre-multiplied by head_dim^-0.5 * log2(e) on the host and the bias table by log2(e):
+//     softmax = exp2(s - max) with a bare v_exp_f32, no multiply;
+//   * the qkv biases initialise the accumulators (no epilogue add);
+//   * the window-invariant one-hot key fragments are built once per wave;
+//   * C = 96 prefetches the next window's x while the current one is computed.
+#include "swin_kernels.h"
+
+namespace nunif {
+
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int kWavesR = 8;
+// the "real key" column 36 of the bias table carries 1000: padded keys end up 1000 (log2 units) below every real one
+constexpr float kRegionR = 100.0f;     // added where query and key share a shift region
+
+struct QkvAttnRArgs {
+    const f16 *x;            // [B,H,W,C]
+    f16 *att;                // [B,H,W,C]
+    const f16 *wres;         // per head: Wq tiles, Wk tiles, Wv tiles, each (nt, ks) fragment-major; q pre-scaled
+    const float *bqkv;       // [3C], q part pre-scaled
+    const f16 *btab;         // [heads][36][48] fp16: log2e * relative-position bias, col 36 = BIG, cols 37.. = 0
+    int B, H, W, shift, n_windows;
+};
+
+__device__ __forceinline__ f16x8 cat8r(f16x4 lo, f16x4 hi) {
+    return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int C, int HD, int HPP, bool PREFETCH>
+__global__ void __launch_bounds__(512)
+qkv_attn_r_kernel(QkvAttnRArgs a) {
+    constexpr int KS = C / 32;
+    constexpr int HEADS = C / HD;
+    constexpr int NTH = HD / 16;                      // 16-row weight tiles per head for each of q, k, v
+    constexpr int FPH = 3 * NTH * KS;                 // weight fragments (KiB) per head
+    constexpr int PASSES = HEADS / HPP;
+    static_assert(HEADS == 6 && HEADS % HPP == 0, "swin_unet uses 6 heads at every level");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+    f16x8 *wl = reinterpret_cast<f16x8 *>(smem_r);                                   // [HPP*FPH][64]
+    f16 *bt = reinterpret_cast<f16 *>(wl + HPP * FPH * 64);                          // [HEADS][36][48]
+    float *bl = reinterpret_cast<float *>(bt + HEADS * 36 * 48);                     // [3C]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r16 = lane & 15;
+    const int grp = lane >> 4;
+    const int nwx = a.W / 6, nwy = a.H / 6;
+    const f16x4 zero4 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+
+    for (int i = tid; i < HEADS * 36 * 48 / 8; i += 512)
+        reinterpret_cast<f16x8 *>(bt)[i] = reinterpret_cast<const f16x8 *>(a.btab)[i];
+    for (int i = tid; i < 3 * C; i += 512) bl[i] = a.bqkv[i];
+
+    // window-invariant part of the key-side one-hot fragments (cols < 36: k_loc == col; col 36: real key)
+    f16x4 rk[3][3];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+        const int tok = 16 * mt + r16;
+#pragma unroll
+        for (int js = 0; js < 3; ++js)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 16 * js + 4 * grp + j;
+                const bool one = col < 36 ? tok == col : (col == 36 ? tok < 36 : false);
+                rk[mt][js][j] = (f16)(one ? 1.f : 0.f);
+            }
+    }
+
+    auto pix_of = [&](int wi, int t) -> long {       // window-local token -> pixel of the un-rolled map
+        const int wx = wi % nwx, t2 = wi / nwx;
+        const int wy = t2 % nwy, b = t2 / nwy;
+        t = min(t, 35);
+        const int iy = t / 6, ix = t - 6 * iy;
+        int yy = wy * 6 + iy + a.shift, xx = wx * 6 + ix + a.shift;
+        if (yy >= a.H) yy -= a.H;
+        if (xx >= a.W) xx -= a.W;
+        return ((long)b * a.H + yy) * a.W + xx;
+    };
+    auto load_x = [&](int wi, f16x8 (&xf)[3][KS], long (&pix)[3]) {
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+            pix[mt] = pix_of(wi, 16 * mt + r16);
+            const f16 *p = a.x + pix[mt] * C + 8 * grp;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = *reinterpret_cast<const f16x8 *>(p + 32 * ks);
+        }
+    };
+
+    const int wstride = kWavesR * gridDim.x;
+    const int w0 = blockIdx.x * kWavesR + wave;
+
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (pass > 0) __syncthreads();                    // every wave is done with the previous pass' weights
+        {
+            const f16x8 *src = reinterpret_cast<const f16x8 *>(a.wres) + (long)pass * HPP * FPH * 64;
+            for (int i = tid; i < HPP * FPH * 64; i += 512) wl[i] = src[i];
+        }
+        __syncthreads();
+
+        f16x8 xf[3][KS];
+        long pix[3];
+        if (w0 < a.n_windows) load_x(w0, xf, pix);
+
+#pragma unroll 1
+        for (int wi = w0; wi < a.n_windows; wi += wstride) {
+            f16x8 xn[PREFETCH ? 3 : 1][PREFETCH ? KS : 1];
+            long pixn[3];
+            if constexpr (PREFETCH) {
+                const int wnext = wi + wstride < a.n_windows ? wi + wstride : wi;
+                load_x(wnext, xn, pixn);
+            }
+            // shift regions of this window (only the last window row / column straddles two regions)
+            f16x4 rkr[3], rqr[3];
+            {
+                const int wx = wi % nwx, wy = (wi / nwx) % nwy;
+                const bool last_y = a.shift > 0 && wy == nwy - 1, last_x = a.shift > 0 && wx == nwx - 1;
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) {
+                    const int t = min(16 * mt + r16, 35);
+                    const int iy = t / 6, ix = t - 6 * iy;
+                    const int reg = ((last_y && iy >= 3) ? 2 : 0) + ((last_x && ix >= 3) ? 1 : 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool on = a.shift > 0 && grp == 2 && reg == j;       // cols 40..43 live in lane group 2
+                        rkr[mt][j] = (f16)(on ? 1.f : 0.f);
+                        rqr[mt][j] = (f16)(on ? kRegionR : 0.f);
+                    }
+                }
+            }
+
+#pragma unroll 1
+            for (int hl = 0; hl < HPP; ++hl) {
+                const int head = pass * HPP + hl;
+                const f16x8 *wh = wl + (hl * FPH) * 64 + lane;
+                // ---- q, k (channels x tokens) and v (tokens x channels: operands swapped) of this head ----------------
+                f16x4 qt4[NTH][3], kt4[NTH][3], vt4[NTH][3];
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                    for (int nt = 0; nt < NTH; ++nt) {
+                        const int ch0 = part * C + head * HD + nt * 16;
+                        f32x4 acc[3];
+                        if (part == 2) {
+                            const float bv = bl[ch0 + r16];
+#pragma unroll
+                            for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){bv, bv, bv, bv};
+                        } else {
+                            const f32x4 bb = *reinterpret_cast<const f32x4 *>(bl + ch0 + 4 * grp);
+#pragma unroll
+                            for (int mt = 0; mt < 3; ++mt) acc[mt] = bb;
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const f16x8 w = wh[((part * NTH + nt) * KS + ks) * 64];
+#pragma unroll
+                            for (int mt = 0; mt < 3; ++mt)
+                                acc[mt] = part == 2 ? MFMA_16x16x32(xf[mt][ks], w, acc[mt]) : MFMA_16x16x32(w, xf[mt][ks], acc[mt]);
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt) {
+                            const f16x4 v = {(f16)acc[mt][0], (f16)acc[mt][1], (f16)acc[mt][2], (f16)acc[mt][3]};
+                            if (part == 0) qt4[nt][mt] = v; else if (part == 1) kt4[nt][mt] = v; else vt4[nt][mt] = v;
+                        }
+                    }
+                }
+
+                // ---- attention of this head: 3 q tiles x 3 key tiles ---------------------------------------------------
+#pragma unroll
+                for (int qt = 0; qt < 3; ++qt) {
+                    const int tokq = min(16 * qt + r16, 35);
+                    const f16 *brow = &bt[(head * 36 + tokq) * 48];
+                    const f16x4 rq0 = *reinterpret_cast<const f16x4 *>(brow + 4 * grp);
+                    const f16x4 rq1 = *reinterpret_cast<const f16x4 *>(brow + 16 + 4 * grp);
+                    const f16x4 rq2 = *reinterpret_cast<const f16x4 *>(brow + 32 + 4 * grp) + rqr[qt];
+                    f32x4 s[3];
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int kt = 0; kt < 3; ++kt) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        const f16x4 rk2 = rk[kt][2] + rkr[kt];
+                        if constexpr (HD == 16) {
+                            acc = MFMA_16x16x32(cat8r(kt4[0][kt], rk[kt][0]), cat8r(qt4[0][qt], rq0), acc);
+                            acc = MFMA_16x16x32(cat8r(rk[kt][1], rk2), cat8r(rq1, rq2), acc);
+                        } else {
+                            acc = MFMA_16x16x32(cat8r(kt4[0][kt], kt4[1][kt]), cat8r(qt4[0][qt], qt4[1][qt]), acc);
+                            acc = MFMA_16x16x32(cat8r(rk[kt][0], rk[kt][1]), cat8r(rq0, rq1), acc);
+                            acc = MFMA_16x16x32(cat8r(rk2, zero4), cat8r(rq2, zero4), acc);
+                        }
+                        s[kt] = acc;
+                        mx = fmaxf(mx, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+                    }
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    float sum = 0.f;
+                    f16x4 pf[3];
+#pragma unroll
+                    for (int kt = 0; kt < 3; ++kt) {
+                        const float p0 = __builtin_amdgcn_exp2f(s[kt][0] - mx), p1 = __builtin_amdgcn_exp2f(s[kt][1] - mx);
+                        const float p2 = __builtin_amdgcn_exp2f(s[kt][2] - mx), p3 = __builtin_amdgcn_exp2f(s[kt][3] - mx);
+                        sum += (p0 + p1) + (p2 + p3);
+                        pf[kt] = (f16x4){(f16)p0, (f16)p1, (f16)p2, (f16)p3};
+                    }
+                    sum += __shfl_xor(sum, 16);
+                    sum += __shfl_xor(sum, 32);
+                    const float inv = __builtin_amdgcn_rcpf(sum);
+                    const bool store = (16 * qt + r16) < 36;
+#pragma unroll
+                    for (int dt = 0; dt < NTH; ++dt) {
+                        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                        o = MFMA_16x16x32(cat8r(vt4[dt][0], vt4[dt][1]), cat8r(pf[0], pf[1]), o);
+                        o = MFMA_16x16x32(cat8r(vt4[dt][2], zero4), cat8r(pf[2], zero4), o);
+                        if (store) {
+                            const f16x4 ov = {(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
+                            *reinterpret_cast<f16x4 *>(a.att + pix[qt] * C + head * HD + dt * 16 + 4 * grp) = ov;
+                        }
+                    }
+                }
+            }
+
+            if constexpr (PREFETCH) {
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) {
+                    pix[mt] = pixn[mt];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = xn[mt][ks];
+                }
+            } else {
+                if (wi + wstride < a.n_windows) load_x(wi + wstride, xf, pix);
+            }
+        }
+    }
+}
+
+int qkv_attn_r_frags(int C) { return 3 * (C / 16) * (C / 32); }
+
+template <int C, int HD, int HPP, bool PREFETCH>
+static int launch_r(const QkvAttnRArgs &a, int grid, hipStream_t s) {
+    constexpr size_t smem = (size_t)HPP * 3 * (HD / 16) * (C / 32) * 1024 + 6 * 36 * 48 * 2 + 3 * C * 4;
+    static bool configured = false;
+    if (!configured) {
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)qkv_attn_r_kernel<C, HD, HPP, PREFETCH>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        configured = true;
+    }
+    qkv_attn_r_kernel<C, HD, HPP, PREFETCH><<<grid, 512, smem, s>>>(a);
+    return NUNIF_HIP_OK;
+}
+
+int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, int B, int H, int W,
+                      int C, int heads, int shift, hipStream_t s) {
+    NUNIF_REQUIRE(H % 6 == 0 && W % 6 == 0, "qkv_attn: %dx%d not a multiple of the 6x6 window", H, W);
+    NUNIF_REQUIRE(heads == 6 && (C == 96 || C == 192), "qkv_attn: C=%d heads=%d unsupported", C, heads);
+    if (H <= 6) shift = 0;                 // torchvision disables the shift when the window covers the map
+    QkvAttnRArgs a;
+    a.x = x; a.att = att; a.wres = wres; a.bqkv = bqkv; a.btab = btab;
+    a.B = B; a.H = H; a.W = W; a.shift = shift;
+    a.n_windows = B * (H / 6) * (W / 6);
+    const double tok = (double)B * H * W;
+    const int wgs = (a.n_windows + kWavesR - 1) / kWavesR;
+    const int grid = wgs < 256 ? wgs : 256;             // persistent: one 8-wave workgroup per CU
+    int rc;
+    if (C == 96) {
+        ProfScope ps("qkv_attn_r_kernel<96,16>", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 4.0);
+        rc = launch_r<96, 16, 6, true>(a, grid, s);
+    } else {
+        ProfScope ps("qkv_attn_r_kernel<192,32>", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 4.0);
+        rc = launch_r<192, 32, 3, false>(a, grid, s);
+    }
+    if (rc) return rc;
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+}  // namespace nunif

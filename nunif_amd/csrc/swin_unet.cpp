@@ -31,6 +31,11 @@ struct Block {
     float *attn_bias = nullptr;   // [heads][36][48]
     f16 *tail_stream = nullptr;   // proj | mlp.0 | mlp.3 fragments in proj_mlp_kernel's consumption order
     f16 *qkv_stream = nullptr;    // per-head Wq | Wk | Wv fragments in qkv_attn_w_kernel's consumption order
+    // LDS-resident variant (swin_qkv_attn_r.hip): same fragment order, q rows / q bias pre-multiplied by
+    // head_dim^-0.5 * log2(e); bias table fp16 [heads][36][48] * log2(e) with the "real key" column 36 = 1000
+    f16 *qkv_res = nullptr;
+    float *qkv_rbias = nullptr;
+    f16 *attn_btab = nullptr;
 };
 
 struct DeviceBuf {
@@ -69,7 +74,7 @@ struct nunif_swin_unet {
     int device = 0;
     // debug taps (tests only): when on, every stage's fp16 output is snapshotted device-side
     struct Tap { std::string name; void *dev; size_t bytes; };
-    int attn_variant = 2;             // see run_stage(); NUNIF_QKV_ATTN=0|1|2 overrides (A/B measurements)
+    int attn_variant = 3;             // see run_stage(); NUNIF_QKV_ATTN=0|1|2|3 overrides (A/B measurements)
     bool taps_on = false;
     std::vector<Tap> taps;
     void clear_taps() { for (auto &t : taps) (void)hipFree(t.dev); taps.clear(); }
@@ -112,8 +117,7 @@ int upload(nunif_swin_unet *h, const std::vector<T> &host, T **dev) {
 // {32ks + 4g + 0..3} (tile 2ks) and {32ks + 16 + 4g + 0..3} (tile 2ks+1).  The reduction order over k is free, so
 // the permutation is absorbed here at zero run-time cost.
 template <typename F>
-int make_linear(nunif_swin_unet *h, int n_real, int K, F wt, const float *bias, Linear *L, bool chained = false,
-                std::vector<f16> *keep = nullptr) {
+std::vector<f16> pack_a_fragments(int n_real, int K, F wt, bool chained) {
     const int N = (n_real + 15) / 16 * 16;
     // + 16 KiB of zeros: the LDS-ring kernels prefetch one 8-KiB chunk past the last fragment they consume
     std::vector<f16> packed((size_t)N * K + 8192, (f16)0.0f);
@@ -127,6 +131,14 @@ int make_linear(nunif_swin_unet *h, int n_real, int K, F wt, const float *bias, 
                     const int k = chained ? ks * 32 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : ks * 32 + g * 8 + j;
                     packed[(((size_t)nt * KS + ks) * 64 + l) * 8 + j] = (f16)(n < n_real ? wt(n, k) : 0.0f);
                 }
+    return packed;
+}
+
+template <typename F>
+int make_linear(nunif_swin_unet *h, int n_real, int K, F wt, const float *bias, Linear *L, bool chained = false,
+                std::vector<f16> *keep = nullptr) {
+    const int N = (n_real + 15) / 16 * 16;
+    std::vector<f16> packed = pack_a_fragments(n_real, K, wt, chained);
     std::vector<float> b(N, 0.0f);
     for (int n = 0; n < n_real; ++n) b[n] = bias[n];
     L->N = N; L->n_real = n_real; L->K = K;
@@ -171,6 +183,29 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
             NUNIF_REQUIRE((int)fi == nf, "internal: qkv stream has %zu fragments, expected %d", fi, nf);
             if ((rc = upload(h, stream, &bl.qkv_stream))) return rc;
         }
+        {
+            const HostTensor *w, *b;
+            if ((rc = find(m, p + "attn.qkv.weight", &w)) || (rc = find(m, p + "attn.qkv.bias", &b))) return rc;
+            const float qs = (1.0f / sqrtf((float)(dim / heads))) * 1.4426950408889634f;
+            const float *wd = w->data;
+            std::vector<f16> hs = pack_a_fragments(3 * dim, dim, [=](int n, int k) {
+                return wd[(size_t)n * dim + k] * (n < dim ? qs : 1.0f); }, false);
+            const int KS = dim / 32, NTH = (dim / heads) / 16, nf = qkv_attn_w_stream_frags(dim);
+            std::vector<f16> stream((size_t)nf * 512, (f16)0.0f);
+            size_t fi = 0;
+            for (int hh = 0; hh < heads; ++hh)
+                for (int part = 0; part < 3; ++part)
+                    for (int nt = 0; nt < NTH; ++nt)
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const size_t frag = (size_t)(part * (dim / 16) + hh * NTH + nt) * KS + ks;
+                            std::copy(hs.begin() + frag * 512, hs.begin() + (frag + 1) * 512, stream.begin() + fi * 512);
+                            ++fi;
+                        }
+            if ((rc = upload(h, stream, &bl.qkv_res))) return rc;
+            std::vector<float> rb(3 * dim);
+            for (int n = 0; n < 3 * dim; ++n) rb[n] = b->data[n] * (n < dim ? qs : 1.0f);
+            if ((rc = upload(h, rb, &bl.qkv_rbias))) return rc;
+        }
         std::vector<f16> hp, h0, h3;
         if ((rc = make_plain_linear(h, m, p + "attn.proj", dim, dim, &bl.proj, false, &hp))) return rc;
         if ((rc = make_plain_linear(h, m, p + "mlp.0", 2 * dim, dim, &bl.mlp0, true, &h0))) return rc;   // chained
@@ -213,6 +248,14 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
                     bias[((size_t)hh * 36 + q) * 48 + k] = v;
                 }
         if ((rc = upload(h, bias, &bl.attn_bias))) return rc;
+        std::vector<f16> btab((size_t)heads * 36 * 48, (f16)0.0f);
+        for (int hh = 0; hh < heads; ++hh)
+            for (int q = 0; q < 36; ++q) {
+                for (int k = 0; k < 36; ++k)
+                    btab[((size_t)hh * 36 + q) * 48 + k] = (f16)(bias[((size_t)hh * 36 + q) * 48 + k] * 1.4426950408889634f);
+                btab[((size_t)hh * 36 + q) * 48 + 36] = (f16)1000.0f;
+            }
+        if ((rc = upload(h, btab, &bl.attn_btab))) return rc;
     }
     return NUNIF_HIP_OK;
 }
@@ -253,9 +296,13 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         const int shift = (i % 2 == 1) ? 3 : 0;      // swin_unet.py:30
         const std::string tn = std::string(name) + ".b" + std::to_string(i);
         // qkv Linear + attention in one kernel; the 3C-wide qkv map never exists in HBM.
-        // variant 2 (default): one window per wave, weights through the LDS ring (both widths);
+        // variant 3 (default): one window per wave, weights resident in LDS, no barrier in the window loop;
+        // variant 2: one window per wave, weights through the LDS ring (both widths);
         // variant 1: one wave per head, 4 windows per workgroup (C = 96 only); variant 0: unfused GEMM + attention.
-        if (h->attn_variant == 2 && h->heads == 6 && (dim == 96 || dim == 192)) {
+        if (h->attn_variant == 3 && h->heads == 6 && (dim == 96 || dim == 192)) {
+            if ((rc = launch_qkv_attn_r(x, att, bl.qkv_res, bl.qkv_rbias, bl.attn_btab, B, S, S, dim, h->heads, shift, s)))
+                return rc;
+        } else if (h->attn_variant == 2 && h->heads == 6 && (dim == 96 || dim == 192)) {
             if ((rc = launch_qkv_attn_w(x, att, bl.qkv_stream, bl.qkv.bias, bl.attn_bias, B, S, S, dim, h->heads, shift, s)))
                 return rc;
         } else if (h->attn_variant >= 1 && dim == 96 && h->heads == 6) {
