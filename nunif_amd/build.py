@@ -19,8 +19,13 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip", "-
 
 
 # the stitcher replays the reference's fp32 recurrence bit-exactly: no FMA contraction in that file
+# the swin kernels are VALU-issue bound: hipcc's SLP vectoriser packs adjacent fp32 ops into v_pk_*_f32, which issue at
+# half rate and drag an s_nop behind each dependent use on gfx950 (tools/ubench_valu.hip) — keep them scalar
+NO_SLP = ["-fno-slp-vectorize"]
 EXTRA_FLAGS = {"stitch.hip": ["-ffp-contract=off"], "iw3_warp.hip": ["-ffp-contract=off"],
-               "iw3_depth.hip": ["-ffp-contract=off"]}
+               "iw3_depth.hip": ["-ffp-contract=off"], "swin_block_tail.hip": NO_SLP, "swin_qkv_attn_r.hip": NO_SLP,
+               "swin_qkv_attn_w.hip": NO_SLP, "swin_qkv_attn.hip": NO_SLP, "swin_kernels.hip": NO_SLP,
+               "cunet_kernels.hip": NO_SLP}
 
 
 def sources():

@@ -153,6 +153,7 @@ int launch_conv(const ConvArgs &g, hipStream_t s) {
         case 1: { ProfScope ps("conv_kernel<1,4>", s, flops, bytes); return launch_conv_t<1, 4>(g, s); }
         case 2: { ProfScope ps("conv_kernel<2,4>", s, flops, bytes); return launch_conv_t<2, 4>(g, s); }
         case 4: { ProfScope ps("conv_kernel<4,4>", s, flops, bytes); return launch_conv_t<4, 4>(g, s); }
+        case 6: { ProfScope ps("conv_kernel<6,4>", s, flops, bytes); return launch_conv_t<6, 4>(g, s); }
         case 8: { ProfScope ps("conv_kernel<8,4>", s, flops, bytes); return launch_conv_t<8, 4>(g, s); }
         case 16: { ProfScope ps("conv_kernel<16,2>", s, flops, bytes); return launch_conv_t<16, 2>(g, s); }
         default:

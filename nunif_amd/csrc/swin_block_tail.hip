@@ -20,6 +20,9 @@
 // ~500-cycle L2 latency that v1 exposed on every fragment is hidden.
 //
 // HBM traffic per token: read att (2C B) + read x (2C B) + write x (2C B).
+#include <algorithm>
+#include <cstdlib>
+
 #include "swin_kernels.h"
 
 namespace nunif {
@@ -32,7 +35,7 @@ namespace nunif {
 // xc = clamp(x, -4, 4) and Q a degree-8 minimax polynomial (Lawson fit on [0,4]; |Phi err| <= 4e-6, gelu abs err
 // <= 1.1e-5 for |x| < 3 and <= 3e-5 * |x| beyond the clamp) — 12 full-rate VALU ops, no transcendental.
 __device__ __forceinline__ float gelu_fast(float v) {
-    const float xc = fminf(fmaxf(v, -4.0f), 4.0f);
+    const float xc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);      // one v_med3_f32, no canonicalising v_max
     const float u = xc * xc;
     float q = 8.063430101e-11f;
     q = fmaf(q, u, -7.003475758e-09f);
@@ -46,9 +49,49 @@ __device__ __forceinline__ float gelu_fast(float v) {
     return v * fmaf(xc, q, 0.5f);
 }
 
+// The same polynomial over 8 values, written stage-major so that consecutive instructions are independent: a single
+// Horner chain is 10 back-to-back dependent VALU ops, and a dependent op issues ~2.5x slower than an independent one
+// on gfx950 (tools/ubench_valu.hip: 11.3 vs 4.6 cycles per instruction for one wave).  This file is built with
+// -fno-slp-vectorize: hipcc otherwise packs the chains into v_pk_fma_f32 (half rate) with an s_nop after each.
+__device__ __forceinline__ f16x8 gelu8(const f32x4 &a, const f32x4 &b) {
+    // degree 6 in u = xc^2 (Lawson minimax fit on |x| <= 4, weight x^2): |gelu err| <= 1.9e-4 everywhere, below the
+    // fp16 quantum (2.4e-4) of the hidden activation it is rounded to.  NUNIF_GELU_DEG8 restores the 1.7e-5 fit.
+#ifdef NUNIF_GELU_DEG8
+    constexpr int ND = 8;
+    constexpr float kc[ND + 1] = {8.063430101e-11f, -7.003475758e-09f, 2.716159007e-07f, -6.295003997e-06f,
+                                  9.890811950e-05f, -1.133922332e-03f, 9.877477530e-03f, -6.641059600e-02f,
+                                  3.989227099e-01f};
+#else
+    constexpr int ND = 6;
+    constexpr float kc[ND + 1] = {2.2779071073841806e-08f, -1.5984835499693872e-06f, 4.795320637640543e-05f,
+                                  -0.0008139933925122023f, 0.008772282861173153f, -0.06457287818193436f,
+                                  0.39788317680358887f};
+#endif
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    float xc[8], u[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xc[i] = __builtin_amdgcn_fmed3f(v[i], -4.0f, 4.0f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = xc[i] * xc[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = fmaf(kc[0], u[i], kc[1]);
+#pragma unroll
+    for (int k = 2; k <= ND; ++k) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = fmaf(q[i], u[i], kc[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = fmaf(xc[i], q[i], 0.5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= q[i];
+    return (f16x8){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3], (f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
+}
+
 constexpr int kChunkFrags = 8;   // 8 KiB per chunk: 256 threads x 2 x 16 B
 
-template <int C, int MF>
+// ABL != 0 are timing-only ablations used to find what bounds the kernel (NUNIF_TAIL_ABL; results are wrong):
+// 1 = no GELU polynomial, 2 = no stores, 4 = no residual read, 8 = no MFMA in the MLP loop, 16 = no ring barrier
+template <int C, int MF, int ABL = 0>
 __global__ void __launch_bounds__(256, 2)
 proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wstream, int n_chunks,
                 const float *__restrict__ bp, const float *__restrict__ b0, const float *__restrict__ b3, long M) {
@@ -76,7 +119,7 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
         if (fi % CH == 0) {
             ring[c & 1][tid] = st0;
             ring[c & 1][tid + 256] = st1;
-            __syncthreads();
+            if constexpr (!(ABL & 16)) __syncthreads();
             if (c + 1 < n_chunks) {
                 st0 = gsrc[(long)(c + 1) * (CH * 64)];
                 st1 = gsrc[(long)(c + 1) * (CH * 64) + 256];
@@ -119,8 +162,11 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
             const float4 bb = *reinterpret_cast<const float4 *>(bp + n0 + 16);
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
-                const f16x4 xa = *reinterpret_cast<const f16x4 *>(x + row[f] * C + n0);
-                const f16x4 xb = *reinterpret_cast<const f16x4 *>(x + row[f] * C + n0 + 16);
+                f16x4 xa = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f}, xb = xa;
+                if constexpr (!(ABL & 4)) {
+                    xa = *reinterpret_cast<const f16x4 *>(x + row[f] * C + n0);
+                    xb = *reinterpret_cast<const f16x4 *>(x + row[f] * C + n0 + 16);
+                }
                 yf[f][s] = (f16x8){(f16)(a0[f][0] + ba.x + (float)xa[0]), (f16)(a0[f][1] + ba.y + (float)xa[1]),
                                    (f16)(a0[f][2] + ba.z + (float)xa[2]), (f16)(a0[f][3] + ba.w + (float)xa[3]),
                                    (f16)(a1[f][0] + bb.x + (float)xb[0]), (f16)(a1[f][1] + bb.y + (float)xb[1]),
@@ -159,6 +205,7 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
             const f16x8 wb = wfrag(F_MLP + s * F_STEP + ks * 2 + 1);
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
+                if constexpr (ABL & 8) { h0[f][0] += (float)wa[0]; h1[f][0] += (float)wb[0]; continue; }
                 h0[f] = MFMA_16x16x32(wa, yf[f][ks], h0[f]);
                 h1[f] = MFMA_16x16x32(wb, yf[f][ks], h1[f]);
             }
@@ -169,16 +216,21 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
         f16x8 hf[MF];
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            hf[f] = (f16x8){(f16)gelu_fast(h0[f][0] + ba.x), (f16)gelu_fast(h0[f][1] + ba.y),
-                            (f16)gelu_fast(h0[f][2] + ba.z), (f16)gelu_fast(h0[f][3] + ba.w),
-                            (f16)gelu_fast(h1[f][0] + bb.x), (f16)gelu_fast(h1[f][1] + bb.y),
-                            (f16)gelu_fast(h1[f][2] + bb.z), (f16)gelu_fast(h1[f][3] + bb.w)};
+            if constexpr (ABL & 1)
+                hf[f] = (f16x8){(f16)(h0[f][0] + ba.x), (f16)(h0[f][1] + ba.y), (f16)(h0[f][2] + ba.z), (f16)(h0[f][3] + ba.w),
+                                (f16)(h1[f][0] + bb.x), (f16)(h1[f][1] + bb.y), (f16)(h1[f][2] + bb.z), (f16)(h1[f][3] + bb.w)};
+            else
+            hf[f] = gelu8((f32x4){h0[f][0] + ba.x, h0[f][1] + ba.y, h0[f][2] + ba.z, h0[f][3] + ba.w},
+                          (f32x4){h1[f][0] + bb.x, h1[f][1] + bb.y, h1[f][2] + bb.z, h1[f][3] + bb.w});
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const f16x8 wv = wfrag(F_MLP + s * F_STEP + 2 * KS + nt);
 #pragma unroll
-            for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(wv, hf[f], acc[nt][f]);
+            for (int f = 0; f < MF; ++f) {
+                if constexpr (ABL & 8) { acc[nt][f][0] += (float)wv[0] + (float)hf[f][nt & 7]; continue; }
+                acc[nt][f] = MFMA_16x16x32(wv, hf[f], acc[nt][f]);
+            }
         }
     }
 #pragma unroll
@@ -188,10 +240,183 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
         for (int f = 0; f < MF; ++f) {
             if (!valid[f]) continue;
             const f16x4 o = {(f16)acc[nt][f][0], (f16)acc[nt][f][1], (f16)acc[nt][f][2], (f16)acc[nt][f][3]};
+            if constexpr (ABL & 2) { if (o[0] == (f16)12345.f) *reinterpret_cast<f16x4 *>(x + row[f] * C + n0) = o; continue; }
             *reinterpret_cast<f16x4 *>(x + row[f] * C + n0) = o;
         }
     }
 }
+
+// ---- LDS-resident form (C = 96: the whole 90-KiB stream fits) ----------------------------------------------------------
+// Same dataflow, but a persistent 8-wave workgroup copies the weight stream into LDS once and every wave then loops
+// over its own 64-token groups with NO barrier: waves drift apart, so one wave's GELU / convert (VALU) phase overlaps
+// its SIMD partner's MFMA phase instead of both stalling at a chunk barrier (same finding as swin_qkv_attn_r.hip).
+template <int C, int MF, int WAVES, bool PF = false>
+__global__ void __launch_bounds__(WAVES * 64)
+proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wstream, const float *__restrict__ bp,
+                  const float *__restrict__ b0, const float *__restrict__ b3, long M) {
+    constexpr int KS = C / 32, NT = C / 16, SH = 2 * C / 32;
+    constexpr int NF = 2 * KS * KS + SH * (2 * KS + NT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
+    f16x8 *wl = reinterpret_cast<f16x8 *>(smem_t);                 // [NF][64]
+    float *bl = reinterpret_cast<float *>(wl + NF * 64);           // bp[C] | b0[2C] | b3[C]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r16 = lane & 15;
+    const int grp = lane >> 4;
+    {
+        const f16x8 *src = reinterpret_cast<const f16x8 *>(wstream);
+        for (int i = tid; i < NF * 64; i += WAVES * 64) wl[i] = src[i];
+        for (int i = tid; i < C; i += WAVES * 64) { bl[i] = bp[i]; bl[3 * C + i] = b3[i]; }
+        for (int i = tid; i < 2 * C; i += WAVES * 64) bl[C + i] = b0[i];
+    }
+    __syncthreads();
+    const f16x8 *wlane = wl + lane;
+    auto wfrag = [&](int fi) -> f16x8 { return wlane[fi * 64]; };
+
+    const long n_groups = (M + MF * 16 - 1) / (MF * 16);
+    const long gstride = (long)gridDim.x * WAVES;
+    // PF: the att / x tiles of the NEXT group are requested before this group's GEMMs start.  Without it every
+    // wave exposes one full HBM latency per group and the kernel sits at ~3.3 TB/s however cheap the math is
+    // (bytes in flight per CU ~ 20 KB; Little's law wants >= 40 KB for 5 TB/s).
+    auto load_group = [&](long g, f16x8 (&of)[MF][KS], f16x4 (&xa)[MF][KS], f16x4 (&xb)[MF][KS]) {
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const long m = g * (MF * 16) + f * 16 + r16;
+            const long r = m < M ? m : M - 1;
+            const f16 *p = att + r * C + grp * 8;
+            const f16 *px = x + r * C + 4 * grp;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                of[f][ks] = *reinterpret_cast<const f16x8 *>(p + ks * 32);
+                xa[f][ks] = *reinterpret_cast<const f16x4 *>(px + ks * 32);
+                xb[f][ks] = *reinterpret_cast<const f16x4 *>(px + ks * 32 + 16);
+            }
+        }
+    };
+    f16x8 ofn[PF ? MF : 1][PF ? KS : 1];
+    f16x4 xan[PF ? MF : 1][PF ? KS : 1], xbn[PF ? MF : 1][PF ? KS : 1];
+    const long g_first = (long)blockIdx.x * WAVES + wave;
+    if constexpr (PF) {
+        if (g_first < n_groups) load_group(g_first, ofn, xan, xbn);
+    }
+#pragma unroll 1
+    for (long g = g_first; g < n_groups; g += gstride) {
+        const long m_base = g * (MF * 16);
+        // opaque per-iteration copies: keeps LICM from hoisting 48 registers of (loop-invariant) LDS bias reads
+        const float *lbp = bl, *lb0 = bl + C, *lb3 = bl + 3 * C;
+        asm volatile("" : "+v"(lbp), "+v"(lb0), "+v"(lb3));
+        long row[MF];
+        bool valid[MF];
+        f16x8 yf[MF][KS];
+        {
+            f16x8 of[MF][KS];
+            f16x4 xa[MF][KS], xb[MF][KS];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const long m = m_base + f * 16 + r16;
+                valid[f] = m < M;
+                row[f] = m < M ? m : M - 1;
+            }
+            if constexpr (PF) {
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) { of[f][ks] = ofn[f][ks]; xa[f][ks] = xan[f][ks]; xb[f][ks] = xbn[f][ks]; }
+                load_group(g + gstride < n_groups ? g + gstride : g, ofn, xan, xbn);
+            } else {
+                load_group(g, of, xa, xb);
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int n0 = 32 * s + 4 * grp;
+                const f32x4 ba = *reinterpret_cast<const f32x4 *>(lbp + n0);
+                const f32x4 bb = *reinterpret_cast<const f32x4 *>(lbp + n0 + 16);
+                f32x4 a0[MF], a1[MF];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) { a0[f] = ba; a1[f] = bb; }        // accumulators start from the bias
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f16x8 wa = wfrag((s * KS + ks) * 2);
+                    const f16x8 wb = wfrag((s * KS + ks) * 2 + 1);
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+                        a0[f] = MFMA_16x16x32(wa, of[f][ks], a0[f]);
+                        a1[f] = MFMA_16x16x32(wb, of[f][ks], a1[f]);
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    const f16x4 va = xa[f][s], vb = xb[f][s];
+                    yf[f][s] = (f16x8){(f16)(a0[f][0] + (float)va[0]), (f16)(a0[f][1] + (float)va[1]),
+                                       (f16)(a0[f][2] + (float)va[2]), (f16)(a0[f][3] + (float)va[3]),
+                                       (f16)(a1[f][0] + (float)vb[0]), (f16)(a1[f][1] + (float)vb[1]),
+                                       (f16)(a1[f][2] + (float)vb[2]), (f16)(a1[f][3] + (float)vb[3])};
+                }
+            }
+        }
+        f32x4 acc[NT][MF];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int n0 = 32 * s + 4 * grp;
+            const f32x4 ca = *reinterpret_cast<const f32x4 *>(lb3 + n0);
+            const f32x4 cb = *reinterpret_cast<const f32x4 *>(lb3 + n0 + 16);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                acc[2 * s][f] = (f32x4){(float)yf[f][s][0] + ca[0], (float)yf[f][s][1] + ca[1],
+                                        (float)yf[f][s][2] + ca[2], (float)yf[f][s][3] + ca[3]};
+                acc[2 * s + 1][f] = (f32x4){(float)yf[f][s][4] + cb[0], (float)yf[f][s][5] + cb[1],
+                                            (float)yf[f][s][6] + cb[2], (float)yf[f][s][7] + cb[3]};
+            }
+        }
+        constexpr int F_MLP = 2 * KS * KS;
+        constexpr int F_STEP = 2 * KS + NT;
+#pragma unroll 1
+        for (int s = 0; s < SH; ++s) {
+            const int n0 = 32 * s + 4 * grp;
+            const f32x4 ba = *reinterpret_cast<const f32x4 *>(lb0 + n0);
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(lb0 + n0 + 16);
+            f32x4 h0[MF], h1[MF];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) { h0[f] = ba; h1[f] = bb; }
+            const f16x8 *wf = wlane + (F_MLP + s * F_STEP) * 64;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 wa = wf[(ks * 2) * 64];
+                const f16x8 wb = wf[(ks * 2 + 1) * 64];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    h0[f] = MFMA_16x16x32(wa, yf[f][ks], h0[f]);
+                    h1[f] = MFMA_16x16x32(wb, yf[f][ks], h1[f]);
+                }
+            }
+            f16x8 hf[MF];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                hf[f] = gelu8(h0[f], h1[f]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f16x8 wv = wf[(2 * KS + nt) * 64];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(wv, hf[f], acc[nt][f]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n0 = 16 * nt + 4 * grp;
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                if (!valid[f]) continue;
+                const f16x4 o = {(f16)acc[nt][f][0], (f16)acc[nt][f][1], (f16)acc[nt][f][2], (f16)acc[nt][f][3]};
+                *reinterpret_cast<f16x4 *>(x + row[f] * C + n0) = o;
+            }
+        }
+    }
+}
+
+constexpr int proj_mlp_stream_frags_c(int C) { return 2 * (C / 32) * (C / 32) + (2 * C / 32) * (2 * (C / 32) + C / 16); }
 
 int proj_mlp_stream_frags(int C) {
     const int KS = C / 32, NT = C / 16, SH = 2 * C / 32;
@@ -204,14 +429,51 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
     ProfScope ps(C == 96 ? "proj_mlp_kernel<96,4>" : "proj_mlp_kernel<192,2>", s, 2.0 * (double)M * C * C * 5.0,
                  (double)M * C * 2.0 * 3.0);
     const int n_chunks = (proj_mlp_stream_frags(C) + kChunkFrags - 1) / kChunkFrags;
-    if (C == 96) {
+    static const bool ring96 = getenv("NUNIF_TAIL_RING") != nullptr;     // A/B switch: the round-1 ring version
+    if (C == 96 && !ring96) {
+        static const int variant = getenv("NUNIF_TAIL_VARIANT") ? atoi(getenv("NUNIF_TAIL_VARIANT")) : 6;
+        constexpr size_t smem = (size_t)proj_mlp_stream_frags_c(96) * 1024 + 4 * 96 * 4;
+        auto go = [&](auto kern, int mf, int waves) -> int {
+            static bool configured[8] = {false};
+            if (!configured[variant & 7]) {
+                NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                configured[variant & 7] = true;
+            }
+            const long groups = (M + mf * 16 - 1) / (mf * 16);
+            const unsigned blocks = (unsigned)std::min<long>((groups + waves - 1) / waves, 256);
+            kern<<<blocks, waves * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M);
+            return NUNIF_HIP_OK;
+        };
+        int rc;
+        switch (variant) {
+            case 1: rc = go(proj_mlp_r_kernel<96, 2, 8>, 2, 8); break;
+            case 2: rc = go(proj_mlp_r_kernel<96, 2, 12>, 2, 12); break;
+            case 3: rc = go(proj_mlp_r_kernel<96, 2, 16>, 2, 16); break;
+            case 4: rc = go(proj_mlp_r_kernel<96, 3, 8>, 3, 8); break;
+            case 5: rc = go(proj_mlp_r_kernel<96, 3, 12>, 3, 12); break;
+            case 6: rc = go(proj_mlp_r_kernel<96, 2, 8, true>, 2, 8); break;
+            case 7: rc = go(proj_mlp_r_kernel<96, 3, 8, true>, 3, 8); break;
+            default: rc = go(proj_mlp_r_kernel<96, 4, 8>, 4, 8); break;
+        }
+        if (rc) return rc;
+    } else if (C == 96) {
         constexpr int MF = 4;
         const unsigned blocks = (unsigned)((M + 4 * MF * 16 - 1) / (4 * MF * 16));
         proj_mlp_kernel<96, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M);
     } else if (C == 192) {
         constexpr int MF = 2;
         const unsigned blocks = (unsigned)((M + 4 * MF * 16 - 1) / (4 * MF * 16));
-        proj_mlp_kernel<192, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M);
+        static const int abl = getenv("NUNIF_TAIL_ABL") ? atoi(getenv("NUNIF_TAIL_ABL")) : 0;
+        switch (abl) {
+            case 1: proj_mlp_kernel<192, MF, 1><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
+            case 2: proj_mlp_kernel<192, MF, 2><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
+            case 4: proj_mlp_kernel<192, MF, 4><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
+            case 8: proj_mlp_kernel<192, MF, 8><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
+            case 9: proj_mlp_kernel<192, MF, 9><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
+            case 16: proj_mlp_kernel<192, MF, 16><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
+            case 6: proj_mlp_kernel<192, MF, 6><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
+            default: proj_mlp_kernel<192, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
+        }
     } else {
         set_error("proj_mlp: channel count %d unsupported (96, 192)", C);
         return NUNIF_HIP_EUNSUPPORTED;

@@ -67,6 +67,8 @@ struct nunif_swin_unet {
     int top_dim = 96;                 // channels of level 1 on the decoder side (C for 1x/2x, 2C for 4x)
     float *stem1_w = nullptr, *stem1_b = nullptr;
     Linear stem2, down1, down2, up2, up1, proj2, to_image;
+    f16 *stem2_stream = nullptr;      // conv2 fragments in [k-step][n-tile] order for conv_kernel (cunet_kernels.hip)
+    int stem2_conv = 0;               // NUNIF_STEM2_CONV=1: conv_kernel<6,4> instead of gemm_kernel<18,2> (measured slower: 1131 vs 914 us)
     bool has_proj2 = false;
     std::vector<Block> swin[5];
     std::vector<void *> owned;        // every device allocation made at create time
@@ -361,8 +363,15 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
     a1.slope = 0.1f;
     if ((rc = launch_stem1(a1, s))) return rc;
     // conv2 3x3 VALID + LeakyReLU(0.1) + crop 6 (swin_unet.py:135-137,182): s1 already starts at conv1 row/col 6
-    if ((rc = run_gemm(h->stem2, s1, B, T - 14, T - 14, h->C1P, S, S, 1, 0, 0, 3, 0, 2, 0.1f, nullptr, f1, C, 1, s,
-                       "gemm_stem2")))
+    if (h->stem2_conv && C == 96) {
+        ConvArgs cv;
+        memset(&cv, 0, sizeof(cv));
+        cv.a = s1; cv.B = B; cv.Hi = T - 14; cv.Wi = T - 14; cv.Cin = h->C1P; cv.Ho = S; cv.Wo = S; cv.stride = 1;
+        cv.kh = 3; cv.kw = 3; cv.wstream = h->stem2_stream; cv.bias = h->stem2.bias; cv.N = C; cv.n_real = C;
+        cv.act = 2; cv.slope = 0.1f; cv.out = f1;
+        if ((rc = launch_conv(cv, s))) return rc;
+    } else if ((rc = run_gemm(h->stem2, s1, B, T - 14, T - 14, h->C1P, S, S, 1, 0, 0, 3, 0, 2, 0.1f, nullptr, f1, C, 1, s,
+                              "gemm_stem2")))
         return rc;
     if ((rc = tap(h, "stem", f1, (size_t)B * S * S * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[0], f1, B, S, C, s, "swin1"))) return rc;                          // swin1 -> x3
@@ -422,6 +431,7 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
     nunif_swin_unet *h = new nunif_swin_unet();
     (void)hipGetDevice(&h->device);
     if (const char *v = getenv("NUNIF_QKV_ATTN")) h->attn_variant = atoi(v);
+    if (const char *v = getenv("NUNIF_STEM2_CONV")) h->stem2_conv = atoi(v);
     h->scale_factor = scale_factor;
     const std::string P = "unet.";
     int rc = NUNIF_HIP_OK;
@@ -446,11 +456,19 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
         {   // conv2 [C][C1][3][3] -> W[n][k = (dy*3+dx)*C1P + ci], zero for the padded input channels
             const float *wd = w2->data;
             const int C1P = h->C1P;
+            std::vector<f16> packed;
             rc = make_linear(h, C, 9 * C1P, [=](int n, int k) {
                 const int tap = k / C1P, ci = k % C1P;
                 return ci < C1 ? wd[((size_t)n * C1 + ci) * 9 + tap] : 0.0f;
-            }, b2->data, &h->stem2);
+            }, b2->data, &h->stem2, false, &packed);
             if (rc) break;
+            const int KS = 9 * C1P / 32, NT = C / 16;
+            std::vector<f16> stream((size_t)KS * NT * 512 + 8192, (f16)0.0f);
+            for (int ks = 0; ks < KS; ++ks)
+                for (int nt = 0; nt < NT; ++nt)
+                    std::copy(packed.begin() + ((size_t)nt * KS + ks) * 512, packed.begin() + ((size_t)nt * KS + ks + 1) * 512,
+                              stream.begin() + ((size_t)ks * NT + nt) * 512);
+            if ((rc = upload(h, stream, &h->stem2_stream))) break;
         }
         if ((rc = make_stage(h, m, P + "swin1", C, 2, &h->swin[0]))) break;
         if ((rc = make_stage(h, m, P + "swin2", 2 * C, 2, &h->swin[1]))) break;
