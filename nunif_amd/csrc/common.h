@@ -54,6 +54,40 @@ typedef _Float16 f16;
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#if defined(__HIPCC__)
+// An MFMA accumulator lane (token l&15, lane group g = l>>4) holds channels 4g..4g+3 of a 16-channel tile: 8 bytes of
+// fp16, and a wave-wide store of them touches 16 rows x 32 B — quarter cache lines.  Two v_permlane16_swap turn the
+// chunks of two adjacent tiles (A: channels 4g.., B: channels 16+4g..) into ONE run of 8 consecutive channels per lane,
+// starting at pair_run_channel(g) inside the 32-channel pair, so loads / stores are 16 B per lane and 64 B per row.
+// (v_permlane16_swap a, b: a.row1 <-> b.row0, a.row3 <-> b.row2, rows = 16 lanes; verified on gfx950.)
+__device__ __forceinline__ int pair_run_channel(int grp) { return ((grp & 1) << 4) | ((grp >> 1) << 3); }   // 0,16,8,24
+
+__device__ __forceinline__ u32x2 lane16_swap(unsigned int a, unsigned int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_permlane16_swap(a, b, false, false);
+#else
+    return (u32x2){a, b};          // host pass of the single-source compile only parses this
+#endif
+}
+
+__device__ __forceinline__ f16x8 pair_to_run(f16x4 a, f16x4 b) {
+    const u32x2 ai = __builtin_bit_cast(u32x2, a), bi = __builtin_bit_cast(u32x2, b);
+    const u32x2 r0 = lane16_swap(ai[0], bi[0]);
+    const u32x2 r1 = lane16_swap(ai[1], bi[1]);
+    return __builtin_bit_cast(f16x8, ((u32x4){r0[0], r1[0], r0[1], r1[1]}));
+}
+
+__device__ __forceinline__ void run_to_pair(f16x8 v, f16x4 &a, f16x4 &b) {          // inverse (the swap is an involution)
+    const u32x4 vi = __builtin_bit_cast(u32x4, v);
+    const u32x2 r0 = lane16_swap(vi[0], vi[2]);
+    const u32x2 r1 = lane16_swap(vi[1], vi[3]);
+    a = __builtin_bit_cast(f16x4, ((u32x2){r0[0], r1[0]}));
+    b = __builtin_bit_cast(f16x4, ((u32x2){r0[1], r1[1]}));
+}
+#endif
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

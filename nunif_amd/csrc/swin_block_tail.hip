@@ -163,10 +163,8 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
                 f16x4 xa = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f}, xb = xa;
-                if constexpr (!(ABL & 4)) {
-                    xa = *reinterpret_cast<const f16x4 *>(x + row[f] * C + n0);
-                    xb = *reinterpret_cast<const f16x4 *>(x + row[f] * C + n0 + 16);
-                }
+                if constexpr (!(ABL & 4))
+                    run_to_pair(*reinterpret_cast<const f16x8 *>(x + row[f] * C + 32 * s + pair_run_channel(grp)), xa, xb);
                 yf[f][s] = (f16x8){(f16)(a0[f][0] + ba.x + (float)xa[0]), (f16)(a0[f][1] + ba.y + (float)xa[1]),
                                    (f16)(a0[f][2] + ba.z + (float)xa[2]), (f16)(a0[f][3] + ba.w + (float)xa[3]),
                                    (f16)(a1[f][0] + bb.x + (float)xb[0]), (f16)(a1[f][1] + bb.y + (float)xb[1]),
@@ -234,14 +232,15 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
         }
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n0 = 16 * nt + 4 * grp;
+    for (int p = 0; p < NT / 2; ++p) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            if (!valid[f]) continue;
-            const f16x4 o = {(f16)acc[nt][f][0], (f16)acc[nt][f][1], (f16)acc[nt][f][2], (f16)acc[nt][f][3]};
-            if constexpr (ABL & 2) { if (o[0] == (f16)12345.f) *reinterpret_cast<f16x4 *>(x + row[f] * C + n0) = o; continue; }
-            *reinterpret_cast<f16x4 *>(x + row[f] * C + n0) = o;
+            const f16x4 oa = {(f16)acc[2 * p][f][0], (f16)acc[2 * p][f][1], (f16)acc[2 * p][f][2], (f16)acc[2 * p][f][3]};
+            const f16x4 ob = {(f16)acc[2 * p + 1][f][0], (f16)acc[2 * p + 1][f][1], (f16)acc[2 * p + 1][f][2],
+                              (f16)acc[2 * p + 1][f][3]};
+            const f16x8 o = pair_to_run(oa, ob);           // all lanes take part in the swap; only valid rows store
+            if constexpr (ABL & 2) { if (o[0] != (f16)12345.f) continue; }
+            if (valid[f]) *reinterpret_cast<f16x8 *>(x + row[f] * C + 32 * p + pair_run_channel(grp)) = o;
         }
     }
 }
@@ -280,26 +279,25 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
     // PF: the att / x tiles of the NEXT group are requested before this group's GEMMs start.  Without it every
     // wave exposes one full HBM latency per group and the kernel sits at ~3.3 TB/s however cheap the math is
     // (bytes in flight per CU ~ 20 KB; Little's law wants >= 40 KB for 5 TB/s).
-    auto load_group = [&](long g, f16x8 (&of)[MF][KS], f16x4 (&xa)[MF][KS], f16x4 (&xb)[MF][KS]) {
+    auto load_group = [&](long g, f16x8 (&of)[MF][KS], f16x8 (&xr)[MF][KS]) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             const long m = g * (MF * 16) + f * 16 + r16;
             const long r = m < M ? m : M - 1;
             const f16 *p = att + r * C + grp * 8;
-            const f16 *px = x + r * C + 4 * grp;
+            const f16 *px = x + r * C + pair_run_channel(grp);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 of[f][ks] = *reinterpret_cast<const f16x8 *>(p + ks * 32);
-                xa[f][ks] = *reinterpret_cast<const f16x4 *>(px + ks * 32);
-                xb[f][ks] = *reinterpret_cast<const f16x4 *>(px + ks * 32 + 16);
+                xr[f][ks] = *reinterpret_cast<const f16x8 *>(px + ks * 32);      // 8-channel run, see pair_to_run()
             }
         }
     };
     f16x8 ofn[PF ? MF : 1][PF ? KS : 1];
-    f16x4 xan[PF ? MF : 1][PF ? KS : 1], xbn[PF ? MF : 1][PF ? KS : 1];
+    f16x8 xrn[PF ? MF : 1][PF ? KS : 1];
     const long g_first = (long)blockIdx.x * WAVES + wave;
     if constexpr (PF) {
-        if (g_first < n_groups) load_group(g_first, ofn, xan, xbn);
+        if (g_first < n_groups) load_group(g_first, ofn, xrn);
     }
 #pragma unroll 1
     for (long g = g_first; g < n_groups; g += gstride) {
@@ -312,7 +310,7 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
         f16x8 yf[MF][KS];
         {
             f16x8 of[MF][KS];
-            f16x4 xa[MF][KS], xb[MF][KS];
+            f16x8 xr[MF][KS];
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
                 const long m = m_base + f * 16 + r16;
@@ -323,10 +321,10 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
 #pragma unroll
                 for (int f = 0; f < MF; ++f)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) { of[f][ks] = ofn[f][ks]; xa[f][ks] = xan[f][ks]; xb[f][ks] = xbn[f][ks]; }
-                load_group(g + gstride < n_groups ? g + gstride : g, ofn, xan, xbn);
+                    for (int ks = 0; ks < KS; ++ks) { of[f][ks] = ofn[f][ks]; xr[f][ks] = xrn[f][ks]; }
+                load_group(g + gstride < n_groups ? g + gstride : g, ofn, xrn);
             } else {
-                load_group(g, of, xa, xb);
+                load_group(g, of, xr);
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -348,7 +346,8 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
                 }
 #pragma unroll
                 for (int f = 0; f < MF; ++f) {
-                    const f16x4 va = xa[f][s], vb = xb[f][s];
+                    f16x4 va, vb;
+                    run_to_pair(xr[f][s], va, vb);
                     yf[f][s] = (f16x8){(f16)(a0[f][0] + (float)va[0]), (f16)(a0[f][1] + (float)va[1]),
                                        (f16)(a0[f][2] + (float)va[2]), (f16)(a0[f][3] + (float)va[3]),
                                        (f16)(a1[f][0] + (float)vb[0]), (f16)(a1[f][1] + (float)vb[1]),
@@ -404,13 +403,14 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
             }
         }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n0 = 16 * nt + 4 * grp;
+        for (int p = 0; p < NT / 2; ++p) {
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
-                if (!valid[f]) continue;
-                const f16x4 o = {(f16)acc[nt][f][0], (f16)acc[nt][f][1], (f16)acc[nt][f][2], (f16)acc[nt][f][3]};
-                *reinterpret_cast<f16x4 *>(x + row[f] * C + n0) = o;
+                const f16x4 oa = {(f16)acc[2 * p][f][0], (f16)acc[2 * p][f][1], (f16)acc[2 * p][f][2], (f16)acc[2 * p][f][3]};
+                const f16x4 ob = {(f16)acc[2 * p + 1][f][0], (f16)acc[2 * p + 1][f][1], (f16)acc[2 * p + 1][f][2],
+                                  (f16)acc[2 * p + 1][f][3]};
+                const f16x8 o = pair_to_run(oa, ob);
+                if (valid[f]) *reinterpret_cast<f16x8 *>(x + row[f] * C + 32 * p + pair_run_channel(grp)) = o;
             }
         }
     }

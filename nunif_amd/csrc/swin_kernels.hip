@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         long m = m_base + f * 16 + r16;
         valid[f] = m < M;
         if (m >= M) m = M - 1;
+        // (a wave-uniform division + per-lane carry loops, and 32-bit division, were both tried: slower / faulting)
         const int x = (int)(m % g.Wo);
         const long t = m / g.Wo;
         const int y = (int)(t % g.Ho);
@@ -80,36 +81,29 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     }
 
     const int NT = g.N >> 4;
+    if (g.mode == 2) {
+        // ToImage: column n = c*s*s + i*s + j -> out[b][c][y*s+i][x*s+j], clamp(0,1)  (swin_unet.py:110-116)
 #pragma unroll 1
-    for (int nt = 0; nt < NT; ++nt) {
-        f32x4 acc[MF];
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 acc[MF];
 #pragma unroll
-        for (int f = 0; f < MF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < MF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const f16x8 wv = wfrag(nt * KS + ks);
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 wv = wfrag(nt * KS + ks);
 #pragma unroll
-            for (int f = 0; f < MF; ++f) acc[f] = MFMA_16x16x32(wv, xf[f][ks], acc[f]);
-        }
-        const int n0 = nt * 16 + grp * 4;
-        const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
-#pragma unroll
-        for (int f = 0; f < MF; ++f) {
-            if (!valid[f]) continue;
-            float v[4] = {acc[f][0] + bv.x, acc[f][1] + bv.y, acc[f][2] + bv.z, acc[f][3] + bv.w};
-            if (g.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            } else if (g.act == 2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * g.slope;
+                for (int f = 0; f < MF; ++f) acc[f] = MFMA_16x16x32(wv, xf[f][ks], acc[f]);
             }
-            if (g.mode == 2) {
-                // ToImage: column n = c*s*s + i*s + j -> out[b][c][y*s+i][x*s+j], clamp(0,1)  (swin_unet.py:110-116)
-                const int s = g.ps, s2 = s * s;
-                const int OC = g.n_real / s2;
-                float *o = reinterpret_cast<float *>(g.out);
-                const long OH = (long)g.Ho * s, OW = (long)g.Wo * s;
+            const int n0 = nt * 16 + grp * 4;
+            const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+            const int s = g.ps, s2 = s * s;
+            const int OC = g.n_real / s2;
+            float *o = reinterpret_cast<float *>(g.out);
+            const long OH = (long)g.Ho * s, OW = (long)g.Wo * s;
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                if (!valid[f]) continue;
+                const float v[4] = {acc[f][0] + bv.x, acc[f][1] + bv.y, acc[f][2] + bv.z, acc[f][3] + bv.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0 + r;
@@ -120,24 +114,67 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                             fminf(fmaxf(v[r], 0.f), 1.f);
                     }
                 }
-            } else {
-                if (n0 >= g.n_real) continue;
-                long off;
-                if (g.mode == 0) {
-                    off = (((long)tb[f] * g.Ho + ty[f]) * g.Wo + tx[f]) * g.ldo + n0;
-                } else {
-                    // PatchUp: column n = q*Cq + c (repacked), q=(i,j) -> pixel (2y+i, 2x+j)  (swin_unet.py:76-82)
-                    const int q = n0 / g.ldo, c = n0 - q * g.ldo;
-                    off = (((long)tb[f] * (2 * g.Ho) + 2 * ty[f] + (q >> 1)) * (2 * g.Wo) + 2 * tx[f] + (q & 1)) * g.ldo + c;
-                }
-                if (g.res) {
-                    const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-                }
-                f16x4 ov = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(g.out) + off) = ov;
             }
+        }
+        return;
+    }
+    // NHWC fp16 outputs: two adjacent 16-channel tiles per trip, so that a lane owns a run of 8 consecutive channels
+    // after pair_to_run() (common.h) and the residual read / store are 16 B per lane, 64 B per pixel row.
+#pragma unroll 1
+    for (int nt = 0; nt < NT; nt += 2) {
+        f32x4 acc0[MF], acc1[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) { acc0[f] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[f] = acc0[f]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 wv = wfrag(nt * KS + ks);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc0[f] = MFMA_16x16x32(wv, xf[f][ks], acc0[f]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 wv = wfrag((nt + 1) * KS + ks);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc1[f] = MFMA_16x16x32(wv, xf[f][ks], acc1[f]);
+        }
+        const int n0 = nt * 16 + grp * 4;
+        const float4 bv0 = *reinterpret_cast<const float4 *>(g.bias + n0);
+        const float4 bv1 = *reinterpret_cast<const float4 *>(g.bias + n0 + 16);
+        const int np = nt * 16;                         // first channel of the 32-channel pair
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            float v0[4] = {acc0[f][0] + bv0.x, acc0[f][1] + bv0.y, acc0[f][2] + bv0.z, acc0[f][3] + bv0.w};
+            float v1[4] = {acc1[f][0] + bv1.x, acc1[f][1] + bv1.y, acc1[f][2] + bv1.z, acc1[f][3] + bv1.w};
+            if (g.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf(v0[r]); v1[r] = gelu_erf(v1[r]); }
+            } else if (g.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0[r] = v0[r] >= 0.f ? v0[r] : v0[r] * g.slope;
+                    v1[r] = v1[r] >= 0.f ? v1[r] : v1[r] * g.slope;
+                }
+            }
+            long off;
+            if (g.mode == 0) {
+                off = (((long)tb[f] * g.Ho + ty[f]) * g.Wo + tx[f]) * g.ldo + np;
+            } else {
+                // PatchUp: column n = q*Cq + c (repacked), q=(i,j) -> pixel (2y+i, 2x+j)  (swin_unet.py:76-82);
+                // Cq is a multiple of 32, so a tile pair never straddles two sub-pixels
+                const int q = np / g.ldo, c = np - q * g.ldo;
+                off = (((long)tb[f] * (2 * g.Ho) + 2 * ty[f] + (q >> 1)) * (2 * g.Wo) + 2 * tx[f] + (q & 1)) * g.ldo + c;
+            }
+            off += pair_run_channel(grp);
+            const bool live = valid[f] && np < g.n_real;
+            if (g.res) {
+                f16x4 ra, rb;
+                run_to_pair(*reinterpret_cast<const f16x8 *>(g.res + (live ? off : 0)), ra, rb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v0[r] += (float)ra[r]; v1[r] += (float)rb[r]; }
+            }
+            const f16x8 ov = pair_to_run((f16x4){(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3]},
+                                         (f16x4){(f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]});
+            if (live) *reinterpret_cast<f16x8 *>(reinterpret_cast<f16 *>(g.out) + off) = ov;
         }
     }
 }
@@ -155,6 +192,8 @@ static int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
 int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
     NUNIF_REQUIRE(g.K % 32 == 0 && g.N % 16 == 0 && g.Cin % 32 == 0, "gemm %s: K=%d N=%d Cin=%d not aligned", tag,
                   g.K, g.N, g.Cin);
+    NUNIF_REQUIRE(g.mode == 2 || (g.N % 32 == 0 && g.n_real % 32 == 0 && g.ldo % 32 == 0),
+                  "gemm %s: NHWC outputs are written in 32-channel pairs (N=%d n_real=%d ldo=%d)", tag, g.N, g.n_real, g.ldo);
     const long M = (long)g.B * g.Ho * g.Wo;
     if (M == 0) return NUNIF_HIP_OK;
     const double flops = 2.0 * (double)M * g.K * g.n_real;
