@@ -8,6 +8,9 @@
 // channel n) and the *activations* as the B operand (cols = token m).  The accumulator of a lane then holds 4
 // consecutive output channels of ONE token (D[n = 4*(lane>>4)+r][m = lane&15]) so the epilogue stores 8 bytes of
 // contiguous NHWC per lane and bias/residual are plain 4-wide loads — no LDS transpose anywhere.
+#include <algorithm>
+#include <cstdlib>
+
 #include "swin_kernels.h"
 
 namespace nunif {
@@ -179,12 +182,208 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     }
 }
 
+// gemm_res_kernel: the same GEMM with the weights RESIDENT in LDS: a persistent 8-wave workgroup per CU copies the WHOLE packed weight matrix into LDS once (launcher
+//   checks it fits in 160 KB) and every wave loops over its own token groups with no barrier.  With few MFMAs per
+//   fragment (MF = 2) the ring's one-chunk-ahead weight prefetch covers only ~256 cycles, less than the L2 latency, and
+//   every chunk boundary stalled; measured on the stem conv (K = 576): 770 us with the ring.
+template <int KS, int MF>
+__global__ void __launch_bounds__(512) gemm_res_kernel(GemmArgs g) {
+    constexpr bool RES = true;
+    constexpr int CH = 8;
+    constexpr int WAVES = RES ? 8 : 4;
+    __shared__ __attribute__((aligned(16))) f16x8 ring[RES ? 1 : 2][RES ? 1 : CH * 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+    const f16x8 *wres = reinterpret_cast<const f16x8 *>(smem_g);
+    const int tid = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r16 = lane & 15;
+    const int grp = lane >> 4;
+    const long M = (long)g.B * g.Ho * g.Wo;
+    const int NT = g.N >> 4;
+    // ring mode: no early exit — every wave joins every chunk barrier; rows beyond M are clamped on load and masked on
+    // store (the host pads every packed weight array with 16 KiB of zeros, so the one-chunk-ahead prefetch never
+    //  leaves the allocation — make_linear in swin_unet.cpp)
+    const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.w);
+    f16x8 st0, st1;
+    if constexpr (RES) {
+        f16x8 *dst = reinterpret_cast<f16x8 *>(smem_g);
+        for (int i = tid; i < NT * KS * 64; i += 512) dst[i] = gsrc[i];
+        __syncthreads();
+    } else {
+        st0 = gsrc[tid]; st1 = gsrc[tid + 256];
+    }
+    auto wfrag = [&](int fi) -> f16x8 {
+        if constexpr (RES) {
+            return wres[fi * 64 + lane];
+        } else {
+            const int c = fi / CH;
+            if (fi % CH == 0) {
+                ring[c & 1][tid] = st0;
+                ring[c & 1][tid + 256] = st1;
+                __syncthreads();
+                st0 = gsrc[(c + 1) * (CH * 64) + tid];
+                st1 = gsrc[(c + 1) * (CH * 64) + tid + 256];
+            }
+            return ring[c & 1][(fi % CH) * 64 + lane];
+        }
+    };
+
+    const long n_groups = (M + MF * 16 - 1) / (MF * 16);
+    const long g_first = (long)blockIdx.x * WAVES + wave;
+    const long g_step = RES ? (long)gridDim.x * WAVES : n_groups + WAVES;      // ring mode: exactly one trip
+#pragma unroll 1
+    for (long gi = g_first; RES ? gi < n_groups : gi == g_first; gi += g_step) {
+    const long m_base = gi * (MF * 16);
+    f16x8 xf[MF][KS];
+    int tb[MF], ty[MF], tx[MF];
+    bool valid[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        long m = m_base + f * 16 + r16;
+        valid[f] = m < M;
+        if (m >= M) m = M - 1;
+        // (a wave-uniform division + per-lane carry loops, and 32-bit division, were both tried: slower / faulting)
+        const int x = (int)(m % g.Wo);
+        const long t = m / g.Wo;
+        const int y = (int)(t % g.Ho);
+        const int b = (int)(t / g.Ho);
+        tb[f] = b; ty[f] = y; tx[f] = x;
+        const long pix0 = ((long)b * g.Hi + (long)y * g.stride + g.oy) * g.Wi + (long)x * g.stride + g.ox;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = ks * 32;
+            const int tap = k0 / g.Cin;
+            const int c0 = k0 - tap * g.Cin;
+            const int dy = tap / g.kw;
+            const int dx = tap - dy * g.kw;
+            const f16 *p = g.a + (pix0 + (long)dy * g.Wi + dx) * g.Cin + c0 + grp * 8;
+            xf[f][ks] = *reinterpret_cast<const f16x8 *>(p);
+        }
+    }
+
+    if (g.mode == 2) {
+        // ToImage: column n = c*s*s + i*s + j -> out[b][c][y*s+i][x*s+j], clamp(0,1)  (swin_unet.py:110-116)
+#pragma unroll 1
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 acc[MF];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 wv = wfrag(nt * KS + ks);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) acc[f] = MFMA_16x16x32(wv, xf[f][ks], acc[f]);
+            }
+            const int n0 = nt * 16 + grp * 4;
+            const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+            const int s = g.ps, s2 = s * s;
+            const int OC = g.n_real / s2;
+            float *o = reinterpret_cast<float *>(g.out);
+            const long OH = (long)g.Ho * s, OW = (long)g.Wo * s;
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                if (!valid[f]) continue;
+                const float v[4] = {acc[f][0] + bv.x, acc[f][1] + bv.y, acc[f][2] + bv.z, acc[f][3] + bv.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + r;
+                    if (n < g.n_real) {
+                        const int c = n / s2, rem = n - c * s2;
+                        const int i = rem / s, j = rem - i * s;
+                        o[(((long)tb[f] * OC + c) * OH + (long)ty[f] * s + i) * OW + (long)tx[f] * s + j] =
+                            fminf(fmaxf(v[r], 0.f), 1.f);
+                    }
+                }
+            }
+        }
+        continue;
+    }
+    // NHWC fp16 outputs: two adjacent 16-channel tiles per trip, so that a lane owns a run of 8 consecutive channels
+    // after pair_to_run() (common.h) and the residual read / store are 16 B per lane, 64 B per pixel row.
+#pragma unroll 1
+    for (int nt = 0; nt < NT; nt += 2) {
+        f32x4 acc0[MF], acc1[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) { acc0[f] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[f] = acc0[f]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 wv = wfrag(nt * KS + ks);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc0[f] = MFMA_16x16x32(wv, xf[f][ks], acc0[f]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 wv = wfrag((nt + 1) * KS + ks);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc1[f] = MFMA_16x16x32(wv, xf[f][ks], acc1[f]);
+        }
+        const int n0 = nt * 16 + grp * 4;
+        const float4 bv0 = *reinterpret_cast<const float4 *>(g.bias + n0);
+        const float4 bv1 = *reinterpret_cast<const float4 *>(g.bias + n0 + 16);
+        const int np = nt * 16;                         // first channel of the 32-channel pair
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            float v0[4] = {acc0[f][0] + bv0.x, acc0[f][1] + bv0.y, acc0[f][2] + bv0.z, acc0[f][3] + bv0.w};
+            float v1[4] = {acc1[f][0] + bv1.x, acc1[f][1] + bv1.y, acc1[f][2] + bv1.z, acc1[f][3] + bv1.w};
+            if (g.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf(v0[r]); v1[r] = gelu_erf(v1[r]); }
+            } else if (g.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0[r] = v0[r] >= 0.f ? v0[r] : v0[r] * g.slope;
+                    v1[r] = v1[r] >= 0.f ? v1[r] : v1[r] * g.slope;
+                }
+            }
+            long off;
+            if (g.mode == 0) {
+                off = (((long)tb[f] * g.Ho + ty[f]) * g.Wo + tx[f]) * g.ldo + np;
+            } else {
+                // PatchUp: column n = q*Cq + c (repacked), q=(i,j) -> pixel (2y+i, 2x+j)  (swin_unet.py:76-82);
+                // Cq is a multiple of 32, so a tile pair never straddles two sub-pixels
+                const int q = np / g.ldo, c = np - q * g.ldo;
+                off = (((long)tb[f] * (2 * g.Ho) + 2 * ty[f] + (q >> 1)) * (2 * g.Wo) + 2 * tx[f] + (q & 1)) * g.ldo + c;
+            }
+            off += pair_run_channel(grp);
+            const bool live = valid[f] && np < g.n_real;
+            if (g.res) {
+                f16x4 ra, rb;
+                run_to_pair(*reinterpret_cast<const f16x8 *>(g.res + (live ? off : 0)), ra, rb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v0[r] += (float)ra[r]; v1[r] += (float)rb[r]; }
+            }
+            const f16x8 ov = pair_to_run((f16x4){(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3]},
+                                         (f16x4){(f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]});
+            if (live) *reinterpret_cast<f16x8 *>(reinterpret_cast<f16 *>(g.out) + off) = ov;
+        }
+    }
+    }   // token-group loop
+}
+
 template <int KS, int MF>
 static int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     const long M = (long)g.B * g.Ho * g.Wo;
-    const long rows_per_block = 4 * MF * 16;
-    const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
-    gemm_kernel<KS, MF><<<blocks, 256, 0, s>>>(g);
+    const size_t wbytes = (size_t)(g.N / 16) * KS * 1024;
+    // resident weights pay where the ring's one-chunk-ahead prefetch is too short (MF = 2: K = 384, 576); measured
+    // slower for the MF = 4 shapes (K = 96, 192), which keep the ring.  NUNIF_GEMM_RING=1 / NUNIF_GEMM_RES=1 force one.
+    static const bool force_ring = getenv("NUNIF_GEMM_RING") != nullptr, force_res = getenv("NUNIF_GEMM_RES") != nullptr;
+    const bool fits = wbytes <= 144 * 1024 && M >= 8 * MF * 16 * 64;
+    if (fits && !force_ring && (MF == 2 || force_res)) {
+        static bool configured = false;
+        if (!configured) {
+            NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_res_kernel<KS, MF>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            configured = true;
+        }
+        const long groups = (M + MF * 16 - 1) / (MF * 16);
+        const unsigned blocks = (unsigned)std::min<long>((groups + 7) / 8, 256);
+        gemm_res_kernel<KS, MF><<<blocks, 512, wbytes, s>>>(g);
+    } else {
+        const long rows_per_block = 4 * MF * 16;
+        const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
+        gemm_kernel<KS, MF><<<blocks, 256, 0, s>>>(g);
+    }
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
