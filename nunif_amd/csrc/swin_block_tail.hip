@@ -426,12 +426,14 @@ int proj_mlp_stream_frags(int C) {
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
                     long M, int C, hipStream_t s) {
     if (M == 0) return NUNIF_HIP_OK;
-    ProfScope ps(C == 96 ? "proj_mlp_kernel<96,4>" : "proj_mlp_kernel<192,2>", s, 2.0 * (double)M * C * C * 5.0,
-                 (double)M * C * 2.0 * 3.0);
-    const int n_chunks = (proj_mlp_stream_frags(C) + kChunkFrags - 1) / kChunkFrags;
     static const bool ring96 = getenv("NUNIF_TAIL_RING") != nullptr;     // A/B switch: the round-1 ring version
+    static const int variant = getenv("NUNIF_TAIL_VARIANT") ? atoi(getenv("NUNIF_TAIL_VARIANT")) : 6;
+    // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
+    const char *sym = C == 192 ? "proj_mlp_kernel<192,2,0>" : ring96 ? "proj_mlp_kernel<96,4,0>"
+                      : variant == 6 ? "proj_mlp_r_kernel<96,2,8,true>" : "proj_mlp_r_kernel<96,*>";
+    ProfScope ps(sym, s, 2.0 * (double)M * C * C * 5.0, (double)M * C * 2.0 * 3.0);
+    const int n_chunks = (proj_mlp_stream_frags(C) + kChunkFrags - 1) / kChunkFrags;
     if (C == 96 && !ring96) {
-        static const int variant = getenv("NUNIF_TAIL_VARIANT") ? atoi(getenv("NUNIF_TAIL_VARIANT")) : 6;
         constexpr size_t smem = (size_t)proj_mlp_stream_frags_c(96) * 1024 + 4 * 96 * 4;
         auto go = [&](auto kern, int mf, int waves) -> int {
             static bool configured[8] = {false};

@@ -362,14 +362,18 @@ __global__ void __launch_bounds__(512) gemm_res_kernel(GemmArgs g) {
 }
 
 template <int KS, int MF>
-static int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
+static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym, const char *res_sym, double flops,
+                         double bytes) {
     const long M = (long)g.B * g.Ho * g.Wo;
     const size_t wbytes = (size_t)(g.N / 16) * KS * 1024;
     // resident weights pay where the ring's one-chunk-ahead prefetch is too short (MF = 2: K = 384, 576); measured
     // slower for the MF = 4 shapes (K = 96, 192), which keep the ring.  NUNIF_GEMM_RING=1 / NUNIF_GEMM_RES=1 force one.
     static const bool force_ring = getenv("NUNIF_GEMM_RING") != nullptr, force_res = getenv("NUNIF_GEMM_RES") != nullptr;
     const bool fits = wbytes <= 144 * 1024 && M >= 8 * MF * 16 * 64;
-    if (fits && !force_ring && (MF == 2 || force_res)) {
+    const bool res = fits && !force_ring && (MF == 2 || force_res);
+    // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
+    ProfScope ps(res ? res_sym : ring_sym, s, flops, bytes);
+    if (res) {
         static bool configured = false;
         if (!configured) {
             NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_res_kernel<KS, MF>,
@@ -398,19 +402,14 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
     const double flops = 2.0 * (double)M * g.K * g.n_real;
     const double bytes = (double)M * (g.Cin * 2.0 * (g.K / g.Cin > 1 ? 1.0 : 1.0) + g.n_real * (g.mode == 2 ? 4.0 : 2.0) +
                                       (g.res ? g.n_real * 2.0 : 0.0));
-    // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
-    const char *sym = g.K == 64 ? "gemm_kernel<2,4>" : g.K == 128 ? "gemm_kernel<4,4>" : g.K == 96 ? "gemm_kernel<3,4>"
-                    : g.K == 192 ? "gemm_kernel<6,4>" : g.K == 384 ? "gemm_kernel<12,2>"
-                    : g.K == 576 ? "gemm_kernel<18,2>" : "gemm_kernel<24,1>";
-    ProfScope ps(sym, s, flops, bytes);
     switch (g.K / 32) {
-        case 2: return launch_gemm_t<2, 4>(g, s);
-        case 4: return launch_gemm_t<4, 4>(g, s);
-        case 3: return launch_gemm_t<3, 4>(g, s);
-        case 6: return launch_gemm_t<6, 4>(g, s);
-        case 12: return launch_gemm_t<12, 2>(g, s);
-        case 18: return launch_gemm_t<18, 2>(g, s);
-        case 24: return launch_gemm_t<24, 1>(g, s);
+        case 2: return launch_gemm_t<2, 4>(g, s, "gemm_kernel<2,4>", "gemm_res_kernel<2,4>", flops, bytes);
+        case 4: return launch_gemm_t<4, 4>(g, s, "gemm_kernel<4,4>", "gemm_res_kernel<4,4>", flops, bytes);
+        case 3: return launch_gemm_t<3, 4>(g, s, "gemm_kernel<3,4>", "gemm_res_kernel<3,4>", flops, bytes);
+        case 6: return launch_gemm_t<6, 4>(g, s, "gemm_kernel<6,4>", "gemm_res_kernel<6,4>", flops, bytes);
+        case 12: return launch_gemm_t<12, 2>(g, s, "gemm_kernel<12,2>", "gemm_res_kernel<12,2>", flops, bytes);
+        case 18: return launch_gemm_t<18, 2>(g, s, "gemm_kernel<18,2>", "gemm_res_kernel<18,2>", flops, bytes);
+        case 24: return launch_gemm_t<24, 1>(g, s, "gemm_kernel<24,1>", "gemm_res_kernel<24,1>", flops, bytes);
         default:
             set_error("gemm %s: unsupported K=%d", tag, g.K);
             return NUNIF_HIP_EUNSUPPORTED;
