@@ -44,6 +44,8 @@ struct C3W { float *w = nullptr, *b = nullptr; int C = 0; };
 
 struct nunif_cunet {
     int no_clip = 0;
+    int up = 0;                 // 1: UpCUNet (unet1 ends in ConvTranspose2d(64, 3, 4, 2, 3); scale 2, offset 36)
+    UpW u1bottom_up;            // that head as a 2x2-window gather GEMM (K = 4*64) with a pixel-shuffle store
     std::vector<void *> owned;
     // unet1
     C3W u1c1a; ConvW u1c1b, u1down, u1c2a, u1c2b, u1c3, u1bottom; SEW u1se2; UpW u1up;
@@ -126,6 +128,36 @@ int make_up(nunif_cunet *h, const TMap &m, const std::string &key, int cin, int 
     return upload(h, bias, &u->bias);
 }
 
+// ConvTranspose2d(cin, cout, 4, 2, 3), weight [cin][cout][4][4]:  out[oy][ox] = b + sum in[iy][ix] W[ky][kx] over
+// oy = 2 iy - 3 + ky.  The 2x2 input window (rows j, j+1; cols i, i+1) produces exactly the 2x2 output pixels
+// (2j-1 .. 2j) x (2i-1 .. 2i): window row dy contributes to output row parity a through ky = a + 2 (1 - dy) (same for
+// columns).  So the head is a gather GEMM over the (H-1)^2 windows, K = (dy*2+dx)*cin + ci (gemm_kernel taps with
+// kw = 2), N = co*4 + a*2 + b, stored by gemm_kernel mode 2 with oshift = -1 into the (2H-4)^2 plane.
+int make_deconv4(nunif_cunet *h, const TMap &m, const std::string &key, int cin, int cout, UpW *u) {
+    const HostT *w, *b;
+    int rc;
+    if ((rc = find(m, key + ".weight", &w)) || (rc = find(m, key + ".bias", &b))) return rc;
+    NUNIF_REQUIRE(w->numel == (int64_t)cin * cout * 16 && b->numel == cout, "%s: unexpected shape", key.c_str());
+    const int n_real = 4 * cout, N = (n_real + 15) / 16 * 16, NT = N / 16, K = 4 * cin, KS = K / 32;
+    std::vector<f16> packed((size_t)N * K + 8192, (f16)0.0f);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = nt * 16 + (l & 15), k = ks * 32 + (l >> 4) * 8 + j;
+                    if (n >= n_real) continue;
+                    const int co = n / 4, a = (n >> 1) & 1, bb = n & 1;
+                    const int tap = k / cin, ci = k % cin, dy = tap >> 1, dx = tap & 1;
+                    const int ky = a + 2 * (1 - dy), kx = bb + 2 * (1 - dx);
+                    packed[(((size_t)nt * KS + ks) * 64 + l) * 8 + j] = (f16)w->data[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+                }
+    std::vector<float> bias(N, 0.0f);
+    for (int n = 0; n < n_real; ++n) bias[n] = b->data[n / 4];
+    u->N = N; u->K = K; u->cq = cout;
+    if ((rc = upload(h, packed, &u->w))) return rc;
+    return upload(h, bias, &u->bias);
+}
+
 int make_c3(nunif_cunet *h, const TMap &m, const std::string &key, int cout, C3W *c) {
     const HostT *w, *b;
     int rc;
@@ -173,15 +205,26 @@ int run_up(const UpW &u, const f16 *a, int B, int Hi, f16 *out, hipStream_t s) {
     return launch_gemm(g, s, "cunet_up");
 }
 
-// x: tile mode [B,3,T,T] or (frame != NULL) frame + grid; z: [B,3,T-56,T-56]
+int run_deconv4(const UpW &u, const f16 *a, int B, int Hi, float *out, int no_clamp, hipStream_t s) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = a; g.B = B; g.Hi = Hi; g.Wi = Hi; g.Cin = u.K / 4; g.Ho = Hi - 1; g.Wo = Hi - 1; g.stride = 1; g.kw = 2;
+    g.K = u.K; g.w = u.w; g.bias = u.bias; g.N = u.N; g.mode = 2; g.act = 0;
+    g.out = out; g.n_real = 4 * u.cq; g.ps = 2; g.oshift = -1; g.OH = 2 * Hi - 4; g.OW = 2 * Hi - 4; g.no_clamp = no_clamp;
+    return launch_gemm(g, s, "upcunet_bottom");
+}
+
+// x: tile mode [B,3,T,T] or (frame != NULL) frame + grid; z: [B,3,T-56,T-56] (CUNet) / [B,3,2T-72,2T-72] (UpCUNet)
 int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif_tile_grid *grid, int tile_begin,
                  float *z, int B, int T, hipStream_t s) {
     NUNIF_REQUIRE(T % 4 == 0 && T >= 64, "tile_size %d is not valid for cunet (multiple of 4, >= 64)", T);
     const size_t b = B;
-    const int a1 = T - 2, x1 = T - 4, d1 = x1 / 2, e1 = d1 - 2, f1 = d1 - 4, g1 = 2 * f1, h1 = g1 - 2, T2 = g1 - 4;
+    const int a1 = T - 2, x1 = T - 4, d1 = x1 / 2, e1 = d1 - 2, f1 = d1 - 4, g1 = 2 * f1, h1 = g1 - 2;
+    const int T2 = h->up ? 2 * h1 - 4 : g1 - 4;
     const int a2 = T2 - 2, y1 = T2 - 4, d2 = y1 / 2, e2 = d2 - 2, y2 = d2 - 4, d3 = y2 / 2, e3 = d3 - 2, f3 = d3 - 4;
     const int g3 = 2 * f3, e4 = g3 - 2, f4 = g3 - 4, g4 = 2 * f4, h5 = g4 - 2, To = g4 - 4;
-    NUNIF_REQUIRE(g1 == x1 - 8 && g3 == y2 - 8 && g4 == y1 - 32 && To == T - 56, "internal: cunet geometry");
+    NUNIF_REQUIRE(g1 == x1 - 8 && g3 == y2 - 8 && g4 == y1 - 32 && To == (h->up ? 2 * T - 72 : T - 56),
+                  "internal: cunet geometry");
     auto sz = [&](int side, int ch) { return b * side * side * ch * sizeof(f16); };
     int rc;
     // live-range packing of the fp16 maps onto 12 buffers
@@ -220,7 +263,10 @@ int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif
     // conv3(crop(x1, 4) + x2)
     if ((rc = run_conv(h->u1c3, tG, tX1, x1, 4, B, g1, tH, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     // conv_bottom -> z1 (clamped unless no_clip, cunet.py:185-186)
-    if ((rc = run_conv(h->u1bottom, tH, nullptr, 0, 0, B, h1, nullptr, z1, nullptr, 0, 0, h->no_clip ? 0 : 1, 0, s))) return rc;
+    if (h->up) {
+        if ((rc = run_deconv4(h->u1bottom_up, tH, B, h1, z1, h->no_clip ? 1 : 0, s))) return rc;
+    } else if ((rc = run_conv(h->u1bottom, tH, nullptr, 0, 0, B, h1, nullptr, z1, nullptr, 0, 0, h->no_clip ? 0 : 1, 0, s)))
+        return rc;
 
     // ---------------- unet2 (cunet.py:99-121) ----------------
     memset(&c3, 0, sizeof(c3));
@@ -267,11 +313,7 @@ extern "C" int nunif_hip_cunet_create(const nunif_tensor_desc *tensors, int32_t 
     do {
         const HostT *bw;
         if ((rc = find(m, "unet1.conv_bottom.weight", &bw))) break;
-        if (bw->shape.size() == 4 && bw->shape[2] == 4) {
-            set_error("UpCUNet (ConvTranspose2d 4x4 head) is not supported by the HIP engine yet");
-            rc = NUNIF_HIP_EUNSUPPORTED;
-            break;
-        }
+        h->up = (bw->shape.size() == 4 && bw->shape[2] == 4) ? 1 : 0;
         const std::string a = "unet1.", b = "unet2.";
         if ((rc = make_c3(h, m, a + "conv1.conv.0", 32, &h->u1c1a))) break;
         if ((rc = make_conv(h, m, a + "conv1.conv.2", 32, 64, 3, 1, &h->u1c1b))) break;
@@ -281,7 +323,9 @@ extern "C" int nunif_hip_cunet_create(const nunif_tensor_desc *tensors, int32_t 
         if ((rc = make_se(h, m, a + "conv2.seblock", 64, &h->u1se2))) break;
         if ((rc = make_up(h, m, a + "conv2_up", 64, 64, &h->u1up))) break;
         if ((rc = make_conv(h, m, a + "conv3", 64, 64, 3, 1, &h->u1c3))) break;
-        if ((rc = make_conv(h, m, a + "conv_bottom", 64, 3, 3, 1, &h->u1bottom))) break;
+        if (h->up) {
+            if ((rc = make_deconv4(h, m, a + "conv_bottom", 64, 3, &h->u1bottom_up))) break;
+        } else if ((rc = make_conv(h, m, a + "conv_bottom", 64, 3, 3, 1, &h->u1bottom))) break;
         if ((rc = make_c3(h, m, b + "conv1.conv.0", 32, &h->u2c1a))) break;
         if ((rc = make_conv(h, m, b + "conv1.conv.2", 32, 64, 3, 1, &h->u2c1b))) break;
         if ((rc = make_conv(h, m, b + "conv1_down", 64, 64, 2, 2, &h->u2down1))) break;
@@ -323,7 +367,8 @@ extern "C" int nunif_hip_cunet_render(nunif_cunet *h, const float *x, float *y, 
                                       int32_t tile_size, int32_t batch_size, void *stream) {
     NUNIF_REQUIRE(h && x && y && batch_size > 0, "cunet_render: bad argument");
     nunif_tile_grid g;
-    int rc = nunif_hip_tile_grid_init(x_h, x_w, 1, 28, tile_size, 0, &g);      // scale 1, offset 28, no blending
+    // CUNet: scale 1, offset 28; UpCUNet: scale 2, offset 36 (cunet.py:143,177); blend_size None -> plain overwrite
+    int rc = nunif_hip_tile_grid_init(x_h, x_w, h->up ? 2 : 1, h->up ? 36 : 28, tile_size, 0, &g);
     if (rc) return rc;
     const int n_tiles = g.h_blocks * g.w_blocks;
     const size_t To = g.out_tile_size;

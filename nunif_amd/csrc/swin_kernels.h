@@ -22,6 +22,9 @@ struct GemmArgs {
     int ldo;                  // channels per output pixel (mode 0: N_real, mode 1: N/4)
     int n_real;               // number of valid output columns
     int ps;                   // mode 2: pixel-shuffle factor s (out channels = n_real/(s*s))
+    int oshift, OH, OW;       // mode 2: output pixel (y*s+i+oshift, x*s+j+oshift) inside an OH x OW plane (0: Ho*s x Wo*s);
+                              //         positions outside the plane are dropped (ConvTranspose2d 4x4 s2 p3 head of UpCUNet)
+    int no_clamp;             // mode 2: 1 = no clamp(0,1)
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag);
 

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
             const int s = g.ps, s2 = s * s;
             const int OC = g.n_real / s2;
             float *o = reinterpret_cast<float *>(g.out);
-            const long OH = (long)g.Ho * s, OW = (long)g.Wo * s;
+            const long OH = g.OH ? g.OH : (long)g.Ho * s, OW = g.OW ? g.OW : (long)g.Wo * s;
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
                 if (!valid[f]) continue;
@@ -113,8 +113,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                     if (n < g.n_real) {
                         const int c = n / s2, rem = n - c * s2;
                         const int i = rem / s, j = rem - i * s;
-                        o[(((long)tb[f] * OC + c) * OH + (long)ty[f] * s + i) * OW + (long)tx[f] * s + j] =
-                            fminf(fmaxf(v[r], 0.f), 1.f);
+                        const long oy = (long)ty[f] * s + i + g.oshift, ox = (long)tx[f] * s + j + g.oshift;
+                        if (oy >= 0 && oy < OH && ox >= 0 && ox < OW)
+                            o[(((long)tb[f] * OC + c) * OH + oy) * OW + ox] = g.no_clamp ? v[r] : fminf(fmaxf(v[r], 0.f), 1.f);
                     }
                 }
             }
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(512) gemm_res_kernel(GemmArgs g) {
             const int s = g.ps, s2 = s * s;
             const int OC = g.n_real / s2;
             float *o = reinterpret_cast<float *>(g.out);
-            const long OH = (long)g.Ho * s, OW = (long)g.Wo * s;
+            const long OH = g.OH ? g.OH : (long)g.Ho * s, OW = g.OW ? g.OW : (long)g.Wo * s;
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
                 if (!valid[f]) continue;
@@ -291,8 +292,9 @@ __global__ void __launch_bounds__(512) gemm_res_kernel(GemmArgs g) {
                     if (n < g.n_real) {
                         const int c = n / s2, rem = n - c * s2;
                         const int i = rem / s, j = rem - i * s;
-                        o[(((long)tb[f] * OC + c) * OH + (long)ty[f] * s + i) * OW + (long)tx[f] * s + j] =
-                            fminf(fmaxf(v[r], 0.f), 1.f);
+                        const long oy = (long)ty[f] * s + i + g.oshift, ox = (long)tx[f] * s + j + g.oshift;
+                        if (oy >= 0 && oy < OH && ox >= 0 && ox < OW)
+                            o[(((long)tb[f] * OC + c) * OH + oy) * OW + ox] = g.no_clamp ? v[r] : fminf(fmaxf(v[r], 0.f), 1.f);
                     }
                 }
             }
@@ -407,6 +409,7 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
         case 4: return launch_gemm_t<4, 4>(g, s, "gemm_kernel<4,4>", "gemm_res_kernel<4,4>", flops, bytes);
         case 3: return launch_gemm_t<3, 4>(g, s, "gemm_kernel<3,4>", "gemm_res_kernel<3,4>", flops, bytes);
         case 6: return launch_gemm_t<6, 4>(g, s, "gemm_kernel<6,4>", "gemm_res_kernel<6,4>", flops, bytes);
+        case 8: return launch_gemm_t<8, 4>(g, s, "gemm_kernel<8,4>", "gemm_res_kernel<8,4>", flops, bytes);
         case 12: return launch_gemm_t<12, 2>(g, s, "gemm_kernel<12,2>", "gemm_res_kernel<12,2>", flops, bytes);
         case 18: return launch_gemm_t<18, 2>(g, s, "gemm_kernel<18,2>", "gemm_res_kernel<18,2>", flops, bytes);
         case 24: return launch_gemm_t<24, 1>(g, s, "gemm_kernel<24,1>", "gemm_res_kernel<24,1>", flops, bytes);

@@ -1,9 +1,10 @@
-"""waifu2x CUNet on the HIP engine.
+"""waifu2x CUNet / UpCUNet on the HIP engine.
 
-Mirrors ``waifu2x/models/cunet.py`` (reference) ``CUNet`` :172-203 — registry name, constructor kwargs, ``i2i_*``
-geometry (scale 1, offset 28, no blending), ``tile_size_validator`` :124-125 and the ``state_dict`` key layout, so
-reference ``.pth`` files load unchanged.  The forward pass is ``nunif_hip_cunet_forward``
-(nunif_amd/csrc/cunet.cpp).  ``UpCUNet`` (4x4 ConvTranspose head) is not on the engine yet.
+Mirrors ``waifu2x/models/cunet.py`` (reference) ``CUNet`` :172-203 and ``UpCUNet`` :139-169 — registry names,
+constructor kwargs, ``i2i_*`` geometry (scale 1 / offset 28 and scale 2 / offset 36, no blending),
+``tile_size_validator`` :124-125 and the ``state_dict`` key layout, so reference ``.pth`` files load unchanged.  The
+forward pass is ``nunif_hip_cunet_forward`` (nunif_amd/csrc/cunet.cpp); which net it runs is decided by the shape of
+``unet1.conv_bottom.weight`` (a 4x4 ConvTranspose2d for UpCUNet).
 """
 import ctypes
 import math
@@ -19,13 +20,13 @@ def tile_size_validator(size):
     return size % 4 == 0
 
 
-def _init_weights(in_channels, out_channels):
+def _init_weights(in_channels, out_channels, up=False):
     """Fresh kaiming-normal(fan_out) weights, zero biases, in the reference's key layout (cunet.py:43-50,89-96)."""
     sd = OrderedDict()
 
     def conv(key, cin, cout, k, transposed=False):
         shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
-        fan_out = (cin if transposed else cout) * k * k
+        fan_out = (cin if transposed else cout) * k * k      # torch's fan_out of a ConvTranspose2d weight [in, out, k, k]
         sd[key + ".weight"] = torch.randn(shape) * math.sqrt(2.0 / fan_out)
         sd[key + ".bias"] = torch.zeros(cout)
 
@@ -41,7 +42,10 @@ def _init_weights(in_channels, out_channels):
     block("unet1.conv2", 64, 128, 64, True)
     conv("unet1.conv2_up", 64, 64, 2, transposed=True)
     conv("unet1.conv3", 64, 64, 3)
-    conv("unet1.conv_bottom", 64, out_channels, 3)
+    if up:
+        conv("unet1.conv_bottom", 64, out_channels, 4, transposed=True)
+    else:
+        conv("unet1.conv_bottom", 64, out_channels, 3)
     block("unet2.conv1", out_channels, 32, 64, False)
     conv("unet2.conv1_down", 64, 64, 2)
     block("unet2.conv2", 64, 64, 128, True)
@@ -58,6 +62,7 @@ def _init_weights(in_channels, out_channels):
 class HipCUNetEngine:
     def __init__(self, state_dict, no_clip, device):
         self.device = torch.device(device)
+        self.up = state_dict["unet1.conv_bottom.weight"].shape[2] == 4
         if self.device.type != "cuda":
             raise RuntimeError("the cunet HIP engine needs a ROCm device (model.to('cuda:N')); no CPU fallback")
         keep, descs = [], []
@@ -86,7 +91,8 @@ class HipCUNetEngine:
     def forward(self, x):
         B, C, T, T2 = x.shape
         assert C == 3 and T == T2
-        z = torch.empty((B, 3, T - 56, T - 56), dtype=torch.float32, device=self.device)
+        To = 2 * T - 72 if self.up else T - 56
+        z = torch.empty((B, 3, To, To), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _hip.check(_hip.lib().nunif_hip_cunet_forward(self.handle, ctypes.c_void_p(x.data_ptr()),
                                                           ctypes.c_void_p(z.data_ptr()), B, T,
@@ -96,7 +102,8 @@ class HipCUNetEngine:
     def render(self, x, tile_size, batch_size):
         C, H, W = x.shape
         assert C == 3
-        y = torch.empty((3, H, W), dtype=torch.float32, device=self.device)
+        sc = 2 if self.up else 1
+        y = torch.empty((3, H * sc, W * sc), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _hip.check(_hip.lib().nunif_hip_cunet_render(self.handle, ctypes.c_void_p(x.data_ptr()),
                                                          ctypes.c_void_p(y.data_ptr()), H, W, tile_size, batch_size,
@@ -104,19 +111,18 @@ class HipCUNetEngine:
         return y
 
 
-@register_model
-class CUNet(I2IBaseModel):
-    name = "waifu2x.cunet"
+class _CUNetBase(I2IBaseModel):
+    _up = False
 
     def __init__(self, in_channels=3, out_channels=3, no_clip=False):
         super().__init__(dict(in_channels=in_channels, out_channels=out_channels, no_clip=no_clip),
-                         scale=1, offset=28, in_channels=in_channels)
+                         scale=2 if self._up else 1, offset=36 if self._up else 28, in_channels=in_channels)
         if in_channels != 3 or out_channels != 3:
             raise ValueError("the HIP cunet engine supports in_channels = out_channels = 3")
         self.register_tile_size_validator(tile_size_validator)
         self.register_buffer("_device_probe", torch.empty(0), persistent=False)
         self.no_clip = no_clip
-        self._weights = _init_weights(in_channels, out_channels)
+        self._weights = _init_weights(in_channels, out_channels, self._up)
         self._engine = None
 
     def get_device(self):
@@ -129,7 +135,7 @@ class CUNet(I2IBaseModel):
         missing = [k for k in self._weights if k not in state_dict]
         unexpected = [k for k in state_dict if k not in self._weights]
         if strict and (missing or unexpected):
-            raise RuntimeError(f"Error(s) in loading state_dict for CUNet: missing {missing[:4]}, "
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: missing {missing[:4]}, "
                                f"unexpected {unexpected[:4]}")
         for k in self._weights:
             if k in state_dict:
@@ -163,3 +169,15 @@ class CUNet(I2IBaseModel):
 
     def render_frame(self, x, tile_size, batch_size):
         return self.engine().render(x.to(device=self.get_device(), dtype=torch.float32).contiguous(), tile_size, batch_size)
+
+
+@register_model
+class CUNet(_CUNetBase):
+    name = "waifu2x.cunet"
+    _up = False
+
+
+@register_model
+class UpCUNet(_CUNetBase):
+    name = "waifu2x.upcunet"
+    _up = True

@@ -145,6 +145,18 @@ def gen_cunet():
     img = synth_image(53, 3, 150, 170)          # 3x3 tiles of 96 (step 40), plain-overwrite stitch
     out["img"] = img
     out["render_t96_b4"] = tiled_render(img, m, tile_size=96, batch_size=4)
+    # UpCUNet (scale 2, offset 36): the released models are trained with no_clip=True (cunet.py:127-134)
+    from waifu2x.models.cunet import UpCUNet
+    sdu = OC.random_state_dict(203, up=True)
+    mu = UpCUNet(no_clip=True).eval()
+    mu.load_state_dict(sdu, strict=True)
+    out["up_y"], out["up_sdsum"] = mu(x), sd_checksum(sdu)
+    muc = UpCUNet().eval()
+    muc.load_state_dict(sdu, strict=True)
+    out["up_y_clip"] = muc(x[:1])
+    imgu = synth_image(54, 3, 100, 130)         # 3x4 tiles of 64 (step 28), plain-overwrite stitch at scale 2
+    out["up_img"] = imgu
+    out["up_render_t64_b5"] = tiled_render(imgu, mu, tile_size=64, batch_size=5)
     save("cunet", **out)
 
 

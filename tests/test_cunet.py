@@ -26,7 +26,20 @@ def test_oracle_matches_reference_fixture(g):
     assert 0.05 < g["y"].std().item() < 0.4 and float((g["y"] <= 0).float().mean()) < 0.15
 
 
+def test_oracle_upcunet_matches_reference_fixture(g):
+    sd = OC.random_state_dict(203, up=True)
+    assert sd_checksum(sd) == pytest.approx(float(g["up_sdsum"]), rel=1e-12)
+    y = OC.model_forward(sd, g["x"], no_clip=True)
+    assert y.shape == g["up_y"].shape == (2, 3, 120, 120) and (y - g["up_y"]).abs().max().item() < 1e-5
+    assert (OC.model_forward(sd, g["x"][:1]) - g["up_y_clip"]).abs().max().item() < 1e-5
+    out = OS.tiled_render(g["up_img"], lambda mb: OC.model_forward(sd, mb, no_clip=True), 2, 36, 0, 64, 5)
+    assert out.shape == g["up_render_t64_b5"].shape == (3, 200, 260)
+    assert (out - g["up_render_t64_b5"]).abs().max().item() < 1e-5
+    assert 0.05 < g["up_y"].std().item() < 0.4 and float((g["up_y"] <= 0).float().mean()) < 0.15
+
+
 def test_geometry():
+    assert OC.GEOMETRY["waifu2x.upcunet"] == (2, 36, 0)
     assert OC.GEOMETRY["waifu2x.cunet"] == (1, 28, 0)
     assert [t for t in range(60, 80) if OC.valid_tile_size(t)] == [60, 64, 68, 72, 76]
     cfg = OS.create_config(512, 512, 1, 28, 256, 0)
@@ -53,6 +66,30 @@ def test_hip_forward_and_render(hiplib, g):
     m2 = CUNet(no_clip=True).eval()
     m2.load_state_dict(sd)
     assert psnr(m2.to("cuda:0")(g["x"][:1].to("cuda:0")).cpu(), g["y_no_clip"]) >= 50.0
+
+
+@pytest.mark.gpu
+def test_hip_upcunet_forward_and_render(hiplib, g):
+    from nunif_amd.waifu2x.models.cunet import UpCUNet
+    from nunif_amd.nunif.utils.render import tiled_render
+    sd = OC.random_state_dict(203, up=True)
+    m = UpCUNet(no_clip=True).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda:0")
+    assert (m.i2i_scale, m.i2i_offset, m.i2i_blend_size) == (2, 36, None)
+    y = m(g["x"].to("cuda:0")).cpu()
+    assert y.shape == g["up_y"].shape and float(y.min()) >= 0 and float(y.max()) <= 1
+    assert psnr(y, g["up_y"]) >= 50.0, psnr(y, g["up_y"])      # vs the reference's own output
+    mc = UpCUNet().eval()
+    mc.load_state_dict(sd)
+    assert psnr(mc.to("cuda:0")(g["x"][:1].to("cuda:0")).cpu(), g["up_y_clip"]) >= 50.0
+    out = tiled_render(g["up_img"], m, tile_size=64, batch_size=5)
+    assert out.shape == (3, 200, 260) and psnr(out.cpu(), g["up_render_t64_b5"]) >= 50.0
+    assert torch.equal(out, tiled_render(g["up_img"], m, tile_size=64, batch_size=12))
+    # a 256 tile (the default): 2*256 - 72 = 440, interior vs the oracle
+    x = synth_image(62, 3, 256, 256)[None]
+    z = m(x.to("cuda:0")).cpu()
+    assert z.shape == (1, 3, 440, 440) and psnr(z, OC.model_forward(sd, x, no_clip=True)) >= 50.0
 
 
 @pytest.mark.gpu
