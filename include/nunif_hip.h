@@ -132,6 +132,24 @@ typedef struct {
 int nunif_hip_forward_warp(const float *c, const float *depth, float *left, float *right, float *lmask,
                            float *rmask, const nunif_forward_warp_params *params, void *stream);
 
+/* iw3 "sbs.row_flow_v3" (iw3/models/row_flow_v3.py :33-107, the default --method): a small window-attention net that
+ * turns the 3-plane feature map [depth | divergence feature | convergence feature] (iw3/backward_warp.py
+ * make_input_tensor :17-64) into a horizontal flow `delta` at depth resolution.  create() takes the reference
+ * state dict (keys blocks.*, last_layer.1.*).  x: [B,3,h,w] f32 device, delta: [B,1,h,w] f32 device.  flip = 1 runs the
+ * net on the horizontally mirrored planes (the right eye of apply_divergence_nn_delta :191-236); delta is then in
+ * the mirrored frame, which is what nunif_hip_delta_warp(flip = 1) expects. */
+typedef struct nunif_row_flow nunif_row_flow;
+int nunif_hip_row_flow_create(const nunif_tensor_desc *tensors, int32_t n_tensors, nunif_row_flow **handle);
+void nunif_hip_row_flow_destroy(nunif_row_flow *handle);
+int nunif_hip_row_flow_delta(nunif_row_flow *handle, const float *x, float *delta, int32_t B, int32_t h, int32_t w,
+                             int32_t flip, void *stream);
+
+/* Replaces iw3/backward_warp.py backward_warp :67-83 for a horizontal flow map: grid = make_grid + [delta, 0] *
+ * delta_scale at (dh, dw), bilinear (align_corners) resize to (H, W), grid_sample(bilinear, border, align_corners) +
+ * clamp(0,1).  flip = 1: out = flip(backward_warp(flip(c), ...)) without materialising the flips. */
+int nunif_hip_delta_warp(const float *c, const float *delta, float *out, int32_t B, int32_t C, int32_t H, int32_t W,
+                         int32_t dh, int32_t dw, double delta_scale, int32_t flip, void *stream);
+
 /* Replaces iw3/backward_warp.py apply_divergence_grid_sample :96-121 (make_grid + backward_warp + grid_sample
  * bilinear/border/align_corners=True + clamp).  c: [B,C,H,W]; depth: [B,1,dh,dw] (grid is built at depth
  * resolution and bilinearly resized, as the reference does). */

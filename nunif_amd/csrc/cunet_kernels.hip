@@ -66,6 +66,11 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
         const int dy = tap / g.kw, dx = tap - dy * g.kw;
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
+            if (g.rpad) {           // replicate padding = clamp of the tap coordinate
+                const int yy = min(max(py[f] + dy - g.rpad, 0), g.Hi - 1), xx = min(max(px[f] + dx - g.rpad, 0), g.Wi - 1);
+                dst[f] = *reinterpret_cast<const f16x8 *>(g.a + (((long)pb[f] * g.Hi + yy) * g.Wi + xx) * g.Cin + 8 * grp + c0);
+                continue;
+            }
             f16x8 v = *reinterpret_cast<const f16x8 *>(g.a + base[f] + ((long)dy * g.Wi + dx) * g.Cin + c0);
             if (g.a2) v += *reinterpret_cast<const f16x8 *>(g.a2 + base2[f] + ((long)dy * g.W2 + dx) * g.Cin + c0);
             dst[f] = v;
@@ -125,8 +130,14 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
                     g.out32[(((long)pb[f] * g.n_real + n) * g.Ho + py[f]) * g.Wo + px[f]] = o;
                 }
             } else if (n0 < g.n_real) {
+                const long off = (((long)pb[f] * g.Ho + py[f]) * g.Wo + px[f]) * g.n_real + n0;
+                if (g.res) {
+                    const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
                 const f16x4 ov = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                *reinterpret_cast<f16x4 *>(g.out + (((long)pb[f] * g.Ho + py[f]) * g.Wo + px[f]) * g.n_real + n0) = ov;
+                *reinterpret_cast<f16x4 *>(g.out + off) = ov;
             }
         }
     }
@@ -143,6 +154,7 @@ static int launch_conv_t(const ConvArgs &g, hipStream_t s) {
 
 int launch_conv(const ConvArgs &g, hipStream_t s) {
     NUNIF_REQUIRE(g.Cin % 32 == 0 && g.N % 16 == 0, "conv: Cin=%d N=%d not aligned", g.Cin, g.N);
+    NUNIF_REQUIRE(!g.rpad || (g.stride == 1 && !g.a2), "conv: replicate padding needs stride 1 and a single input");
     const long M = (long)g.B * g.Ho * g.Wo;
     if (M == 0) return NUNIF_HIP_OK;
     const double K = (double)g.kh * g.kw * g.Cin;

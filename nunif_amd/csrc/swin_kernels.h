@@ -83,6 +83,9 @@ struct ConvArgs {
     float *out32;             // image head: planar fp32 [B,n_real,Ho,Wo]
     const float *add32; int addH, addW, add_crop;   // optional + add32[b][n][y+add_crop][x+add_crop]
     int clamp01;
+    int rpad;                 // > 0: ReplicationPad2d(rpad) folded into the gather (tap coordinates clamped; the
+                              //      caller passes Ho = Hi + 2*rpad - k + 1); stride must be 1, no second input
+    const f16 *res;           // optional residual added AFTER the activation, NHWC [B,Ho,Wo,n_real]
 };
 int launch_conv(const ConvArgs &g, hipStream_t s);
 

@@ -146,3 +146,17 @@ def map_depth(x, kind, p0=0.0, p1=0.0):
         _hip.check(_hip.lib().nunif_hip_map_depth(_p(x), _p(y), x.numel(), kind, float(p0), float(p1),
                                                   _hip.current_stream_ptr(x.device)))
     return y
+
+
+def delta_warp(c, delta, delta_scale, flip=False):
+    """backward_warp(c, make_grid, [delta, 0], delta_scale) (+ the right eye's mirror) — iw3/backward_warp.py:67-93."""
+    c = _cuda_f32(c, "delta_warp")
+    delta = _cuda_f32(delta, "delta_warp")
+    b, ch, h, w = c.shape
+    assert delta.shape[0] == b and delta.shape[1] == 1
+    out = torch.empty_like(c)
+    with torch.cuda.device(c.device):
+        _hip.check(_hip.lib().nunif_hip_delta_warp(_p(c), _p(delta), _p(out), b, ch, h, w, delta.shape[2], delta.shape[3],
+                                                   float(delta_scale), 1 if flip else 0,
+                                                   _hip.current_stream_ptr(c.device)))
+    return out

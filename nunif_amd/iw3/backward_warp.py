@@ -1,13 +1,99 @@
-"""Grid-sample backward warp on the HIP engine.  Mirrors ``iw3/backward_warp.py`` ``apply_divergence_grid_sample``
-:96-121 (``make_grid`` :86-93 and ``backward_warp`` :67-83 are folded into ``nunif_hip_backward_warp``).
-
-The NN-delta variants (``apply_divergence_nn_*``, row_flow / MLBW side models, :124-379) are "next" rows
- and are not provided here.
+"""Backward warps on the HIP engine.  Mirrors ``iw3/backward_warp.py``: ``apply_divergence_grid_sample`` :96-121
+(``make_grid`` :86-93 and ``backward_warp`` :67-83 folded into ``nunif_hip_backward_warp``) and the NN-delta path the
+default ``--method row_flow_v3`` takes — ``make_divergence_feature_value`` :8-14, ``make_input_tensor`` :17-64 (c=None),
+``apply_divergence_nn_LR`` :124-160, ``apply_divergence_nn`` :163-188, ``apply_divergence_nn_delta`` :191-236.
+The multi-layer variant (``apply_divergence_nn_delta_weight``, MLBW) and the symmetric models are not provided yet.
 """
+import torch
+
 from . import _ops
+from .mapper import get_mapper
 
 
 def apply_divergence_grid_sample(c, depth, divergence, convergence, synthetic_view):
     assert synthetic_view in {"both", "right", "left"}
     left, right = _ops.backward_warp(c, depth, divergence, convergence, synthetic_view)
     return (c if left is None else left.to(c.dtype)), (c if right is None else right.to(c.dtype))
+
+
+def make_divergence_feature_value(divergence, convergence, image_width):
+    divergence_pix = divergence * 0.5 * 0.01 * image_width
+    divergence_feature_value = divergence_pix / 32.0
+    convergence_feature_value = (-divergence_pix * convergence) / 32.0
+    return divergence_feature_value, convergence_feature_value
+
+
+def make_input_tensor(c, depth, divergence, convergence, image_width, mapper=None, preserve_screen_border=False):
+    """CHW depth -> the 3-plane feature tensor (depth | divergence | convergence).  ``c`` must be None (the inference
+    form); the screen-border taper multiplies the two constant planes by linear ramps exactly like the reference."""
+    if c is not None:
+        raise NotImplementedError("make_input_tensor with an image (training layout) is not used at inference")
+    depth = depth.squeeze(0)
+    if mapper is not None:
+        depth = get_mapper(mapper)(depth)
+    divergence_value, convergence_value = make_divergence_feature_value(divergence, convergence, image_width)
+    divergence_feat = torch.full_like(depth, divergence_value)
+    if torch.is_tensor(convergence_value):
+        convergence_feat = convergence_value.to(depth.device).expand_as(depth).clone()
+    else:
+        convergence_feat = torch.full_like(depth, convergence_value)
+    if preserve_screen_border:
+        border_pix = round(divergence * 0.75 * 0.01 * image_width * (depth.shape[-1] / image_width))
+        if border_pix > 0:
+            wl = torch.linspace(0.0, 1.0, border_pix, device=depth.device)[None, :]
+            wr = torch.linspace(1.0, 0.0, border_pix, device=depth.device)[None, :]
+            for feat in (divergence_feat, convergence_feat):
+                feat[:, :border_pix] = wl * feat[:, :border_pix]
+                feat[:, -border_pix:] = wr * feat[:, -border_pix:]
+    return torch.stack([depth, divergence_feat, convergence_feat], dim=0)
+
+
+def apply_divergence_nn_delta(model, c, depth, divergence, convergence, steps, shift, preserve_screen_border=False,
+                              enable_amp=True):
+    """One eye.  The reference flips ``c`` and ``depth`` for the right eye, runs the same net and flips the result back;
+    here the mirror is folded into the first and the last kernel (no flipped copies)."""
+    assert model.delta_output
+    if steps != 1:
+        raise NotImplementedError("warp_steps > 1 is not on the HIP engine yet")
+    flip = shift > 0
+    B, _, H, W = depth.shape
+    base_size = max(H, W)
+    if torch.is_tensor(convergence):
+        convergence = convergence.flatten()
+    else:
+        convergence = [convergence] * B
+    # (the screen-border taper is mirror-symmetric — linspace(0,1,n) on the left, linspace(1,0,n) on the right — so the
+    #  planes can be built un-mirrored and mirrored together with the depth inside the first kernel)
+    x = torch.stack([make_input_tensor(None, depth[i], divergence=divergence, convergence=convergence[i],
+                                       image_width=base_size, preserve_screen_border=preserve_screen_border)
+                     for i in range(B)])
+    delta = model.infer_delta(x, flip=flip)
+    delta_scale = 1.0 / (W // 2 - 1)
+    return _ops.delta_warp(c, delta, delta_scale, flip=flip).to(c.dtype)
+
+
+def apply_divergence_nn(model, c, depth, divergence, convergence, steps, shift, preserve_screen_border=False,
+                        enable_amp=True):
+    if model.name == "sbs.mlbw":
+        raise NotImplementedError("sbs.mlbw (multi-layer backward warp) is not on the HIP engine yet")
+    return apply_divergence_nn_delta(model, c, depth, divergence=divergence, convergence=convergence, steps=steps,
+                                     shift=shift, preserve_screen_border=preserve_screen_border, enable_amp=enable_amp)
+
+
+def apply_divergence_nn_LR(model, c, depth, divergence, convergence, steps, synthetic_view="both",
+                           preserve_screen_border=False, enable_amp=True):
+    assert synthetic_view in {"both", "right", "left"}
+    steps = 1 if steps is None else steps
+    if getattr(model, "symmetric", False):
+        raise NotImplementedError("symmetric side models are not on the HIP engine yet")
+    kw = dict(preserve_screen_border=preserve_screen_border, enable_amp=enable_amp)
+    if synthetic_view == "both":
+        left_eye = apply_divergence_nn(model, c, depth, divergence, convergence, steps, shift=-1, **kw)
+        right_eye = apply_divergence_nn(model, c, depth, divergence, convergence, steps, shift=1, **kw)
+    elif synthetic_view == "right":
+        left_eye = c
+        right_eye = apply_divergence_nn(model, c, depth, divergence * 2, convergence, steps, shift=1, **kw)
+    else:
+        left_eye = apply_divergence_nn(model, c, depth, divergence * 2, convergence, steps, shift=-1, **kw)
+        right_eye = c
+    return left_eye, right_eye

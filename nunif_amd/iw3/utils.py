@@ -3,12 +3,13 @@
 ``postprocess_image`` :430-487 (IPD pad, half-SBS / half-TB bicubic-antialias resize, SBS / TB / cross-eyed compose,
 max-output resize) and ``nunif/utils/video.py`` ``to_tensor`` / ``to_frame`` :218-269 (``to_frame_tensor`` here returns
 the quantised HWC tensor; wrapping it into an ``av.VideoFrame`` is the caller's codec business).
-NN side-model methods (row_flow / mlbw / inpaint), anaglyph and VR180 projection are "next" rows."""
+``row_flow_v3`` (the default method) runs on the engine; mlbw / inpaint side models, anaglyph and VR180 projection are
+"next" rows."""
 import torch
 import torch.nn.functional as F
 
 from . import _ops
-from .backward_warp import apply_divergence_grid_sample
+from .backward_warp import apply_divergence_grid_sample, apply_divergence_nn_LR
 from .forward_warp import apply_divergence_forward_warp
 from .mapper import get_mapper
 
@@ -28,8 +29,23 @@ def apply_divergence(depth, im, args, side_model=None, reset_pts=None):
         left, right = apply_divergence_forward_warp(im, depth, args.divergence, convergence=convergence,
                                                     method=args.method, synthetic_view=args.synthetic_view,
                                                     width_base=False)
+    elif args.method in {"row_flow_v3", "row_flow"}:
+        # iw3/utils.py:369-387: optional --stereo-width resize of the depth, then the NN backward warp
+        if side_model is None:
+            raise ValueError(f"method={args.method} needs a side model (nunif_amd.iw3.models.row_flow_v3.RowFlowV3)")
+        stereo_width = getattr(args, "stereo_width", None)
+        if stereo_width is not None:
+            H, W = im.shape[2:]
+            stereo_width = min(W, stereo_width)
+            if depth.shape[3] != stereo_width:
+                new_h = int(H * (stereo_width / W))
+                depth = _ops.resize_aa(depth, (new_h, stereo_width), mode="bilinear", align_corners=True, clamp01=True)
+        left, right = apply_divergence_nn_LR(side_model, im, depth, args.divergence, convergence,
+                                             getattr(args, "warp_steps", None), synthetic_view=args.synthetic_view,
+                                             preserve_screen_border=getattr(args, "preserve_screen_border", False),
+                                             enable_amp=not getattr(args, "disable_amp", False))
     else:
-        raise NotImplementedError(f"method={args.method}: NN side models are not on the HIP engine yet")
+        raise NotImplementedError(f"method={args.method}: this side model is not on the HIP engine yet")
     if not batch:
         left, right = left.squeeze(0), right.squeeze(0)
     return left, right

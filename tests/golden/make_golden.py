@@ -160,7 +160,37 @@ def gen_cunet():
     save("cunet", **out)
 
 
-GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet}
+def gen_row_flow():
+    """sbs.row_flow_v3 (iw3/models/row_flow_v3.py) + apply_divergence_nn_LR (iw3/backward_warp.py) on the reference."""
+    from iw3.models.row_flow_v3 import RowFlowV3
+    from iw3 import backward_warp as RB
+    from oracle import row_flow_v3 as ORF
+    from oracle.forward_warp import synth_depth
+    out = {}
+    sd = ORF.random_state_dict(301)
+    m = RowFlowV3().eval()
+    m.load_state_dict(sd, strict=True)
+    m.delta_output = True
+    depth = synth_depth(3, 2, 58, 104, "smooth_edges")          # pads to 60 x 192 -> 60 x 24 tokens
+    x = ORF.make_input(depth, 2.0, 0.5, 104)
+    out["depth"], out["sdsum"] = depth, sd_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    out["delta"] = m(x)[:, :1]
+    c = torch.stack([synth_image(71, 3, 116, 208), synth_image(72, 3, 116, 208)])
+    out["c"] = c
+    out["left"], out["right"] = RB.apply_divergence_nn_LR(m, c, depth, 2.0, 0.5, steps=1, synthetic_view="both",
+                                                          enable_amp=False)
+    _, out["right_only"] = RB.apply_divergence_nn_LR(m, c[:1], depth[:1], 2.0, 0.5, steps=1, synthetic_view="right",
+                                                     enable_amp=False)
+    lb, rb = RB.apply_divergence_nn_LR(m, c[:1], depth[:1], 2.5, 0.4, steps=1, synthetic_view="both",
+                                       preserve_screen_border=True, enable_amp=False)
+    out["left_border"], out["right_border"] = lb, rb
+    # same resolution for image and depth (no grid resize)
+    out["left_same"], out["right_same"] = RB.apply_divergence_nn_LR(m, c[:1, :, :58, :104].contiguous(), depth[:1], 2.0, 0.5,
+                                                                    steps=1, synthetic_view="both", enable_amp=False)
+    save("row_flow", **out)
+
+
+GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)
