@@ -150,6 +150,24 @@ int nunif_hip_row_flow_delta(nunif_row_flow *handle, const float *x, float *delt
 int nunif_hip_delta_warp(const float *c, const float *delta, float *out, int32_t B, int32_t C, int32_t H, int32_t W,
                          int32_t dh, int32_t dw, double delta_scale, int32_t flip, void *stream);
 
+/* iw3 "sbs.mlbw" (iw3/models/mlbw.py :37-247; --method mlbw_l2 / mlbw_l4 / mlbw_l2s / mlbw_l4s): multi-layer backward
+ * warp.  create() takes the reference state dict (lv1_in.1, lv2.N.*, lv1_out.1); the layer count (2 / 4) and the
+ * small / full block stack are read from the tensor shapes.  x: [B,3,h,w] feature planes; delta, weight: [B,L,h,w] f32
+ * (weight = softmax over the L layer logits).  flip as in nunif_hip_row_flow_delta. */
+typedef struct nunif_mlbw nunif_mlbw;
+int nunif_hip_mlbw_create(const nunif_tensor_desc *tensors, int32_t n_tensors, nunif_mlbw **handle);
+void nunif_hip_mlbw_destroy(nunif_mlbw *handle);
+int32_t nunif_hip_mlbw_num_layers(const nunif_mlbw *handle);
+int nunif_hip_mlbw_delta(nunif_mlbw *handle, const float *x, float *delta, float *weight, int32_t B, int32_t h, int32_t w,
+                         int32_t flip, void *stream);
+
+/* The composite of iw3/backward_warp.py apply_divergence_nn_delta_weight :300-321: out = clamp(sum_i
+ * backward_warp(c, delta_i) * weight_i).  delta: [B,L,dh,dw]; weight: [B,L,H,W] already at image resolution (the
+ * reference resizes it with bilinear + antialias: nunif_hip_resize_aa).  L <= 4, C <= 4. */
+int nunif_hip_delta_weight_warp(const float *c, const float *delta, const float *weight, float *out, int32_t B, int32_t C,
+                                int32_t H, int32_t W, int32_t dh, int32_t dw, int32_t L, double delta_scale, int32_t flip,
+                                void *stream);
+
 /* Replaces iw3/backward_warp.py apply_divergence_grid_sample :96-121 (make_grid + backward_warp + grid_sample
  * bilinear/border/align_corners=True + clamp).  c: [B,C,H,W]; depth: [B,1,dh,dw] (grid is built at depth
  * resolution and bilinearly resized, as the reference does). */

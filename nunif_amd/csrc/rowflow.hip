@@ -71,31 +71,39 @@ __global__ void __launch_bounds__(256) rf_input_kernel(RfInputArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 struct WmhaArgs {
-    f16 *x;                  // [B,H,W,64], updated in place: x += head_proj(attention(x))
-    const f16 *wfrag;        // 24 qkv fragments (part, nt, ks) + 8 head_proj fragments (nt, ks; chained k order)
-    const float *bqkv;       // [192] (q part pre-scaled by hd^-0.5 * log2e)
-    const float *bproj;      // [64]
+    f16 *x;                  // [B,H,W,C], updated in place: x += head_proj(attention(x))
+    const f16 *wfrag;        // 3*NT*KS qkv fragments (part, nt, ks) + NT*KS head_proj fragments (nt, ks; chained k order)
+    const float *bqkv;       // [3C] (q part pre-scaled by hd^-0.5 * log2e)
+    const float *bproj;      // [C]
     const float *btab;       // [16][16] log2e * score bias [query][key]; -1e30 for keys beyond the window
     int B, H, W, n_windows;
+    int sy, sx;              // WindowMHA2d shift: the map is ZERO-padded by (sy, sx) on both sides, windows tile the
+                             // padded map, padded positions act as (all-zero input) tokens and are cropped away again
 };
 
 __device__ __forceinline__ f16x8 cat8f(f16x4 lo, f16x4 hi) {
     return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int WS>
-__global__ void __launch_bounds__(256) rf_wmha_kernel(WmhaArgs a) {
-    constexpr int N = WS * WS;
-    __shared__ __attribute__((aligned(16))) f16x8 wl[32 * 64];
-    __shared__ __attribute__((aligned(16))) float tb[256], bq[192], bp[64];
+// One window (WS x WS <= 16 tokens = one MFMA tile) per wave; C channels = C/32 heads of 32; weights resident in LDS.
+template <int WS, int C>
+__global__ void __launch_bounds__(256) wmha_kernel(WmhaArgs a) {
+    constexpr int N = WS * WS, KS = C / 32, NT = C / 16, HEADS = C / 32;
+    constexpr int NF = 4 * NT * KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    f16x8 *wl = reinterpret_cast<f16x8 *>(smem_w);                                  // [NF][64]
+    float *tb = reinterpret_cast<float *>(wl + NF * 64);                            // [256]
+    float *bq = tb + 256;                                                           // [3C]
+    float *bp = bq + 3 * C;                                                         // [C]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, grp = lane >> 4;
-    for (int i = tid; i < 32 * 64; i += 256) wl[i] = reinterpret_cast<const f16x8 *>(a.wfrag)[i];
+    for (int i = tid; i < NF * 64; i += 256) wl[i] = reinterpret_cast<const f16x8 *>(a.wfrag)[i];
     tb[tid] = a.btab[tid];
-    if (tid < 192) bq[tid] = a.bqkv[tid];
-    if (tid < 64) bp[tid] = a.bproj[tid];
+    for (int i = tid; i < 3 * C; i += 256) bq[i] = a.bqkv[i];
+    for (int i = tid; i < C; i += 256) bp[i] = a.bproj[i];
     __syncthreads();
     const f16x4 zero4 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-    const int nwx = a.W / WS, nwy = a.H / WS;
+    const f16x8 zero8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    const int nwx = (a.W + 2 * a.sx) / WS, nwy = (a.H + 2 * a.sy) / WS;
     const int tt = min(r16, N - 1);
     const int iy = tt / WS, ix = tt - iy * WS;
     const f16x8 *wq = wl + lane;
@@ -103,33 +111,36 @@ __global__ void __launch_bounds__(256) rf_wmha_kernel(WmhaArgs a) {
     for (int wi = blockIdx.x * 4 + wave; wi < a.n_windows; wi += gridDim.x * 4) {
         const int wx = wi % nwx, t2 = wi / nwx;
         const int wy = t2 % nwy, b = t2 / nwy;
-        const long pix = ((long)b * a.H + wy * WS + iy) * a.W + wx * WS + ix;
-        f16x8 xf[2];
-        xf[0] = *reinterpret_cast<const f16x8 *>(a.x + pix * 64 + 8 * grp);
-        xf[1] = *reinterpret_cast<const f16x8 *>(a.x + pix * 64 + 32 + 8 * grp);
+        const int y = wy * WS + iy - a.sy, x = wx * WS + ix - a.sx;
+        const bool inside = y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const long pix = ((long)b * a.H + min(max(y, 0), a.H - 1)) * a.W + min(max(x, 0), a.W - 1);
+        f16x8 xf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            xf[ks] = inside ? *reinterpret_cast<const f16x8 *>(a.x + pix * C + ks * 32 + 8 * grp) : zero8;
         // q, k: [channel 4g+r of tile nt][token l&15];  v (operands swapped): [token 4g+r][channel l&15 of tile nt]
-        f16x4 q4[4], k4[4], v4[4];
+        f16x4 q4[NT], k4[NT], v4[NT];
 #pragma unroll
         for (int part = 0; part < 3; ++part)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int ch0 = part * 64 + nt * 16;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int ch0 = part * C + nt * 16;
                 f32x4 acc;
                 if (part == 2) { const float bv = bq[ch0 + r16]; acc = (f32x4){bv, bv, bv, bv}; }
                 else acc = *reinterpret_cast<const f32x4 *>(bq + ch0 + 4 * grp);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const f16x8 w = wq[((part * 4 + nt) * 2 + ks) * 64];
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f16x8 w = wq[((part * NT + nt) * KS + ks) * 64];
                     acc = part == 2 ? MFMA_16x16x32(xf[ks], w, acc) : MFMA_16x16x32(w, xf[ks], acc);
                 }
                 const f16x4 v = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
                 if (part == 0) q4[nt] = v; else if (part == 1) k4[nt] = v; else v4[nt] = v;
             }
-        // two heads of 32 channels: S^T[key][query] = K Q^T + bias; softmax over keys; O^T = V^T P^T
-        f16x4 o4[4];
+        // heads of 32 channels: S^T[key][query] = K Q^T + bias; softmax over keys; O^T = V^T P^T
+        f16x4 o4[NT];
         const f32x4 bias = *reinterpret_cast<const f32x4 *>(tb + r16 * 16 + 4 * grp);          // [query l&15][keys 4g..]
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < HEADS; ++hh) {
             f32x4 s = MFMA_16x16x32(cat8f(k4[2 * hh], k4[2 * hh + 1]), cat8f(q4[2 * hh], q4[2 * hh + 1]), bias);
             float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -150,18 +161,46 @@ __global__ void __launch_bounds__(256) rf_wmha_kernel(WmhaArgs a) {
         }
         // head_proj (weights packed in the chained k order: two accumulator tiles = one 32-wide k-step) + residual
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             f32x4 acc = *reinterpret_cast<const f32x4 *>(bp + nt * 16 + 4 * grp);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                acc = MFMA_16x16x32(wq[(24 + nt * 2 + ks) * 64], cat8f(o4[2 * ks], o4[2 * ks + 1]), acc);
-            f16 *px = a.x + pix * 64 + nt * 16 + 4 * grp;
-            const f16x4 xr = *reinterpret_cast<const f16x4 *>(px);
-            const f16x4 ov = {(f16)(acc[0] + (float)xr[0]), (f16)(acc[1] + (float)xr[1]), (f16)(acc[2] + (float)xr[2]),
-                              (f16)(acc[3] + (float)xr[3])};
-            if (r16 < N) *reinterpret_cast<f16x4 *>(px) = ov;
+            for (int ks = 0; ks < KS; ++ks)
+                acc = MFMA_16x16x32(wq[(3 * NT * KS + nt * KS + ks) * 64], cat8f(o4[2 * ks], o4[2 * ks + 1]), acc);
+            if (inside && r16 < N) {
+                f16 *px = a.x + pix * C + nt * 16 + 4 * grp;
+                const f16x4 xr = *reinterpret_cast<const f16x4 *>(px);
+                const f16x4 ov = {(f16)(acc[0] + (float)xr[0]), (f16)(acc[1] + (float)xr[1]), (f16)(acc[2] + (float)xr[2]),
+                                  (f16)(acc[3] + (float)xr[3])};
+                *reinterpret_cast<f16x4 *>(px) = ov;
+            }
         }
     }
+}
+
+template <int WS, int C>
+static int launch_wmha_t(const WmhaArgs &a, hipStream_t s) {
+    constexpr size_t smem = (size_t)4 * (C / 16) * (C / 32) * 1024 + 256 * 4 + 4 * C * 4;
+    static bool configured = false;
+    if (!configured) {
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)wmha_kernel<WS, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        configured = true;
+    }
+    const int grid = std::min((a.n_windows + 3) / 4, C == 64 ? 2048 : 256);
+    wmha_kernel<WS, C><<<grid, 256, smem, s>>>(a);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+int launch_wmha(WmhaArgs a, int window, int C, hipStream_t s) {
+    NUNIF_REQUIRE((a.H + 2 * a.sy) % window == 0 && (a.W + 2 * a.sx) % window == 0, "window attention: %dx%d (+%d,%d) is not "
+                  "a multiple of the %dx%d window", a.H, a.W, a.sy, a.sx, window, window);
+    a.n_windows = a.B * ((a.H + 2 * a.sy) / window) * ((a.W + 2 * a.sx) / window);
+    const double tok = (double)a.B * a.H * a.W;
+    if (window == 4 && C == 64) { ProfScope ps("wmha_kernel<4,64>", s, tok * (8.0 * C * C + 4.0 * 16 * C), tok * C * 4.0); return launch_wmha_t<4, 64>(a, s); }
+    if (window == 3 && C == 64) { ProfScope ps("wmha_kernel<3,64>", s, tok * (8.0 * C * C + 4.0 * 9 * C), tok * C * 4.0); return launch_wmha_t<3, 64>(a, s); }
+    if (window == 4 && C == 128) { ProfScope ps("wmha_kernel<4,128>", s, tok * (8.0 * C * C + 4.0 * 16 * C), tok * C * 4.0); return launch_wmha_t<4, 128>(a, s); }
+    set_error("window attention: window %d / %d channels unsupported", window, C);
+    return NUNIF_HIP_EUNSUPPORTED;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -199,9 +238,10 @@ __global__ void __launch_bounds__(256) rf_output_kernel(RfOutputArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 struct DeltaWarpArgs {
     const float *c;          // [B,C,H,W]
-    const float *delta;      // [B,1,h,w] (horizontal flow at depth resolution, in the mirrored frame when flip)
+    const float *delta;      // [B,L,h,w] (horizontal flows at depth resolution, in the mirrored frame when flip)
+    const float *weight;     // NULL (L = 1, weight 1) or [B,L,H,W] layer weights at IMAGE resolution (mirrored frame)
     float *out;              // [B,C,H,W]
-    int B, C, H, W, h, w, flip;
+    int B, C, H, W, h, w, flip, L;
     float delta_scale;
 };
 
@@ -219,7 +259,9 @@ __global__ void __launch_bounds__(256) delta_warp_kernel(DeltaWarpArgs a) {
     const long t = id / a.W;
     const int Y = (int)(t % a.H), b = (int)(t / a.H);
     const int X = a.flip ? a.W - 1 - Xo : Xo;                         // position in the (possibly mirrored) frame
-    const float *dmap = a.delta + (long)b * a.h * a.w;
+    float accum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int layer = 0; layer < a.L; ++layer) {
+    const float *dmap = a.delta + ((long)b * a.L + layer) * a.h * a.w;
     auto gx_at = [&](int yy, int xx) -> float { return lin_pm1(xx, a.w) + dmap[(long)yy * a.w + xx] * a.delta_scale; };
     float gx, gy;
     if (a.h == a.H && a.w == a.W) {
@@ -250,13 +292,103 @@ __global__ void __launch_bounds__(256) delta_warp_kernel(DeltaWarpArgs a) {
     const bool xin = x1 <= a.W - 1, yin = y1 <= a.H - 1;
     // the sampled image is the mirrored one when flip: column x of it is column W-1-x of c
     const int cx0 = a.flip ? a.W - 1 - x0 : x0, cx1 = a.flip ? a.W - 1 - x1 : x1;
-    for (int ch = 0; ch < a.C; ++ch) {
+    const float lw = a.weight ? a.weight[(((long)b * a.L + layer) * a.H + Y) * a.W + X] : 1.0f;
+    for (int ch = 0; ch < a.C && ch < 4; ++ch) {
         const float *p = a.c + ((long)b * a.C + ch) * a.H * a.W;
         float v = p[(long)y0 * a.W + cx0] * w_nw;
         if (xin) v += p[(long)y0 * a.W + cx1] * w_ne;
         if (yin) v += p[(long)y1 * a.W + cx0] * w_sw;
         if (xin && yin) v += p[(long)y1 * a.W + cx1] * w_se;
-        a.out[(((long)b * a.C + ch) * a.H + Y) * a.W + Xo] = fminf(fmaxf(v, 0.f), 1.f);
+        accum[ch] += fminf(fmaxf(v, 0.f), 1.f) * lw;                  // backward_warp clamps, then the layer weight
+    }
+    }
+    for (int ch = 0; ch < a.C && ch < 4; ++ch)
+        a.out[(((long)b * a.C + ch) * a.H + Y) * a.W + Xo] = fminf(fmaxf(accum[ch], 0.f), 1.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MLBW (iw3/models/mlbw.py): lv1_in = centred replicate pad to multiples of 32 x 4, ReplicationPad (4,4,0,0) + 1x9 conv
+// 3 -> C/8 + LeakyReLU(0.2), written directly in the pixel_unshuffle (1,8) layout (channel c*8 + x%8 of token x/8).
+struct MlbwInArgs {
+    const float *x;          // [B,3,h,w]
+    const float *w;          // [27][Cs] (k = ci*9 + tap) then bias[Cs]
+    f16 *out, *x1;           // [B,Hp,Wq,C] twice: the working map and the preserved skip (x + x1 before lv1_out)
+    int B, h, w_, Hp, Wp, ph1, pw1, Cs, flip;
+};
+
+__global__ void __launch_bounds__(256) mlbw_in_kernel(MlbwInArgs a) {
+    __shared__ float sw[28 * 16];
+    for (int i = threadIdx.x; i < 28 * a.Cs; i += 256) sw[i] = a.w[i];
+    __syncthreads();
+    const long total = (long)a.B * a.Hp * a.Wp;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int xp = (int)(id % a.Wp);
+    const long t = id / a.Wp;
+    const int yp = (int)(t % a.Hp), b = (int)(t / a.Hp);
+    const int y = min(max(yp - a.ph1, 0), a.h - 1);
+    float in[27];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int xs = min(max(xp + k - 4, 0), a.Wp - 1);              // lv1_in's own replicate pad, on the padded map
+        int xx = min(max(xs - a.pw1, 0), a.w_ - 1);
+        if (a.flip) xx = a.w_ - 1 - xx;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) in[ci * 9 + k] = a.x[(((long)b * 3 + ci) * a.h + y) * a.w_ + xx];
+    }
+    const int C = a.Cs * 8;
+    const long base = (((long)b * a.Hp + yp) * (a.Wp >> 3) + (xp >> 3)) * C + (xp & 7);
+    for (int co = 0; co < a.Cs; ++co) {
+        float acc = sw[27 * a.Cs + co];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc = fmaf(in[k], sw[k * a.Cs + co], acc);
+        acc = acc >= 0.f ? acc : acc * 0.2f;
+        a.out[base + co * 8] = (f16)acc;
+        a.x1[base + co * 8] = (f16)acc;
+    }
+}
+
+// lv1_out: pixel_shuffle + (x + x1) + ReplicationPad (4,4,0,0) + 1x9 conv C/8 -> 2L, crop, softmax over the L logits
+struct MlbwOutArgs {
+    const f16 *f, *x1;       // [B,Hp,Wq,C]
+    const float *w;          // [Cs*9][2L] (k = ci*9 + tap) then bias[2L]
+    float *delta, *weight;   // [B,L,h,w] each
+    int B, h, w_, Hp, Wp, ph1, pw1, Cs, L;
+};
+
+__global__ void __launch_bounds__(256) mlbw_out_kernel(MlbwOutArgs a) {
+    __shared__ float sw[(16 * 9 + 1) * 8];
+    const int no = 2 * a.L;
+    for (int i = threadIdx.x; i < (a.Cs * 9 + 1) * no; i += 256) sw[i] = a.w[i];
+    __syncthreads();
+    const long total = (long)a.B * a.h * a.w_;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int x = (int)(id % a.w_);
+    const long t = id / a.w_;
+    const int y = (int)(t % a.h), b = (int)(t / a.h);
+    const int yp = y + a.ph1, xp = x + a.pw1, C = a.Cs * 8;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = o < no ? sw[a.Cs * 9 * no + o] : 0.f;
+    for (int k = 0; k < 9; ++k) {
+        const int xs = min(max(xp + k - 4, 0), a.Wp - 1);
+        const long base = (((long)b * a.Hp + yp) * (a.Wp >> 3) + (xs >> 3)) * C + (xs & 7);
+        for (int ci = 0; ci < a.Cs; ++ci) {
+            const float v = (float)a.f[base + ci * 8] + (float)a.x1[base + ci * 8];
+            const float *wr = sw + (ci * 9 + k) * no;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) if (o < no) acc[o] = fmaf(v, wr[o], acc[o]);
+        }
+    }
+    float mx = -3.0e38f;
+    for (int i = 0; i < a.L; ++i) mx = fmaxf(mx, acc[a.L + i]);
+    float e[4], sum = 0.f;
+    for (int i = 0; i < a.L; ++i) { e[i] = expf(acc[a.L + i] - mx); sum += e[i]; }
+    const long hw = (long)a.h * a.w_, o0 = (long)b * a.L * hw + (long)y * a.w_ + x;
+    for (int i = 0; i < a.L; ++i) {
+        a.delta[o0 + i * hw] = acc[i];
+        a.weight[o0 + i * hw] = e[i] / sum;
     }
 }
 
@@ -310,8 +442,8 @@ struct nunif_row_flow {
 
 namespace {
 
-template <typename T>
-int upload(nunif_row_flow *h, const std::vector<T> &host, T **dev) {
+template <typename H, typename T>
+int upload(H *h, const std::vector<T> &host, T **dev) {
     void *p = nullptr;
     if (hipMalloc(&p, host.size() * sizeof(T)) != hipSuccess) { set_error("hipMalloc failed"); return NUNIF_HIP_ENOMEM; }
     h->owned.push_back(p);
@@ -333,7 +465,9 @@ void put_frag(std::vector<f16> &dst, size_t frag, int nt, int ks, bool chained, 
 
 double gelu_erf_d(double v) { return 0.5 * v * (1.0 + erf(v * 0.70710678118654752440)); }
 
-int make_block(nunif_row_flow *h, const TMap &m, const std::string &p, int window, WaBlock *bk) {
+template <typename H>
+int make_block(H *h, const TMap &m, const std::string &p, int window, int C, WaBlock *bk) {
+    const int NT = C / 16, KS = C / 32;
     const HostT *wqkv, *bqkv, *wp, *bp, *w1, *b1, *w3, *b3, *tw0, *tb0, *tw2, *tb2;
     int rc;
     if ((rc = find(m, p + "mha.mha.qkv_proj.weight", &wqkv)) || (rc = find(m, p + "mha.mha.qkv_proj.bias", &bqkv)) ||
@@ -343,25 +477,25 @@ int make_block(nunif_row_flow *h, const TMap &m, const std::string &p, int windo
         (rc = find(m, p + "bias.to_bias.0.weight", &tw0)) || (rc = find(m, p + "bias.to_bias.0.bias", &tb0)) ||
         (rc = find(m, p + "bias.to_bias.2.weight", &tw2)) || (rc = find(m, p + "bias.to_bias.2.bias", &tb2)))
         return rc;
-    NUNIF_REQUIRE(wqkv->numel == 192 * 64 && wp->numel == 64 * 64 && w1->numel == 64 * 64 && w3->numel == 64 * 64 * 9,
-                  "%s: row_flow_v3 expects 64 channels, 2 heads", p.c_str());
+    NUNIF_REQUIRE(wqkv->numel == (int64_t)3 * C * C && wp->numel == (int64_t)C * C && w1->numel == (int64_t)C * C &&
+                  w3->numel == (int64_t)C * C * 9, "%s: expected %d channels (heads of 32)", p.c_str(), C);
     bk->window = window;
     const float qs = (1.0f / sqrtf(32.0f)) * 1.4426950408889634f;       // head_dim^-0.5 * log2(e), folded into q
     {
-        std::vector<f16> frags((size_t)32 * 512);
+        std::vector<f16> frags((size_t)4 * NT * KS * 512);
         const float *wd = wqkv->data;
         for (int part = 0; part < 3; ++part)
-            for (int nt = 0; nt < 4; ++nt)
-                for (int ks = 0; ks < 2; ++ks)
-                    put_frag(frags, (size_t)(part * 4 + nt) * 2 + ks, nt, ks, false, [=](int n, int k) {
-                        return wd[(size_t)(part * 64 + n) * 64 + k] * (part == 0 ? qs : 1.0f); });
+            for (int nt = 0; nt < NT; ++nt)
+                for (int ks = 0; ks < KS; ++ks)
+                    put_frag(frags, (size_t)(part * NT + nt) * KS + ks, nt, ks, false, [=](int n, int k) {
+                        return wd[(size_t)(part * C + n) * C + k] * (part == 0 ? qs : 1.0f); });
         const float *pd = wp->data;
-        for (int nt = 0; nt < 4; ++nt)
-            for (int ks = 0; ks < 2; ++ks)
-                put_frag(frags, (size_t)24 + nt * 2 + ks, nt, ks, true, [=](int n, int k) { return pd[(size_t)n * 64 + k]; });
+        for (int nt = 0; nt < NT; ++nt)
+            for (int ks = 0; ks < KS; ++ks)
+                put_frag(frags, (size_t)3 * NT * KS + nt * KS + ks, nt, ks, true, [=](int n, int k) { return pd[(size_t)n * C + k]; });
         if ((rc = upload(h, frags, &bk->wfrag))) return rc;
-        std::vector<float> bq(192), bpv(bp->data, bp->data + 64);
-        for (int n = 0; n < 192; ++n) bq[n] = bqkv->data[n] * (n < 64 ? qs : 1.0f);
+        std::vector<float> bq(3 * C), bpv(bp->data, bp->data + C);
+        for (int n = 0; n < 3 * C; ++n) bq[n] = bqkv->data[n] * (n < C ? qs : 1.0f);
         if ((rc = upload(h, bq, &bk->bqkv)) || (rc = upload(h, bpv, &bk->bproj))) return rc;
     }
     {   // WindowScoreBias (attention.py:375-419): to_bias MLP on the normalised relative offsets, evaluated once here
@@ -382,23 +516,23 @@ int make_block(nunif_row_flow *h, const TMap &m, const std::string &p, int windo
         if ((rc = upload(h, tab, &bk->btab))) return rc;
     }
     {   // conv_mlp[0]: 1x1 as a Linear, gemm_kernel packing [nt][ks] (+16 KiB pad for the ring prefetch)
-        std::vector<f16> packed((size_t)64 * 64 + 8192, (f16)0.f);
+        std::vector<f16> packed((size_t)C * C + 8192, (f16)0.f);
         const float *wd = w1->data;
-        for (int nt = 0; nt < 4; ++nt)
-            for (int ks = 0; ks < 2; ++ks) put_frag(packed, (size_t)nt * 2 + ks, nt, ks, false, [=](int n, int k) { return wd[(size_t)n * 64 + k]; });
-        std::vector<float> bb(b1->data, b1->data + 64);
+        for (int nt = 0; nt < NT; ++nt)
+            for (int ks = 0; ks < KS; ++ks) put_frag(packed, (size_t)nt * KS + ks, nt, ks, false, [=](int n, int k) { return wd[(size_t)n * C + k]; });
+        std::vector<float> bb(b1->data, b1->data + C);
         if ((rc = upload(h, packed, &bk->w1)) || (rc = upload(h, bb, &bk->b1))) return rc;
     }
-    {   // conv_mlp[3]: 3x3, conv_kernel stream [ks][nt], k = tap*64 + ci
-        const int KS = 18, NT = 4;
-        std::vector<f16> stream((size_t)KS * NT * 512 + 8192, (f16)0.f);
+    {   // conv_mlp[3]: 3x3, conv_kernel stream [ks][nt], k = tap*C + ci
+        const int KS3 = 9 * C / 32;
+        std::vector<f16> stream((size_t)KS3 * NT * 512 + 8192, (f16)0.f);
         const float *wd = w3->data;
-        for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < KS3; ++ks)
             for (int nt = 0; nt < NT; ++nt)
                 put_frag(stream, (size_t)ks * NT + nt, nt, ks, false, [=](int n, int k) {
-                    const int tap = k / 64, ci = k % 64;
-                    return wd[((size_t)n * 64 + ci) * 9 + tap]; });
-        std::vector<float> bb(b3->data, b3->data + 64);
+                    const int tap = k / C, ci = k % C;
+                    return wd[((size_t)n * C + ci) * 9 + tap]; });
+        std::vector<float> bb(b3->data, b3->data + C);
         if ((rc = upload(h, stream, &bk->w3)) || (rc = upload(h, bb, &bk->b3))) return rc;
     }
     return NUNIF_HIP_OK;
@@ -430,8 +564,8 @@ extern "C" int nunif_hip_row_flow_create(const nunif_tensor_desc *tensors, int32
         for (int i = 0; i < 72; ++i) wout[i] = wl->data[i];
         wout[72] = bl->data[0];
         if ((rc = upload(h, win, &h->w_in)) || (rc = upload(h, wout, &h->w_out))) break;
-        if ((rc = make_block(h, m, "blocks.1.", 4, &h->blk[0]))) break;
-        if ((rc = make_block(h, m, "blocks.2.", 3, &h->blk[1]))) break;
+        if ((rc = make_block(h, m, "blocks.1.", 4, 64, &h->blk[0]))) break;
+        if ((rc = make_block(h, m, "blocks.2.", 3, 64, &h->blk[1]))) break;
     } while (0);
     if (rc) { nunif_hip_row_flow_destroy(h); return rc; }
     *handle = h;
@@ -468,13 +602,10 @@ extern "C" int nunif_hip_row_flow_delta(nunif_row_flow *h, const float *x, float
         const WaBlock &bk = h->blk[bi];
         {
             WmhaArgs a;
+            memset(&a, 0, sizeof(a));
             a.x = cur; a.wfrag = bk.wfrag; a.bqkv = bk.bqkv; a.bproj = bk.bproj; a.btab = bk.btab;
-            a.B = B; a.H = Hp; a.W = Wq; a.n_windows = B * (Hp / bk.window) * (Wq / bk.window);
-            const int grid = std::min((a.n_windows + 3) / 4, 2048);
-            ProfScope ps(bk.window == 4 ? "rf_wmha_kernel<4>" : "rf_wmha_kernel<3>", s,
-                         (double)tok * (2.0 * 64 * 256 + 4.0 * bk.window * bk.window * 64), (double)tok * 256.0);
-            if (bk.window == 4) rf_wmha_kernel<4><<<grid, 256, 0, s>>>(a); else rf_wmha_kernel<3><<<grid, 256, 0, s>>>(a);
-            NUNIF_LAUNCH_CHECK();
+            a.B = B; a.H = Hp; a.W = Wq;
+            if ((rc = launch_wmha(a, bk.window, 64, s))) return rc;
         }
         {   // conv_mlp[0..1]: 1x1 + GELU(erf)
             GemmArgs g;
@@ -504,16 +635,151 @@ extern "C" int nunif_hip_row_flow_delta(nunif_row_flow *h, const float *x, float
     return NUNIF_HIP_OK;
 }
 
-extern "C" int nunif_hip_delta_warp(const float *c, const float *delta, float *out, int32_t B, int32_t C, int32_t H,
-                                    int32_t W, int32_t dh, int32_t dw, double delta_scale, int32_t flip, void *stream) {
-    NUNIF_REQUIRE(c && delta && out && B > 0 && C > 0 && H > 0 && W > 0 && dh > 0 && dw > 0, "delta_warp: bad argument");
-    hipStream_t s = (hipStream_t)stream;
+static int run_delta_warp(const float *c, const float *delta, const float *weight, float *out, int B, int C, int H,
+                          int W, int dh, int dw, int L, double delta_scale, int flip, hipStream_t s) {
     DeltaWarpArgs a;
-    a.c = c; a.delta = delta; a.out = out; a.B = B; a.C = C; a.H = H; a.W = W; a.h = dh; a.w = dw; a.flip = flip;
-    a.delta_scale = (float)delta_scale;
+    a.c = c; a.delta = delta; a.weight = weight; a.out = out; a.B = B; a.C = C; a.H = H; a.W = W; a.h = dh; a.w = dw;
+    a.flip = flip; a.L = L; a.delta_scale = (float)delta_scale;
     const long total = (long)B * H * W;
-    ProfScope ps("delta_warp_kernel", s, 0.0, (double)total * (4.0 + 8.0 * C));
+    ProfScope ps("delta_warp_kernel", s, 0.0, (double)total * (4.0 + 8.0 * C + (weight ? 4.0 * L : 0.0)));
     delta_warp_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(a);
     NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_delta_warp(const float *c, const float *delta, float *out, int32_t B, int32_t C, int32_t H,
+                                    int32_t W, int32_t dh, int32_t dw, double delta_scale, int32_t flip, void *stream) {
+    NUNIF_REQUIRE(c && delta && out && B > 0 && C > 0 && C <= 4 && H > 0 && W > 0 && dh > 0 && dw > 0, "delta_warp: bad argument");
+    return run_delta_warp(c, delta, nullptr, out, B, C, H, W, dh, dw, 1, delta_scale, flip, (hipStream_t)stream);
+}
+
+extern "C" int nunif_hip_delta_weight_warp(const float *c, const float *delta, const float *weight, float *out, int32_t B,
+                                           int32_t C, int32_t H, int32_t W, int32_t dh, int32_t dw, int32_t L,
+                                           double delta_scale, int32_t flip, void *stream) {
+    NUNIF_REQUIRE(c && delta && weight && out && B > 0 && C > 0 && C <= 4 && H > 0 && W > 0 && dh > 0 && dw > 0 && L > 0 && L <= 4,
+                  "delta_weight_warp: bad argument");
+    return run_delta_warp(c, delta, weight, out, B, C, H, W, dh, dw, L, delta_scale, flip, (hipStream_t)stream);
+}
+
+// ---- MLBW --------------------------------------------------------------------------------------------------------------
+struct nunif_mlbw {
+    std::vector<void *> owned;
+    int L = 2, C = 64, n_blocks = 4;
+    float *w_in = nullptr, *w_out = nullptr;
+    WaBlock blk[4];
+    int sy[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
+    Buf f, x1, t1, t2;
+};
+
+extern "C" int nunif_hip_mlbw_create(const nunif_tensor_desc *tensors, int32_t n_tensors, nunif_mlbw **handle) {
+    NUNIF_REQUIRE(tensors && handle && n_tensors > 0, "mlbw_create: NULL argument");
+    TMap m;
+    for (int i = 0; i < n_tensors; ++i) {
+        HostT t;
+        t.data = tensors[i].data;
+        t.numel = 1;
+        for (int d = 0; d < tensors[i].ndim; ++d) { t.shape.push_back(tensors[i].shape[d]); t.numel *= tensors[i].shape[d]; }
+        m[tensors[i].name] = t;
+    }
+    nunif_mlbw *h = new nunif_mlbw();
+    int rc = NUNIF_HIP_OK;
+    do {
+        const HostT *wi, *bi, *wo, *bo;
+        if ((rc = find(m, "lv1_in.1.weight", &wi)) || (rc = find(m, "lv1_in.1.bias", &bi)) ||
+            (rc = find(m, "lv1_out.1.weight", &wo)) || (rc = find(m, "lv1_out.1.bias", &bo)))
+            break;
+        const int Cs = (int)bi->numel;                  // C / 8
+        h->C = Cs * 8; h->L = h->C / 32;
+        if ((Cs != 8 && Cs != 16) || wi->numel != (int64_t)Cs * 27 || bo->numel != 2 * h->L || wo->numel != (int64_t)2 * h->L * Cs * 9) {
+            set_error("mlbw: unsupported shape (C/8 = %d, %lld outputs; hole-mask variants are not on the engine yet)", Cs,
+                      (long long)bo->numel);
+            rc = NUNIF_HIP_EUNSUPPORTED;
+            break;
+        }
+        h->n_blocks = m.count("lv2.3.mha.mha.qkv_proj.weight") ? 4 : 2;
+        // shifts (mlbw.py:57-68): full (T,T),(F,F),(T,T),(F,F); small (F,T),(F,F)
+        if (h->n_blocks == 4) { h->sy[0] = h->sx[0] = 2; h->sy[2] = h->sx[2] = 2; }
+        else { h->sx[0] = 2; }
+        std::vector<float> win(28 * Cs), wout((size_t)(Cs * 9 + 1) * 2 * h->L);
+        for (int k = 0; k < 27; ++k) for (int co = 0; co < Cs; ++co) win[k * Cs + co] = wi->data[co * 27 + k];
+        for (int co = 0; co < Cs; ++co) win[27 * Cs + co] = bi->data[co];
+        const int no = 2 * h->L;
+        for (int k = 0; k < Cs * 9; ++k) for (int o = 0; o < no; ++o) wout[(size_t)k * no + o] = wo->data[(size_t)o * Cs * 9 + k];
+        for (int o = 0; o < no; ++o) wout[(size_t)Cs * 9 * no + o] = bo->data[o];
+        if ((rc = upload(h, win, &h->w_in)) || (rc = upload(h, wout, &h->w_out))) break;
+        for (int i = 0; i < h->n_blocks && !rc; ++i)
+            rc = make_block(h, m, "lv2." + std::to_string(i) + ".", 4, h->C, &h->blk[i]);
+    } while (0);
+    if (rc) { nunif_hip_mlbw_destroy(h); return rc; }
+    *handle = h;
+    return NUNIF_HIP_OK;
+}
+
+extern "C" void nunif_hip_mlbw_destroy(nunif_mlbw *h) {
+    if (!h) return;
+    for (void *p : h->owned) (void)hipFree(p);
+    h->f.release(); h->x1.release(); h->t1.release(); h->t2.release();
+    delete h;
+}
+
+extern "C" int32_t nunif_hip_mlbw_num_layers(const nunif_mlbw *h) { return h ? h->L : 0; }
+
+extern "C" int nunif_hip_mlbw_delta(nunif_mlbw *h, const float *x, float *delta, float *weight, int32_t B, int32_t hh,
+                                    int32_t ww, int32_t flip, void *stream) {
+    NUNIF_REQUIRE(h && x && delta && weight && B > 0 && hh > 0 && ww > 0, "mlbw_delta: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int pad_w = 32 - ww % 32, pad_h = 4 - hh % 4;                 // mlbw.py:78-93 (eval: centred)
+    const int pw1 = pad_w / 2, ph1 = pad_h / 2;
+    const int Hp = hh + pad_h, Wp = ww + pad_w, Wq = Wp / 8, C = h->C, Cs = C / 8;
+    const size_t tok = (size_t)B * Hp * Wq;
+    int rc;
+    if ((rc = h->f.ensure(tok * C * sizeof(f16))) || (rc = h->x1.ensure(tok * C * sizeof(f16))) ||
+        (rc = h->t1.ensure(tok * C * sizeof(f16))) || (rc = h->t2.ensure(tok * C * sizeof(f16))))
+        return rc;
+    f16 *f = (f16 *)h->f.p, *x1 = (f16 *)h->x1.p, *t1 = (f16 *)h->t1.p, *t2 = (f16 *)h->t2.p;
+    {
+        const long px = (long)B * Hp * Wp;
+        ProfScope ps("mlbw_in_kernel", s, 2.0 * 27 * Cs * (double)px, (double)px * (12.0 + 4.0 * Cs));
+        MlbwInArgs a;
+        a.x = x; a.w = h->w_in; a.out = f; a.x1 = x1; a.B = B; a.h = hh; a.w_ = ww; a.Hp = Hp; a.Wp = Wp; a.ph1 = ph1;
+        a.pw1 = pw1; a.Cs = Cs; a.flip = flip;
+        mlbw_in_kernel<<<(unsigned)((px + 255) / 256), 256, 0, s>>>(a);
+        NUNIF_LAUNCH_CHECK();
+    }
+    f16 *cur = f, *other = t2;
+    for (int bi = 0; bi < h->n_blocks; ++bi) {
+        const WaBlock &bk = h->blk[bi];
+        {
+            WmhaArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = cur; a.wfrag = bk.wfrag; a.bqkv = bk.bqkv; a.bproj = bk.bproj; a.btab = bk.btab;
+            a.B = B; a.H = Hp; a.W = Wq; a.sy = h->sy[bi]; a.sx = h->sx[bi];
+            if ((rc = launch_wmha(a, 4, C, s))) return rc;
+        }
+        {
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.a = cur; g.B = B; g.Hi = Hp; g.Wi = Wq; g.Cin = C; g.Ho = Hp; g.Wo = Wq; g.stride = 1; g.kw = 1;
+            g.K = C; g.w = bk.w1; g.bias = bk.b1; g.N = C; g.mode = 0; g.act = 1; g.out = t1; g.ldo = C; g.n_real = C; g.ps = 1;
+            if ((rc = launch_gemm(g, s, "mlbw_mlp0"))) return rc;
+        }
+        {   // ReplicationPad2d(1) + 3x3 (no activation), then the block's residual
+            ConvArgs c;
+            memset(&c, 0, sizeof(c));
+            c.a = t1; c.B = B; c.Hi = Hp; c.Wi = Wq; c.Cin = C; c.Ho = Hp; c.Wo = Wq; c.stride = 1; c.kh = 3; c.kw = 3;
+            c.wstream = bk.w3; c.bias = bk.b3; c.N = C; c.n_real = C; c.act = 0; c.out = other; c.rpad = 1; c.res = cur;
+            if ((rc = launch_conv(c, s))) return rc;
+        }
+        std::swap(cur, other);
+    }
+    {
+        const long px = (long)B * hh * ww;
+        ProfScope ps("mlbw_out_kernel", s, 2.0 * 9 * Cs * 2 * h->L * (double)px, (double)px * (8.0 * h->L + 36.0 * Cs));
+        MlbwOutArgs a;
+        a.f = cur; a.x1 = x1; a.w = h->w_out; a.delta = delta; a.weight = weight; a.B = B; a.h = hh; a.w_ = ww; a.Hp = Hp;
+        a.Wp = Wp; a.ph1 = ph1; a.pw1 = pw1; a.Cs = Cs; a.L = h->L;
+        mlbw_out_kernel<<<(unsigned)((px + 255) / 256), 256, 0, s>>>(a);
+        NUNIF_LAUNCH_CHECK();
+    }
     return NUNIF_HIP_OK;
 }

@@ -160,3 +160,17 @@ def delta_warp(c, delta, delta_scale, flip=False):
                                                    float(delta_scale), 1 if flip else 0,
                                                    _hip.current_stream_ptr(c.device)))
     return out
+
+
+def delta_weight_warp(c, delta, weight, delta_scale, flip=False):
+    """clamp(sum_i backward_warp(c, delta_i) * weight_i) — iw3/backward_warp.py:300-321; weight at image resolution."""
+    c, delta, weight = _cuda_f32(c, "delta_weight_warp"), _cuda_f32(delta, "delta_weight_warp"), _cuda_f32(weight, "delta_weight_warp")
+    b, ch, h, w = c.shape
+    layers = delta.shape[1]
+    assert weight.shape == (b, layers, h, w)
+    out = torch.empty_like(c)
+    with torch.cuda.device(c.device):
+        _hip.check(_hip.lib().nunif_hip_delta_weight_warp(_p(c), _p(delta), _p(weight), _p(out), b, ch, h, w, delta.shape[2],
+                                                          delta.shape[3], layers, float(delta_scale), 1 if flip else 0,
+                                                          _hip.current_stream_ptr(c.device)))
+    return out

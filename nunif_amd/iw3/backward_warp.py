@@ -2,7 +2,8 @@
 (``make_grid`` :86-93 and ``backward_warp`` :67-83 folded into ``nunif_hip_backward_warp``) and the NN-delta path the
 default ``--method row_flow_v3`` takes — ``make_divergence_feature_value`` :8-14, ``make_input_tensor`` :17-64 (c=None),
 ``apply_divergence_nn_LR`` :124-160, ``apply_divergence_nn`` :163-188, ``apply_divergence_nn_delta`` :191-236.
-The multi-layer variant (``apply_divergence_nn_delta_weight``, MLBW) and the symmetric models are not provided yet.
+and the multi-layer variant ``apply_divergence_nn_delta_weight`` :262-341 (MLBW).  Symmetric models and the hole-mask
+output are not provided yet.
 """
 import torch
 
@@ -72,10 +73,36 @@ def apply_divergence_nn_delta(model, c, depth, divergence, convergence, steps, s
     return _ops.delta_warp(c, delta, delta_scale, flip=flip).to(c.dtype)
 
 
+def apply_divergence_nn_delta_weight(model, c, depth, divergence, convergence, steps, shift, preserve_screen_border=False,
+                                     enable_amp=True, return_mask=False):
+    """MLBW: L flows + softmax layer weights; composite = clamp(sum_i backward_warp(c, delta_i) * w_i)."""
+    assert model.delta_output
+    if return_mask or getattr(model, "hole_mask", False):
+        raise NotImplementedError("the hole-mask MLBW output is not on the HIP engine yet")
+    flip = shift > 0
+    B, _, H, W = depth.shape
+    base_size = max(H, W)
+    if torch.is_tensor(convergence):
+        convergence = convergence.flatten()
+    else:
+        convergence = [convergence] * B
+    x = torch.stack([make_input_tensor(None, depth[i], divergence=divergence, convergence=convergence[i],
+                                       image_width=base_size, preserve_screen_border=preserve_screen_border)
+                     for i in range(B)])
+    delta, layer_weight = model.infer_delta(x, flip=flip)
+    if c.shape[2] != layer_weight.shape[2] or c.shape[3] != layer_weight.shape[3]:
+        # F.interpolate(layer_weight, size, bilinear, align_corners=True, antialias=True)  :295-297
+        layer_weight = _ops.resize_aa(layer_weight, c.shape[-2:], mode="bilinear", align_corners=True)
+    delta_scale = 1.0 / (W // 2 - 1)
+    return _ops.delta_weight_warp(c, delta, layer_weight, delta_scale, flip=flip).to(c.dtype)
+
+
 def apply_divergence_nn(model, c, depth, divergence, convergence, steps, shift, preserve_screen_border=False,
                         enable_amp=True):
     if model.name == "sbs.mlbw":
-        raise NotImplementedError("sbs.mlbw (multi-layer backward warp) is not on the HIP engine yet")
+        return apply_divergence_nn_delta_weight(model, c, depth, divergence=divergence, convergence=convergence,
+                                                steps=steps, shift=shift, preserve_screen_border=preserve_screen_border,
+                                                enable_amp=enable_amp)
     return apply_divergence_nn_delta(model, c, depth, divergence=divergence, convergence=convergence, steps=steps,
                                      shift=shift, preserve_screen_border=preserve_screen_border, enable_amp=enable_amp)
 

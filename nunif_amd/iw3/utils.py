@@ -3,7 +3,7 @@
 ``postprocess_image`` :430-487 (IPD pad, half-SBS / half-TB bicubic-antialias resize, SBS / TB / cross-eyed compose,
 max-output resize) and ``nunif/utils/video.py`` ``to_tensor`` / ``to_frame`` :218-269 (``to_frame_tensor`` here returns
 the quantised HWC tensor; wrapping it into an ``av.VideoFrame`` is the caller's codec business).
-``row_flow_v3`` (the default method) runs on the engine; mlbw / inpaint side models, anaglyph and VR180 projection are
+``row_flow_v3`` (the default method) and ``mlbw_l2/l4/l2s/l4s`` run on the engine; inpaint side models, anaglyph and VR180 projection are
 "next" rows."""
 import torch
 import torch.nn.functional as F
@@ -29,7 +29,7 @@ def apply_divergence(depth, im, args, side_model=None, reset_pts=None):
         left, right = apply_divergence_forward_warp(im, depth, args.divergence, convergence=convergence,
                                                     method=args.method, synthetic_view=args.synthetic_view,
                                                     width_base=False)
-    elif args.method in {"row_flow_v3", "row_flow"}:
+    elif args.method in {"row_flow_v3", "row_flow", "mlbw_l2", "mlbw_l4", "mlbw_l2s", "mlbw_l4s"}:
         # iw3/utils.py:369-387: optional --stereo-width resize of the depth, then the NN backward warp
         if side_model is None:
             raise ValueError(f"method={args.method} needs a side model (nunif_amd.iw3.models.row_flow_v3.RowFlowV3)")

@@ -190,7 +190,32 @@ def gen_row_flow():
     save("row_flow", **out)
 
 
-GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow}
+def gen_mlbw():
+    """sbs.mlbw (iw3/models/mlbw.py) + apply_divergence_nn_delta_weight on the reference: l2, l4 and the small l2s."""
+    from iw3.models.mlbw import MLBW
+    from iw3 import backward_warp as RB
+    from oracle import mlbw as OM, row_flow_v3 as ORF
+    from oracle.forward_warp import synth_depth
+    out = {}
+    depth = synth_depth(4, 2, 58, 104, "smooth_edges")          # pads to 60 x 128 -> 60 x 16 tokens
+    c = torch.stack([synth_image(74, 3, 116, 208), synth_image(75, 3, 116, 208)])
+    out["depth"], out["c"] = depth, c
+    for tag, L, small in (("l2", 2, False), ("l4", 4, False), ("l2s", 2, True)):
+        sd = OM.random_state_dict(400 + L + (10 if small else 0), L, small)
+        m = MLBW(num_layers=L, base_dim=32, small=small).eval()
+        m.load_state_dict(sd, strict=True)
+        m.delta_output = True
+        d, w = m(ORF.make_input(depth[:1], 2.0, 0.5, 104))
+        out[tag + "_delta"], out[tag + "_weight"] = d, w
+        out[tag + "_sdsum"] = sd_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+        nb = 2 if tag == "l2" else 1
+        out[tag + "_left"], out[tag + "_right"] = RB.apply_divergence_nn_LR(m, c[:nb], depth[:nb], 2.0, 0.5, steps=1,
+                                                                            synthetic_view="both", enable_amp=False)
+    save("mlbw", **out)
+
+
+GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
+          "mlbw": gen_mlbw}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)
