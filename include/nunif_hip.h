@@ -132,6 +132,15 @@ typedef struct {
 int nunif_hip_forward_warp(const float *c, const float *depth, float *left, float *right, float *lmask,
                            float *rmask, const nunif_forward_warp_params *params, void *stream);
 
+/* iw3 "iw3.depth_aa" (iw3/models/depth_aa.py :29-95, --depth-aa): depth anti-aliasing net.  x, y: [B,1,h,w] f32 device.
+ * mode 0: forward(clamp=False); 1: forward(clamp=True) (eval default); 2: infer() = tensor-wide min-max normalise,
+ * forward(clamp=False), de-normalise (what BaseDepthModel.infer(depth_aa=True) calls). */
+typedef struct nunif_depth_aa nunif_depth_aa;
+int nunif_hip_depth_aa_create(const nunif_tensor_desc *tensors, int32_t n_tensors, nunif_depth_aa **handle);
+void nunif_hip_depth_aa_destroy(nunif_depth_aa *handle);
+int nunif_hip_depth_aa_forward(nunif_depth_aa *handle, const float *x, float *y, int32_t B, int32_t h, int32_t w,
+                               int32_t mode, void *stream);
+
 /* iw3 "sbs.row_flow_v3" (iw3/models/row_flow_v3.py :33-107, the default --method): a small window-attention net that
  * turns the 3-plane feature map [depth | divergence feature | convergence feature] (iw3/backward_warp.py
  * make_input_tensor :17-64) into a horizontal flow `delta` at depth resolution.  create() takes the reference

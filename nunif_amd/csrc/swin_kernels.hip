@@ -405,6 +405,7 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
     const double bytes = (double)M * (g.Cin * 2.0 * (g.K / g.Cin > 1 ? 1.0 : 1.0) + g.n_real * (g.mode == 2 ? 4.0 : 2.0) +
                                       (g.res ? g.n_real * 2.0 : 0.0));
     switch (g.K / 32) {
+        case 1: return launch_gemm_t<1, 4>(g, s, "gemm_kernel<1,4>", "gemm_res_kernel<1,4>", flops, bytes);
         case 2: return launch_gemm_t<2, 4>(g, s, "gemm_kernel<2,4>", "gemm_res_kernel<2,4>", flops, bytes);
         case 4: return launch_gemm_t<4, 4>(g, s, "gemm_kernel<4,4>", "gemm_res_kernel<4,4>", flops, bytes);
         case 3: return launch_gemm_t<3, 4>(g, s, "gemm_kernel<3,4>", "gemm_res_kernel<3,4>", flops, bytes);

@@ -40,12 +40,14 @@ def batch_preprocess(x, lower_bound=392, max_aspect_ratio=4, limit_resolution=Fa
 
 @torch.inference_mode()
 def batch_infer(model, im, flip_aug=True, enable_amp=False, edge_dilation=2, lower_bound=392,
-                limit_resolution=False, metric_depth=False, **_):
+                limit_resolution=False, metric_depth=False, depth_aa=None, **_):
     single = im.dim() == 3
     x = batch_preprocess(im.unsqueeze(0) if single else im, lower_bound, limit_resolution=limit_resolution)
     if flip_aug:
         x = torch.cat([x, torch.flip(x, dims=[3])], dim=0)
     out = torch.nan_to_num(model(x).unsqueeze(1).float())
+    if depth_aa is not None:
+        out = depth_aa.infer(out)                      # depth_anything_model.py:153-154 (nunif_amd.iw3.models.DepthAA)
     if edge_dilation_is_enabled(edge_dilation):
         out = dilate_edge(-out if metric_depth else out, edge_dilation)
         out = -out if metric_depth else out

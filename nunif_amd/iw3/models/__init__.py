@@ -1,1 +1,2 @@
-from . import mlbw, row_flow_v3  # noqa: F401  (registers sbs.row_flow_v3, sbs.mlbw and the mlbw_l* factories)
+from . import depth_aa, mlbw, row_flow_v3  # noqa: F401  (registers iw3.depth_aa, sbs.row_flow_v3, sbs.mlbw + factories)
+from .depth_aa import DepthAA  # noqa: F401

@@ -214,8 +214,26 @@ def gen_mlbw():
     save("mlbw", **out)
 
 
+def gen_depth_aa():
+    """iw3.depth_aa (iw3/models/depth_aa.py) on the reference: forward (clamped / unclamped) and infer()."""
+    from iw3.models.depth_aa import DepthAA
+    from oracle import depth_aa as ODA
+    from oracle.forward_warp import synth_depth
+    out = {}
+    sd = ODA.random_state_dict(501)
+    m = DepthAA().eval()
+    m.load_state_dict(sd, strict=True)
+    x = synth_depth(7, 2, 70, 100, "smooth_edges")             # pads to 80 x 112 -> 40 x 56 tokens
+    out["x"], out["sdsum"] = x, sd_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    out["y"] = m(x)
+    out["y_noclamp"] = m(x, clamp=False)
+    xi = x[:1] * 7.0 + 3.0                                      # un-normalised (metric-like) depth
+    out["xi"], out["y_infer"] = xi, m.infer(xi)
+    save("depth_aa", **out)
+
+
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw}
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)
