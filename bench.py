@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--batch-size", type=int, default=int(os.environ.get("NUNIF_BENCH_BATCH", "45")),
                     help="tiles per model launch (the reference's tile minibatch; results do not depend on it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-frames", action="store_true",
+                    help="skip the extra (reported, never `value`) PCIe-inclusive measurement through the pinned frame ring")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -196,6 +198,25 @@ def main():
             "model_mfma_frac": round(45 * 98e9 * args.steps * world / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
             "roofline": roofline, "kernel_classes": classes,
         }
+        if not args.no_host_frames:
+            # host uint8 frame -> pinned ring -> H2D -> to_tensor -> render -> quantise -> D2H -> host uint8 frame
+            from nunif_amd.frame_ring import FrameRing
+            import numpy as np
+            host = [(f.clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy() for f in frames]
+            ring = FrameRing(lambda x: tiled_render(x, model, tile_size=TILE, batch_size=args.batch_size),
+                             (FRAME_H, FRAME_W, 3), (2 * FRAME_H, 2 * FRAME_W, 3), device=dev, depth=3)
+            for i in range(3):
+                ring.submit(host[i % len(host)])
+            ring.drain()
+            n_host = max(8, args.steps)
+            t1 = time.perf_counter()
+            for i in range(n_host):
+                ring.submit(host[i % len(host)])
+            ring.drain()
+            dt = time.perf_counter() - t1
+            result["host_frames"] = {"mpix_per_s": round(mpix_in * n_host / dt, 2), "ms_per_frame": round(1e3 * dt / n_host, 3),
+                                     "frames": n_host, "path": "uint8 HWC host -> pinned ring (depth 3) -> H2D -> render -> "
+                                     "quantise -> D2H -> uint8 HWC host", "bytes_per_frame": int(FRAME_H * FRAME_W * 3 * 5)}
         if not args.no_cpu_baseline:
             base, crop, ref = cpu_baseline(sd, frames[0].cpu())
             got = tiled_render(crop, model, tile_size=TILE, batch_size=args.batch_size).cpu()

@@ -203,7 +203,8 @@ int nunif_hip_minmax_normalize(const float *x, float *y, float *minmax, int32_t 
 /* Frame edge.  frame: HWC [H,W,3] uint8 (bits=8) or uint16 (bits=16) device memory.
  * frame_to_tensor replaces nunif/utils/video.py to_tensor :218-223 (x.permute(2,0,1) / iinfo.max).
  * stereo_to_frame fuses iw3/utils.py postprocess_image :468-479 (cat + clamp) with video.py from_tensor :236-245
- * ((x*max).round().to(uint)); layout 0 = left|right, 1 = right|left (cross-eyed), 2 = left over right (top-bottom).
+ * ((x*max).round().to(uint)); layout 0 = left|right, 1 = right|left (cross-eyed), 2 = left over right (top-bottom),
+ * 3 = the left image alone (right may be NULL): clamp + quantise of a single frame.
  * stereo_compose is the same composition with a planar fp32 result [3,Ho,Wo]. */
 int nunif_hip_frame_to_tensor(const void *frame, float *chw, int32_t H, int32_t W, int32_t bits, void *stream);
 int nunif_hip_stereo_to_frame(const float *left, const float *right, void *frame, int32_t H, int32_t W,

@@ -21,18 +21,20 @@ frame_to_tensor_kernel(const T *__restrict__ in, float *__restrict__ out, long h
     out[2 * hw + i] = (float)in[i * 3 + 2] / maxv;
 }
 
-// out HWC [Ho, Wo, 3]; layout 0: left|right, 1: right|left (cross-eyed), 2: left over right (top-bottom)
+// out HWC [Ho, Wo, 3]; layout 0: left|right, 1: right|left (cross-eyed), 2: left over right (top-bottom),
+// 3: the left image alone (VU.to_frame of a single frame, video.py:236-245)
 template <typename T>
 __global__ void __launch_bounds__(256)
 stereo_to_frame_kernel(const float *__restrict__ left, const float *__restrict__ right, T *__restrict__ out, int H,
                        int W, int layout, float maxv) {
-    const int Ho = layout == 2 ? 2 * H : H, Wo = layout == 2 ? W : 2 * W;
+    const int Ho = layout == 2 ? 2 * H : H, Wo = (layout == 2 || layout == 3) ? W : 2 * W;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)Ho * Wo) return;
     const int x = (int)(i % Wo), y = (int)(i / Wo);
     const float *src;
     int sx = x, sy = y;
-    if (layout == 2) { src = y < H ? left : right; if (y >= H) sy = y - H; }
+    if (layout == 3) src = left;
+    else if (layout == 2) { src = y < H ? left : right; if (y >= H) sy = y - H; }
     else {
         const bool first = x < W;
         src = (first == (layout == 0)) ? left : right;
@@ -115,10 +117,10 @@ extern "C" int nunif_hip_frame_to_tensor(const void *frame, float *chw, int32_t 
 
 extern "C" int nunif_hip_stereo_to_frame(const float *left, const float *right, void *frame, int32_t H, int32_t W,
                                          int32_t layout, int32_t bits, void *stream) {
-    NUNIF_REQUIRE(left && right && frame && H > 0 && W > 0 && layout >= 0 && layout <= 2 && (bits == 8 || bits == 16),
-                  "stereo_to_frame: bad argument");
+    NUNIF_REQUIRE(left && (right || layout == 3) && frame && H > 0 && W > 0 && layout >= 0 && layout <= 3 &&
+                  (bits == 8 || bits == 16), "stereo_to_frame: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    const long n = 2L * H * W;
+    const long n = (layout == 3 ? 1L : 2L) * H * W;
     ProfScope ps("stereo_to_frame_kernel", s, 0.0, (double)n * (12.0 + 3.0 * bits / 8));
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (bits == 8) stereo_to_frame_kernel<uint8_t><<<blocks, 256, 0, s>>>(left, right, (uint8_t *)frame, H, W, layout, 255.0f);

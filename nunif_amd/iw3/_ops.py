@@ -95,10 +95,22 @@ def backward_warp(c, depth, divergence, convergence, synthetic_view):
     return left, right
 
 
-def frame_to_tensor(frame_hwc):
-    """uint8 / int32-held-uint16 HWC [H,W,3] on the device -> CHW float (VU.to_tensor, video.py:218-223)."""
+def frame_to_tensor(frame_hwc, device=None):
+    """uint8 / int16-held-uint16 HWC [H,W,3] -> CHW float on the device (VU.to_tensor, video.py:218-223).
+    The frame is either a device tensor or a PINNED host tensor (zero-copy: the kernel reads it over PCIe; pass
+    ``device``)."""
     if frame_hwc.device.type != "cuda":
-        raise RuntimeError("frame_to_tensor: tensor must live on a ROCm device; there is no CPU fallback")
+        if not (frame_hwc.is_pinned() and device is not None):
+            raise RuntimeError("frame_to_tensor: tensor must live on a ROCm device or in pinned host memory "
+                               "(with device=...); there is no CPU fallback")
+        dev = torch.device(device)
+        assert frame_hwc.dim() == 3 and frame_hwc.shape[2] == 3 and frame_hwc.is_contiguous()
+        bits = 8 if frame_hwc.dtype == torch.uint8 else 16
+        h, w, _ = frame_hwc.shape
+        out = torch.empty((3, h, w), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().nunif_hip_frame_to_tensor(_p(frame_hwc), _p(out), h, w, bits, _hip.current_stream_ptr(dev)))
+        return out
     assert frame_hwc.dim() == 3 and frame_hwc.shape[2] == 3
     if frame_hwc.dtype == torch.uint8:
         bits, src = 8, frame_hwc.contiguous()
@@ -125,6 +137,22 @@ def stereo_to_frame(left, right, layout="sbs", bits=8):
     with torch.cuda.device(left.device):
         _hip.check(_hip.lib().nunif_hip_stereo_to_frame(_p(left), _p(right), _p(out), h, w, LAYOUT[layout], bits,
                                                         _hip.current_stream_ptr(left.device)))
+    return out
+
+
+def to_frame(x, bits=8, out=None):
+    """CHW float -> clamp + quantise -> HWC uint8 (or uint16 bit pattern in int16): VU.to_frame (video.py:236-245).
+    ``out`` may be a PINNED host tensor: the kernel then writes the frame straight into host memory (zero-copy)."""
+    x = _cuda_f32(x, "to_frame")
+    _, h, w = x.shape
+    if out is None:
+        out = torch.empty((h, w, 3), dtype=torch.uint8 if bits == 8 else torch.int16, device=x.device)
+    else:
+        assert out.shape == (h, w, 3) and out.is_contiguous() and (out.device.type == "cuda" or out.is_pinned())
+        assert out.dtype == (torch.uint8 if bits == 8 else torch.int16)
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_stereo_to_frame(_p(x), None, _p(out), h, w, 3, bits,
+                                                        _hip.current_stream_ptr(x.device)))
     return out
 
 

@@ -107,7 +107,5 @@ def to_tensor(frame_hwc, device=None):
 
 def to_frame_tensor(x, use_16bit=False):
     """CHW float -> HWC uint8 (or uint16 bit pattern in int16), (x*max).round() like video.py:236-245."""
-    # the stereo kernel with the top half of a top-bottom layout == clamp + quantise of `x` (video frames normally
-    # leave through stereo_to_frame directly, which fuses the SBS compose as well)
-    h = x.shape[1]
-    return _ops.stereo_to_frame(x, x, "tb", 16 if use_16bit else 8)[:h]
+    # (stereo frames normally leave through stereo_to_frame directly, which fuses the SBS compose as well)
+    return _ops.to_frame(x, 16 if use_16bit else 8)

@@ -234,10 +234,27 @@ class SwinUNet4x(_HipSwinUNetModel):
         super().__init__(dict(in_channels=in_channels, out_channels=out_channels, pre_antialias=pre_antialias,
                               base_dim=base_dim, layer_norm=layer_norm),
                          scale=4, offset=32, in_channels=in_channels, blend_size=16)
-        if pre_antialias:
-            raise ValueError("pre_antialias=True is not supported by the HIP engine yet")
         self.out_channels = out_channels
+        self.pre_antialias = pre_antialias
+        self.antialias = True
         self._setup(in_channels, out_channels, base_dim, layer_norm)
+
+    def __getattribute__(self, name):
+        # with pre_antialias every TILE is resized before the net (reference :281-282), so the fused whole-frame
+        # render (tile gather inside the first conv) does not apply: hide it and let tiled_render loop over tiles
+        if name == "render_frame" and object.__getattribute__(self, "__dict__").get("pre_antialias", False):
+            raise AttributeError(name)
+        return super().__getattribute__(name)
+
+    def forward(self, x):
+        if self.pre_antialias:
+            # resize_antialias (reference :252-258): bicubic x2 up, then bicubic /2 down, both with antialias
+            from ...iw3 import _ops
+            h, w = x.shape[-2:]
+            xf = self._prepare(x)
+            xf = _ops.resize_aa(xf, (h * 2, w * 2), mode="bicubic", align_corners=False)
+            x = _ops.resize_aa(xf, (h, w), mode="bicubic", align_corners=False).to(x.dtype)
+        return super().forward(x)
 
     def to_2x(self, shared=True):
         return SwinUNetDownscaled(in_channels=self.i2i_in_channels, out_channels=self.out_channels,
@@ -259,7 +276,7 @@ class SwinUNetDownscaled(I2IBaseModel):
                          scale=4 // downscale_factor, offset=32 // downscale_factor, in_channels=in_channels,
                          blend_size=4 * downscale_factor)
         self.register_tile_size_validator(tile_size_validator)
-        self.net4x = unet if unet is not None else SwinUNet4x(in_channels, out_channels)
+        self.net4x = unet if unet is not None else SwinUNet4x(in_channels, out_channels, pre_antialias=pre_antialias)
         self.downscale_factor = downscale_factor
 
     def get_device(self):

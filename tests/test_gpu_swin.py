@@ -99,6 +99,29 @@ def test_downscaled_4x_to_2x_and_1x(hiplib, golden_swin):
         assert y.shape == ref.shape and psnr(y, ref) >= PSNR_MIN, psnr(y, ref)
 
 
+def test_4x_pre_antialias(hiplib):
+    """SwinUNet4x(pre_antialias=True): every tile goes through bicubic x2 up / x2 down before the net (swin_unet.py
+    :252-258,281-282); the fused whole-frame render is bypassed, tiled_render loops over tiles."""
+    import torch.nn.functional as F
+    from nunif_amd.waifu2x.models import swin_unet as M
+    from nunif_amd.nunif.utils.render import tiled_render
+    sd = O.random_state_dict(104, 4)
+    m = M.SwinUNet4x(pre_antialias=True).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda:0")
+    assert not hasattr(m, "render_frame") and hasattr(M.SwinUNet4x().eval(), "render_frame")
+    x = synth_image(81, 3, 64, 64)[None]
+    xa = F.interpolate(F.interpolate(x, size=(128, 128), mode="bicubic", align_corners=False, antialias=True),
+                       size=(64, 64), mode="bicubic", align_corners=False, antialias=True)
+    ref = O.model_forward(sd, xa, NAMES[4])
+    y = m(x.to("cuda:0")).cpu()
+    assert y.shape == ref.shape and psnr(y, ref) >= PSNR_MIN, psnr(y, ref)
+    img = synth_image(82, 3, 80, 100)
+    out = tiled_render(img, m, tile_size=64, batch_size=3)
+    assert out.shape == (3, 320, 400) and float(out.min()) >= 0 and float(out.max()) <= 1
+    assert torch.equal(out, tiled_render(img, m, tile_size=64, batch_size=5))
+
+
 def test_forward_112_batch3_and_half_input(hiplib, golden_swin):
     m, sd = make_model(2, 102)
     x = torch.from_numpy(golden_swin["x_112"])
