@@ -132,6 +132,19 @@ typedef struct {
 int nunif_hip_forward_warp(const float *c, const float *depth, float *left, float *right, float *lmask,
                            float *rmask, const nunif_forward_warp_params *params, void *stream);
 
+/* Depth-Anything-V2 ViT-S (DINOv2 ViT-S/14 + DPT head): the depth backbone that iw3/depth_anything_model.py:200-230 loads
+ * through torch.hub and calls in _forward :113-119.  The network is NOT part of the reference tree; this engine follows
+ * the published architecture (state-dict keys of the public checkpoint: pretrained.*, depth_head.*), see
+ * oracle/depth_anything_v2.py — parity is against that restatement only.
+ * x: [B,3,h,w] f32 device, ImageNet-normalised (batch_preprocess), h and w multiples of 14;
+ * pos: [1 + (h/14)*(w/14)][384] f32 device = the position embedding already interpolated to this grid (host side,
+ * once per resolution); depth: [B,h,w] f32 device (relu'd inverse depth, larger = nearer). */
+typedef struct nunif_depth_anything nunif_depth_anything;
+int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors, int32_t n_tensors, nunif_depth_anything **handle);
+void nunif_hip_depth_anything_destroy(nunif_depth_anything *handle);
+int nunif_hip_depth_anything_forward(nunif_depth_anything *handle, const float *x, const float *pos, float *depth,
+                                     int32_t B, int32_t h, int32_t w, void *stream);
+
 /* iw3 "iw3.depth_aa" (iw3/models/depth_aa.py :29-95, --depth-aa): depth anti-aliasing net.  x, y: [B,1,h,w] f32 device.
  * mode 0: forward(clamp=False); 1: forward(clamp=True) (eval default); 2: infer() = tensor-wide min-max normalise,
  * forward(clamp=False), de-normalise (what BaseDepthModel.infer(depth_aa=True) calls). */

@@ -71,6 +71,18 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
                 dst[f] = *reinterpret_cast<const f16x8 *>(g.a + (((long)pb[f] * g.Hi + yy) * g.Wi + xx) * g.Cin + 8 * grp + c0);
                 continue;
             }
+            if (g.zpad || g.relu_in) {      // zero padding (any stride) and / or pre-activation ReLU
+                const int yy = py[f] * g.stride + dy - g.zpad, xx = px[f] * g.stride + dx - g.zpad;
+                f16x8 v = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+                if (yy >= 0 && yy < g.Hi && xx >= 0 && xx < g.Wi)
+                    v = *reinterpret_cast<const f16x8 *>(g.a + (((long)pb[f] * g.Hi + yy) * g.Wi + xx) * g.Cin + 8 * grp + c0);
+                if (g.relu_in) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] > (f16)0.f ? v[j] : (f16)0.f;
+                }
+                dst[f] = v;
+                continue;
+            }
             f16x8 v = *reinterpret_cast<const f16x8 *>(g.a + base[f] + ((long)dy * g.Wi + dx) * g.Cin + c0);
             if (g.a2) v += *reinterpret_cast<const f16x8 *>(g.a2 + base2[f] + ((long)dy * g.W2 + dx) * g.Cin + c0);
             dst[f] = v;
@@ -116,6 +128,9 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
             if (g.act == 2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * g.slope;
+            } else if (g.act == 3) {                       // ReLU
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             if (g.out32) {
                 // image head: planar fp32, optional `+ crop(add32)` and clamp  (cunet.py:183-196)
@@ -133,6 +148,11 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
                 const long off = (((long)pb[f] * g.Ho + py[f]) * g.Wo + px[f]) * g.n_real + n0;
                 if (g.res) {
                     const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
+                if (g.res2) {
+                    const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res2 + off);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
                 }
@@ -155,6 +175,7 @@ static int launch_conv_t(const ConvArgs &g, hipStream_t s) {
 int launch_conv(const ConvArgs &g, hipStream_t s) {
     NUNIF_REQUIRE(g.Cin % 32 == 0 && g.N % 16 == 0, "conv: Cin=%d N=%d not aligned", g.Cin, g.N);
     NUNIF_REQUIRE(!g.rpad || (g.stride == 1 && !g.a2), "conv: replicate padding needs stride 1 and a single input");
+    NUNIF_REQUIRE(!(g.zpad || g.relu_in) || (!g.a2 && !g.rpad), "conv: zero padding / relu_in need a single input");
     const long M = (long)g.B * g.Ho * g.Wo;
     if (M == 0) return NUNIF_HIP_OK;
     const double K = (double)g.kh * g.kw * g.Cin;
@@ -167,7 +188,9 @@ int launch_conv(const ConvArgs &g, hipStream_t s) {
         case 4: { ProfScope ps("conv_kernel<4,4>", s, flops, bytes); return launch_conv_t<4, 4>(g, s); }
         case 6: { ProfScope ps("conv_kernel<6,4>", s, flops, bytes); return launch_conv_t<6, 4>(g, s); }
         case 8: { ProfScope ps("conv_kernel<8,4>", s, flops, bytes); return launch_conv_t<8, 4>(g, s); }
+        case 12: { ProfScope ps("conv_kernel<12,2>", s, flops, bytes); return launch_conv_t<12, 2>(g, s); }
         case 16: { ProfScope ps("conv_kernel<16,2>", s, flops, bytes); return launch_conv_t<16, 2>(g, s); }
+        case 24: { ProfScope ps("conv_kernel<24,1>", s, flops, bytes); return launch_conv_t<24, 1>(g, s); }
         default:
             set_error("conv: unsupported Cout=%d", g.N);
             return NUNIF_HIP_EUNSUPPORTED;

@@ -1,0 +1,582 @@
+// Depth-Anything-V2 ViT-S (DINOv2 ViT-S/14 encoder + DPT head) on gfx950 — the depth backbone behind
+// BaseDepthModel.infer (iw3/depth_anything_model.py:113-119,200-230 loads it through torch.hub; the network itself is
+// NOT in the reference tree, see oracle/depth_anything_v2.py: parity is against that restatement of the published
+// architecture only — "parity unpinned").
+//
+// Layout: tokens [B][1 + gh*gw][384] fp16 (class token first), DPT maps NHWC fp16.  GEMM-shaped work reuses the engine's
+// kernels: gemm_kernel (Linear with K <= 608: patch embed, qkv, proj, fc1, 1x1 convs, the k = stride ConvTranspose2d
+// resize layers as pixel-shuffle GEMMs), conv_kernel (K-looped: fc2 with K = 1536, every 3x3 of the head with zero
+// padding, pre-activation ReLU and up to two residuals fused).  LayerScale is folded into proj / fc2 on the host, the
+// softmax scale * log2(e) into Wq.  New kernels here:
+//   da_layernorm_kernel   one wave per token (384 channels), fp32 statistics
+//   da_attn_kernel        global softmax attention over 1 + gh*gw tokens, 6 heads of 64: one wave per 16 queries,
+//                         32 keys per step, online softmax; S^T = K Q^T so that exp2(S^T) is directly the P^T operand of
+//                         O^T = V^T P^T (V^T is written once per layer by da_vt_kernel, so every operand is a 16-byte
+//                         per-lane load); the key -> MFMA-row permutation that makes P^T's k-slots contiguous keys is
+//                         free because the K fragment is a per-lane row gather
+//   da_upsample_kernel    bilinear, align_corners=True, NHWC
+//   im2col / assemble / final 1x1 + ReLU
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "swin_kernels.h"
+
+namespace nunif {
+
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int kD = 384, kHeads = 6, kHd = 64, kPatch = 14, kKp = 608;   // 3*14*14 = 588 padded to 19 k-steps
+
+__global__ void __launch_bounds__(256) da_im2col_kernel(const float *__restrict__ x, f16 *__restrict__ a, int B, int h,
+                                                        int w, int gh, int gw) {
+    const long total = (long)B * gh * gw * kKp;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int k = (int)(id % kKp);
+    const long m = id / kKp;
+    float v = 0.f;
+    if (k < 3 * kPatch * kPatch) {
+        const int gx = (int)(m % gw);
+        const long t = m / gw;
+        const int gy = (int)(t % gh), b = (int)(t / gh);
+        const int ci = k / (kPatch * kPatch), r = k - ci * kPatch * kPatch, ky = r / kPatch, kx = r - ky * kPatch;
+        v = x[(((long)b * 3 + ci) * h + gy * kPatch + ky) * w + gx * kPatch + kx];
+    }
+    a[id] = (f16)v;
+}
+
+// t[b][0] = cls + pos[0];  t[b][1+m] = patch[b][m] + pos[1+m]
+__global__ void __launch_bounds__(256) da_assemble_kernel(const f16 *__restrict__ pe, const float *__restrict__ cls,
+                                                          const float *__restrict__ pos, f16 *__restrict__ t, int B, int Np) {
+    const long total = (long)B * Np * kD;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int c = (int)(id % kD);
+    const long r = id / kD;
+    const int n = (int)(r % Np), b = (int)(r / Np);
+    const float v = n == 0 ? cls[c] : (float)pe[((long)b * (Np - 1) + n - 1) * kD + c];
+    t[id] = (f16)(v + pos[(long)n * kD + c]);
+}
+
+__global__ void __launch_bounds__(256) da_layernorm_kernel(const f16 *__restrict__ x, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, f16 *__restrict__ y, long T) {
+    const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= T) return;
+    const int lane = threadIdx.x & 63;
+    float v[6];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { v[i] = (float)x[tok * kD + lane + 64 * i]; s += v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / kD);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const float d = v[i] - mean; q += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * (1.0f / kD) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = lane + 64 * i;
+        y[tok * kD + c] = (f16)((v[i] - mean) * rstd * gamma[c] + beta[c]);
+    }
+}
+
+// vt[b][h][ch][t] = V[b][t][h*64 + ch]; zero for t >= Np (t < Tp)
+__global__ void __launch_bounds__(256) da_vt_kernel(const f16 *__restrict__ qkv, f16 *__restrict__ vt, int B, int Np, int Tp) {
+    const long total = (long)B * kHeads * kHd * Tp;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int t = (int)(id % Tp);
+    const long r = id / Tp;
+    const int ch = (int)(r % kHd);
+    const long r2 = r / kHd;
+    const int hh = (int)(r2 % kHeads), b = (int)(r2 / kHeads);
+    vt[id] = t < Np ? qkv[((long)b * Np + t) * (3 * kD) + 2 * kD + hh * kHd + ch] : (f16)0.f;
+}
+
+__device__ __forceinline__ f16x8 cat8a(f16x4 lo, f16x4 hi) {
+    return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// grid (ceil(Np/16)/4 rounded up, heads, B), 4 waves per workgroup = 4 query tiles
+__global__ void __launch_bounds__(256) da_attn_kernel(const f16 *__restrict__ qkv, const f16 *__restrict__ vt,
+                                                      f16 *__restrict__ att, int Np, int Tp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, grp = lane >> 4;
+    const int qt = blockIdx.x * 4 + wave;
+    if (qt * 16 >= Np) return;
+    const int hh = blockIdx.y, b = blockIdx.z;
+    const f16 *base = qkv + (long)b * Np * (3 * kD);
+    const int q = min(qt * 16 + r16, Np - 1);
+    f16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        qf[ks] = *reinterpret_cast<const f16x8 *>(base + (long)q * (3 * kD) + hh * kHd + 32 * ks + 8 * grp);
+    const f16 *vbase = vt + ((long)(b * kHeads + hh) * kHd) * Tp;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -1.0e30f, l_run = 0.f;
+    // MFMA row i of key tile 0 / 1 <-> key k0 + 8*(i>>2) + (i&3) [+ 4]: lane's 8 P^T slots are then keys k0 + 8g + 0..7
+    const int krow = 8 * (r16 >> 2) + (r16 & 3);
+    for (int k0 = 0; k0 < Tp; k0 += 32) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        const int ka = min(k0 + krow, Np - 1), kb = min(k0 + krow + 4, Np - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 k_a = *reinterpret_cast<const f16x8 *>(base + (long)ka * (3 * kD) + kD + hh * kHd + 32 * ks + 8 * grp);
+            const f16x8 k_b = *reinterpret_cast<const f16x8 *>(base + (long)kb * (3 * kD) + kD + hh * kHd + 32 * ks + 8 * grp);
+            s0 = MFMA_16x16x32(k_a, qf[ks], s0);
+            s1 = MFMA_16x16x32(k_b, qf[ks], s1);
+        }
+        // accumulator row 4g+r of tile 0 is key k0 + 8g + r, of tile 1 key k0 + 8g + 4 + r
+        float mx = -1.0e30f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (k0 + 8 * grp + r >= Np) s0[r] = -1.0e30f;
+            if (k0 + 8 * grp + 4 + r >= Np) s1[r] = -1.0e30f;
+            mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float p[8], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            p[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            sum += p[r] + p[4 + r];
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+        const f16x8 pf = {(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3], (f16)p[4], (f16)p[5], (f16)p[6], (f16)p[7]};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f16x8 vf = *reinterpret_cast<const f16x8 *>(vbase + (long)(dt * 16 + r16) * Tp + k0 + 8 * grp);
+            o[dt] = (f32x4){o[dt][0] * alpha, o[dt][1] * alpha, o[dt][2] * alpha, o[dt][3] * alpha};
+            o[dt] = MFMA_16x16x32(vf, pf, o[dt]);
+        }
+    }
+    if (qt * 16 + r16 < Np) {
+        const float inv = 1.0f / l_run;
+        f16 *dst = att + ((long)b * Np + qt * 16 + r16) * kD + hh * kHd + 4 * grp;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<f16x4 *>(dst + dt * 16) =
+                (f16x4){(f16)(o[dt][0] * inv), (f16)(o[dt][1] * inv), (f16)(o[dt][2] * inv), (f16)(o[dt][3] * inv)};
+    }
+}
+
+// F.interpolate(bilinear, align_corners=True) on NHWC fp16; one thread = 8 channels of one output pixel
+__global__ void __launch_bounds__(256) da_upsample_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int B, int Hi,
+                                                          int Wi, int Ho, int Wo, int C) {
+    const int cq = C / 8;
+    const long total = (long)B * Ho * Wo * cq;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int c8 = (int)(id % cq);
+    long t = id / cq;
+    const int X = (int)(t % Wo); t /= Wo;
+    const int Y = (int)(t % Ho), b = (int)(t / Ho);
+    const float ry = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    const float sy = ry * (float)Y, sx = rx * (float)X;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    auto ld = [&](int yy, int xx) { return *reinterpret_cast<const f16x8 *>(x + (((long)b * Hi + yy) * Wi + xx) * C + c8 * 8); };
+    const f16x8 a = ld(y0, x0), bq = ld(y0, x1), c = ld(y1, x0), d = ld(y1, x1);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        o[j] = (f16)(hy * (hx * (float)a[j] + lx * (float)bq[j]) + ly * (hx * (float)c[j] + lx * (float)d[j]));
+    *reinterpret_cast<f16x8 *>(y + (((long)b * Ho + Y) * Wo + X) * C + c8 * 8) = o;
+}
+
+// relu(conv1x1 32 -> 1) (+ the model's final relu, idempotent) -> fp32 [B,h,w]
+__global__ void __launch_bounds__(256) da_final_kernel(const f16 *__restrict__ x, const float *__restrict__ w, float *__restrict__ y,
+                                                       long n) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    float acc = w[32];
+    const f16 *p = x + id * 32;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc = fmaf((float)p[k], w[k], acc);
+    y[id] = fmaxf(acc, 0.f);
+}
+
+}  // namespace nunif
+
+using namespace nunif;
+
+// =====================================================================================================================
+namespace {
+struct HostT { const float *data; std::vector<int64_t> shape; int64_t numel; };
+typedef std::map<std::string, HostT> TMap;
+int find(const TMap &m, const std::string &key, const HostT **out) {
+    auto it = m.find(key);
+    if (it == m.end()) { set_error("state_dict is missing '%s'", key.c_str()); return NUNIF_HIP_EMISSING; }
+    *out = &it->second;
+    return NUNIF_HIP_OK;
+}
+struct Buf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return NUNIF_HIP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) { set_error("hipMalloc(%zu) failed", bytes); return NUNIF_HIP_ENOMEM; }
+        cap = bytes;
+        return NUNIF_HIP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct Lin { f16 *w = nullptr; float *b = nullptr; int N = 0, K = 0; };              // gemm_kernel packing [nt][ks]
+struct Cnv { f16 *w = nullptr; float *b = nullptr; int N = 0, Cin = 0, k = 3; };     // conv_kernel stream [ks][nt]
+struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1; Cnv fc2; };
+struct Rcu { Cnv c1, c2; };
+struct Fus { Rcu r1, r2; Lin out; };
+}  // namespace
+
+struct nunif_depth_anything {
+    std::vector<void *> owned;
+    Lin patch; float *cls = nullptr, *norm_g = nullptr, *norm_b = nullptr;
+    Blk blk[12];
+    Lin proj[4], rs0, rs1; Cnv rs3, rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
+    Buf a_col, pe, t, y, qkv, vt, att, hid, feat[4], m1, m2, m3, m4, m5;
+};
+
+namespace {
+template <typename T>
+int upload(nunif_depth_anything *h, const std::vector<T> &host, T **dev) {
+    void *p = nullptr;
+    if (hipMalloc(&p, host.size() * sizeof(T)) != hipSuccess) { set_error("hipMalloc failed"); return NUNIF_HIP_ENOMEM; }
+    h->owned.push_back(p);
+    NUNIF_HIP_CHECK(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = reinterpret_cast<T *>(p);
+    return NUNIF_HIP_OK;
+}
+int up_f32(nunif_depth_anything *h, const HostT *t, float **dev) {
+    std::vector<float> v(t->data, t->data + t->numel);
+    return upload(h, v, dev);
+}
+template <typename F>
+void put_frag(std::vector<f16> &dst, size_t frag, int nt, int ks, F wt) {
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j)
+            dst[(frag * 64 + l) * 8 + j] = (f16)wt(nt * 16 + (l & 15), ks * 32 + (l >> 4) * 8 + j);
+}
+// Linear / 1x1 / pixel-shuffle GEMM: W'(n, k) given by wt (zero outside the real range), N and K already padded
+template <typename F, typename G>
+int make_lin(nunif_depth_anything *h, int N, int K, F wt, G bias, Lin *L) {
+    const int NT = N / 16, KS = K / 32;
+    std::vector<f16> packed((size_t)N * K + 8192, (f16)0.f);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int ks = 0; ks < KS; ++ks) put_frag(packed, (size_t)nt * KS + ks, nt, ks, wt);
+    std::vector<float> b(N);
+    for (int n = 0; n < N; ++n) b[n] = bias(n);
+    L->N = N; L->K = K;
+    int rc = upload(h, packed, &L->w);
+    return rc ? rc : upload(h, b, &L->b);
+}
+// k x k conv, stream [ks][nt], reduction index = tap*Cin + ci (Cin padded), wt(n, tap, ci)
+template <typename F, typename G>
+int make_cnv(nunif_depth_anything *h, int N, int Cin, int k, F wt, G bias, Cnv *C) {
+    const int NT = N / 16, KS = k * k * Cin / 32;
+    std::vector<f16> stream((size_t)KS * NT * 512 + 8192, (f16)0.f);
+    for (int ks = 0; ks < KS; ++ks)
+        for (int nt = 0; nt < NT; ++nt)
+            put_frag(stream, (size_t)ks * NT + nt, nt, ks, [&](int n, int kk) { return wt(n, kk / Cin, kk % Cin); });
+    std::vector<float> b(N);
+    for (int n = 0; n < N; ++n) b[n] = bias(n);
+    C->N = N; C->Cin = Cin; C->k = k;
+    int rc = upload(h, stream, &C->w);
+    return rc ? rc : upload(h, b, &C->b);
+}
+int conv_from(nunif_depth_anything *h, const TMap &m, const std::string &key, int cout, int cin, int cin_pad, int k, bool has_bias,
+              Cnv *C) {
+    const HostT *w, *b = nullptr;
+    int rc;
+    if ((rc = find(m, key + ".weight", &w)) || (has_bias && (rc = find(m, key + ".bias", &b)))) return rc;
+    NUNIF_REQUIRE(w->numel == (int64_t)cout * cin * k * k, "%s: unexpected shape", key.c_str());
+    const float *wd = w->data, *bd = b ? b->data : nullptr;
+    return make_cnv(h, cout, cin_pad, k, [=](int n, int tap, int ci) { return ci < cin ? wd[((size_t)n * cin + ci) * k * k + tap] : 0.f; },
+                    [=](int n) { return bd ? bd[n] : 0.f; }, C);
+}
+
+int run_lin(const Lin &L, const f16 *a, int B, int Wi, int Wo, int ox, int act, const f16 *res, f16 *out, hipStream_t s,
+            const char *tag, int mode = 0, int ldo = 0, int ps = 1, int Hi = 1) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = a; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = L.K; g.Ho = Hi; g.Wo = Wo; g.stride = 1; g.ox = ox; g.kw = 1;
+    g.K = L.K; g.w = L.w; g.bias = L.b; g.N = L.N; g.mode = mode; g.act = act; g.res = res; g.out = out;
+    g.ldo = ldo ? ldo : L.N; g.n_real = L.N; g.ps = ps;
+    return launch_gemm(g, s, tag);
+}
+int run_cnv(const Cnv &C, const f16 *a, int B, int Hi, int Wi, int stride, int zpad, int relu_in, int act, const f16 *res,
+            const f16 *res2, f16 *out, hipStream_t s) {
+    ConvArgs c;
+    memset(&c, 0, sizeof(c));
+    c.a = a; c.B = B; c.Hi = Hi; c.Wi = Wi; c.Cin = C.Cin; c.stride = stride; c.kh = C.k; c.kw = C.k;
+    c.Ho = (Hi + 2 * zpad - C.k) / stride + 1; c.Wo = (Wi + 2 * zpad - C.k) / stride + 1;
+    c.wstream = C.w; c.bias = C.b; c.N = C.N; c.n_real = C.N; c.act = act; c.out = out; c.zpad = zpad; c.relu_in = relu_in;
+    c.res = res; c.res2 = res2;
+    return launch_conv(c, s);
+}
+}  // namespace
+
+extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors, int32_t n_tensors,
+                                               nunif_depth_anything **handle) {
+    NUNIF_REQUIRE(tensors && handle && n_tensors > 0, "depth_anything_create: NULL argument");
+    TMap m;
+    for (int i = 0; i < n_tensors; ++i) {
+        HostT t;
+        t.data = tensors[i].data;
+        t.numel = 1;
+        for (int d = 0; d < tensors[i].ndim; ++d) { t.shape.push_back(tensors[i].shape[d]); t.numel *= tensors[i].shape[d]; }
+        m[tensors[i].name] = t;
+    }
+    nunif_depth_anything *h = new nunif_depth_anything();
+    int rc = NUNIF_HIP_OK;
+    do {
+        const std::string P = "pretrained.", H = "depth_head.";
+        const HostT *w, *b, *t1, *t2;
+        if ((rc = find(m, P + "patch_embed.proj.weight", &w)) || (rc = find(m, P + "patch_embed.proj.bias", &b))) break;
+        if (w->numel != (int64_t)kD * 588) { set_error("depth_anything: only ViT-S/14 (embed 384) is supported"); rc = NUNIF_HIP_EUNSUPPORTED; break; }
+        {
+            const float *wd = w->data, *bd = b->data;
+            if ((rc = make_lin(h, kD, kKp, [=](int n, int k) { return k < 588 ? wd[(size_t)n * 588 + k] : 0.f; },
+                               [=](int n) { return bd[n]; }, &h->patch))) break;
+        }
+        if ((rc = find(m, P + "cls_token", &t1)) || (rc = up_f32(h, t1, &h->cls))) break;
+        if ((rc = find(m, P + "norm.weight", &t1)) || (rc = find(m, P + "norm.bias", &t2)) || (rc = up_f32(h, t1, &h->norm_g)) ||
+            (rc = up_f32(h, t2, &h->norm_b)))
+            break;
+        const float qs = (1.0f / sqrtf((float)kHd)) * 1.4426950408889634f;
+        for (int i = 0; i < 12 && !rc; ++i) {
+            const std::string bp = P + "blocks." + std::to_string(i) + ".";
+            Blk &bk = h->blk[i];
+            const HostT *g1, *b1, *g2, *b2, *wq, *bq, *wp, *bpj, *w1, *bb1, *w2, *bb2, *ls1, *ls2;
+            if ((rc = find(m, bp + "norm1.weight", &g1)) || (rc = find(m, bp + "norm1.bias", &b1)) ||
+                (rc = find(m, bp + "norm2.weight", &g2)) || (rc = find(m, bp + "norm2.bias", &b2)) ||
+                (rc = find(m, bp + "attn.qkv.weight", &wq)) || (rc = find(m, bp + "attn.qkv.bias", &bq)) ||
+                (rc = find(m, bp + "attn.proj.weight", &wp)) || (rc = find(m, bp + "attn.proj.bias", &bpj)) ||
+                (rc = find(m, bp + "mlp.fc1.weight", &w1)) || (rc = find(m, bp + "mlp.fc1.bias", &bb1)) ||
+                (rc = find(m, bp + "mlp.fc2.weight", &w2)) || (rc = find(m, bp + "mlp.fc2.bias", &bb2)) ||
+                (rc = find(m, bp + "ls1.gamma", &ls1)) || (rc = find(m, bp + "ls2.gamma", &ls2)))
+                break;
+            if ((rc = up_f32(h, g1, &bk.g1)) || (rc = up_f32(h, b1, &bk.b1)) || (rc = up_f32(h, g2, &bk.g2)) || (rc = up_f32(h, b2, &bk.b2))) break;
+            const float *d;
+            const float *e;
+            d = wq->data; e = bq->data;
+            if ((rc = make_lin(h, 3 * kD, kD, [=](int n, int k) { return d[(size_t)n * kD + k] * (n < kD ? qs : 1.f); },
+                               [=](int n) { return e[n] * (n < kD ? qs : 1.f); }, &bk.qkv))) break;
+            {   // LayerScale folded: ls * (W x + b)
+                const float *wd = wp->data, *bd = bpj->data, *ls = ls1->data;
+                if ((rc = make_lin(h, kD, kD, [=](int n, int k) { return wd[(size_t)n * kD + k] * ls[n]; },
+                                   [=](int n) { return bd[n] * ls[n]; }, &bk.proj))) break;
+            }
+            d = w1->data; e = bb1->data;
+            if ((rc = make_lin(h, 4 * kD, kD, [=](int n, int k) { return d[(size_t)n * kD + k]; }, [=](int n) { return e[n]; }, &bk.fc1))) break;
+            {
+                const float *wd = w2->data, *bd = bb2->data, *ls = ls2->data;
+                if ((rc = make_cnv(h, kD, 4 * kD, 1, [=](int n, int, int ci) { return wd[(size_t)n * 4 * kD + ci] * ls[n]; },
+                                   [=](int n) { return bd[n] * ls[n]; }, &bk.fc2))) break;
+            }
+        }
+        if (rc) break;
+        // ---- DPT head.  Channel counts: 48 (stored padded to 64), 96, 192, 384; fusion features 64
+        static const int OC[4] = {48, 96, 192, 384}, OCP[4] = {64, 96, 192, 384};
+        for (int i = 0; i < 4 && !rc; ++i) {
+            const HostT *pw, *pb;
+            if ((rc = find(m, H + "projects." + std::to_string(i) + ".weight", &pw)) ||
+                (rc = find(m, H + "projects." + std::to_string(i) + ".bias", &pb)))
+                break;
+            const float *wd = pw->data, *bd = pb->data;
+            const int oc = OC[i];
+            if ((rc = make_lin(h, OCP[i], kD, [=](int n, int k) { return n < oc ? wd[(size_t)n * kD + k] : 0.f; },
+                               [=](int n) { return n < oc ? bd[n] : 0.f; }, &h->proj[i])))
+                break;
+            rc = conv_from(h, m, H + "scratch.layer" + std::to_string(i + 1) + "_rn", 64, oc, OCP[i], 3, false, &h->rn[i]);
+        }
+        if (rc) break;
+        {   // resize_layers.0: ConvTranspose2d(48, 48, 4, 4): N = (i*4+j)*64 + co, K = ci (padded to 64); weight [ci][co][4][4]
+            if ((rc = find(m, H + "resize_layers.0.weight", &w)) || (rc = find(m, H + "resize_layers.0.bias", &b))) break;
+            const float *wd = w->data, *bd = b->data;
+            if ((rc = make_lin(h, 16 * 64, 64, [=](int n, int k) {
+                    const int q = n / 64, co = n % 64;
+                    return (co < 48 && k < 48) ? wd[((size_t)k * 48 + co) * 16 + q] : 0.f; },
+                    [=](int n) { return n % 64 < 48 ? bd[n % 64] : 0.f; }, &h->rs0))) break;
+            // resize_layers.1: ConvTranspose2d(96, 96, 2, 2)
+            if ((rc = find(m, H + "resize_layers.1.weight", &w)) || (rc = find(m, H + "resize_layers.1.bias", &b))) break;
+            const float *w1d = w->data, *b1d = b->data;
+            if ((rc = make_lin(h, 4 * 96, 96, [=](int n, int k) { return w1d[((size_t)k * 96 + n % 96) * 4 + n / 96]; },
+                               [=](int n) { return b1d[n % 96]; }, &h->rs1))) break;
+            if ((rc = conv_from(h, m, H + "resize_layers.3", 384, 384, 384, 3, true, &h->rs3))) break;
+        }
+        for (int k = 0; k < 4 && !rc; ++k) {
+            const std::string r = H + "scratch.refinenet" + std::to_string(k + 1) + ".";
+            Fus &f = h->fus[k];
+            if ((rc = conv_from(h, m, r + "resConfUnit1.conv1", 64, 64, 64, 3, true, &f.r1.c1)) ||
+                (rc = conv_from(h, m, r + "resConfUnit1.conv2", 64, 64, 64, 3, true, &f.r1.c2)) ||
+                (rc = conv_from(h, m, r + "resConfUnit2.conv1", 64, 64, 64, 3, true, &f.r2.c1)) ||
+                (rc = conv_from(h, m, r + "resConfUnit2.conv2", 64, 64, 64, 3, true, &f.r2.c2)))
+                break;
+            const HostT *ow, *ob;
+            if ((rc = find(m, r + "out_conv.weight", &ow)) || (rc = find(m, r + "out_conv.bias", &ob))) break;
+            const float *wd = ow->data, *bd = ob->data;
+            rc = make_lin(h, 64, 64, [=](int n, int kk) { return wd[(size_t)n * 64 + kk]; }, [=](int n) { return bd[n]; }, &f.out);
+        }
+        if (rc) break;
+        if ((rc = conv_from(h, m, H + "scratch.output_conv1", 32, 64, 64, 3, true, &h->oc1)) ||
+            (rc = conv_from(h, m, H + "scratch.output_conv2.0", 32, 32, 32, 3, true, &h->oc2)))
+            break;
+        if ((rc = find(m, H + "scratch.output_conv2.2.weight", &w)) || (rc = find(m, H + "scratch.output_conv2.2.bias", &b))) break;
+        std::vector<float> wf(33);
+        for (int k = 0; k < 32; ++k) wf[k] = w->data[k];
+        wf[32] = b->data[0];
+        rc = upload(h, wf, &h->w_final);
+    } while (0);
+    if (rc) { nunif_hip_depth_anything_destroy(h); return rc; }
+    *handle = h;
+    return NUNIF_HIP_OK;
+}
+
+extern "C" void nunif_hip_depth_anything_destroy(nunif_depth_anything *h) {
+    if (!h) return;
+    for (void *p : h->owned) (void)hipFree(p);
+    Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->vt, &h->att, &h->hid, &h->feat[0], &h->feat[1], &h->feat[2],
+                   &h->feat[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5};
+    for (Buf *b : bufs) b->release();
+    delete h;
+}
+
+// x: [B,3,h,w] f32 (ImageNet-normalised), pos: [1 + gh*gw][384] f32 (interpolated position embedding, device),
+// depth: [B,h,w] f32
+extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const float *x, const float *pos, float *depth,
+                                                int32_t B, int32_t hh, int32_t ww, void *stream) {
+    NUNIF_REQUIRE(h && x && pos && depth && B > 0 && hh >= 28 && ww >= 28 && hh % kPatch == 0 && ww % kPatch == 0,
+                  "depth_anything_forward: h, w must be multiples of 14 (>= 28)");
+    hipStream_t s = (hipStream_t)stream;
+    const int gh = hh / kPatch, gw = ww / kPatch, N = gh * gw, Np = N + 1, Tp = (Np + 31) / 32 * 32;
+    const long T = (long)B * Np;
+    const size_t e2 = sizeof(f16);
+    // DPT map sizes
+    const int H1 = gh * 4, W1 = gw * 4, H2 = gh * 2, W2 = gw * 2, H3 = gh, W3 = gw, H4 = (gh + 2 - 3) / 2 + 1, W4 = (gw + 2 - 3) / 2 + 1;
+    const int HF = 2 * H1, WF = 2 * W1;
+    const size_t big = std::max<size_t>((size_t)B * HF * WF * 64, (size_t)B * hh * ww * 32);
+    int rc;
+    if ((rc = h->a_col.ensure((size_t)B * N * kKp * e2)) || (rc = h->pe.ensure((size_t)B * N * kD * e2)) ||
+        (rc = h->t.ensure(T * kD * e2)) || (rc = h->y.ensure(T * kD * e2)) || (rc = h->qkv.ensure(T * 3 * kD * e2)) ||
+        (rc = h->vt.ensure((size_t)B * kHeads * kHd * Tp * e2)) || (rc = h->att.ensure(T * kD * e2)) ||
+        (rc = h->hid.ensure(T * 4 * kD * e2)) || (rc = h->m1.ensure(big * e2)) || (rc = h->m2.ensure(big * e2)) ||
+        (rc = h->m3.ensure(big * e2)) || (rc = h->m4.ensure(big * e2)) || (rc = h->m5.ensure(big * e2)))
+        return rc;
+    for (int i = 0; i < 4; ++i) if ((rc = h->feat[i].ensure(T * kD * e2))) return rc;
+    f16 *a_col = (f16 *)h->a_col.p, *pe = (f16 *)h->pe.p, *t = (f16 *)h->t.p, *y = (f16 *)h->y.p, *qkv = (f16 *)h->qkv.p;
+    f16 *vt = (f16 *)h->vt.p, *att = (f16 *)h->att.p, *hid = (f16 *)h->hid.p;
+    auto blocks = [](long n) { return (unsigned)((n + 255) / 256); };
+
+    {   // patch embedding
+        ProfScope ps("da_im2col_kernel", s, 0.0, (double)B * N * (kKp * 2.0 + 588 * 4.0));
+        da_im2col_kernel<<<blocks((long)B * N * kKp), 256, 0, s>>>(x, a_col, B, hh, ww, gh, gw);
+        NUNIF_LAUNCH_CHECK();
+    }
+    if ((rc = run_lin(h->patch, a_col, 1, B * N, B * N, 0, 0, nullptr, pe, s, "da_patch"))) return rc;
+    da_assemble_kernel<<<blocks(T * kD), 256, 0, s>>>(pe, h->cls, pos, t, B, Np);
+    NUNIF_LAUNCH_CHECK();
+
+    int tap = 0;
+    for (int i = 0; i < 12; ++i) {
+        const Blk &bk = h->blk[i];
+        {
+            ProfScope ps("da_layernorm_kernel", s, 0.0, (double)T * kD * 4.0);
+            da_layernorm_kernel<<<(unsigned)((T + 3) / 4), 256, 0, s>>>(t, bk.g1, bk.b1, y, T);
+            NUNIF_LAUNCH_CHECK();
+        }
+        if ((rc = run_lin(bk.qkv, y, 1, (int)T, (int)T, 0, 0, nullptr, qkv, s, "da_qkv"))) return rc;
+        da_vt_kernel<<<blocks((long)B * kHeads * kHd * Tp), 256, 0, s>>>(qkv, vt, B, Np, Tp);
+        NUNIF_LAUNCH_CHECK();
+        {
+            ProfScope ps("da_attn_kernel", s, 4.0 * B * (double)Np * Np * kD, (double)T * kD * 8.0);
+            dim3 grid((unsigned)(((Np + 15) / 16 + 3) / 4), kHeads, B);
+            da_attn_kernel<<<grid, 256, 0, s>>>(qkv, vt, att, Np, Tp);
+            NUNIF_LAUNCH_CHECK();
+        }
+        if ((rc = run_lin(bk.proj, att, 1, (int)T, (int)T, 0, 0, t, t, s, "da_proj"))) return rc;        // t += ls1 * proj(att)
+        da_layernorm_kernel<<<(unsigned)((T + 3) / 4), 256, 0, s>>>(t, bk.g2, bk.b2, y, T);
+        NUNIF_LAUNCH_CHECK();
+        if ((rc = run_lin(bk.fc1, y, 1, (int)T, (int)T, 0, 1, nullptr, hid, s, "da_fc1"))) return rc;      // GELU(erf)
+        if ((rc = run_cnv(bk.fc2, hid, 1, 1, (int)T, 1, 0, 0, 0, t, nullptr, t, s))) return rc;              // t += ls2 * fc2(.)
+        if (i == 2 || i == 5 || i == 8 || i == 11) {
+            da_layernorm_kernel<<<(unsigned)((T + 3) / 4), 256, 0, s>>>(t, h->norm_g, h->norm_b, (f16 *)h->feat[tap].p, T);
+            NUNIF_LAUNCH_CHECK();
+            ++tap;
+        }
+    }
+
+    // ---- DPT head ----------------------------------------------------------------------------------------------------
+    f16 *m1 = (f16 *)h->m1.p, *m2 = (f16 *)h->m2.p, *m3 = (f16 *)h->m3.p, *m4 = (f16 *)h->m4.p, *m5 = (f16 *)h->m5.p;
+    f16 *rn[4];                                       // layer{1..4}_rn outputs live in the (now free) encoder buffers
+    rn[0] = hid; rn[1] = qkv; rn[2] = att; rn[3] = y;
+    NUNIF_REQUIRE((size_t)B * H1 * W1 * 64 <= (size_t)T * 4 * kD && (size_t)B * H2 * W2 * 64 <= (size_t)T * 3 * kD,
+                  "internal: DPT buffer reuse");
+    const int Hs[4] = {H1, H2, H3, H4}, Ws[4] = {W1, W2, W3, W4};
+    for (int i = 0; i < 4; ++i) {
+        const f16 *feat = (const f16 *)h->feat[i].p;
+        // projects[i]: 1x1 on the patch tokens (row 0 of every image = class token is skipped: Wi = Np, ox = 1)
+        if ((rc = run_lin(h->proj[i], feat, B, Np, N, 1, 0, nullptr, m1, s, "da_project"))) return rc;
+        const f16 *src = m1;
+        if (i == 0) { if ((rc = run_lin(h->rs0, m1, B, gw, gw, 0, 0, nullptr, m2, s, "da_resize0", 1, 64, 4, gh))) return rc; src = m2; }
+        else if (i == 1) { if ((rc = run_lin(h->rs1, m1, B, gw, gw, 0, 0, nullptr, m2, s, "da_resize1", 1, 96, 2, gh))) return rc; src = m2; }
+        else if (i == 3) { if ((rc = run_cnv(h->rs3, m1, B, gh, gw, 2, 1, 0, 0, nullptr, nullptr, m2, s))) return rc; src = m2; }
+        if ((rc = run_cnv(h->rn[i], src, B, Hs[i], Ws[i], 1, 1, 0, 0, nullptr, nullptr, rn[i], s))) return rc;
+    }
+    // refinenet k: x = path (+ RCU1(skip)); x = RCU2(x); upsample; out_conv
+    auto rcu = [&](const Rcu &r, const f16 *in, int Hc, int Wc, const f16 *extra, f16 *tmp, f16 *out) -> int {
+        // out = conv2(relu(conv1(relu(in)))) + in (+ extra)
+        int e = run_cnv(r.c1, in, B, Hc, Wc, 1, 1, 1, 3, nullptr, nullptr, tmp, s);
+        return e ? e : run_cnv(r.c2, tmp, B, Hc, Wc, 1, 1, 0, 0, in, extra, out, s);
+    };
+    auto upsample = [&](const f16 *in, int Hi_, int Wi_, int Ho_, int Wo_, int C, f16 *out) -> int {
+        ProfScope ps("da_upsample_kernel", s, 0.0, (double)B * Ho_ * Wo_ * C * 2.0 * 5.0);
+        da_upsample_kernel<<<blocks((long)B * Ho_ * Wo_ * (C / 8)), 256, 0, s>>>(in, out, B, Hi_, Wi_, Ho_, Wo_, C);
+        NUNIF_LAUNCH_CHECK();
+        return NUNIF_HIP_OK;
+    };
+    // path4
+    if ((rc = rcu(h->fus[3].r2, rn[3], H4, W4, nullptr, m1, m2))) return rc;
+    if ((rc = upsample(m2, H4, W4, H3, W3, 64, m3))) return rc;
+    if ((rc = run_lin(h->fus[3].out, m3, B, W3, W3, 0, 0, nullptr, m4, s, "da_out_conv", 0, 0, 1, H3))) return rc;      // path4 in m4
+    // path3 .. path1
+    const f16 *path = m4;
+    f16 *pout = m5;
+    for (int k = 2; k >= 0; --k) {
+        const int Hc = Hs[k], Wc = Ws[k];
+        const int Hn = k > 0 ? Hs[k - 1] : HF, Wn = k > 0 ? Ws[k - 1] : WF;
+        if ((rc = rcu(h->fus[k].r1, rn[k], Hc, Wc, path, m1, m2))) return rc;        // m2 = path + RCU1(skip)
+        if ((rc = rcu(h->fus[k].r2, m2, Hc, Wc, nullptr, m1, m3))) return rc;        // m3 = RCU2(m2)
+        if ((rc = upsample(m3, Hc, Wc, Hn, Wn, 64, m2))) return rc;
+        if ((rc = run_lin(h->fus[k].out, m2, B, Wn, Wn, 0, 0, nullptr, pout, s, "da_out_conv", 0, 0, 1, Hn))) return rc;
+        path = pout;
+        pout = (pout == m5) ? m4 : m5;
+    }
+    // output_conv1 (64 -> 32) at 8x the patch grid, resize to the input size, output_conv2
+    if ((rc = run_cnv(h->oc1, path, B, HF, WF, 1, 1, 0, 0, nullptr, nullptr, m1, s))) return rc;
+    if ((rc = upsample(m1, HF, WF, hh, ww, 32, m2))) return rc;
+    if ((rc = run_cnv(h->oc2, m2, B, hh, ww, 1, 1, 0, 3, nullptr, nullptr, m3, s))) return rc;
+    {
+        const long n = (long)B * hh * ww;
+        ProfScope ps("da_final_kernel", s, 64.0 * n, (double)n * 68.0);
+        da_final_kernel<<<blocks(n), 256, 0, s>>>(m3, h->w_final, depth, n);
+        NUNIF_LAUNCH_CHECK();
+    }
+    return NUNIF_HIP_OK;
+}

@@ -86,6 +86,10 @@ struct ConvArgs {
     int rpad;                 // > 0: ReplicationPad2d(rpad) folded into the gather (tap coordinates clamped; the
                               //      caller passes Ho = Hi + 2*rpad - k + 1); stride must be 1, no second input
     const f16 *res;           // optional residual added AFTER the activation, NHWC [B,Ho,Wo,n_real]
+    int zpad;                 // > 0: zero padding `zpad` (Conv2d(padding=zpad)): taps outside the map read 0; any stride;
+                              //      the caller passes Ho = (Hi + 2*zpad - k) / stride + 1
+    int relu_in;              // 1: ReLU applied to the input as it is loaded (pre-activation residual units)
+    const f16 *res2;          // optional second residual (same indexing as res)
 };
 int launch_conv(const ConvArgs &g, hipStream_t s);
 

@@ -166,7 +166,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                 // PatchUp: column n = q*Cq + c (repacked), q=(i,j) -> pixel (2y+i, 2x+j)  (swin_unet.py:76-82);
                 // Cq is a multiple of 32, so a tile pair never straddles two sub-pixels
                 const int q = np / g.ldo, c = np - q * g.ldo;
-                off = (((long)tb[f] * (2 * g.Ho) + 2 * ty[f] + (q >> 1)) * (2 * g.Wo) + 2 * tx[f] + (q & 1)) * g.ldo + c;
+                const int sf = g.ps > 1 ? g.ps : 2;                       // ConvTranspose2d(k = stride = sf): q = i*sf + j
+                const int qi = q / sf, qj = q - qi * sf;
+                off = (((long)tb[f] * (sf * g.Ho) + sf * ty[f] + qi) * (sf * g.Wo) + sf * tx[f] + qj) * g.ldo + c;
             }
             off += pair_run_channel(grp);
             const bool live = valid[f] && np < g.n_real;
@@ -345,7 +347,9 @@ __global__ void __launch_bounds__(512) gemm_res_kernel(GemmArgs g) {
                 // PatchUp: column n = q*Cq + c (repacked), q=(i,j) -> pixel (2y+i, 2x+j)  (swin_unet.py:76-82);
                 // Cq is a multiple of 32, so a tile pair never straddles two sub-pixels
                 const int q = np / g.ldo, c = np - q * g.ldo;
-                off = (((long)tb[f] * (2 * g.Ho) + 2 * ty[f] + (q >> 1)) * (2 * g.Wo) + 2 * tx[f] + (q & 1)) * g.ldo + c;
+                const int sf = g.ps > 1 ? g.ps : 2;                       // ConvTranspose2d(k = stride = sf): q = i*sf + j
+                const int qi = q / sf, qj = q - qi * sf;
+                off = (((long)tb[f] * (sf * g.Ho) + sf * ty[f] + qi) * (sf * g.Wo) + sf * tx[f] + qj) * g.ldo + c;
             }
             off += pair_run_channel(grp);
             const bool live = valid[f] && np < g.n_real;
@@ -413,6 +417,7 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
         case 8: return launch_gemm_t<8, 4>(g, s, "gemm_kernel<8,4>", "gemm_res_kernel<8,4>", flops, bytes);
         case 12: return launch_gemm_t<12, 2>(g, s, "gemm_kernel<12,2>", "gemm_res_kernel<12,2>", flops, bytes);
         case 18: return launch_gemm_t<18, 2>(g, s, "gemm_kernel<18,2>", "gemm_res_kernel<18,2>", flops, bytes);
+        case 19: return launch_gemm_t<19, 1>(g, s, "gemm_kernel<19,1>", "gemm_res_kernel<19,1>", flops, bytes);
         case 24: return launch_gemm_t<24, 1>(g, s, "gemm_kernel<24,1>", "gemm_res_kernel<24,1>", flops, bytes);
         default:
             set_error("gemm %s: unsupported K=%d", tag, g.K);

@@ -1,0 +1,168 @@
+"""Oracle: Depth-Anything-V2 (DINOv2 ViT-S/14 encoder + DPT head), torch CPU fp32 — **parity unpinned**.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+The reference does not contain this network: ``iw3/depth_anything_model.py:200-230`` loads it with
+``torch.hub.load("nagadomi/Depth-Anything_iw3", "DepthAnything", encoder="v2_vits")`` (branch ``main``, unpinned), and
+neither that repository nor its weights exist offline.  This file restates the PUBLISHED architecture
+(Depth-Anything-V2 ``dpt.py`` / ``dinov2.py``: ViT-S/14, 12 blocks with LayerScale, features from blocks 2/5/8/11
+through the final norm without the class token; DPT head with out_channels 48/96/192/384 and 64 fusion features) from
+the call-site contract in SURVEY.md §8c: input B x 3 x h x w ImageNet-normalised with h, w multiples of 14, output
+B x h x w (ReLU'd inverse depth).  State-dict key names follow the public checkpoint (``pretrained.*``, ``depth_head.*``)
+so that a real ``depth_anything_v2_vits.pth`` can be tried as soon as one is available; until then nothing here is
+pinned against the real network, and tests compare the HIP engine with THIS restatement only.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+EMBED, HEADS, DEPTH, PATCH, MLP = 384, 6, 12, 14, 1536
+TAPS = (2, 5, 8, 11)
+OUT_CH = (48, 96, 192, 384)
+FEAT = 64
+
+
+def interpolate_pos_embed(pos_embed, gh, gw):
+    """DINOv2 interpolate_pos_encoding for a gh x gw patch grid (bicubic, +0.1 offset, no antialias)."""
+    n = pos_embed.shape[1] - 1
+    s = int(math.sqrt(n))
+    if gh == s and gw == s:
+        return pos_embed
+    cls, patch = pos_embed[:, :1], pos_embed[:, 1:]
+    patch = patch.reshape(1, s, s, EMBED).permute(0, 3, 1, 2)
+    patch = F.interpolate(patch, scale_factor=((gh + 0.1) / s, (gw + 0.1) / s), mode="bicubic", antialias=False)
+    assert patch.shape[-2:] == (gh, gw)
+    return torch.cat([cls, patch.permute(0, 2, 3, 1).reshape(1, gh * gw, EMBED)], dim=1)
+
+
+def encoder_features(sd, x):
+    """-> 4 tensors [B, gh*gw, 384]: blocks 2, 5, 8, 11 through the final LayerNorm, class token dropped."""
+    B, _, h, w = x.shape
+    gh, gw = h // PATCH, w // PATCH
+    p = "pretrained."
+    t = F.conv2d(x, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"], stride=PATCH)
+    t = t.flatten(2).transpose(1, 2)
+    t = torch.cat([sd[p + "cls_token"].expand(B, -1, -1), t], dim=1) + interpolate_pos_embed(sd[p + "pos_embed"], gh, gw)
+    feats = []
+    hd = EMBED // HEADS
+    for i in range(DEPTH):
+        b = f"{p}blocks.{i}."
+        y = F.layer_norm(t, (EMBED,), sd[b + "norm1.weight"], sd[b + "norm1.bias"], eps=1e-6)
+        qkv = F.linear(y, sd[b + "attn.qkv.weight"], sd[b + "attn.qkv.bias"]).reshape(B, -1, 3, HEADS, hd).permute(2, 0, 3, 1, 4)
+        a = torch.softmax((qkv[0] * hd ** -0.5) @ qkv[1].transpose(-2, -1), dim=-1) @ qkv[2]
+        a = F.linear(a.transpose(1, 2).reshape(B, -1, EMBED), sd[b + "attn.proj.weight"], sd[b + "attn.proj.bias"])
+        t = t + a * sd[b + "ls1.gamma"]
+        y = F.layer_norm(t, (EMBED,), sd[b + "norm2.weight"], sd[b + "norm2.bias"], eps=1e-6)
+        y = F.linear(F.gelu(F.linear(y, sd[b + "mlp.fc1.weight"], sd[b + "mlp.fc1.bias"])), sd[b + "mlp.fc2.weight"], sd[b + "mlp.fc2.bias"])
+        t = t + y * sd[b + "ls2.gamma"]
+        if i in TAPS:
+            feats.append(F.layer_norm(t, (EMBED,), sd[p + "norm.weight"], sd[p + "norm.bias"], eps=1e-6)[:, 1:])
+    return feats, gh, gw
+
+
+def _rcu(sd, p, x):
+    y = F.conv2d(F.relu(x), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
+    y = F.conv2d(F.relu(y), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    return y + x
+
+
+def _fusion(sd, p, x, skip=None, size=None):
+    if skip is not None:
+        x = x + _rcu(sd, p + "resConfUnit1.", skip)
+    x = _rcu(sd, p + "resConfUnit2.", x)
+    if size is None:
+        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    else:
+        x = F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+    return F.conv2d(x, sd[p + "out_conv.weight"], sd[p + "out_conv.bias"])
+
+
+def head(sd, feats, gh, gw):
+    p = "depth_head."
+    layers = []
+    for i, f in enumerate(feats):
+        x = f.permute(0, 2, 1).reshape(f.shape[0], EMBED, gh, gw)
+        x = F.conv2d(x, sd[f"{p}projects.{i}.weight"], sd[f"{p}projects.{i}.bias"])
+        if i == 0:
+            x = F.conv_transpose2d(x, sd[p + "resize_layers.0.weight"], sd[p + "resize_layers.0.bias"], stride=4)
+        elif i == 1:
+            x = F.conv_transpose2d(x, sd[p + "resize_layers.1.weight"], sd[p + "resize_layers.1.bias"], stride=2)
+        elif i == 3:
+            x = F.conv2d(x, sd[p + "resize_layers.3.weight"], sd[p + "resize_layers.3.bias"], stride=2, padding=1)
+        layers.append(F.conv2d(x, sd[f"{p}scratch.layer{i + 1}_rn.weight"], None, padding=1))
+    l1, l2, l3, l4 = layers
+    s = p + "scratch."
+    path4 = _fusion(sd, s + "refinenet4.", l4, size=l3.shape[2:])
+    path3 = _fusion(sd, s + "refinenet3.", path4, l3, size=l2.shape[2:])
+    path2 = _fusion(sd, s + "refinenet2.", path3, l2, size=l1.shape[2:])
+    path1 = _fusion(sd, s + "refinenet1.", path2, l1)
+    out = F.conv2d(path1, sd[s + "output_conv1.weight"], sd[s + "output_conv1.bias"], padding=1)
+    out = F.interpolate(out, (gh * PATCH, gw * PATCH), mode="bilinear", align_corners=True)
+    out = F.relu(F.conv2d(out, sd[s + "output_conv2.0.weight"], sd[s + "output_conv2.0.bias"], padding=1))
+    out = F.relu(F.conv2d(out, sd[s + "output_conv2.2.weight"], sd[s + "output_conv2.2.bias"]))
+    return out
+
+
+def model_forward(sd, x):
+    """x: [B,3,h,w] ImageNet-normalised, h and w multiples of 14 -> [B,h,w] (relu(depth), larger = nearer)."""
+    feats, gh, gw = encoder_features(sd, x)
+    return F.relu(head(sd, feats, gh, gw)).squeeze(1)
+
+
+def random_state_dict(seed, grid=37):
+    """Seeded weights in the public checkpoint's key layout.  LayerScale gammas are O(1) * 0.3 and the residual branches
+    are damped so that 12 blocks keep the token rms O(1) (a trained ViT's regime), every bias is non-zero."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def rnd(*shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    def lin(key, *shape, std=None, bstd=0.02, bias=True):
+        fan = 1
+        for s in shape[1:]:
+            fan *= s
+        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
+        if bias:
+            sd[key + ".bias"] = rnd(shape[0], std=bstd)
+
+    p = "pretrained."
+    lin(p + "patch_embed.proj", EMBED, 3, PATCH, PATCH)
+    sd[p + "cls_token"] = rnd(1, 1, EMBED, std=0.5)
+    sd[p + "pos_embed"] = rnd(1, 1 + grid * grid, EMBED, std=0.3)
+    for i in range(DEPTH):
+        b = f"{p}blocks.{i}."
+        for n in ("norm1", "norm2"):
+            sd[b + n + ".weight"] = 1.0 + rnd(EMBED, std=0.1)
+            sd[b + n + ".bias"] = rnd(EMBED, std=0.05)
+        lin(b + "attn.qkv", 3 * EMBED, EMBED, std=1.5 * math.sqrt(1.0 / EMBED))
+        lin(b + "attn.proj", EMBED, EMBED)
+        lin(b + "mlp.fc1", MLP, EMBED)
+        lin(b + "mlp.fc2", EMBED, MLP)
+        sd[b + "ls1.gamma"] = 0.3 + rnd(EMBED, std=0.05)
+        sd[b + "ls2.gamma"] = 0.3 + rnd(EMBED, std=0.05)
+    sd[p + "norm.weight"] = 1.0 + rnd(EMBED, std=0.1)
+    sd[p + "norm.bias"] = rnd(EMBED, std=0.05)
+    h = "depth_head."
+    for i, oc in enumerate(OUT_CH):
+        lin(f"{h}projects.{i}", oc, EMBED, 1, 1)
+        lin(f"{h}scratch.layer{i + 1}_rn", FEAT, oc, 3, 3, bias=False)
+    sd[h + "resize_layers.0.weight"] = rnd(OUT_CH[0], OUT_CH[0], 4, 4, std=math.sqrt(1.0 / OUT_CH[0]))
+    sd[h + "resize_layers.0.bias"] = rnd(OUT_CH[0], std=0.02)
+    sd[h + "resize_layers.1.weight"] = rnd(OUT_CH[1], OUT_CH[1], 2, 2, std=math.sqrt(1.0 / OUT_CH[1]))
+    sd[h + "resize_layers.1.bias"] = rnd(OUT_CH[1], std=0.02)
+    lin(h + "resize_layers.3", OUT_CH[3], OUT_CH[3], 3, 3)
+    for k in (1, 2, 3, 4):
+        r = f"{h}scratch.refinenet{k}."
+        lin(r + "out_conv", FEAT, FEAT, 1, 1)
+        for u in ("resConfUnit1.", "resConfUnit2."):
+            lin(r + u + "conv1", FEAT, FEAT, 3, 3, std=0.7 * math.sqrt(2.0 / (9 * FEAT)))
+            lin(r + u + "conv2", FEAT, FEAT, 3, 3, std=0.7 * math.sqrt(2.0 / (9 * FEAT)))
+    lin(h + "scratch.output_conv1", FEAT // 2, FEAT, 3, 3)
+    lin(h + "scratch.output_conv2.0", 32, FEAT // 2, 3, 3, std=math.sqrt(2.0 / (9 * 32)))
+    lin(h + "scratch.output_conv2.2", 1, 32, 1, 1, std=math.sqrt(2.0 / 32), bstd=0.5)
+    # a depth map, not a mostly-clipped one: positive mixing weights and bias in the last 1x1 (the ReLU then rarely bites)
+    sd[h + "scratch.output_conv2.2.weight"] = sd[h + "scratch.output_conv2.2.weight"].abs() * 0.5
+    sd[h + "scratch.output_conv2.2.bias"] = sd[h + "scratch.output_conv2.2.bias"].abs() * 0.2 + 0.1
+    return sd

@@ -1,0 +1,63 @@
+"""Depth-Anything-V2 ViT-S backbone: HIP engine vs the architecture restatement (oracle/depth_anything_v2.py).
+
+PARITY UNPINNED: the real network lives in an external hub repository that is not available offline;
+these tests compare the engine with our restatement of the published architecture only."""
+import pytest
+import torch
+
+from conftest import psnr, synth_image
+from oracle import depth_anything_v2 as ODA
+
+
+def test_oracle_shapes_and_parameter_count():
+    sd = ODA.random_state_dict(601)
+    assert abs(sum(v.numel() for v in sd.values()) / 1e6 - 24.78) < 0.01          # Depth-Anything-V2-Small: 24.8 M
+    x = torch.randn(2, 3, 56, 84)
+    y = ODA.model_forward(sd, x)
+    assert y.shape == (2, 56, 84) and float(y.min()) >= 0 and float(y.std()) > 0.1
+    pe = ODA.interpolate_pos_embed(sd["pretrained.pos_embed"], 4, 6)
+    assert pe.shape == (1, 25, 384) and torch.equal(pe[:, 0], sd["pretrained.pos_embed"][:, 0])
+
+
+def _norm(img):
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return (img - mean) / std
+
+
+@pytest.mark.gpu
+def test_hip_backbone_vs_restatement(hiplib):
+    from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+    sd = ODA.random_state_dict(601)
+    net = HipDepthAnythingV2(sd, "cuda:0")
+    for shape in ((2, 3, 84, 126), (1, 3, 56, 56)):
+        x = _norm(torch.stack([synth_image(90 + i, 3, shape[2], shape[3]) for i in range(shape[0])]))
+        ref = ODA.model_forward(sd, x)
+        y = net(x.to("cuda:0")).cpu()
+        assert y.shape == ref.shape
+        span = float(ref.max() - ref.min())
+        p = psnr(y / span, ref / span)
+        rel = ((y - ref).pow(2).mean().sqrt() / ref.std()).item()
+        assert p >= 50.0 and rel < 1e-2, (shape, p, rel)
+    assert torch.equal(net(x.to("cuda:0")).cpu(), y)                        # deterministic
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 50, 56))
+
+
+@pytest.mark.gpu
+def test_hip_backbone_full_size_in_the_pipeline(hiplib):
+    """392 x 686 (what batch_preprocess produces for 1080p) through BaseDepthModel.infer with the HIP backbone."""
+    from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+    from nunif_amd.iw3.base_depth_model import CallableDepthModel
+    sd = ODA.random_state_dict(602)
+    net = HipDepthAnythingV2(sd, "cuda:0")
+    x = _norm(synth_image(95, 3, 392, 686)[None])
+    ref = ODA.model_forward(sd, x)
+    y = net(x.to("cuda:0")).cpu()
+    span = float(ref.max() - ref.min())
+    assert psnr(y / span, ref / span) >= 50.0, psnr(y / span, ref / span)
+    model = CallableDepthModel(net)
+    model.load(gpu=0)
+    frame = synth_image(96, 3, 1080, 1920)
+    d = model.infer(frame.to("cuda:0"), tta=False, edge_dilation=2)
+    assert d.shape == (1, 392, 686) and torch.isfinite(d).all() and float(d.std()) > 0
