@@ -240,7 +240,7 @@ struct Buf {
 };
 struct Lin { f16 *w = nullptr; float *b = nullptr; int N = 0, K = 0; };              // gemm_kernel packing [nt][ks]
 struct Cnv { f16 *w = nullptr; float *b = nullptr; int N = 0, Cin = 0, k = 3; };     // conv_kernel stream [ks][nt]
-struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1; Cnv fc2; };
+struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2a, fc2b; };   // fc2 (K = 1536) = two K = 768 GEMMs
 struct Rcu { Cnv c1, c2; };
 struct Fus { Rcu r1, r2; Lin out; };
 }  // namespace
@@ -312,12 +312,12 @@ int conv_from(nunif_depth_anything *h, const TMap &m, const std::string &key, in
 }
 
 int run_lin(const Lin &L, const f16 *a, int B, int Wi, int Wo, int ox, int act, const f16 *res, f16 *out, hipStream_t s,
-            const char *tag, int mode = 0, int ldo = 0, int ps = 1, int Hi = 1) {
+            const char *tag, int mode = 0, int ldo = 0, int ps = 1, int Hi = 1, int lda = 0) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = L.K; g.Ho = Hi; g.Wo = Wo; g.stride = 1; g.ox = ox; g.kw = 1;
     g.K = L.K; g.w = L.w; g.bias = L.b; g.N = L.N; g.mode = mode; g.act = act; g.res = res; g.out = out;
-    g.ldo = ldo ? ldo : L.N; g.n_real = L.N; g.ps = ps;
+    g.ldo = ldo ? ldo : L.N; g.n_real = L.N; g.ps = ps; g.lda = lda;
     return launch_gemm(g, s, tag);
 }
 int run_cnv(const Cnv &C, const f16 *a, int B, int Hi, int Wi, int stride, int zpad, int relu_in, int act, const f16 *res,
@@ -385,10 +385,13 @@ extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors,
             }
             d = w1->data; e = bb1->data;
             if ((rc = make_lin(h, 4 * kD, kD, [=](int n, int k) { return d[(size_t)n * kD + k]; }, [=](int n) { return e[n]; }, &bk.fc1))) break;
-            {
+            {   // fc2 with LayerScale folded, split along K into two halves that accumulate into the residual stream
                 const float *wd = w2->data, *bd = bb2->data, *ls = ls2->data;
-                if ((rc = make_cnv(h, kD, 4 * kD, 1, [=](int n, int, int ci) { return wd[(size_t)n * 4 * kD + ci] * ls[n]; },
-                                   [=](int n) { return bd[n] * ls[n]; }, &bk.fc2))) break;
+                if ((rc = make_lin(h, kD, 2 * kD, [=](int n, int k) { return wd[(size_t)n * 4 * kD + k] * ls[n]; },
+                                   [=](int n) { return bd[n] * ls[n]; }, &bk.fc2a)) ||
+                    (rc = make_lin(h, kD, 2 * kD, [=](int n, int k) { return wd[(size_t)n * 4 * kD + 2 * kD + k] * ls[n]; },
+                                   [=](int) { return 0.f; }, &bk.fc2b)))
+                    break;
             }
         }
         if (rc) break;
@@ -514,7 +517,9 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         da_layernorm_kernel<<<(unsigned)((T + 3) / 4), 256, 0, s>>>(t, bk.g2, bk.b2, y, T);
         NUNIF_LAUNCH_CHECK();
         if ((rc = run_lin(bk.fc1, y, 1, (int)T, (int)T, 0, 1, nullptr, hid, s, "da_fc1"))) return rc;      // GELU(erf)
-        if ((rc = run_cnv(bk.fc2, hid, 1, 1, (int)T, 1, 0, 0, 0, t, nullptr, t, s))) return rc;              // t += ls2 * fc2(.)
+        // t += ls2 * fc2(.): two K = 768 halves of the 1536-wide hidden rows (lda = 1536)
+        if ((rc = run_lin(bk.fc2a, hid, 1, (int)T, (int)T, 0, 0, t, t, s, "da_fc2", 0, 0, 1, 1, 4 * kD))) return rc;
+        if ((rc = run_lin(bk.fc2b, hid + 2 * kD, 1, (int)T, (int)T, 0, 0, t, t, s, "da_fc2", 0, 0, 1, 1, 4 * kD))) return rc;
         if (i == 2 || i == 5 || i == 8 || i == 11) {
             da_layernorm_kernel<<<(unsigned)((T + 3) / 4), 256, 0, s>>>(t, h->norm_g, h->norm_b, (f16 *)h->feat[tap].p, T);
             NUNIF_LAUNCH_CHECK();

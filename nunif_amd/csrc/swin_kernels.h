@@ -25,6 +25,8 @@ struct GemmArgs {
     int oshift, OH, OW;       // mode 2: output pixel (y*s+i+oshift, x*s+j+oshift) inside an OH x OW plane (0: Ho*s x Wo*s);
                               //         positions outside the plane are dropped (ConvTranspose2d 4x4 s2 p3 head of UpCUNet)
     int no_clamp;             // mode 2: 1 = no clamp(0,1)
+    int lda;                  // element stride between input pixels (0: Cin) — lets a GEMM read a K-slice of wider rows
+    int nt_chunk;             // set by the launcher: output tiles per workgroup column (blockIdx.y) for small-M GEMMs
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag);
 

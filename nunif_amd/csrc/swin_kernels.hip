@@ -41,7 +41,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     // no early exit: every wave joins every chunk barrier; rows beyond M are clamped on load and masked on store
     // (the host pads every packed weight array with 16 KiB of zeros, so the one-chunk-ahead prefetch never
     //  leaves the allocation — make_linear in swin_unet.cpp)
-    const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.w);
+    // small-M GEMMs (ViT token matrices) split the output tiles over blockIdx.y so that the grid still fills the chip
+    const int NT_all = g.N >> 4;
+    const int nt_lo = g.nt_chunk ? (int)blockIdx.y * g.nt_chunk : 0;
+    const int nt_hi = g.nt_chunk ? min(NT_all, nt_lo + g.nt_chunk) : NT_all;
+    const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.w) + (long)nt_lo * KS * 64;
     auto fetch = [&](int e) -> f16x8 { return gsrc[e]; };
     f16x8 st0 = fetch(tid), st1 = fetch(tid + 256);
     auto wfrag = [&](int fi) -> f16x8 {
@@ -78,12 +82,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
             const int c0 = k0 - tap * g.Cin;
             const int dy = tap / g.kw;
             const int dx = tap - dy * g.kw;
-            const f16 *p = g.a + (pix0 + (long)dy * g.Wi + dx) * g.Cin + c0 + grp * 8;
+            const f16 *p = g.a + (pix0 + (long)dy * g.Wi + dx) * (g.lda ? g.lda : g.Cin) + c0 + grp * 8;
             xf[f][ks] = *reinterpret_cast<const f16x8 *>(p);
         }
     }
 
-    const int NT = g.N >> 4;
+    const int NT = nt_hi - nt_lo;
     if (g.mode == 2) {
         // ToImage: column n = c*s*s + i*s + j -> out[b][c][y*s+i][x*s+j], clamp(0,1)  (swin_unet.py:110-116)
 #pragma unroll 1
@@ -97,7 +101,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int f = 0; f < MF; ++f) acc[f] = MFMA_16x16x32(wv, xf[f][ks], acc[f]);
             }
-            const int n0 = nt * 16 + grp * 4;
+            const int n0 = (nt_lo + nt) * 16 + grp * 4;
             const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
             const int s = g.ps, s2 = s * s;
             const int OC = g.n_real / s2;
@@ -141,10 +145,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int f = 0; f < MF; ++f) acc1[f] = MFMA_16x16x32(wv, xf[f][ks], acc1[f]);
         }
-        const int n0 = nt * 16 + grp * 4;
+        const int n0 = (nt_lo + nt) * 16 + grp * 4;
         const float4 bv0 = *reinterpret_cast<const float4 *>(g.bias + n0);
         const float4 bv1 = *reinterpret_cast<const float4 *>(g.bias + n0 + 16);
-        const int np = nt * 16;                         // first channel of the 32-channel pair
+        const int np = (nt_lo + nt) * 16;               // first channel of the 32-channel pair
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             float v0[4] = {acc0[f][0] + bv0.x, acc0[f][1] + bv0.y, acc0[f][2] + bv0.z, acc0[f][3] + bv0.w};
@@ -260,7 +264,7 @@ __global__ void __launch_bounds__(512) gemm_res_kernel(GemmArgs g) {
             const int c0 = k0 - tap * g.Cin;
             const int dy = tap / g.kw;
             const int dx = tap - dy * g.kw;
-            const f16 *p = g.a + (pix0 + (long)dy * g.Wi + dx) * g.Cin + c0 + grp * 8;
+            const f16 *p = g.a + (pix0 + (long)dy * g.Wi + dx) * (g.lda ? g.lda : g.Cin) + c0 + grp * 8;
             xf[f][ks] = *reinterpret_cast<const f16x8 *>(p);
         }
     }
@@ -392,7 +396,18 @@ static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym,
     } else {
         const long rows_per_block = 4 * MF * 16;
         const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
-        gemm_kernel<KS, MF><<<blocks, 256, 0, s>>>(g);
+        GemmArgs gg = g;
+        unsigned ny = 1;
+        const int NT = g.N / 16;
+        if (blocks < 128 && NT >= 4 && g.mode != 2) {       // few token groups: also split the output tiles (even chunks)
+            const unsigned want = (512 + blocks - 1) / blocks;
+            int chunk = std::max(2, (int)((NT + want - 1) / want));
+            chunk += chunk & 1;
+            ny = (unsigned)((NT + chunk - 1) / chunk);
+            gg.nt_chunk = ny > 1 ? chunk : 0;
+            if (ny <= 1) ny = 1;
+        }
+        gemm_kernel<KS, MF><<<dim3(blocks, ny), 256, 0, s>>>(gg);
     }
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;

@@ -270,7 +270,7 @@ int run_gemm(const Linear &L, const f16 *a, int B, int Hi, int Wi, int Cin, int 
     g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.oy = oy; g.ox = ox; g.kw = kw;
     g.K = L.K; g.w = L.w; g.bias = L.bias; g.N = L.N;
     g.mode = mode; g.act = act; g.slope = slope; g.res = res; g.out = out; g.ldo = ldo;
-    g.n_real = L.n_real; g.ps = ps; g.oshift = 0; g.OH = 0; g.OW = 0; g.no_clamp = 0;
+    g.n_real = L.n_real; g.ps = ps; g.oshift = 0; g.OH = 0; g.OW = 0; g.no_clamp = 0; g.lda = 0; g.nt_chunk = 0;
     return launch_gemm(g, s, tag);
 }
 

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""iw3 per-frame pipeline timing (BASELINE config 4 shape): 1080p frame -> batch_preprocess -> Depth-Anything-V2 ViT-S
+(random-init weights of the published architecture) -> min-max normalise -> stereo synthesis -> SBS compose + quantise.
+Prints one JSON object; per-kernel classes come from the library's HIP-event profiler.  Not the contract benchmark."""
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nunif_amd import _hip  # noqa: E402
+from nunif_amd.iw3 import _ops  # noqa: E402
+from nunif_amd.iw3.base_depth_model import CallableDepthModel  # noqa: E402
+from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2  # noqa: E402
+from nunif_amd.iw3.models.row_flow_v3 import RowFlowV3  # noqa: E402
+from nunif_amd.iw3.utils import apply_divergence  # noqa: E402
+from oracle import depth_anything_v2 as ODA  # noqa: E402  (seeded weight generators only)
+from oracle import row_flow_v3 as ORF  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def main():
+    torch.set_grad_enabled(False)
+    H, W = 1080, 1920
+    depth_model = CallableDepthModel(HipDepthAnythingV2(ODA.random_state_dict(601), DEV))
+    depth_model.load(gpu=0)
+    side = RowFlowV3().eval()
+    side.load_state_dict(ORF.random_state_dict(301))
+    side = side.to(DEV)
+    side.delta_output = True
+    frames = [torch.rand(3, H, W, device=DEV) for _ in range(3)]
+    res = {}
+    for method in ("row_flow_v3", "forward_fill", "grid_sample"):
+        args = SimpleNamespace(mapper="none", convergence=0.5, divergence=2.0, method=method, synthetic_view="both",
+                               warp_steps=None, stereo_width=None, preserve_screen_border=False, disable_amp=False)
+
+        def step(i):
+            x = frames[i % 3]
+            d = depth_model.infer(x, tta=False, edge_dilation=2)                 # [1,h,w] raw
+            d = depth_model.minmax_normalize_chw(d)
+            left, right = apply_divergence(d, x, args, side_model=side)
+            return _ops.stereo_to_frame(left, right, "sbs")
+
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 20
+        for i in range(n):
+            step(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        res[method] = {"ms_per_frame": round(dt * 1e3, 3), "fps": round(1 / dt, 1), "input_MPix_s": round(H * W / dt / 1e6, 1)}
+    _hip.profile_enable(True)
+    step(0)
+    torch.cuda.synchronize()
+    recs = _hip.profile_read()
+    _hip.profile_enable(False)
+    tot = sum(r["total_ms"] for r in recs)
+    res["kernel_classes_last_method"] = [{"kernel": r["name"], "us": round(r["total_ms"] * 1e3, 1), "launches": r["launches"]}
+                                         for r in sorted(recs, key=lambda r: -r["total_ms"])[:14]]
+    res["gpu_ms_profiled"] = round(tot, 3)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
