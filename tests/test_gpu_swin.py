@@ -208,6 +208,31 @@ def test_full_size_1080p_properties(hiplib):
     assert out208.shape == out.shape and float(out208.min()) >= 0 and float(out208.max()) <= 1
 
 
+def test_full_size_4k_4x_properties(hiplib):
+    """BASELINE config 3 geometry: swin_unet 4x on a 2160x3840 frame, tile 256 -> 8640x15360 (170 tiles, 1.6 GB of
+    fp32 output).  Whole-frame oracle is minutes of CPU, so: grid facts, determinism across tile batch sizes, range,
+    and oracle parity on an interior tile and on the bottom-right (mostly padding) tile."""
+    from nunif_amd.nunif.utils.render import tiled_render
+    m, sd = make_model(4, 104)
+    img = synth_image(78, 3, 2160, 3840)
+    cfg = OS.create_config(2160, 3840, 4, 32, 256, 16)
+    assert (cfg["h_blocks"], cfg["w_blocks"], cfg["input_tile_step"], cfg["output_tile_step"]) == (10, 17, 236, 944)
+    out = tiled_render(img, m, tile_size=256, batch_size=34)
+    assert out.shape == (3, 8640, 15360) and float(out.min()) >= 0 and float(out.max()) <= 1
+    ref_rows = tiled_render(img, m, tile_size=256, batch_size=7)
+    assert torch.equal(out[:, 4000:4200], ref_rows[:, 4000:4200]) and torch.equal(out[:, -64:], ref_rows[:, -64:])
+    del ref_rows
+    xp = torch.nn.functional.pad(img[None], cfg["pad"], mode="replicate")[0]
+    t = xp[:, 3 * 236:3 * 236 + 256, 5 * 236:5 * 236 + 256][None]              # tile (3,5)
+    z = O.model_forward(sd, t, NAMES[4])[0]                                      # [3,960,960] -> output [3*944 : +960)
+    y0, x0 = 3 * 944, 5 * 944
+    assert psnr(out[:, y0 + 16:y0 + 944, x0 + 16:x0 + 944].cpu(), z[:, 16:944, 16:944]) >= PSNR_MIN
+    t = xp[:, 9 * 236:9 * 236 + 256, 16 * 236:16 * 236 + 256][None]             # last tile (9,16)
+    z = O.model_forward(sd, t, NAMES[4])[0]
+    y0, x0 = 9 * 944, 16 * 944
+    assert psnr(out[:, y0 + 16:8640, x0 + 16:15360].cpu(), z[:, 16:8640 - y0, 16:15360 - x0]) >= PSNR_MIN
+
+
 def test_load_save_roundtrip_and_errors(hiplib, tmp_path):
     from nunif_amd.nunif.models import load_model, save_model, create_model
     m, sd = make_model(2, 102)
