@@ -114,6 +114,17 @@ int nunif_hip_cunet_forward(nunif_cunet *handle, const float *x, float *z, int32
 int nunif_hip_cunet_render(nunif_cunet *handle, const float *x, float *y, int32_t x_h, int32_t x_w,
                            int32_t tile_size, int32_t batch_size, void *stream);
 
+/* waifu2x image-side helpers.
+ * tta_view: one of the 8 dihedral views of nunif/transforms/tta.py tta_split :20-34; view = rot90*4 + vflip*2 + hflip in
+ * the reference's tuple order; x: [C,H,W] -> y: [C,H,W] (views 0-3) or [C,W,H] (views 4-7).
+ * tta_merge :37-48: views[k]: the model's output for view k ([C,H,W] / [C,W,H]); out = clamp(sum of the inverse-transformed
+ * views * 1/8) added in the reference's order (bit-exact).
+ * alpha_border_padding: nunif/utils/alpha.py AlphaBorderPadding :32-57; rgb [3,H,W], alpha [1,H,W], work: 8*H*W floats. */
+int nunif_hip_tta_view(const float *x, float *y, int32_t C, int32_t H, int32_t W, int32_t view, void *stream);
+int nunif_hip_tta_merge(const float *const *views, float *out, int32_t C, int32_t H, int32_t W, void *stream);
+int nunif_hip_alpha_border_padding(const float *rgb, const float *alpha, float *out, float *work, int32_t H, int32_t W,
+                                   int32_t offset, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * iw3 stereo synthesis + depth post-processing.
  * ---------------------------------------------------------------------------------------------------------- */

@@ -84,6 +84,9 @@ SIGNATURES = {
     "nunif_hip_depth_anything_create": (c_int32, [ctypes.POINTER(TensorDesc), c_int32, ctypes.POINTER(c_void_p)]),
     "nunif_hip_depth_anything_destroy": (None, [c_void_p]),
     "nunif_hip_depth_anything_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_tta_view": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_tta_merge": (c_int32, [ctypes.POINTER(c_void_p), c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_alpha_border_padding": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "nunif_hip_resize_aa": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64] + [c_int32] * 7 +
                             [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
     "nunif_hip_dilate_edge": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),

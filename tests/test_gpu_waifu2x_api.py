@@ -145,3 +145,49 @@ def test_cunet_through_the_context(tmp_path, hiplib):
         rgb, _ = ctx.convert(x, None, "noise", 1, tile_size=96, batch_size=4)
     ref = OS.tiled_render(x, lambda mb: OC.model_forward(sd, mb), 1, 28, 0, 96, 4)
     assert rgb.shape == (3, 128, 128) and psnr(rgb, ref) >= 50.0
+
+
+@pytest.mark.gpu
+def test_hip_tta_views_and_merge_bit_exact(hiplib):
+    from nunif_amd.nunif.transforms.tta import tta_merge, tta_split
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(3, 37, 53, generator=g)
+    views = tta_split(x.to("cuda:0"))
+    ref_views = OA.tta_split(x)
+    assert len(views) == 8
+    for v, r in zip(views, ref_views):
+        assert v.shape == r.shape and torch.equal(v.cpu(), r)
+    # merge of arbitrary per-view "model outputs" (different per view), reference order of additions
+    outs = [torch.rand(r.shape, generator=g) for r in ref_views]
+    import nunif_amd.nunif.transforms.tta as T
+    got = tta_merge([o.to("cuda:0") for o in outs]).cpu()
+    avg = outs[0].clone()
+    for k, y in enumerate(outs[1:], start=1):
+        if k & 1:
+            y = torch.flip(y, (2,))
+        if k & 2:
+            y = torch.flip(y, (1,))
+        if k & 4:
+            y = torch.rot90(y, -1, (1, 2))
+        avg += y
+    avg *= 1 / 8.0
+    assert torch.equal(got, torch.clamp(avg, 0, 1))
+    assert T.tta_merge.__module__.startswith("nunif_amd")
+    with pytest.raises(RuntimeError):
+        tta_split(x)                                        # CPU tensor: no fallback
+
+
+@pytest.mark.gpu
+def test_hip_alpha_border_padding(hiplib):
+    from nunif_amd.nunif.utils.alpha import AlphaBorderPadding
+    g = torch.Generator().manual_seed(12)
+    rgb = torch.rand(3, 64, 80, generator=g)
+    alpha = ((torch.rand(1, 64, 80, generator=g) > 0.6).float() * torch.rand(1, 64, 80, generator=g)).contiguous()
+    alpha[:, 20:44, 30:60] = 0.0                              # a hole wider than the padding radius
+    pad = AlphaBorderPadding()
+    for offset in (0, 1, 4, 16):
+        got = pad(rgb.to("cuda:0"), alpha.to("cuda:0"), offset).cpu()
+        ref = OA.alpha_border_padding(rgb, alpha, offset)
+        assert (got - ref).abs().max().item() < 1e-5, offset
+    # pixels deeper than `offset` inside the hole stay zero
+    assert float(pad(rgb.to("cuda:0"), alpha.to("cuda:0"), 4)[:, 30:34, 42:48].abs().max()) == 0.0
