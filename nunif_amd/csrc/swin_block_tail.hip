@@ -91,14 +91,14 @@ constexpr int kChunkFrags = 8;   // 8 KiB per chunk: 256 threads x 2 x 16 B
 
 // ABL != 0 are timing-only ablations used to find what bounds the kernel (NUNIF_TAIL_ABL; results are wrong):
 // 1 = no GELU polynomial, 2 = no stores, 4 = no residual read, 8 = no MFMA in the MLP loop, 16 = no ring barrier
-template <int C, int MF, int ABL = 0, int WAVES = 4>
+template <int C, int MF, int ABL = 0, int WAVES = 4, int CHF = kChunkFrags>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1)
 proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wstream, int n_chunks,
                 const float *__restrict__ bp, const float *__restrict__ b0, const float *__restrict__ b3, long M) {
     constexpr int KS = C / 32;       // K chunks of the C-wide GEMMs (proj, mlp.0)
     constexpr int NT = C / 16;       // 16-channel output tiles of a C-wide result
     constexpr int SH = 2 * C / 32;   // K chunks of the hidden (2C) dimension
-    constexpr int CH = kChunkFrags;
+    constexpr int CH = CHF;          // fragments (KiB) per ring chunk; 16 doubles the prefetch distance (4 staging regs)
     __shared__ f16x8 ring[2][CH * 64];
 
     const int tid = threadIdx.x;
@@ -113,8 +113,9 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
     // 360 KiB per workgroup, i.e. 1.8 GB of L2 -> LDS traffic per launch with 128-token workgroups (more than twice
     // the kernel's HBM traffic); 512 threads load one 16-byte piece of a chunk each
     const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(wstream) + tid;
-    f16x8 st0 = gsrc[0], st1;
+    f16x8 st0 = gsrc[0], st1, st2, st3;
     if constexpr (WAVES == 4) st1 = gsrc[256];       // chunk 0 in flight
+    if constexpr (CH == 16) { st2 = gsrc[512]; st3 = gsrc[768]; }
 
     // fragment `fi` of the stream (fi is a compile-time constant at every call site after unrolling, and call
     // sites are in increasing fi order)
@@ -123,10 +124,12 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
         if (fi % CH == 0) {
             ring[c & 1][tid] = st0;
             if constexpr (WAVES == 4) ring[c & 1][tid + 256] = st1;
+            if constexpr (CH == 16) { ring[c & 1][tid + 512] = st2; ring[c & 1][tid + 768] = st3; }
             if constexpr (!(ABL & 16)) __syncthreads();
             if (c + 1 < n_chunks) {
                 st0 = gsrc[(long)(c + 1) * (CH * 64)];
                 if constexpr (WAVES == 4) st1 = gsrc[(long)(c + 1) * (CH * 64) + 256];
+                if constexpr (CH == 16) { st2 = gsrc[(long)(c + 1) * (CH * 64) + 512]; st3 = gsrc[(long)(c + 1) * (CH * 64) + 768]; }
             }
         }
         return ring[c & 1][(fi % CH) * 64 + lane];
@@ -481,6 +484,11 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
             case 64: {   // 8-wave workgroups (half the L2 -> LDS weight traffic): measured SLOWER, 242 vs 221 us
                 const unsigned blocks8 = (unsigned)((M + 8 * MF * 16 - 1) / (8 * MF * 16));
                 proj_mlp_kernel<192, MF, 0, 8><<<blocks8, 512, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M);
+                break;
+            }
+            case 128: {  // 16-KiB ring chunks: twice the prefetch distance
+                const int nc16 = (proj_mlp_stream_frags(C) + 15) / 16;
+                proj_mlp_kernel<192, MF, 0, 4, 16><<<blocks, 256, 0, s>>>(att, x, wstream, nc16, bp, b0, b3, M);
                 break;
             }
             default: proj_mlp_kernel<192, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;

@@ -215,7 +215,7 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
         {   // one linear stream of 1-KiB fragments in the order proj_mlp_kernel consumes them (swin_block_tail.hip)
             const int KS = dim / 32, NT = dim / 16, SH = 2 * dim / 32;
             const int nf = proj_mlp_stream_frags(dim);
-            std::vector<f16> stream((size_t)(nf + 7) / 8 * 8 * 512, (f16)0.0f);
+            std::vector<f16> stream((size_t)(nf + 15) / 16 * 16 * 512, (f16)0.0f);     // whole 16-fragment chunks
             size_t fi = 0;
             auto put = [&](const std::vector<f16> &src, int frag) {
                 std::copy(src.begin() + (size_t)frag * 512, src.begin() + (size_t)(frag + 1) * 512,
