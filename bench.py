@@ -198,7 +198,7 @@ def main():
             "model_mfma_frac": round(45 * 98e9 * args.steps * world / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
             "roofline": roofline, "kernel_classes": classes,
         }
-        if not args.no_host_frames:
+        if not args.no_host_frames and world == 1:
             # host uint8 frame -> pinned ring -> H2D -> to_tensor -> render -> quantise -> D2H -> host uint8 frame
             from nunif_amd.frame_ring import FrameRing
             import numpy as np
@@ -217,7 +217,7 @@ def main():
             result["host_frames"] = {"mpix_per_s": round(mpix_in * n_host / dt, 2), "ms_per_frame": round(1e3 * dt / n_host, 3),
                                      "frames": n_host, "path": "uint8 HWC host -> pinned ring (depth 3) -> H2D -> render -> "
                                      "quantise -> D2H -> uint8 HWC host", "bytes_per_frame": int(FRAME_H * FRAME_W * 3 * 5)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
             base, crop, ref = cpu_baseline(sd, frames[0].cpu())
             got = tiled_render(crop, model, tile_size=TILE, batch_size=args.batch_size).cpu()
             mse = torch.mean((got.double() - ref.double()) ** 2).item()
