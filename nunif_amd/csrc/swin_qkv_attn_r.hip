@@ -15,6 +15,8 @@
 //   * the qkv biases initialise the accumulators (no epilogue add);
 //   * the window-invariant one-hot key fragments are built once per wave;
 //   * C = 96 prefetches the next window's x while the current one is computed.
+#include <algorithm>
+
 #include "swin_kernels.h"
 
 namespace nunif {
@@ -99,12 +101,15 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
         }
     };
 
-    const int wstride = kWavesR * gridDim.x;
-    const int w0 = blockIdx.x * kWavesR + wave;
-
-#pragma unroll 1
-    for (int pass = 0; pass < PASSES; ++pass) {
-        if (pass > 0) __syncthreads();                    // every wave is done with the previous pass' weights
+    // Head passes are spread over WORKGROUPS, not run back to back inside one: workgroup i serves pass i % PASSES for the
+    // windows (i / PASSES) + k * gridDim.x / PASSES.  Every workgroup loads its weight slice exactly once, there is no
+    // mid-kernel barrier, and the unit of work is (window, pass): with 4 500 windows on the 60 x 60 level a wave gets
+    // 4.4 units instead of 2.2 windows x 2 passes, i.e. the last-round quantisation loss drops from 36 % to 12 %.
+    const int n_wg = gridDim.x / PASSES;
+    const int wstride = kWavesR * n_wg;
+    const int w0 = (blockIdx.x / PASSES) * kWavesR + wave;
+    {
+        const int pass = blockIdx.x % PASSES;
         {
             const f16x8 *src = reinterpret_cast<const f16x8 *>(a.wres) + (long)pass * HPP * FPH * 64;
             for (int i = tid; i < HPP * FPH * 64; i += 512) wl[i] = src[i];
@@ -279,7 +284,8 @@ int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv
     a.n_windows = B * (H / 6) * (W / 6);
     const double tok = (double)B * H * W;
     const int wgs = (a.n_windows + kWavesR - 1) / kWavesR;
-    const int grid = wgs < 256 ? wgs : 256;             // persistent: one 8-wave workgroup per CU
+    int grid = wgs < 256 ? wgs : 256;                   // persistent: one 8-wave workgroup per CU
+    if (C == 192) grid = std::max(2, grid & ~1);        // two head passes = two kinds of workgroup
     int rc;
     if (C == 96) {
         ProfScope ps("qkv_attn_r_kernel<96,16>", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 4.0);
