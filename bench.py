@@ -110,10 +110,10 @@ def main():
     from nunif_amd import _hip
     from nunif_amd.nunif.utils.render import tiled_render
     from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x
-    from oracle import swin_unet as O      # seeded weight generator + (rank 0) CPU baseline / parity check only
+    from nunif_amd.synthetic import swin_unet_state_dict    # seeded random-init weights (no checkpoints offline)
 
     torch.set_grad_enabled(False)
-    sd = O.random_state_dict(102, 2)
+    sd = swin_unet_state_dict(102, 2)
     model = SwinUNet2x().eval()
     model.load_state_dict(sd)
     model = model.to(dev)

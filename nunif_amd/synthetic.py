@@ -1,0 +1,322 @@
+"""Seeded synthetic weights and inputs (no pretrained weights or datasets exist offline).
+
+Product-side data generators: ``bench.py``, ``tools/`` and the tests draw their random-init state dicts (in the
+reference's / the public checkpoints' key layouts) and synthetic depth maps from here.  Pure torch on the CPU, no HIP.
+Every generator conditions the weights so that the random net sits in the numeric regime of a trained one (residual
+branches damped, image heads scaled into [0,1]) and makes every bias / bias table non-zero, so that parity tests exercise
+them; the reasoning is in each docstring.  ``oracle/*.random_state_dict`` are thin aliases of these functions.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ---- swin_unet --------------------------------------------------------------------------------------------------------
+# Conditioning of the seeded test weights.  With plain xavier/kaiming init the residual stream of this 14-block
+# net doubles every two blocks (rms 0.1 -> 13), attention logits reach +-60 and the softmax becomes a hard argmax:
+# a regime no trained net is in, where fp16 storage (the reference's own GPU mode) flips winners and PSNR measures
+# chaos instead of kernel correctness (measured: rel. error 1e-2 in the last attention).  So the two residual
+# branch outputs (attn.proj, mlp.3) are scaled by BRANCH_GAIN (stream rms ends ~1.3, logits O(1)), and the head is
+# scaled so the un-clamped image sits around 0.5 +- 0.2 like a real picture instead of saturating the clamp.
+BRANCH_GAIN = 0.8
+HEAD_GAIN = 0.12
+WINDOW = (6, 6)
+
+# ---- Depth-Anything-V2 ViT-S (published architecture) --------------------------------------------------------------------
+EMBED, HEADS, DEPTH, PATCH, MLP = 384, 6, 12, 14, 1536
+OUT_CH = (48, 96, 192, 384)
+FEAT = 64
+
+
+def relative_position_index(wh, ww):
+    """torchvision's ``relative_position_index`` buffer for a wh x ww window: (yi - yj + wh - 1) * (2 ww - 1) + (xi - xj + ww - 1)."""
+    ys, xs = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
+    coords = torch.stack([ys.flatten(), xs.flatten()])
+    rel = coords[:, :, None] - coords[:, None, :]
+    return ((rel[0] + wh - 1) * (2 * ww - 1) + rel[1] + ww - 1).flatten()
+
+
+def window_score_bias_input(window):
+    """WindowScoreBias buffers (index [N*N], unique normalised offsets [U,2]; nunif/modules/attention.py:347-372)."""
+    sh, sw = window
+    pos = [(y, x) for y in range(sh) for x in range(sw)]
+    delta = [(a[0] - b[0], a[1] - b[1]) for a in pos for b in pos]
+    uniq = sorted(set(delta))
+    index = torch.tensor([uniq.index(d) for d in delta], dtype=torch.int64)
+    ud = torch.tensor(uniq, dtype=torch.float32)
+    return index, ud / ud.abs().max()
+
+
+def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_channels=3):
+    """Seeded random weights in the reference's key layout and shapes.
+
+    Magnitudes follow the reference initialisers (kaiming/xavier) but every bias and relative-position
+    table is drawn N(0, 0.02) instead of zero so that bias handling is exercised.
+    Deterministic for a given torch build (CPU generator).
+    """
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def normal(shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    def uniform(shape, bound):
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+    def lin(key, cin, cout, gain=1.0, bias_mean=0.0):
+        sd[key + ".weight"] = uniform((cout, cin), gain * math.sqrt(6.0 / (cin + cout)))
+        sd[key + ".bias"] = normal((cout,), 0.02) + bias_mean
+
+    def conv(key, cin, cout, k):
+        sd[key + ".weight"] = normal((cout, cin, k, k), math.sqrt(2.0 / (cout * k * k)))
+        sd[key + ".bias"] = normal((cout,), 0.02)
+
+    def stage(key, dim, heads, layers):
+        for i in range(layers):
+            p = f"{key}.block.{i}."
+            lin(p + "attn.qkv", dim, dim * 3)
+            lin(p + "attn.proj", dim, dim, BRANCH_GAIN)
+            sd[p + "attn.relative_position_bias_table"] = normal((121, heads), 0.02)
+            sd[p + "attn.relative_position_index"] = relative_position_index(*WINDOW)
+            lin(p + "mlp.0", dim, dim * 2)
+            lin(p + "mlp.3", dim * 2, dim, BRANCH_GAIN)
+
+    c, h = base_dim, base_dim // 16
+    P = "unet."
+    conv(P + "patch.0", in_channels, c // 2, 3)
+    conv(P + "patch.2", c // 2, c, 3)
+    stage(P + "swin1", c, h, 2)
+    conv(P + "down1.conv", c, c * 2, 2)
+    stage(P + "swin2", c * 2, h, 2)
+    conv(P + "down2.conv", c * 2, c * 2, 2)
+    stage(P + "swin3", c * 2, h, 6)
+    lin(P + "up2.proj", c * 2, c * 2 * 4)
+    stage(P + "swin4", c * 2, h, 2)
+    if scale_factor in (1, 2):
+        lin(P + "up1.proj", c * 2, c * 4)
+        stage(P + "swin5", c, h, 2)
+        lin(P + "to_image.proj", c, out_channels * scale_factor ** 2, HEAD_GAIN, 0.5)
+    else:
+        lin(P + "proj2", c, c * 2)
+        lin(P + "up1.proj", c * 2, c * 2 * 4)
+        stage(P + "swin5", c * 2, h, 2)
+        assert scale_factor == 4, "8x head not generated here"
+        lin(P + "to_image.proj", c * 2, out_channels * scale_factor ** 2, HEAD_GAIN, 0.5)
+    return sd
+
+
+def cunet_state_dict(seed, up=False, in_channels=3, out_channels=3):
+    """Seeded weights in the reference's key layout; biases non-zero; the two image heads are scaled so that z1 and
+    the final image sit inside [0,1] like a trained net's (same reasoning as oracle.swin_unet.random_state_dict)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(key, cin, cout, k, gain=1.0, bias_mean=0.0, transposed=False):
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        sd[key + ".weight"] = torch.randn(shape, generator=g) * (gain * math.sqrt(2.0 / (cout * k * k)))
+        sd[key + ".bias"] = torch.randn(cout, generator=g) * 0.02 + bias_mean
+
+    def unet_conv_w(key, cin, mid, cout, se):
+        conv(key + ".conv.0", cin, mid, 3)
+        conv(key + ".conv.2", mid, cout, 3)
+        if se:
+            conv(key + ".seblock.conv1", cout, cout // 8, 1)
+            conv(key + ".seblock.conv2", cout // 8, cout, 1)
+
+    def bottom(key, deconv, gain):
+        if deconv:
+            conv(key, 64, out_channels, 4, gain=gain, bias_mean=0.5, transposed=True)
+        else:
+            conv(key, 64, out_channels, 3, gain=gain, bias_mean=0.5)
+
+    p = "unet1."
+    unet_conv_w(p + "conv1", in_channels, 32, 64, False)
+    conv(p + "conv1_down", 64, 64, 2)
+    unet_conv_w(p + "conv2", 64, 128, 64, True)
+    conv(p + "conv2_up", 64, 64, 2, transposed=True)
+    conv(p + "conv3", 64, 64, 3)
+    bottom(p + "conv_bottom", up, 0.3)
+    p = "unet2."
+    unet_conv_w(p + "conv1", out_channels, 32, 64, False)
+    conv(p + "conv1_down", 64, 64, 2)
+    unet_conv_w(p + "conv2", 64, 64, 128, True)
+    conv(p + "conv2_down", 128, 128, 2)
+    unet_conv_w(p + "conv3", 128, 256, 128, True)
+    conv(p + "conv3_up", 128, 128, 2, transposed=True)
+    unet_conv_w(p + "conv4", 128, 64, 64, True)
+    conv(p + "conv4_up", 64, 64, 2, transposed=True)
+    conv(p + "conv5", 64, 64, 3)
+    conv(p + "conv_bottom", 64, out_channels, 3, gain=0.12, bias_mean=0.0)
+    return sd
+
+
+def row_flow_v3_state_dict(seed):
+    """Seeded weights in the reference's key layout, every bias non-zero; the last layer is scaled so that delta sits
+    in the range of a trained model's (a few depth pixels), i.e. the warp really moves pixels."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def rnd(*shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    def lin(key, cout, cin, k=None, std=None, bstd=0.05):
+        shape = (cout, cin) if k is None else (cout, cin, k, k)
+        fan = cin * (1 if k is None else k * k)
+        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
+        sd[key + ".bias"] = rnd(cout, std=bstd)
+
+    lin("blocks.0", 64, 24, 1)
+    for bi, (window, hidden) in ((1, ((4, 4), 8)), (2, ((3, 3), 6))):
+        p = f"blocks.{bi}."
+        lin(p + "mha.mha.qkv_proj", 192, 64)
+        lin(p + "mha.mha.head_proj", 64, 64, std=0.5 * math.sqrt(1.0 / 64))
+        lin(p + "conv_mlp.0", 64, 64, 1)
+        lin(p + "conv_mlp.3", 64, 64, 3, std=0.5 * math.sqrt(1.0 / 576))
+        lin(p + "bias.to_bias.0", hidden, 2, std=1.0, bstd=0.3)
+        lin(p + "bias.to_bias.2", 1, hidden, std=1.0, bstd=0.3)
+        index, delta = window_score_bias_input(window)
+        sd[p + "bias.index"], sd[p + "bias.delta"] = index, delta
+    lin("last_layer.1", 1, 8, 3, std=2.0 * math.sqrt(1.0 / 72), bstd=1.0)
+    sd["delta_scale"] = torch.tensor(1.0 / 127.0)
+    return sd
+
+
+def mlbw_state_dict(seed, num_layers=2, small=False):
+    """Seeded weights in the reference's key layout (every bias non-zero); the output conv is scaled so that the layer
+    deltas differ by a few depth pixels and the layer-weight logits really select between them."""
+    g = torch.Generator().manual_seed(seed)
+    C = 32 * num_layers
+    sd = {}
+
+    def rnd(*shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    def lin(key, *shape, std=None, bstd=0.05):
+        fan = 1
+        for s in shape[1:]:
+            fan *= s
+        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
+        sd[key + ".bias"] = rnd(shape[0], std=bstd)
+
+    lin("lv1_in.1", C // 8, 3, 1, 9, std=math.sqrt(2.0 / 27))
+    for i in range(2 if small else 4):
+        p = f"lv2.{i}."
+        lin(p + "mha.mha.qkv_proj", 3 * C, C)
+        lin(p + "mha.mha.head_proj", C, C, std=0.5 * math.sqrt(1.0 / C))
+        lin(p + "conv_mlp.0", C, C, 1, 1)
+        lin(p + "conv_mlp.3", C, C, 3, 3, std=0.5 * math.sqrt(1.0 / (9 * C)))
+        lin(p + "bias.to_bias.0", 8, 2, std=1.0, bstd=0.3)
+        lin(p + "bias.to_bias.2", 1, 8, std=1.0, bstd=0.3)
+        sd[p + "bias.index"], sd[p + "bias.delta"] = window_score_bias_input((4, 4))
+    lin("lv1_out.1", 2 * num_layers, C // 8, 1, 9, std=2.0 * math.sqrt(1.0 / (9 * C // 8)), bstd=1.0)
+    return sd
+
+
+def depth_aa_state_dict(seed):
+    """Seeded weights in the reference's key layout, all biases non-zero; proj_out (zero-initialised in the reference
+    constructor) is given small weights so that the net really changes the depth (a few percent of its range)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def rnd(*shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    def lin(key, *shape, std=None, bstd=0.05):
+        fan = 1
+        for s in shape[1:]:
+            fan *= s
+        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
+        sd[key + ".bias"] = rnd(shape[0], std=bstd)
+
+    lin("proj_in", 32, 4, 1, 1, std=0.7)
+    for i in range(3):
+        p = f"blocks.{i}."
+        lin(p + "mha.mha.qkv_proj", 96, 32)
+        lin(p + "mha.mha.head_proj", 32, 32, std=0.5 * math.sqrt(1.0 / 32))
+        lin(p + "conv_mlp.0", 32, 32, 1, 1)
+        lin(p + "conv_mlp.3", 32, 32, 3, 3, std=0.5 * math.sqrt(1.0 / 288))
+        lin(p + "bias.to_bias.0", 16, 2, std=1.0, bstd=0.3)
+        lin(p + "bias.to_bias.2", 1, 16, std=1.0, bstd=0.3)
+        sd[p + "bias.index"], sd[p + "bias.delta"] = window_score_bias_input((8, 8))
+    lin("proj_out", 4, 32, 1, 1, std=0.006, bstd=0.003)
+    return sd
+
+
+def depth_anything_v2_state_dict(seed, grid=37):
+    """Seeded weights in the public checkpoint's key layout.  LayerScale gammas are O(1) * 0.3 and the residual branches
+    are damped so that 12 blocks keep the token rms O(1) (a trained ViT's regime), every bias is non-zero."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def rnd(*shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    def lin(key, *shape, std=None, bstd=0.02, bias=True):
+        fan = 1
+        for s in shape[1:]:
+            fan *= s
+        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
+        if bias:
+            sd[key + ".bias"] = rnd(shape[0], std=bstd)
+
+    p = "pretrained."
+    lin(p + "patch_embed.proj", EMBED, 3, PATCH, PATCH)
+    sd[p + "cls_token"] = rnd(1, 1, EMBED, std=0.5)
+    sd[p + "pos_embed"] = rnd(1, 1 + grid * grid, EMBED, std=0.3)
+    for i in range(DEPTH):
+        b = f"{p}blocks.{i}."
+        for n in ("norm1", "norm2"):
+            sd[b + n + ".weight"] = 1.0 + rnd(EMBED, std=0.1)
+            sd[b + n + ".bias"] = rnd(EMBED, std=0.05)
+        lin(b + "attn.qkv", 3 * EMBED, EMBED, std=1.5 * math.sqrt(1.0 / EMBED))
+        lin(b + "attn.proj", EMBED, EMBED)
+        lin(b + "mlp.fc1", MLP, EMBED)
+        lin(b + "mlp.fc2", EMBED, MLP)
+        sd[b + "ls1.gamma"] = 0.3 + rnd(EMBED, std=0.05)
+        sd[b + "ls2.gamma"] = 0.3 + rnd(EMBED, std=0.05)
+    sd[p + "norm.weight"] = 1.0 + rnd(EMBED, std=0.1)
+    sd[p + "norm.bias"] = rnd(EMBED, std=0.05)
+    h = "depth_head."
+    for i, oc in enumerate(OUT_CH):
+        lin(f"{h}projects.{i}", oc, EMBED, 1, 1)
+        lin(f"{h}scratch.layer{i + 1}_rn", FEAT, oc, 3, 3, bias=False)
+    sd[h + "resize_layers.0.weight"] = rnd(OUT_CH[0], OUT_CH[0], 4, 4, std=math.sqrt(1.0 / OUT_CH[0]))
+    sd[h + "resize_layers.0.bias"] = rnd(OUT_CH[0], std=0.02)
+    sd[h + "resize_layers.1.weight"] = rnd(OUT_CH[1], OUT_CH[1], 2, 2, std=math.sqrt(1.0 / OUT_CH[1]))
+    sd[h + "resize_layers.1.bias"] = rnd(OUT_CH[1], std=0.02)
+    lin(h + "resize_layers.3", OUT_CH[3], OUT_CH[3], 3, 3)
+    for k in (1, 2, 3, 4):
+        r = f"{h}scratch.refinenet{k}."
+        lin(r + "out_conv", FEAT, FEAT, 1, 1)
+        for u in ("resConfUnit1.", "resConfUnit2."):
+            lin(r + u + "conv1", FEAT, FEAT, 3, 3, std=0.7 * math.sqrt(2.0 / (9 * FEAT)))
+            lin(r + u + "conv2", FEAT, FEAT, 3, 3, std=0.7 * math.sqrt(2.0 / (9 * FEAT)))
+    lin(h + "scratch.output_conv1", FEAT // 2, FEAT, 3, 3)
+    lin(h + "scratch.output_conv2.0", 32, FEAT // 2, 3, 3, std=math.sqrt(2.0 / (9 * 32)))
+    lin(h + "scratch.output_conv2.2", 1, 32, 1, 1, std=math.sqrt(2.0 / 32), bstd=0.5)
+    # a depth map, not a mostly-clipped one: positive mixing weights and bias in the last 1x1 (the ReLU then rarely bites)
+    sd[h + "scratch.output_conv2.2.weight"] = sd[h + "scratch.output_conv2.2.weight"].abs() * 0.5
+    sd[h + "scratch.output_conv2.2.bias"] = sd[h + "scratch.output_conv2.2.bias"].abs() * 0.2 + 0.1
+    return sd
+
+
+def synth_depth(seed, b, h, w, kind="edges"):
+    """Synthetic normalised depth maps: the step pattern of the reference's ``_bench`` (forward_warp.py:309-316)
+    blurred, plus a ramp / smooth noise so that floor/ceil collisions, holes and layered holes all occur."""
+    g = torch.Generator().manual_seed(seed)
+    yy = torch.linspace(0, 1, h).view(1, 1, h, 1)
+    xx = torch.linspace(0, 1, w).view(1, 1, 1, w)
+    if kind == "ramp":
+        d = (0.2 + 0.6 * xx + 0.1 * yy).expand(b, 1, h, w).clone()
+    elif kind == "const":
+        d = torch.full((b, 1, h, w), 0.5)
+    else:
+        d = torch.zeros(b, 1, h, w)
+        d[:, :, h // 8:h - h // 8, w // 8:w - w // 8] = 0.3
+        d[:, :, h // 4:h - h // 4, w // 4:w - w // 3] = 0.7
+        d[:, :, h // 3:h // 2, w // 2:w - w // 6] = 1.0
+        low = torch.rand(b, 1, max(2, h // 32), max(2, w // 32), generator=g)
+        d = d * 0.85 + 0.15 * F.interpolate(low, size=(h, w), mode="bilinear", align_corners=False)
+        if kind == "smooth_edges":
+            d = F.avg_pool2d(F.pad(d, (2, 2, 2, 2), mode="replicate"), 5, stride=1)
+    return torch.clamp(d, 0, 1)

@@ -80,46 +80,8 @@ def valid_tile_size(size):
     return size % 4 == 0
 
 
-def random_state_dict(seed, up=False, in_channels=3, out_channels=3):
-    """Seeded weights in the reference's key layout; biases non-zero; the two image heads are scaled so that z1 and
-    the final image sit inside [0,1] like a trained net's (same reasoning as oracle.swin_unet.random_state_dict)."""
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-
-    def conv(key, cin, cout, k, gain=1.0, bias_mean=0.0, transposed=False):
-        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
-        sd[key + ".weight"] = torch.randn(shape, generator=g) * (gain * math.sqrt(2.0 / (cout * k * k)))
-        sd[key + ".bias"] = torch.randn(cout, generator=g) * 0.02 + bias_mean
-
-    def unet_conv_w(key, cin, mid, cout, se):
-        conv(key + ".conv.0", cin, mid, 3)
-        conv(key + ".conv.2", mid, cout, 3)
-        if se:
-            conv(key + ".seblock.conv1", cout, cout // 8, 1)
-            conv(key + ".seblock.conv2", cout // 8, cout, 1)
-
-    def bottom(key, deconv, gain):
-        if deconv:
-            conv(key, 64, out_channels, 4, gain=gain, bias_mean=0.5, transposed=True)
-        else:
-            conv(key, 64, out_channels, 3, gain=gain, bias_mean=0.5)
-
-    p = "unet1."
-    unet_conv_w(p + "conv1", in_channels, 32, 64, False)
-    conv(p + "conv1_down", 64, 64, 2)
-    unet_conv_w(p + "conv2", 64, 128, 64, True)
-    conv(p + "conv2_up", 64, 64, 2, transposed=True)
-    conv(p + "conv3", 64, 64, 3)
-    bottom(p + "conv_bottom", up, 0.3)
-    p = "unet2."
-    unet_conv_w(p + "conv1", out_channels, 32, 64, False)
-    conv(p + "conv1_down", 64, 64, 2)
-    unet_conv_w(p + "conv2", 64, 64, 128, True)
-    conv(p + "conv2_down", 128, 128, 2)
-    unet_conv_w(p + "conv3", 128, 256, 128, True)
-    conv(p + "conv3_up", 128, 128, 2, transposed=True)
-    unet_conv_w(p + "conv4", 128, 64, 64, True)
-    conv(p + "conv4_up", 64, 64, 2, transposed=True)
-    conv(p + "conv5", 64, 64, 3)
-    conv(p + "conv_bottom", 64, out_channels, 3, gain=0.12, bias_mean=0.0)
-    return sd
+def random_state_dict(*args, **kwargs):
+    """Seeded test weights: alias of ``nunif_amd.synthetic.cunet_state_dict`` (moved there so that bench.py and the tools do
+    not import the oracle for their inputs)."""
+    from nunif_amd.synthetic import cunet_state_dict
+    return cunet_state_dict(*args, **kwargs)

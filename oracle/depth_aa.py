@@ -55,31 +55,8 @@ def infer(sd, x):
     return forward(sd, z, clamp=False) * scale + mn
 
 
-def random_state_dict(seed):
-    """Seeded weights in the reference's key layout, all biases non-zero; proj_out (zero-initialised in the reference
-    constructor) is given small weights so that the net really changes the depth (a few percent of its range)."""
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-
-    def rnd(*shape, std):
-        return torch.randn(shape, generator=g) * std
-
-    def lin(key, *shape, std=None, bstd=0.05):
-        fan = 1
-        for s in shape[1:]:
-            fan *= s
-        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
-        sd[key + ".bias"] = rnd(shape[0], std=bstd)
-
-    lin("proj_in", 32, 4, 1, 1, std=0.7)
-    for i in range(3):
-        p = f"blocks.{i}."
-        lin(p + "mha.mha.qkv_proj", 96, 32)
-        lin(p + "mha.mha.head_proj", 32, 32, std=0.5 * math.sqrt(1.0 / 32))
-        lin(p + "conv_mlp.0", 32, 32, 1, 1)
-        lin(p + "conv_mlp.3", 32, 32, 3, 3, std=0.5 * math.sqrt(1.0 / 288))
-        lin(p + "bias.to_bias.0", 16, 2, std=1.0, bstd=0.3)
-        lin(p + "bias.to_bias.2", 1, 16, std=1.0, bstd=0.3)
-        sd[p + "bias.index"], sd[p + "bias.delta"] = RF.window_score_bias_input((8, 8))
-    lin("proj_out", 4, 32, 1, 1, std=0.006, bstd=0.003)
-    return sd
+def random_state_dict(*args, **kwargs):
+    """Seeded test weights: alias of ``nunif_amd.synthetic.depth_aa_state_dict`` (moved there so that bench.py and the tools do
+    not import the oracle for their inputs)."""
+    from nunif_amd.synthetic import depth_aa_state_dict
+    return depth_aa_state_dict(*args, **kwargs)

@@ -110,59 +110,8 @@ def model_forward(sd, x):
     return F.relu(head(sd, feats, gh, gw)).squeeze(1)
 
 
-def random_state_dict(seed, grid=37):
-    """Seeded weights in the public checkpoint's key layout.  LayerScale gammas are O(1) * 0.3 and the residual branches
-    are damped so that 12 blocks keep the token rms O(1) (a trained ViT's regime), every bias is non-zero."""
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-
-    def rnd(*shape, std):
-        return torch.randn(shape, generator=g) * std
-
-    def lin(key, *shape, std=None, bstd=0.02, bias=True):
-        fan = 1
-        for s in shape[1:]:
-            fan *= s
-        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
-        if bias:
-            sd[key + ".bias"] = rnd(shape[0], std=bstd)
-
-    p = "pretrained."
-    lin(p + "patch_embed.proj", EMBED, 3, PATCH, PATCH)
-    sd[p + "cls_token"] = rnd(1, 1, EMBED, std=0.5)
-    sd[p + "pos_embed"] = rnd(1, 1 + grid * grid, EMBED, std=0.3)
-    for i in range(DEPTH):
-        b = f"{p}blocks.{i}."
-        for n in ("norm1", "norm2"):
-            sd[b + n + ".weight"] = 1.0 + rnd(EMBED, std=0.1)
-            sd[b + n + ".bias"] = rnd(EMBED, std=0.05)
-        lin(b + "attn.qkv", 3 * EMBED, EMBED, std=1.5 * math.sqrt(1.0 / EMBED))
-        lin(b + "attn.proj", EMBED, EMBED)
-        lin(b + "mlp.fc1", MLP, EMBED)
-        lin(b + "mlp.fc2", EMBED, MLP)
-        sd[b + "ls1.gamma"] = 0.3 + rnd(EMBED, std=0.05)
-        sd[b + "ls2.gamma"] = 0.3 + rnd(EMBED, std=0.05)
-    sd[p + "norm.weight"] = 1.0 + rnd(EMBED, std=0.1)
-    sd[p + "norm.bias"] = rnd(EMBED, std=0.05)
-    h = "depth_head."
-    for i, oc in enumerate(OUT_CH):
-        lin(f"{h}projects.{i}", oc, EMBED, 1, 1)
-        lin(f"{h}scratch.layer{i + 1}_rn", FEAT, oc, 3, 3, bias=False)
-    sd[h + "resize_layers.0.weight"] = rnd(OUT_CH[0], OUT_CH[0], 4, 4, std=math.sqrt(1.0 / OUT_CH[0]))
-    sd[h + "resize_layers.0.bias"] = rnd(OUT_CH[0], std=0.02)
-    sd[h + "resize_layers.1.weight"] = rnd(OUT_CH[1], OUT_CH[1], 2, 2, std=math.sqrt(1.0 / OUT_CH[1]))
-    sd[h + "resize_layers.1.bias"] = rnd(OUT_CH[1], std=0.02)
-    lin(h + "resize_layers.3", OUT_CH[3], OUT_CH[3], 3, 3)
-    for k in (1, 2, 3, 4):
-        r = f"{h}scratch.refinenet{k}."
-        lin(r + "out_conv", FEAT, FEAT, 1, 1)
-        for u in ("resConfUnit1.", "resConfUnit2."):
-            lin(r + u + "conv1", FEAT, FEAT, 3, 3, std=0.7 * math.sqrt(2.0 / (9 * FEAT)))
-            lin(r + u + "conv2", FEAT, FEAT, 3, 3, std=0.7 * math.sqrt(2.0 / (9 * FEAT)))
-    lin(h + "scratch.output_conv1", FEAT // 2, FEAT, 3, 3)
-    lin(h + "scratch.output_conv2.0", 32, FEAT // 2, 3, 3, std=math.sqrt(2.0 / (9 * 32)))
-    lin(h + "scratch.output_conv2.2", 1, 32, 1, 1, std=math.sqrt(2.0 / 32), bstd=0.5)
-    # a depth map, not a mostly-clipped one: positive mixing weights and bias in the last 1x1 (the ReLU then rarely bites)
-    sd[h + "scratch.output_conv2.2.weight"] = sd[h + "scratch.output_conv2.2.weight"].abs() * 0.5
-    sd[h + "scratch.output_conv2.2.bias"] = sd[h + "scratch.output_conv2.2.bias"].abs() * 0.2 + 0.1
-    return sd
+def random_state_dict(*args, **kwargs):
+    """Seeded test weights: alias of ``nunif_amd.synthetic.depth_anything_v2_state_dict`` (moved there so that bench.py and the tools do
+    not import the oracle for their inputs)."""
+    from nunif_amd.synthetic import depth_anything_v2_state_dict
+    return depth_anything_v2_state_dict(*args, **kwargs)

@@ -85,32 +85,8 @@ def apply_divergence_nn_LR(sd, c, depth, divergence, convergence, num_layers, sy
     return f(divergence * 2, -1), c
 
 
-def random_state_dict(seed, num_layers=2, small=False):
-    """Seeded weights in the reference's key layout (every bias non-zero); the output conv is scaled so that the layer
-    deltas differ by a few depth pixels and the layer-weight logits really select between them."""
-    g = torch.Generator().manual_seed(seed)
-    C = 32 * num_layers
-    sd = {}
-
-    def rnd(*shape, std):
-        return torch.randn(shape, generator=g) * std
-
-    def lin(key, *shape, std=None, bstd=0.05):
-        fan = 1
-        for s in shape[1:]:
-            fan *= s
-        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
-        sd[key + ".bias"] = rnd(shape[0], std=bstd)
-
-    lin("lv1_in.1", C // 8, 3, 1, 9, std=math.sqrt(2.0 / 27))
-    for i in range(2 if small else 4):
-        p = f"lv2.{i}."
-        lin(p + "mha.mha.qkv_proj", 3 * C, C)
-        lin(p + "mha.mha.head_proj", C, C, std=0.5 * math.sqrt(1.0 / C))
-        lin(p + "conv_mlp.0", C, C, 1, 1)
-        lin(p + "conv_mlp.3", C, C, 3, 3, std=0.5 * math.sqrt(1.0 / (9 * C)))
-        lin(p + "bias.to_bias.0", 8, 2, std=1.0, bstd=0.3)
-        lin(p + "bias.to_bias.2", 1, 8, std=1.0, bstd=0.3)
-        sd[p + "bias.index"], sd[p + "bias.delta"] = RF.window_score_bias_input((4, 4))
-    lin("lv1_out.1", 2 * num_layers, C // 8, 1, 9, std=2.0 * math.sqrt(1.0 / (9 * C // 8)), bstd=1.0)
-    return sd
+def random_state_dict(*args, **kwargs):
+    """Seeded test weights: alias of ``nunif_amd.synthetic.mlbw_state_dict`` (moved there so that bench.py and the tools do
+    not import the oracle for their inputs)."""
+    from nunif_amd.synthetic import mlbw_state_dict
+    return mlbw_state_dict(*args, **kwargs)

@@ -136,32 +136,8 @@ def apply_divergence_nn_LR(sd, c, depth, divergence, convergence, synthetic_view
     return apply_divergence_nn_delta(sd, c, depth, divergence * 2, convergence, -1), c
 
 
-def random_state_dict(seed):
-    """Seeded weights in the reference's key layout, every bias non-zero; the last layer is scaled so that delta sits
-    in the range of a trained model's (a few depth pixels), i.e. the warp really moves pixels."""
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-
-    def rnd(*shape, std):
-        return torch.randn(shape, generator=g) * std
-
-    def lin(key, cout, cin, k=None, std=None, bstd=0.05):
-        shape = (cout, cin) if k is None else (cout, cin, k, k)
-        fan = cin * (1 if k is None else k * k)
-        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
-        sd[key + ".bias"] = rnd(cout, std=bstd)
-
-    lin("blocks.0", 64, 24, 1)
-    for bi, (window, hidden) in ((1, ((4, 4), 8)), (2, ((3, 3), 6))):
-        p = f"blocks.{bi}."
-        lin(p + "mha.mha.qkv_proj", 192, 64)
-        lin(p + "mha.mha.head_proj", 64, 64, std=0.5 * math.sqrt(1.0 / 64))
-        lin(p + "conv_mlp.0", 64, 64, 1)
-        lin(p + "conv_mlp.3", 64, 64, 3, std=0.5 * math.sqrt(1.0 / 576))
-        lin(p + "bias.to_bias.0", hidden, 2, std=1.0, bstd=0.3)
-        lin(p + "bias.to_bias.2", 1, hidden, std=1.0, bstd=0.3)
-        index, delta = window_score_bias_input(window)
-        sd[p + "bias.index"], sd[p + "bias.delta"] = index, delta
-    lin("last_layer.1", 1, 8, 3, std=2.0 * math.sqrt(1.0 / 72), bstd=1.0)
-    sd["delta_scale"] = torch.tensor(1.0 / 127.0)
-    return sd
+def random_state_dict(*args, **kwargs):
+    """Seeded test weights: alias of ``nunif_amd.synthetic.row_flow_v3_state_dict`` (moved there so that bench.py and the tools do
+    not import the oracle for their inputs)."""
+    from nunif_amd.synthetic import row_flow_v3_state_dict
+    return row_flow_v3_state_dict(*args, **kwargs)

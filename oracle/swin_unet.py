@@ -178,59 +178,8 @@ BRANCH_GAIN = 0.8
 HEAD_GAIN = 0.12
 
 
-def random_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_channels=3):
-    """Seeded random weights in the reference's key layout and shapes.
-
-    Magnitudes follow the reference initialisers (kaiming/xavier) but every bias and relative-position
-    table is drawn N(0, 0.02) instead of zero so that bias handling is exercised.
-    Deterministic for a given torch build (CPU generator).
-    """
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-
-    def normal(shape, std):
-        return torch.randn(shape, generator=g) * std
-
-    def uniform(shape, bound):
-        return (torch.rand(shape, generator=g) * 2 - 1) * bound
-
-    def lin(key, cin, cout, gain=1.0, bias_mean=0.0):
-        sd[key + ".weight"] = uniform((cout, cin), gain * math.sqrt(6.0 / (cin + cout)))
-        sd[key + ".bias"] = normal((cout,), 0.02) + bias_mean
-
-    def conv(key, cin, cout, k):
-        sd[key + ".weight"] = normal((cout, cin, k, k), math.sqrt(2.0 / (cout * k * k)))
-        sd[key + ".bias"] = normal((cout,), 0.02)
-
-    def stage(key, dim, heads, layers):
-        for i in range(layers):
-            p = f"{key}.block.{i}."
-            lin(p + "attn.qkv", dim, dim * 3)
-            lin(p + "attn.proj", dim, dim, BRANCH_GAIN)
-            sd[p + "attn.relative_position_bias_table"] = normal((121, heads), 0.02)
-            sd[p + "attn.relative_position_index"] = relative_position_index(*WINDOW)
-            lin(p + "mlp.0", dim, dim * 2)
-            lin(p + "mlp.3", dim * 2, dim, BRANCH_GAIN)
-
-    c, h = base_dim, base_dim // 16
-    P = "unet."
-    conv(P + "patch.0", in_channels, c // 2, 3)
-    conv(P + "patch.2", c // 2, c, 3)
-    stage(P + "swin1", c, h, 2)
-    conv(P + "down1.conv", c, c * 2, 2)
-    stage(P + "swin2", c * 2, h, 2)
-    conv(P + "down2.conv", c * 2, c * 2, 2)
-    stage(P + "swin3", c * 2, h, 6)
-    lin(P + "up2.proj", c * 2, c * 2 * 4)
-    stage(P + "swin4", c * 2, h, 2)
-    if scale_factor in (1, 2):
-        lin(P + "up1.proj", c * 2, c * 4)
-        stage(P + "swin5", c, h, 2)
-        lin(P + "to_image.proj", c, out_channels * scale_factor ** 2, HEAD_GAIN, 0.5)
-    else:
-        lin(P + "proj2", c, c * 2)
-        lin(P + "up1.proj", c * 2, c * 2 * 4)
-        stage(P + "swin5", c * 2, h, 2)
-        assert scale_factor == 4, "8x head not generated here"
-        lin(P + "to_image.proj", c * 2, out_channels * scale_factor ** 2, HEAD_GAIN, 0.5)
-    return sd
+def random_state_dict(*args, **kwargs):
+    """Seeded test weights: alias of ``nunif_amd.synthetic.swin_unet_state_dict`` (moved there so that bench.py and the tools do
+    not import the oracle for their inputs)."""
+    from nunif_amd.synthetic import swin_unet_state_dict
+    return swin_unet_state_dict(*args, **kwargs)

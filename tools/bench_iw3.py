@@ -17,8 +17,7 @@ from nunif_amd.iw3.base_depth_model import CallableDepthModel  # noqa: E402
 from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2  # noqa: E402
 from nunif_amd.iw3.models.row_flow_v3 import RowFlowV3  # noqa: E402
 from nunif_amd.iw3.utils import apply_divergence  # noqa: E402
-from oracle import depth_anything_v2 as ODA  # noqa: E402  (seeded weight generators only)
-from oracle import row_flow_v3 as ORF  # noqa: E402
+from nunif_amd.synthetic import depth_anything_v2_state_dict, row_flow_v3_state_dict  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -26,10 +25,10 @@ DEV = "cuda:0"
 def main():
     torch.set_grad_enabled(False)
     H, W = 1080, 1920
-    depth_model = CallableDepthModel(HipDepthAnythingV2(ODA.random_state_dict(601), DEV))
+    depth_model = CallableDepthModel(HipDepthAnythingV2(depth_anything_v2_state_dict(601), DEV))
     depth_model.load(gpu=0)
     side = RowFlowV3().eval()
-    side.load_state_dict(ORF.random_state_dict(301))
+    side.load_state_dict(row_flow_v3_state_dict(301))
     side = side.to(DEV)
     side.delta_output = True
     frames = [torch.rand(3, H, W, device=DEV) for _ in range(3)]

@@ -16,7 +16,7 @@ from nunif_amd.iw3.backward_warp import apply_divergence_grid_sample  # noqa: E4
 from nunif_amd.iw3.dilation import dilate_edge  # noqa: E402
 from nunif_amd.iw3.depth_anything_model import batch_preprocess  # noqa: E402
 from nunif_amd.nunif.utils.seam_blending import SeamBlending  # noqa: E402
-from oracle.forward_warp import synth_depth  # noqa: E402
+from nunif_amd.synthetic import synth_depth  # noqa: E402
 
 DEV = "cuda:0"
 HBM = 8000.0

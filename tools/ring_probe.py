@@ -3,9 +3,9 @@ sys.path.insert(0, ".")
 from nunif_amd.iw3 import _ops
 from nunif_amd.nunif.utils.render import tiled_render
 from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x
-from oracle import swin_unet as O
+from nunif_amd.synthetic import swin_unet_state_dict
 torch.set_grad_enabled(False)
-m = SwinUNet2x().eval(); m.load_state_dict(O.random_state_dict(102, 2)); m = m.to("cuda:0")
+m = SwinUNet2x().eval(); m.load_state_dict(swin_unet_state_dict(102, 2)); m = m.to("cuda:0")
 H, W = 1080, 1920
 host = [np.random.randint(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(4)]
 dev = torch.device("cuda:0")
