@@ -22,6 +22,7 @@
 // HBM traffic per token: read att (2C B) + read x (2C B) + write x (2C B).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "swin_kernels.h"
 
@@ -259,12 +260,12 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
 template <int C, int MF, int WAVES, bool PF = false>
 __global__ void __launch_bounds__(WAVES * 64)
 proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wstream, const float *__restrict__ bp,
-                  const float *__restrict__ b0, const float *__restrict__ b3, long M) {
+                  const float *__restrict__ b0, const float *__restrict__ b3, long M, TailToImage ti) {
     constexpr int KS = C / 32, NT = C / 16, SH = 2 * C / 32;
     constexpr int NF = 2 * KS * KS + SH * (2 * KS + NT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
-    f16x8 *wl = reinterpret_cast<f16x8 *>(smem_t);                 // [NF][64]
-    float *bl = reinterpret_cast<float *>(wl + NF * 64);           // bp[C] | b0[2C] | b3[C]
+    f16x8 *wl = reinterpret_cast<f16x8 *>(smem_t);                 // [NF + KS][64] (KS image-head fragments at the end)
+    float *bl = reinterpret_cast<float *>(wl + (NF + KS) * 64);    // bp[C] | b0[2C] | b3[C] | image-head bias[16]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -276,6 +277,10 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
         for (int i = tid; i < NF * 64; i += WAVES * 64) wl[i] = src[i];
         for (int i = tid; i < C; i += WAVES * 64) { bl[i] = bp[i]; bl[3 * C + i] = b3[i]; }
         for (int i = tid; i < 2 * C; i += WAVES * 64) bl[C + i] = b0[i];
+        if (ti.w) {
+            for (int i = tid; i < KS * 64; i += WAVES * 64) wl[NF * 64 + i] = reinterpret_cast<const f16x8 *>(ti.w)[i];
+            if (tid < 16) bl[4 * C + tid] = tid < ti.n_real ? ti.bias[tid] : 0.f;
+        }
     }
     __syncthreads();
     const f16x8 *wlane = wl + lane;
@@ -409,6 +414,40 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
                 for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(wv, hf[f], acc[nt][f]);
             }
         }
+        if (ti.w) {
+            // fused image head: img[n][token] = sum_c Wt[n][c] x'[c] with x' rounded to fp16 exactly as the stored map
+            // would be; the accumulator tile pairs are the B fragments (chained k order), n = c*ps*ps + i*ps + j
+            const int s2 = ti.ps * ti.ps;
+            const f32x4 tb = *reinterpret_cast<const f32x4 *>(bl + 4 * C + 4 * grp);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                f32x4 img = tb;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f16x8 bfrag = {(f16)acc[2 * ks][f][0], (f16)acc[2 * ks][f][1], (f16)acc[2 * ks][f][2], (f16)acc[2 * ks][f][3],
+                                         (f16)acc[2 * ks + 1][f][0], (f16)acc[2 * ks + 1][f][1], (f16)acc[2 * ks + 1][f][2],
+                                         (f16)acc[2 * ks + 1][f][3]};
+                    img = MFMA_16x16x32(wlane[(NF + ks) * 64], bfrag, img);
+                }
+                if (!valid[f]) continue;
+                const long m = row[f];
+                const int px = (int)(m % ti.W);
+                const long t2 = m / ti.W;
+                const int py = (int)(t2 % ti.H), pb = (int)(t2 / ti.H);
+                const int OC = ti.n_real / s2;
+                const long OH = (long)ti.H * ti.ps, OW = (long)ti.W * ti.ps;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 4 * grp + r;
+                    if (n < ti.n_real) {
+                        const int c = n / s2, rem = n - c * s2, i = rem / ti.ps, j = rem - i * ti.ps;
+                        ti.out[(((long)pb * OC + c) * OH + (long)py * ti.ps + i) * OW + (long)px * ti.ps + j] =
+                            fminf(fmaxf(img[r], 0.f), 1.f);
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int p = 0; p < NT / 2; ++p) {
 #pragma unroll
@@ -431,8 +470,10 @@ int proj_mlp_stream_frags(int C) {
 }
 
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
-                    long M, int C, hipStream_t s) {
+                    long M, int C, hipStream_t s, const TailToImage *to_image) {
     if (M == 0) return NUNIF_HIP_OK;
+    NUNIF_REQUIRE(!to_image || (C == 96 && !getenv("NUNIF_TAIL_RING") && to_image->n_real <= 16),
+                  "proj_mlp: the fused image head needs the resident C = 96 kernel");
     static const bool ring96 = getenv("NUNIF_TAIL_RING") != nullptr;     // A/B switch: the round-1 ring version
     static const int variant = getenv("NUNIF_TAIL_VARIANT") ? atoi(getenv("NUNIF_TAIL_VARIANT")) : 6;
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
@@ -441,7 +482,10 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
     ProfScope ps(sym, s, 2.0 * (double)M * C * C * 5.0, (double)M * C * 2.0 * 3.0);
     const int n_chunks = (proj_mlp_stream_frags(C) + kChunkFrags - 1) / kChunkFrags;
     if (C == 96 && !ring96) {
-        constexpr size_t smem = (size_t)proj_mlp_stream_frags_c(96) * 1024 + 4 * 96 * 4;
+        constexpr size_t smem = (size_t)(proj_mlp_stream_frags_c(96) + 3) * 1024 + (4 * 96 + 16) * 4;
+        TailToImage ti;
+        memset(&ti, 0, sizeof(ti));
+        if (to_image) ti = *to_image;
         auto go = [&](auto kern, int mf, int waves) -> int {
             static bool configured[8] = {false};
             if (!configured[variant & 7]) {
@@ -450,7 +494,7 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
             }
             const long groups = (M + mf * 16 - 1) / (mf * 16);
             const unsigned blocks = (unsigned)std::min<long>((groups + waves - 1) / waves, 256);
-            kern<<<blocks, waves * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M);
+            kern<<<blocks, waves * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti);
             return NUNIF_HIP_OK;
         };
         int rc;

@@ -47,8 +47,12 @@ int launch_stem1(const Stem1Args &a, hipStream_t s);
 // wstream: proj (plain packed) | mlp.0 | mlp.3 ("chained" packed) fragments in consumption order, padded to a
 // multiple of 8 fragments (swin_block_tail.hip; assembled in make_stage, swin_unet.cpp).
 int proj_mlp_stream_frags(int C);
+// Optional fused image head for the LAST block of the net (C = 96): instead of storing x the kernel applies
+// ToImage (Linear C -> 3*ps*ps, pixel_shuffle, clamp(0,1); swin_unet.py:85-116) to the fp16-rounded result and writes
+// planar fp32.  w: KS fragments of a 16-row tile in the chained k order; tokens are (b, y, x) over [B, H, W].
+struct TailToImage { const f16 *w; const float *bias; float *out; int H, W, ps, n_real; };
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
-                    long M, int C, hipStream_t s);
+                    long M, int C, hipStream_t s, const TailToImage *to_image = nullptr);
 
 // ---- fused qkv Linear + (shifted) window attention, C = 96 / 6 heads of 16 (swin_qkv_attn.hip) ---------------------
 // x: [B,H,W,C] -> att: [B,H,W,C] (pre-projection attention output at the un-rolled positions)

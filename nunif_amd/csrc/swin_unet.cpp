@@ -67,6 +67,8 @@ struct nunif_swin_unet {
     int top_dim = 96;                 // channels of level 1 on the decoder side (C for 1x/2x, 2C for 4x)
     float *stem1_w = nullptr, *stem1_b = nullptr;
     Linear stem2, down1, down2, up2, up1, proj2, to_image;
+    f16 *to_image_chained = nullptr;  // ToImage weights in the chained k order, for the fused head of the last C = 96 block
+    int fuse_to_image = 1;            // NUNIF_FUSE_TOIMAGE=0: separate gemm_kernel launch (A/B)
     f16 *stem2_stream = nullptr;      // conv2 fragments in [k-step][n-tile] order for conv_kernel (cunet_kernels.hip)
     int stem2_conv = 0;               // NUNIF_STEM2_CONV=1: conv_kernel<6,4> instead of gemm_kernel<18,2> (measured slower: 1131 vs 914 us)
     bool has_proj2 = false;
@@ -289,7 +291,7 @@ int tap(nunif_swin_unet *h, const std::string &name, const void *src, size_t byt
 }
 
 int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int S, int dim, hipStream_t s,
-              const char *name) {
+              const char *name, const TailToImage *to_image = nullptr) {
     f16 *qkv = (f16 *)h->qkv.p, *att = (f16 *)h->att.p;
     const size_t tok = (size_t)B * S * S;
     int rc;
@@ -318,8 +320,11 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         }
         if ((rc = tap(h, tn + ".attn", att, tok * dim * 2, s))) return rc;
         // x = y + mlp(y), y = x + proj(attn): three GEMMs chained through registers, one read + one write of x
-        if ((rc = launch_proj_mlp(att, x, bl.tail_stream, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, dim, s)))
+        const bool last = i + 1 == blocks.size();
+        if ((rc = launch_proj_mlp(att, x, bl.tail_stream, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, dim, s,
+                                  last ? to_image : nullptr)))
             return rc;
+        if (last && to_image) break;               // x of the last block is not materialised
         if ((rc = tap(h, tn + ".out", x, tok * dim * 2, s))) return rc;
     }
     return NUNIF_HIP_OK;
@@ -401,8 +406,15 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
                        h->top_dim, 1, s, "gemm_up")))
         return rc;
     if ((rc = tap(h, "up1", top, (size_t)B * S * S * h->top_dim * 2, s))) return rc;
+    // to_image + pixel_shuffle + clamp(0,1) (ToImage.forward :110-116, wrapper eval clamp :225-226): fused into the
+    // last block's tail kernel when that block runs on the resident C = 96 kernel (1x / 2x nets)
+    if (h->fuse_to_image && h->top_dim == 96 && h->to_image_chained && !h->taps_on && !getenv("NUNIF_TAIL_RING")) {
+        TailToImage ti;
+        ti.w = h->to_image_chained; ti.bias = h->to_image.bias; ti.out = z; ti.H = S; ti.W = S; ti.ps = h->scale_factor;
+        ti.n_real = h->to_image.n_real;
+        return run_stage(h, h->swin[4], top, B, S, h->top_dim, s, "swin5", &ti);
+    }
     if ((rc = run_stage(h, h->swin[4], top, B, S, h->top_dim, s, "swin5"))) return rc;                // swin5
-    // to_image + pixel_shuffle + clamp(0,1) (ToImage.forward :110-116, wrapper eval clamp :225-226)
     if ((rc = run_gemm(h->to_image, top, B, S, S, h->top_dim, S, S, 1, 0, 0, 1, 2, 0, 0.f, nullptr, z, 0,
                        h->scale_factor, s, "gemm_to_image")))
         return rc;
@@ -432,6 +444,7 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
     (void)hipGetDevice(&h->device);
     if (const char *v = getenv("NUNIF_QKV_ATTN")) h->attn_variant = atoi(v);
     if (const char *v = getenv("NUNIF_STEM2_CONV")) h->stem2_conv = atoi(v);
+    if (const char *v = getenv("NUNIF_FUSE_TOIMAGE")) h->fuse_to_image = atoi(v);
     h->scale_factor = scale_factor;
     const std::string P = "unet.";
     int rc = NUNIF_HIP_OK;
@@ -507,6 +520,14 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
         if ((rc = make_plain_linear(h, m, P + "to_image.proj", 3 * scale_factor * scale_factor, h->top_dim,
                                     &h->to_image)))
             break;
+        if (h->top_dim == 96 && 3 * scale_factor * scale_factor <= 16) {
+            const HostTensor *tw;
+            if ((rc = find(m, P + "to_image.proj.weight", &tw))) break;
+            const float *wd = tw->data;
+            const int nr = 3 * scale_factor * scale_factor, K = h->top_dim;
+            std::vector<f16> ch = pack_a_fragments(nr, K, [=](int n, int k) { return wd[(size_t)n * K + k]; }, true);
+            if ((rc = upload(h, ch, &h->to_image_chained))) break;
+        }
     } while (0);
     if (rc) {
         nunif_hip_swin_unet_destroy(h);
