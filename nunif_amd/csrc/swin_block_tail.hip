@@ -68,12 +68,12 @@ __device__ __forceinline__ f16x8 gelu8(const f32x4 &a, const f32x4 &b) {
                                   -0.0008139933925122023f, 0.008772282861173153f, -0.06457287818193436f,
                                   0.39788317680358887f};
 #endif
+    // Phi(x) ~= clamp01(0.5 + x P(x^2)): the odd polynomial is monotone beyond the fit interval (-> +-inf), so the [0, 1]
+    // clamp of the LAST fma (a free output modifier) replaces the input clamp; 9 VALU ops per element + the convert.
     float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    float xc[8], u[8], q[8];
+    float u[8], q[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xc[i] = __builtin_amdgcn_fmed3f(v[i], -4.0f, 4.0f);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = xc[i] * xc[i];
+    for (int i = 0; i < 8; ++i) u[i] = v[i] * v[i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = fmaf(kc[0], u[i], kc[1]);
 #pragma unroll
@@ -82,7 +82,7 @@ __device__ __forceinline__ f16x8 gelu8(const f32x4 &a, const f32x4 &b) {
         for (int i = 0; i < 8; ++i) q[i] = fmaf(q[i], u[i], kc[k]);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = fmaf(xc[i], q[i], 0.5f);
+    for (int i = 0; i < 8; ++i) asm("v_fma_f32 %0, %1, %2, 0.5 clamp" : "=v"(q[i]) : "v"(v[i]), "v"(q[i]));
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= q[i];
     return (f16x8){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3], (f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
@@ -200,11 +200,23 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
     constexpr int F_STEP = 2 * KS + NT;           // fragments per 32 hidden channels
     // a real loop (not unrolled): full unrolling lets the scheduler hoist ~100 loads and spill; the chunk-boundary
     // test inside wfrag() is wave-uniform, so a run-time fragment index costs one scalar branch
+    // mlp.0 bias = C operand of the first MFMA of each hidden slice; the next slice's 8 values are fetched one trip ahead
+    float4 ba_n = *reinterpret_cast<const float4 *>(b0 + 4 * grp);
+    float4 bb_n = *reinterpret_cast<const float4 *>(b0 + 4 * grp + 16);
 #pragma unroll 1
     for (int s = 0; s < SH; ++s) {               // 32 hidden channels at a time
+        const float4 ba0 = ba_n, bb0 = bb_n;
+        {
+            const int sn = s + 1 < SH ? s + 1 : s;
+            ba_n = *reinterpret_cast<const float4 *>(b0 + 32 * sn + 4 * grp);
+            bb_n = *reinterpret_cast<const float4 *>(b0 + 32 * sn + 4 * grp + 16);
+        }
         f32x4 h0[MF], h1[MF];
 #pragma unroll
-        for (int f = 0; f < MF; ++f) { h0[f] = (f32x4){0.f, 0.f, 0.f, 0.f}; h1[f] = h0[f]; }
+        for (int f = 0; f < MF; ++f) {
+            h0[f] = (f32x4){ba0.x, ba0.y, ba0.z, ba0.w};
+            h1[f] = (f32x4){bb0.x, bb0.y, bb0.z, bb0.w};
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const f16x8 wa = wfrag(F_MLP + s * F_STEP + ks * 2);
@@ -216,18 +228,14 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
                 h1[f] = MFMA_16x16x32(wb, yf[f][ks], h1[f]);
             }
         }
-        const int n0 = 32 * s + 4 * grp;
-        const float4 ba = *reinterpret_cast<const float4 *>(b0 + n0);
-        const float4 bb = *reinterpret_cast<const float4 *>(b0 + n0 + 16);
         f16x8 hf[MF];
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             if constexpr (ABL & 1)
-                hf[f] = (f16x8){(f16)(h0[f][0] + ba.x), (f16)(h0[f][1] + ba.y), (f16)(h0[f][2] + ba.z), (f16)(h0[f][3] + ba.w),
-                                (f16)(h1[f][0] + bb.x), (f16)(h1[f][1] + bb.y), (f16)(h1[f][2] + bb.z), (f16)(h1[f][3] + bb.w)};
+                hf[f] = (f16x8){(f16)h0[f][0], (f16)h0[f][1], (f16)h0[f][2], (f16)h0[f][3],
+                                (f16)h1[f][0], (f16)h1[f][1], (f16)h1[f][2], (f16)h1[f][3]};
             else
-            hf[f] = gelu8((f32x4){h0[f][0] + ba.x, h0[f][1] + ba.y, h0[f][2] + ba.z, h0[f][3] + ba.w},
-                          (f32x4){h1[f][0] + bb.x, h1[f][1] + bb.y, h1[f][2] + bb.z, h1[f][3] + bb.w});
+                hf[f] = gelu8(h0[f], h1[f]);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {

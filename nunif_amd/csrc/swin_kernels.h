@@ -63,8 +63,9 @@ int launch_qkv_attn(const f16 *x, f16 *att, const f16 *wqkv, const float *bqkv, 
 // wstream: per head Wq | Wk | Wv fragments in consumption order (assembled in make_stage, swin_unet.cpp)
 int qkv_attn_w_stream_frags(int C);
 // ---- same, qkv weights resident in LDS, no barrier in the window loop (swin_qkv_attn_r.hip) -------------------------
-int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, int B, int H, int W,
-                      int C, int heads, int shift, hipStream_t s);
+// btab: fp16 [heads][36][48] one-hot-MFMA bias table (NUNIF_ATTN_CBIAS=0); btab32: fp32 [heads][36][52] C-operand table
+int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, const float *btab32,
+                      int B, int H, int W, int C, int heads, int shift, hipStream_t s);
 int launch_qkv_attn_w(const f16 *x, f16 *att, const f16 *wstream, const float *bqkv, const float *bias, int B, int H,
                       int W, int C, int heads, int shift, hipStream_t s);
 

@@ -16,6 +16,7 @@
 //   * the window-invariant one-hot key fragments are built once per wave;
 //   * C = 96 prefetches the next window's x while the current one is computed.
 #include <algorithm>
+#include <cstdlib>
 
 #include "swin_kernels.h"
 
@@ -23,7 +24,6 @@ namespace nunif {
 
 #define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
-constexpr int kWavesR = 8;
 // the "real key" column 36 of the bias table carries 1000: padded keys end up 1000 (log2 units) below every real one
 constexpr float kRegionR = 100.0f;     // added where query and key share a shift region
 
@@ -33,6 +33,7 @@ struct QkvAttnRArgs {
     const f16 *wres;         // per head: Wq tiles, Wk tiles, Wv tiles, each (nt, ks) fragment-major; q pre-scaled
     const float *bqkv;       // [3C], q part pre-scaled
     const f16 *btab;         // [heads][36][48] fp16: log2e * relative-position bias, col 36 = BIG, cols 37.. = 0
+    const float *btab32;     // CBIAS: [heads][36][52] fp32: log2e * bias, cols 36..47 = -1000 (padded keys), 48..51 unused
     int B, H, W, shift, n_windows;
 };
 
@@ -40,9 +41,18 @@ __device__ __forceinline__ f16x8 cat8r(f16x4 lo, f16x4 hi) {
     return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int C, int HD, int HPP, bool PREFETCH>
-__global__ void __launch_bounds__(512)
+constexpr int kBiasStride = 52;        // fp32 row stride of the CBIAS table: 16 lanes x 16 B land in 16 distinct bank quads
+
+// CBIAS (default): the score accumulators are INITIALISED from an fp32 bias table in LDS (relative-position bias and
+// the padded-key mask are the MFMA C operand), the softmax denominator comes from one MFMA against a ones fragment, and
+// the shift-region term rides in the unused half of the K = 32 step (head_dim 16) or in one extra MFMA that only the
+// windows of the last row / column issue (head_dim 32).  Per head this removes 9 (hd 16) / 18 (hd 32) one-hot MFMAs and
+// ~45 VALU instructions; MFMA and VALU do not overlap on a SIMD, so both count.
+template <int C, int HD, int HPP, bool PREFETCH, bool CBIAS, int WAVES = 8>
+__global__ void __launch_bounds__(WAVES * 64)
 qkv_attn_r_kernel(QkvAttnRArgs a) {
+    constexpr int kWavesR = WAVES;
+    constexpr int NTHR = WAVES * 64;
     constexpr int KS = C / 32;
     constexpr int HEADS = C / HD;
     constexpr int NTH = HD / 16;                      // 16-row weight tiles per head for each of q, k, v
@@ -52,7 +62,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
     f16x8 *wl = reinterpret_cast<f16x8 *>(smem_r);                                   // [HPP*FPH][64]
     f16 *bt = reinterpret_cast<f16 *>(wl + HPP * FPH * 64);                          // [HEADS][36][48]
-    float *bl = reinterpret_cast<float *>(bt + HEADS * 36 * 48);                     // [3C]
+    float *bt32 = reinterpret_cast<float *>(wl + HPP * FPH * 64);                    // CBIAS: [HPP][36][52]
+    float *bl = CBIAS ? bt32 + HPP * 36 * kBiasStride : reinterpret_cast<float *>(bt + HEADS * 36 * 48);   // [3C]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -62,14 +73,16 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     const int nwx = a.W / 6, nwy = a.H / 6;
     const f16x4 zero4 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
 
-    for (int i = tid; i < HEADS * 36 * 48 / 8; i += 512)
-        reinterpret_cast<f16x8 *>(bt)[i] = reinterpret_cast<const f16x8 *>(a.btab)[i];
-    for (int i = tid; i < 3 * C; i += 512) bl[i] = a.bqkv[i];
+    if constexpr (!CBIAS)
+        for (int i = tid; i < HEADS * 36 * 48 / 8; i += NTHR)
+            reinterpret_cast<f16x8 *>(bt)[i] = reinterpret_cast<const f16x8 *>(a.btab)[i];
+    for (int i = tid; i < 3 * C; i += NTHR) bl[i] = a.bqkv[i];
+    const f16x8 ones8 = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
 
     // window-invariant part of the key-side one-hot fragments (cols < 36: k_loc == col; col 36: real key)
-    f16x4 rk[3][3];
+    f16x4 rk[CBIAS ? 1 : 3][3];
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) {
+    for (int mt = 0; mt < (CBIAS ? 0 : 3); ++mt) {
         const int tok = 16 * mt + r16;
 #pragma unroll
         for (int js = 0; js < 3; ++js)
@@ -112,7 +125,11 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
         const int pass = blockIdx.x % PASSES;
         {
             const f16x8 *src = reinterpret_cast<const f16x8 *>(a.wres) + (long)pass * HPP * FPH * 64;
-            for (int i = tid; i < HPP * FPH * 64; i += 512) wl[i] = src[i];
+            for (int i = tid; i < HPP * FPH * 64; i += NTHR) wl[i] = src[i];
+            if constexpr (CBIAS) {
+                const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.btab32 + (long)pass * HPP * 36 * kBiasStride);
+                for (int i = tid; i < HPP * 36 * kBiasStride / 4; i += NTHR) reinterpret_cast<f32x4 *>(bt32)[i] = bsrc[i];
+            }
         }
         __syncthreads();
 
@@ -130,9 +147,11 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
             }
             // shift regions of this window (only the last window row / column straddles two regions)
             f16x4 rkr[3], rqr[3];
+            bool special;
             {
                 const int wx = wi % nwx, wy = (wi / nwx) % nwy;
                 const bool last_y = a.shift > 0 && wy == nwy - 1, last_x = a.shift > 0 && wx == nwx - 1;
+                special = __builtin_amdgcn_readfirstlane((int)(last_y || last_x)) != 0;   // one window per wave: uniform
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) {
                     const int t = min(16 * mt + r16, 35);
@@ -187,26 +206,44 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
 #pragma unroll
                 for (int qt = 0; qt < 3; ++qt) {
                     const int tokq = min(16 * qt + r16, 35);
-                    const f16 *brow = &bt[(head * 36 + tokq) * 48];
-                    const f16x4 rq0 = *reinterpret_cast<const f16x4 *>(brow + 4 * grp);
-                    const f16x4 rq1 = *reinterpret_cast<const f16x4 *>(brow + 16 + 4 * grp);
-                    const f16x4 rq2 = *reinterpret_cast<const f16x4 *>(brow + 32 + 4 * grp) + rqr[qt];
                     f32x4 s[3];
                     float mx = -3.0e38f;
+                    if constexpr (CBIAS) {
+                        const float *brow = bt32 + (hl * 36 + tokq) * kBiasStride + 4 * grp;
 #pragma unroll
-                    for (int kt = 0; kt < 3; ++kt) {
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                        const f16x4 rk2 = rk[kt][2] + rkr[kt];
-                        if constexpr (HD == 16) {
-                            acc = MFMA_16x16x32(cat8r(kt4[0][kt], rk[kt][0]), cat8r(qt4[0][qt], rq0), acc);
-                            acc = MFMA_16x16x32(cat8r(rk[kt][1], rk2), cat8r(rq1, rq2), acc);
-                        } else {
-                            acc = MFMA_16x16x32(cat8r(kt4[0][kt], kt4[1][kt]), cat8r(qt4[0][qt], qt4[1][qt]), acc);
-                            acc = MFMA_16x16x32(cat8r(rk[kt][0], rk[kt][1]), cat8r(rq0, rq1), acc);
-                            acc = MFMA_16x16x32(cat8r(rk2, zero4), cat8r(rq2, zero4), acc);
+                        for (int kt = 0; kt < 3; ++kt) {
+                            f32x4 acc = *reinterpret_cast<const f32x4 *>(brow + 16 * kt);
+                            if constexpr (HD == 16) {
+                                acc = MFMA_16x16x32(cat8r(kt4[0][kt], rkr[kt]), cat8r(qt4[0][qt], rqr[qt]), acc);
+                            } else {
+                                acc = MFMA_16x16x32(cat8r(kt4[0][kt], kt4[1][kt]), cat8r(qt4[0][qt], qt4[1][qt]), acc);
+                                if (special) acc = MFMA_16x16x32(cat8r(rkr[kt], zero4), cat8r(rqr[qt], zero4), acc);
+                            }
+                            s[kt] = acc;
                         }
-                        s[kt] = acc;
-                        mx = fmaxf(mx, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+                        mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
+                                   fmaxf(fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])),
+                                         fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3]))));
+                    } else {
+                        const f16 *brow = &bt[(head * 36 + tokq) * 48];
+                        const f16x4 rq0 = *reinterpret_cast<const f16x4 *>(brow + 4 * grp);
+                        const f16x4 rq1 = *reinterpret_cast<const f16x4 *>(brow + 16 + 4 * grp);
+                        const f16x4 rq2 = *reinterpret_cast<const f16x4 *>(brow + 32 + 4 * grp) + rqr[qt];
+#pragma unroll
+                        for (int kt = 0; kt < 3; ++kt) {
+                            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                            const f16x4 rk2 = rk[kt][2] + rkr[kt];
+                            if constexpr (HD == 16) {
+                                acc = MFMA_16x16x32(cat8r(kt4[0][kt], rk[kt][0]), cat8r(qt4[0][qt], rq0), acc);
+                                acc = MFMA_16x16x32(cat8r(rk[kt][1], rk2), cat8r(rq1, rq2), acc);
+                            } else {
+                                acc = MFMA_16x16x32(cat8r(kt4[0][kt], kt4[1][kt]), cat8r(qt4[0][qt], qt4[1][qt]), acc);
+                                acc = MFMA_16x16x32(cat8r(rk[kt][0], rk[kt][1]), cat8r(rq0, rq1), acc);
+                                acc = MFMA_16x16x32(cat8r(rk2, zero4), cat8r(rq2, zero4), acc);
+                            }
+                            s[kt] = acc;
+                            mx = fmaxf(mx, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+                        }
                     }
                     mx = fmaxf(mx, __shfl_xor(mx, 16));
                     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -216,11 +253,18 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     for (int kt = 0; kt < 3; ++kt) {
                         const float p0 = __builtin_amdgcn_exp2f(s[kt][0] - mx), p1 = __builtin_amdgcn_exp2f(s[kt][1] - mx);
                         const float p2 = __builtin_amdgcn_exp2f(s[kt][2] - mx), p3 = __builtin_amdgcn_exp2f(s[kt][3] - mx);
-                        sum += (p0 + p1) + (p2 + p3);
+                        if constexpr (!CBIAS) sum += (p0 + p1) + (p2 + p3);
                         pf[kt] = (f16x4){(f16)p0, (f16)p1, (f16)p2, (f16)p3};
                     }
-                    sum += __shfl_xor(sum, 16);
-                    sum += __shfl_xor(sum, 32);
+                    if constexpr (CBIAS) {
+                        // denominator = sum of the fp16 probabilities the PV product actually uses: ones x P on the MFMA
+                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                        const f32x4 sm = MFMA_16x16x32(ones8, cat8r(pf[0] + pf[1], pf[2]), z4);
+                        sum = sm[0];
+                    } else {
+                        sum += __shfl_xor(sum, 16);
+                        sum += __shfl_xor(sum, 32);
+                    }
                     const float inv = __builtin_amdgcn_rcpf(sum);
                     const bool store = (16 * qt + r16) < 36;
                     // 16-byte stores: two adjacent 16-channel tiles -> one 8-channel run per lane (common.h pair_to_run).
@@ -260,39 +304,46 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
 
 int qkv_attn_r_frags(int C) { return 3 * (C / 16) * (C / 32); }
 
-template <int C, int HD, int HPP, bool PREFETCH>
+template <int C, int HD, int HPP, bool PREFETCH, bool CBIAS, int WAVES = 8>
 static int launch_r(const QkvAttnRArgs &a, int grid, hipStream_t s) {
-    constexpr size_t smem = (size_t)HPP * 3 * (HD / 16) * (C / 32) * 1024 + 6 * 36 * 48 * 2 + 3 * C * 4;
+    constexpr size_t smem = (size_t)HPP * 3 * (HD / 16) * (C / 32) * 1024 +
+                            (CBIAS ? HPP * 36 * kBiasStride * 4 : 6 * 36 * 48 * 2) + 3 * C * 4;
     static bool configured = false;
     if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)qkv_attn_r_kernel<C, HD, HPP, PREFETCH>,
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)qkv_attn_r_kernel<C, HD, HPP, PREFETCH, CBIAS, WAVES>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = true;
     }
-    qkv_attn_r_kernel<C, HD, HPP, PREFETCH><<<grid, 512, smem, s>>>(a);
+    qkv_attn_r_kernel<C, HD, HPP, PREFETCH, CBIAS, WAVES><<<grid, WAVES * 64, smem, s>>>(a);
     return NUNIF_HIP_OK;
 }
 
-int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, int B, int H, int W,
-                      int C, int heads, int shift, hipStream_t s) {
+int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, const float *btab32,
+                      int B, int H, int W, int C, int heads, int shift, hipStream_t s) {
     NUNIF_REQUIRE(H % 6 == 0 && W % 6 == 0, "qkv_attn: %dx%d not a multiple of the 6x6 window", H, W);
     NUNIF_REQUIRE(heads == 6 && (C == 96 || C == 192), "qkv_attn: C=%d heads=%d unsupported", C, heads);
     if (H <= 6) shift = 0;                 // torchvision disables the shift when the window covers the map
     QkvAttnRArgs a;
-    a.x = x; a.att = att; a.wres = wres; a.bqkv = bqkv; a.btab = btab;
+    a.x = x; a.att = att; a.wres = wres; a.bqkv = bqkv; a.btab = btab; a.btab32 = btab32;
     a.B = B; a.H = H; a.W = W; a.shift = shift;
     a.n_windows = B * (H / 6) * (W / 6);
     const double tok = (double)B * H * W;
+    static const bool cbias = !(getenv("NUNIF_ATTN_CBIAS") && atoi(getenv("NUNIF_ATTN_CBIAS")) == 0);   // A/B switch
+    static const int waves96 = getenv("NUNIF_ATTN_WAVES") ? atoi(getenv("NUNIF_ATTN_WAVES")) : 16;
+    const int kWavesR = (C == 96 && cbias) ? waves96 : 8;
     const int wgs = (a.n_windows + kWavesR - 1) / kWavesR;
     int grid = wgs < 256 ? wgs : 256;                   // persistent: one 8-wave workgroup per CU
     if (C == 192) grid = std::max(2, grid & ~1);        // two head passes = two kinds of workgroup
     int rc;
     if (C == 96) {
         ProfScope ps("qkv_attn_r_kernel<96,16>", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 4.0);
-        rc = launch_r<96, 16, 6, true>(a, grid, s);
+        if (!cbias) rc = launch_r<96, 16, 6, true, false>(a, grid, s);
+        else if (kWavesR == 12) rc = launch_r<96, 16, 6, true, true, 12>(a, grid, s);
+        else if (kWavesR == 16) rc = launch_r<96, 16, 6, false, true, 16>(a, grid, s);
+        else rc = launch_r<96, 16, 6, true, true>(a, grid, s);
     } else {
         ProfScope ps("qkv_attn_r_kernel<192,32>", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 4.0);
-        rc = launch_r<192, 32, 3, false>(a, grid, s);
+        rc = cbias ? launch_r<192, 32, 3, false, true>(a, grid, s) : launch_r<192, 32, 3, false, false>(a, grid, s);
     }
     if (rc) return rc;
     NUNIF_LAUNCH_CHECK();

@@ -36,6 +36,7 @@ struct Block {
     f16 *qkv_res = nullptr;
     float *qkv_rbias = nullptr;
     f16 *attn_btab = nullptr;
+    float *attn_btab32 = nullptr;
 };
 
 struct DeviceBuf {
@@ -260,6 +261,14 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
                 btab[((size_t)hh * 36 + q) * 48 + 36] = (f16)1000.0f;
             }
         if ((rc = upload(h, btab, &bl.attn_btab))) return rc;
+        // fp32 table read as the MFMA C operand: [heads][36][52], log2(e) * bias, padded keys 1000 log2-units down
+        std::vector<float> btab32((size_t)heads * 36 * 52, 0.0f);
+        for (int hh = 0; hh < heads; ++hh)
+            for (int q = 0; q < 36; ++q)
+                for (int k = 0; k < 48; ++k)
+                    btab32[((size_t)hh * 36 + q) * 52 + k] =
+                        k < 36 ? bias[((size_t)hh * 36 + q) * 48 + k] * 1.4426950408889634f : -1000.0f;
+        if ((rc = upload(h, btab32, &bl.attn_btab32))) return rc;
     }
     return NUNIF_HIP_OK;
 }
@@ -304,7 +313,7 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         // variant 2: one window per wave, weights through the LDS ring (both widths);
         // variant 1: one wave per head, 4 windows per workgroup (C = 96 only); variant 0: unfused GEMM + attention.
         if (h->attn_variant == 3 && h->heads == 6 && (dim == 96 || dim == 192)) {
-            if ((rc = launch_qkv_attn_r(x, att, bl.qkv_res, bl.qkv_rbias, bl.attn_btab, B, S, S, dim, h->heads, shift, s)))
+            if ((rc = launch_qkv_attn_r(x, att, bl.qkv_res, bl.qkv_rbias, bl.attn_btab, bl.attn_btab32, B, S, S, dim, h->heads, shift, s)))
                 return rc;
         } else if (h->attn_variant == 2 && h->heads == 6 && (dim == 96 || dim == 192)) {
             if ((rc = launch_qkv_attn_w(x, att, bl.qkv_stream, bl.qkv.bias, bl.attn_bias, B, S, S, dim, h->heads, shift, s)))
