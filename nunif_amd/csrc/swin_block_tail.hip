@@ -95,7 +95,7 @@ constexpr int kChunkFrags = 8;   // 8 KiB per chunk: 256 threads x 2 x 16 B
 template <int C, int MF, int ABL = 0, int WAVES = 4, int CHF = kChunkFrags>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1)
 proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wstream, int n_chunks,
-                const float *__restrict__ bp, const float *__restrict__ b0, const float *__restrict__ b3, long M) {
+                const float *__restrict__ bp, const float *__restrict__ b0, const float *__restrict__ b3, long M, int rev) {
     constexpr int KS = C / 32;       // K chunks of the C-wide GEMMs (proj, mlp.0)
     constexpr int NT = C / 16;       // 16-channel output tiles of a C-wide result
     constexpr int SH = 2 * C / 32;   // K chunks of the hidden (2C) dimension
@@ -107,7 +107,7 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
     const int wave = tid >> 6;
     const int r16 = lane & 15;
     const int grp = lane >> 4;
-    const long m_base = ((long)blockIdx.x * WAVES + wave) * (MF * 16);
+    const long m_base = ((long)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * WAVES + wave) * (MF * 16);   // snake order
     // NOTE: no early exit — every wave takes part in every chunk barrier; out-of-range rows are clamped + masked.
 
     // WAVES = 8: the workgroup covers twice the tokens per pass over the weight stream — at C = 192 the stream is
@@ -268,7 +268,7 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
 template <int C, int MF, int WAVES, bool PF = false>
 __global__ void __launch_bounds__(WAVES * 64)
 proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wstream, const float *__restrict__ bp,
-                  const float *__restrict__ b0, const float *__restrict__ b3, long M, TailToImage ti) {
+                  const float *__restrict__ b0, const float *__restrict__ b3, long M, TailToImage ti, int rev) {
     constexpr int KS = C / 32, NT = C / 16, SH = 2 * C / 32;
     constexpr int NF = 2 * KS * KS + SH * (2 * KS + NT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
@@ -299,10 +299,11 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
     // PF: the att / x tiles of the NEXT group are requested before this group's GEMMs start.  Without it every
     // wave exposes one full HBM latency per group and the kernel sits at ~3.3 TB/s however cheap the math is
     // (bytes in flight per CU ~ 20 KB; Little's law wants >= 40 KB for 5 TB/s).
+    auto gmap = [&](long g) { return rev ? n_groups - 1 - g : g; };          // snake order between kernels
     auto load_group = [&](long g, f16x8 (&of)[MF][KS], f16x8 (&xr)[MF][KS]) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            const long m = g * (MF * 16) + f * 16 + r16;
+            const long m = gmap(g) * (MF * 16) + f * 16 + r16;
             const long r = m < M ? m : M - 1;
             const f16 *p = att + r * C + grp * 8;
             const f16 *px = x + r * C + pair_run_channel(grp);
@@ -321,7 +322,7 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
     }
 #pragma unroll 1
     for (long g = g_first; g < n_groups; g += gstride) {
-        const long m_base = g * (MF * 16);
+        const long m_base = gmap(g) * (MF * 16);
         // opaque per-iteration copies: keeps LICM from hoisting 48 registers of (loop-invariant) LDS bias reads
         const float *lbp = bl, *lb0 = bl + C, *lb3 = bl + 3 * C;
         asm volatile("" : "+v"(lbp), "+v"(lb0), "+v"(lb3));
@@ -478,7 +479,7 @@ int proj_mlp_stream_frags(int C) {
 }
 
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
-                    long M, int C, hipStream_t s, const TailToImage *to_image) {
+                    long M, int C, hipStream_t s, const TailToImage *to_image, int rev) {
     if (M == 0) return NUNIF_HIP_OK;
     NUNIF_REQUIRE(!to_image || (C == 96 && !getenv("NUNIF_TAIL_RING") && to_image->n_real <= 16),
                   "proj_mlp: the fused image head needs the resident C = 96 kernel");
@@ -502,7 +503,7 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
             }
             const long groups = (M + mf * 16 - 1) / (mf * 16);
             const unsigned blocks = (unsigned)std::min<long>((groups + waves - 1) / waves, 256);
-            kern<<<blocks, waves * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti);
+            kern<<<blocks, waves * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti, rev);
             return NUNIF_HIP_OK;
         };
         int rc;
@@ -520,30 +521,30 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
     } else if (C == 96) {
         constexpr int MF = 4;
         const unsigned blocks = (unsigned)((M + 4 * MF * 16 - 1) / (4 * MF * 16));
-        proj_mlp_kernel<96, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M);
+        proj_mlp_kernel<96, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev);
     } else if (C == 192) {
         constexpr int MF = 2;
         const unsigned blocks = (unsigned)((M + 4 * MF * 16 - 1) / (4 * MF * 16));
         static const int abl = getenv("NUNIF_TAIL_ABL") ? atoi(getenv("NUNIF_TAIL_ABL")) : 0;
         switch (abl) {
-            case 1: proj_mlp_kernel<192, MF, 1><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
-            case 2: proj_mlp_kernel<192, MF, 2><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
-            case 4: proj_mlp_kernel<192, MF, 4><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
-            case 8: proj_mlp_kernel<192, MF, 8><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
-            case 9: proj_mlp_kernel<192, MF, 9><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
-            case 16: proj_mlp_kernel<192, MF, 16><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
-            case 6: proj_mlp_kernel<192, MF, 6><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
+            case 1: proj_mlp_kernel<192, MF, 1><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
+            case 2: proj_mlp_kernel<192, MF, 2><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
+            case 4: proj_mlp_kernel<192, MF, 4><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
+            case 8: proj_mlp_kernel<192, MF, 8><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
+            case 9: proj_mlp_kernel<192, MF, 9><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
+            case 16: proj_mlp_kernel<192, MF, 16><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
+            case 6: proj_mlp_kernel<192, MF, 6><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
             case 64: {   // 8-wave workgroups (half the L2 -> LDS weight traffic): measured SLOWER, 242 vs 221 us
                 const unsigned blocks8 = (unsigned)((M + 8 * MF * 16 - 1) / (8 * MF * 16));
-                proj_mlp_kernel<192, MF, 0, 8><<<blocks8, 512, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M);
+                proj_mlp_kernel<192, MF, 0, 8><<<blocks8, 512, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev);
                 break;
             }
             case 128: {  // 16-KiB ring chunks: twice the prefetch distance
                 const int nc16 = (proj_mlp_stream_frags(C) + 15) / 16;
-                proj_mlp_kernel<192, MF, 0, 4, 16><<<blocks, 256, 0, s>>>(att, x, wstream, nc16, bp, b0, b3, M);
+                proj_mlp_kernel<192, MF, 0, 4, 16><<<blocks, 256, 0, s>>>(att, x, wstream, nc16, bp, b0, b3, M, rev);
                 break;
             }
-            default: proj_mlp_kernel<192, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M); break;
+            default: proj_mlp_kernel<192, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
         }
     } else {
         set_error("proj_mlp: channel count %d unsupported (96, 192)", C);

@@ -26,6 +26,7 @@ struct GemmArgs {
                               //         positions outside the plane are dropped (ConvTranspose2d 4x4 s2 p3 head of UpCUNet)
     int no_clamp;             // mode 2: 1 = no clamp(0,1)
     int lda;                  // element stride between input pixels (0: Cin) — lets a GEMM read a K-slice of wider rows
+    int rev;                  // 1: walk the token groups downwards (snake order, swin_unet.cpp next_dir)
     int nt_chunk;             // set by the launcher: output tiles per workgroup column (blockIdx.y) for small-M GEMMs
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag);
@@ -52,7 +53,7 @@ int proj_mlp_stream_frags(int C);
 // planar fp32.  w: KS fragments of a 16-row tile in the chained k order; tokens are (b, y, x) over [B, H, W].
 struct TailToImage { const f16 *w; const float *bias; float *out; int H, W, ps, n_real; };
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
-                    long M, int C, hipStream_t s, const TailToImage *to_image = nullptr);
+                    long M, int C, hipStream_t s, const TailToImage *to_image = nullptr, int rev = 0);
 
 // ---- fused qkv Linear + (shifted) window attention, C = 96 / 6 heads of 16 (swin_qkv_attn.hip) ---------------------
 // x: [B,H,W,C] -> att: [B,H,W,C] (pre-projection attention output at the un-rolled positions)
@@ -65,7 +66,7 @@ int qkv_attn_w_stream_frags(int C);
 // ---- same, qkv weights resident in LDS, no barrier in the window loop (swin_qkv_attn_r.hip) -------------------------
 // btab: fp16 [heads][36][48] one-hot-MFMA bias table (NUNIF_ATTN_CBIAS=0); btab32: fp32 [heads][36][52] C-operand table
 int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, const float *btab32,
-                      int B, int H, int W, int C, int heads, int shift, hipStream_t s);
+                      int B, int H, int W, int C, int heads, int shift, hipStream_t s, int rev = 0);
 int launch_qkv_attn_w(const f16 *x, f16 *att, const f16 *wstream, const float *bqkv, const float *bias, int B, int H,
                       int W, int C, int heads, int shift, hipStream_t s);
 

@@ -37,7 +37,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     const int r16 = lane & 15;
     const int grp = lane >> 4;
     const long M = (long)g.B * g.Ho * g.Wo;
-    const long m_base = ((long)blockIdx.x * 4 + wave) * (MF * 16);
+    // g.rev: the token groups are walked from the last to the first ("snake" order between consecutive kernels: a kernel
+    // starts on the lines its predecessor touched last, which the 256-MB memory-side cache still holds)
+    const long m_base = ((long)(g.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 4 + wave) * (MF * 16);
     // no early exit: every wave joins every chunk barrier; rows beyond M are clamped on load and masked on store
     // (the host pads every packed weight array with 16 KiB of zeros, so the one-chunk-ahead prefetch never
     //  leaves the allocation — make_linear in swin_unet.cpp)
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(512) gemm_res_kernel(GemmArgs g) {
     const long g_step = RES ? (long)gridDim.x * WAVES : n_groups + WAVES;      // ring mode: exactly one trip
 #pragma unroll 1
     for (long gi = g_first; RES ? gi < n_groups : gi == g_first; gi += g_step) {
-    const long m_base = gi * (MF * 16);
+    const long m_base = (g.rev ? n_groups - 1 - gi : gi) * (MF * 16);
     f16x8 xf[MF][KS];
     int tb[MF], ty[MF], tx[MF];
     bool valid[MF];

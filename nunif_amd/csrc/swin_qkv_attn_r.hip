@@ -35,6 +35,7 @@ struct QkvAttnRArgs {
     const f16 *btab;         // [heads][36][48] fp16: log2e * relative-position bias, col 36 = BIG, cols 37.. = 0
     const float *btab32;     // CBIAS: [heads][36][52] fp32: log2e * bias, cols 36..47 = -1000 (padded keys), 48..51 unused
     int B, H, W, shift, n_windows;
+    int rev;                 // 1: walk the windows from the last to the first (snake order, see launch_qkv_attn_r)
 };
 
 __device__ __forceinline__ f16x8 cat8r(f16x4 lo, f16x4 hi) {
@@ -135,7 +136,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
 
         f16x8 xf[3][KS];
         long pix[3];
-        if (w0 < a.n_windows) load_x(w0, xf, pix);
+        auto wmap = [&](int wi) { return a.rev ? a.n_windows - 1 - wi : wi; };
+        if (w0 < a.n_windows) load_x(wmap(w0), xf, pix);
 
 #pragma unroll 1
         for (int wi = w0; wi < a.n_windows; wi += wstride) {
@@ -143,13 +145,14 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
             long pixn[3];
             if constexpr (PREFETCH) {
                 const int wnext = wi + wstride < a.n_windows ? wi + wstride : wi;
-                load_x(wnext, xn, pixn);
+                load_x(wmap(wnext), xn, pixn);
             }
             // shift regions of this window (only the last window row / column straddles two regions)
             f16x4 rkr[3], rqr[3];
             bool special;
             {
-                const int wx = wi % nwx, wy = (wi / nwx) % nwy;
+                const int wq = wmap(wi);
+                const int wx = wq % nwx, wy = (wq / nwx) % nwy;
                 const bool last_y = a.shift > 0 && wy == nwy - 1, last_x = a.shift > 0 && wx == nwx - 1;
                 special = __builtin_amdgcn_readfirstlane((int)(last_y || last_x)) != 0;   // one window per wave: uniform
 #pragma unroll
@@ -296,7 +299,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = xn[mt][ks];
                 }
             } else {
-                if (wi + wstride < a.n_windows) load_x(wi + wstride, xf, pix);
+                if (wi + wstride < a.n_windows) load_x(wmap(wi + wstride), xf, pix);
             }
         }
     }
@@ -319,7 +322,7 @@ static int launch_r(const QkvAttnRArgs &a, int grid, hipStream_t s) {
 }
 
 int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, const float *btab32,
-                      int B, int H, int W, int C, int heads, int shift, hipStream_t s) {
+                      int B, int H, int W, int C, int heads, int shift, hipStream_t s, int rev) {
     NUNIF_REQUIRE(H % 6 == 0 && W % 6 == 0, "qkv_attn: %dx%d not a multiple of the 6x6 window", H, W);
     NUNIF_REQUIRE(heads == 6 && (C == 96 || C == 192), "qkv_attn: C=%d heads=%d unsupported", C, heads);
     if (H <= 6) shift = 0;                 // torchvision disables the shift when the window covers the map
@@ -327,6 +330,7 @@ int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv
     a.x = x; a.att = att; a.wres = wres; a.bqkv = bqkv; a.btab = btab; a.btab32 = btab32;
     a.B = B; a.H = H; a.W = W; a.shift = shift;
     a.n_windows = B * (H / 6) * (W / 6);
+    a.rev = rev;            // snake order between consecutive kernels (swin_unet.cpp next_dir)
     const double tok = (double)B * H * W;
     static const bool cbias = !(getenv("NUNIF_ATTN_CBIAS") && atoi(getenv("NUNIF_ATTN_CBIAS")) == 0);   // A/B switch
     static const int waves96 = getenv("NUNIF_ATTN_WAVES") ? atoi(getenv("NUNIF_ATTN_WAVES")) : 16;

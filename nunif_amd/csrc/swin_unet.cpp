@@ -69,6 +69,8 @@ struct nunif_swin_unet {
     float *stem1_w = nullptr, *stem1_b = nullptr;
     Linear stem2, down1, down2, up2, up1, proj2, to_image;
     f16 *to_image_chained = nullptr;  // ToImage weights in the chained k order, for the fused head of the last C = 96 block
+    int snake = 1;                    // NUNIF_SNAKE=0: every kernel walks its tokens upwards
+    int dir = 0;                      // direction of the next kernel; next_dir() flips it
     int fuse_to_image = 1;            // NUNIF_FUSE_TOIMAGE=0: separate gemm_kernel launch (A/B)
     f16 *stem2_stream = nullptr;      // conv2 fragments in [k-step][n-tile] order for conv_kernel (cunet_kernels.hip)
     int stem2_conv = 0;               // NUNIF_STEM2_CONV=1: conv_kernel<6,4> instead of gemm_kernel<18,2> (measured slower: 1131 vs 914 us)
@@ -275,19 +277,19 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
 
 int run_gemm(const Linear &L, const f16 *a, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int stride, int oy,
              int ox, int kw, int mode, int act, float slope, const f16 *res, void *out, int ldo, int ps,
-             hipStream_t s, const char *tag) {
+             hipStream_t s, const char *tag, int rev = 0) {
     GemmArgs g;
     g.a = a; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin;
     g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.oy = oy; g.ox = ox; g.kw = kw;
     g.K = L.K; g.w = L.w; g.bias = L.bias; g.N = L.N;
     g.mode = mode; g.act = act; g.slope = slope; g.res = res; g.out = out; g.ldo = ldo;
-    g.n_real = L.n_real; g.ps = ps; g.oshift = 0; g.OH = 0; g.OW = 0; g.no_clamp = 0; g.lda = 0; g.nt_chunk = 0;
+    g.n_real = L.n_real; g.ps = ps; g.oshift = 0; g.OH = 0; g.OW = 0; g.no_clamp = 0; g.lda = 0; g.nt_chunk = 0; g.rev = rev;
     return launch_gemm(g, s, tag);
 }
 
 int run_linear(const Linear &L, const f16 *a, int B, int H, int W, int act, const f16 *res, f16 *out,
-               hipStream_t s, const char *tag) {
-    return run_gemm(L, a, B, H, W, L.K, H, W, 1, 0, 0, 1, 0, act, 0.f, res, out, L.n_real, 1, s, tag);
+               hipStream_t s, const char *tag, int rev = 0) {
+    return run_gemm(L, a, B, H, W, L.K, H, W, 1, 0, 0, 1, 0, act, 0.f, res, out, L.n_real, 1, s, tag, rev);
 }
 
 int tap(nunif_swin_unet *h, const std::string &name, const void *src, size_t bytes, hipStream_t s) {
@@ -297,6 +299,15 @@ int tap(nunif_swin_unet *h, const std::string &name, const void *src, size_t byt
     NUNIF_HIP_CHECK(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToDevice, s));
     h->taps.push_back({name, p, bytes});
     return NUNIF_HIP_OK;
+}
+
+// Snake order: consecutive kernels walk their tokens in opposite directions, so each one starts on the lines its
+// predecessor touched last (still in the 256-MB memory-side cache) — measured +1.3 % on the 1080p 2x frame with only the
+// attention kernels reversed.  Results do not depend on the walk order.
+static int next_dir(nunif_swin_unet *h) {
+    const int d = h->snake ? h->dir : 0;
+    h->dir ^= 1;
+    return d;
 }
 
 int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int S, int dim, hipStream_t s,
@@ -313,7 +324,8 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         // variant 2: one window per wave, weights through the LDS ring (both widths);
         // variant 1: one wave per head, 4 windows per workgroup (C = 96 only); variant 0: unfused GEMM + attention.
         if (h->attn_variant == 3 && h->heads == 6 && (dim == 96 || dim == 192)) {
-            if ((rc = launch_qkv_attn_r(x, att, bl.qkv_res, bl.qkv_rbias, bl.attn_btab, bl.attn_btab32, B, S, S, dim, h->heads, shift, s)))
+            if ((rc = launch_qkv_attn_r(x, att, bl.qkv_res, bl.qkv_rbias, bl.attn_btab, bl.attn_btab32, B, S, S, dim, h->heads, shift, s,
+                                        next_dir(h))))
                 return rc;
         } else if (h->attn_variant == 2 && h->heads == 6 && (dim == 96 || dim == 192)) {
             if ((rc = launch_qkv_attn_w(x, att, bl.qkv_stream, bl.qkv.bias, bl.attn_bias, B, S, S, dim, h->heads, shift, s)))
@@ -331,7 +343,7 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         // x = y + mlp(y), y = x + proj(attn): three GEMMs chained through registers, one read + one write of x
         const bool last = i + 1 == blocks.size();
         if ((rc = launch_proj_mlp(att, x, bl.tail_stream, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, dim, s,
-                                  last ? to_image : nullptr)))
+                                  last ? to_image : nullptr, next_dir(h))))
             return rc;
         if (last && to_image) break;               // x of the last block is not materialised
         if ((rc = tap(h, tn + ".out", x, tok * dim * 2, s))) return rc;
@@ -375,6 +387,7 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
     }
     a1.B = B; a1.T = T; a1.w = h->stem1_w; a1.bias = h->stem1_b; a1.C1 = h->C1; a1.C1P = h->C1P; a1.out = s1;
     a1.slope = 0.1f;
+    h->dir = 1;                                    // stem1 walks upwards; everything after it alternates
     if ((rc = launch_stem1(a1, s))) return rc;
     // conv2 3x3 VALID + LeakyReLU(0.1) + crop 6 (swin_unet.py:135-137,182): s1 already starts at conv1 row/col 6
     if (h->stem2_conv && C == 96) {
@@ -385,23 +398,23 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
         cv.act = 2; cv.slope = 0.1f; cv.out = f1;
         if ((rc = launch_conv(cv, s))) return rc;
     } else if ((rc = run_gemm(h->stem2, s1, B, T - 14, T - 14, h->C1P, S, S, 1, 0, 0, 3, 0, 2, 0.1f, nullptr, f1, C, 1, s,
-                              "gemm_stem2")))
+                              "gemm_stem2", next_dir(h))))
         return rc;
     if ((rc = tap(h, "stem", f1, (size_t)B * S * S * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[0], f1, B, S, C, s, "swin1"))) return rc;                          // swin1 -> x3
     if ((rc = run_gemm(h->down1, f1, B, S, S, C, S / 2, S / 2, 2, 0, 0, 2, 0, 0, 0.f, nullptr, f2, 2 * C, 1, s,
-                       "gemm_down")))
+                       "gemm_down", next_dir(h))))
         return rc;
     if ((rc = tap(h, "down1", f2, (size_t)B * (S / 2) * (S / 2) * 2 * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[1], f2, B, S / 2, 2 * C, s, "swin2"))) return rc;                  // swin2 -> x4
     if ((rc = run_gemm(h->down2, f2, B, S / 2, S / 2, 2 * C, S / 4, S / 4, 2, 0, 0, 2, 0, 0, 0.f, nullptr, f3,
-                       2 * C, 1, s, "gemm_down")))
+                       2 * C, 1, s, "gemm_down", next_dir(h))))
         return rc;
     if ((rc = tap(h, "down2", f3, (size_t)B * (S / 4) * (S / 4) * 2 * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[2], f3, B, S / 4, 2 * C, s, "swin3"))) return rc;                  // swin3
     // x = up2(x5) + x4, written in place over x4 (each lane reads then writes its own 8 bytes)
     if ((rc = run_gemm(h->up2, f3, B, S / 4, S / 4, 2 * C, S / 4, S / 4, 1, 0, 0, 1, 1, 0, 0.f, f2, f2, 2 * C, 1, s,
-                       "gemm_up")))
+                       "gemm_up", next_dir(h))))
         return rc;
     if ((rc = tap(h, "up2", f2, (size_t)B * (S / 2) * (S / 2) * 2 * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[3], f2, B, S / 2, 2 * C, s, "swin4"))) return rc;                  // swin4
@@ -409,10 +422,10 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
     if (h->has_proj2) {
         // 4x: x = up1(x) + proj2(x3)   (swin_unet.py:166,195-196)
         top = (f16 *)h->g1.p;
-        if ((rc = run_linear(h->proj2, f1, B, S, S, 0, nullptr, top, s, "gemm_proj2"))) return rc;
+        if ((rc = run_linear(h->proj2, f1, B, S, S, 0, nullptr, top, s, "gemm_proj2", next_dir(h)))) return rc;
     }
     if ((rc = run_gemm(h->up1, f2, B, S / 2, S / 2, 2 * C, S / 2, S / 2, 1, 0, 0, 1, 1, 0, 0.f, top, top,
-                       h->top_dim, 1, s, "gemm_up")))
+                       h->top_dim, 1, s, "gemm_up", next_dir(h))))
         return rc;
     if ((rc = tap(h, "up1", top, (size_t)B * S * S * h->top_dim * 2, s))) return rc;
     // to_image + pixel_shuffle + clamp(0,1) (ToImage.forward :110-116, wrapper eval clamp :225-226): fused into the
@@ -425,7 +438,7 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
     }
     if ((rc = run_stage(h, h->swin[4], top, B, S, h->top_dim, s, "swin5"))) return rc;                // swin5
     if ((rc = run_gemm(h->to_image, top, B, S, S, h->top_dim, S, S, 1, 0, 0, 1, 2, 0, 0.f, nullptr, z, 0,
-                       h->scale_factor, s, "gemm_to_image")))
+                       h->scale_factor, s, "gemm_to_image", next_dir(h))))
         return rc;
     return NUNIF_HIP_OK;
 }
@@ -454,6 +467,7 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
     if (const char *v = getenv("NUNIF_QKV_ATTN")) h->attn_variant = atoi(v);
     if (const char *v = getenv("NUNIF_STEM2_CONV")) h->stem2_conv = atoi(v);
     if (const char *v = getenv("NUNIF_FUSE_TOIMAGE")) h->fuse_to_image = atoi(v);
+    if (const char *v = getenv("NUNIF_SNAKE")) h->snake = atoi(v);
     h->scale_factor = scale_factor;
     const std::string P = "unet.";
     int rc = NUNIF_HIP_OK;
