@@ -44,6 +44,21 @@ struct Stem1Args {
 };
 int launch_stem1(const Stem1Args &a, hipStream_t s);
 
+// ---- fused stem (swin_stem.hip): conv1 + LeakyReLU + conv2 + LeakyReLU + crop in one kernel, C1 = 48 / C = 96 ----------
+struct StemFusedArgs {
+    const float *x;           // tile mode: [B,3,T,T]; frame mode: [3,H,W]  (as Stem1Args)
+    int frame_mode, H, W, wb, istep, pad_t, pad_l, tile_begin;
+    int B, T;
+    const f16 *w1;            // 3 A fragments: rows = conv1 channels, k = ci*9 + ky*3 + kx (27), k = 27: bias, rest 0
+    const f16 *w2;            // 14 x 6 A fragments in [k-step][n-tile] order, k = (dy*3 + dx) * 48 + ci, zero beyond 432
+    const float *b2;          // [96]
+    f16 *out;                 // [B, T-16, T-16, 96]
+    float slope;
+    int rev;                  // snake order flag
+};
+bool stem_fused_supported(int C1, int C);
+int launch_stem_fused(const StemFusedArgs &a, hipStream_t s);
+
 // ---- tail of a swin block: x = y + W3 gelu(W0 y + b0) + b3 with y = x + Wp att + bp, in place on x ------------------
 // wstream: proj (plain packed) | mlp.0 | mlp.3 ("chained" packed) fragments in consumption order, padded to a
 // multiple of 8 fragments (swin_block_tail.hip; assembled in make_stage, swin_unet.cpp).

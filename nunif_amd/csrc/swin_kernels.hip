@@ -373,6 +373,8 @@ __global__ void __launch_bounds__(512) gemm_res_kernel(GemmArgs g) {
     }   // token-group loop
 }
 
+static thread_local const char *g_prof_tag = nullptr;
+
 template <int KS, int MF>
 static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym, const char *res_sym, double flops,
                          double bytes) {
@@ -384,7 +386,8 @@ static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym,
     const bool fits = wbytes <= 144 * 1024 && M >= 8 * MF * 16 * 64;
     const bool res = fits && !force_ring && (MF == 2 || force_res);
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
-    ProfScope ps(res ? res_sym : ring_sym, s, flops, bytes);
+    // (NUNIF_PROF_TAGS=1 names the class after the call site instead: separates e.g. the two gemm_kernel<6,4> users)
+    ProfScope ps(g_prof_tag ? g_prof_tag : res ? res_sym : ring_sym, s, flops, bytes);
     if (res) {
         static bool configured = false;
         if (!configured) {
@@ -422,6 +425,8 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
                   "gemm %s: NHWC outputs are written in 32-channel pairs (N=%d n_real=%d ldo=%d)", tag, g.N, g.n_real, g.ldo);
     const long M = (long)g.B * g.Ho * g.Wo;
     if (M == 0) return NUNIF_HIP_OK;
+    static const bool prof_tags = getenv("NUNIF_PROF_TAGS") != nullptr;
+    g_prof_tag = prof_tags ? tag : nullptr;
     const double flops = 2.0 * (double)M * g.K * g.n_real;
     const double bytes = (double)M * (g.Cin * 2.0 * (g.K / g.Cin > 1 ? 1.0 : 1.0) + g.n_real * (g.mode == 2 ? 4.0 : 2.0) +
                                       (g.res ? g.n_real * 2.0 : 0.0));

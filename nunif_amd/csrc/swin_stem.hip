@@ -1,0 +1,226 @@
+// Fused swin_unet stem for gfx950: conv1 3x3 (3 -> 48) + LeakyReLU + conv2 3x3 (48 -> 96) + LeakyReLU + crop, one kernel.
+//
+// Replaces PatchDown's conv stack as SwinUNetBase.forward runs it (waifu2x/models/swin_unet.py:135-137 `patch`, :182 the
+// F.pad(x, [-6] * 4) crop) and, in frame mode, the replicate-pad + tile slicing of nunif/utils/seam_blending.py:82,90.
+//
+// The two-kernel stem (stem1_kernel on the VALU + the gather GEMM) cost 0.84 ms of an 8.5 ms frame: 0.37 GB of conv1
+// activations written to HBM, then gathered nine times through the L2 with 64-bit index math per 16-byte piece, at 23 %
+// MFMA issue.  Here a persistent 8-wave workgroup owns one 16 x 16 output tile at a time and nothing but the input image
+// and the 96-channel result touches memory:
+//   1. the 20 x 20 x 3 input patch goes to LDS as fp16 (the next tile's patch is fetched into registers during step 3);
+//   2. conv1 runs on the MFMA: K = 27 taps + a constant-one column carrying the bias (28 of 32), 18 x 18 pixels = 21 token
+//      tiles, result (LeakyReLU, fp16) written to an 18 x 18 x 48 LDS tile with a 112-byte pixel stride (odd multiple
+//      of 16 B: 16 consecutive pixels hit 16 distinct bank quads for ds_read_b128);
+//   3. conv2 reads its B operands straight from that tile — k = tap * 48 + c, so K = 432 -> 14 k-steps instead of the 18
+//      of the channel-padded gather GEMM — against W2 resident in LDS (84 KiB), wave w owning output rows 2w, 2w + 1.
+// LDS: 84 (W2) + 3 (W1) + 35.4 (conv1 tile) + 2.4 (input) KiB = 125 KiB, one workgroup per CU.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "swin_kernels.h"
+
+namespace nunif {
+
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+namespace {
+constexpr int kC1 = 48, kC = 96;
+constexpr int kTile = 16;                 // output tile side
+constexpr int kS1 = kTile + 2;            // conv1 tile side
+constexpr int kIn = kTile + 4;            // input patch side
+constexpr int kPix = 112;                 // bytes per conv1 pixel in LDS (48 ch x 2 B = 96, padded)
+constexpr int kKS2 = 14;                  // ceil(9 * 48 / 32)
+constexpr int kNT2 = kC / 16;
+constexpr int kWaves = 8;
+constexpr int kW2Bytes = kKS2 * kNT2 * 1024, kW1Bytes = 3 * 1024, kS1Bytes = kS1 * kS1 * kPix;
+constexpr int kInElems = 3 * kIn * kIn;   // + [kInElems] = 1.0, [kInElems + 1] = 0.0
+constexpr int kInBytes = (kInElems + 8) * 2;
+constexpr int kSmem = kW2Bytes + kW1Bytes + kS1Bytes + kInBytes + kC * 4;
+}  // namespace
+
+__global__ void __launch_bounds__(kWaves * 64) stem_fused_kernel(StemFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+    const f16x8 *w2l = reinterpret_cast<const f16x8 *>(smem_s);
+    unsigned char *s1l = smem_s + kW2Bytes + kW1Bytes;
+    f16 *inl = reinterpret_cast<f16 *>(s1l + kS1Bytes);
+    float *b2l = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(inl) + kInBytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r16 = lane & 15;
+    const int grp = lane >> 4;
+
+    {
+        f16x8 *dst = reinterpret_cast<f16x8 *>(smem_s);
+        const f16x8 *src2 = reinterpret_cast<const f16x8 *>(a.w2);
+        for (int i = tid; i < kW2Bytes / 16; i += kWaves * 64) dst[i] = src2[i];
+        if (tid < kC) b2l[tid] = a.b2[tid];
+        if (tid == 0) { inl[kInElems] = (f16)1.0f; inl[kInElems + 1] = (f16)0.0f; }
+    }
+
+    // conv1 B operand: k = 8 grp + j -> (ci, ky, kx) = (k / 9, (k % 9) / 3, k % 3); k = 27: the constant one; k > 27: zero
+    int ioff[8], imul[8];                 // element = ioff + imul * (pixel offset): the two constants do not move
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * grp + j;
+        const int ci = k / 9, r = k - 9 * ci;
+        ioff[j] = k < 27 ? ci * (kIn * kIn) + (r / 3) * kIn + (r % 3) : (k == 27 ? kInElems : kInElems + 1);
+        imul[j] = k < 27 ? 1 : 0;
+    }
+    // conv2 B operand: k0 = 32 ks + 8 grp is one 8-channel run of tap k0 / 48 (48 % 8 == 0: a run never straddles taps);
+    // the zero-weight tail k >= 432 re-reads tap 0 (finite data x 0)
+    int koff[kKS2];
+#pragma unroll
+    for (int ks = 0; ks < kKS2; ++ks) {
+        int k0 = 32 * ks + 8 * grp;
+        if (k0 >= 9 * kC1) k0 = 0;
+        const int tap = k0 / kC1, c = k0 - tap * kC1;
+        koff[ks] = ((tap / 3) * kS1 + tap % 3) * kPix + c * 2;
+    }
+    const f16x8 *w1g = reinterpret_cast<const f16x8 *>(a.w1);
+    const f16x8 w1f[3] = {w1g[lane], w1g[64 + lane], w1g[128 + lane]};
+
+    const int S = a.T - 16;
+    const int ntx = (S + kTile - 1) / kTile;
+    const int n_tiles = a.B * ntx * ntx;
+
+    // input patch element e = tid + 512 i of tile t -> fp32 value (replicate clamp at the frame border in frame mode)
+    auto fetch_in = [&](int t, float (&v)[3]) {
+        const int txt = t % ntx, t2 = t / ntx;
+        const int tyt = t2 % ntx, b = t2 / ntx;
+        int fy = 0, fx = 0;
+        if (a.frame_mode) {
+            const int k = a.tile_begin + b;
+            const int ti = k / a.wb, tj = k - ti * a.wb;
+            fy = ti * a.istep - a.pad_t;
+            fx = tj * a.istep - a.pad_l;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = tid + kWaves * 64 * i;
+            v[i] = 0.f;
+            if (e < kInElems) {
+                const int ci = e / (kIn * kIn), r = e - ci * (kIn * kIn);
+                const int iy = r / kIn, ix = r - iy * kIn;
+                const int yy = min(kTile * tyt + 6 + iy, a.T - 1), xx = min(kTile * txt + 6 + ix, a.T - 1);
+                if (a.frame_mode) {
+                    const int sy = min(max(fy + yy, 0), a.H - 1), sx = min(max(fx + xx, 0), a.W - 1);
+                    v[i] = a.x[((long)ci * a.H + sy) * a.W + sx];
+                } else {
+                    v[i] = a.x[(((long)b * 3 + ci) * a.T + yy) * a.T + xx];
+                }
+            }
+        }
+    };
+    auto tmap = [&](int t) { return a.rev ? n_tiles - 1 - t : t; };
+
+    float pin[3];
+    if ((int)blockIdx.x < n_tiles) fetch_in(tmap(blockIdx.x), pin);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int tm = tmap(t);
+        const int txt = tm % ntx, t2 = tm / ntx;
+        const int tyt = t2 % ntx, b = t2 / ntx;
+        // ---- 1. input patch -> LDS (fp16) ---------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = tid + kWaves * 64 * i;
+            if (e < kInElems) inl[e] = (f16)pin[i];
+        }
+        __syncthreads();
+        // ---- 2. conv1 on the MFMA: 21 tiles of 16 pixels x 48 channels ---------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int mt = wave + kWaves * i;
+            if (mt * 16 < kS1 * kS1) {
+                const int p = min(mt * 16 + r16, kS1 * kS1 - 1);
+                const int py = p / kS1, px = p - py * kS1;
+                const int pb = py * kIn + px;
+                f16x8 bfrag;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bfrag[j] = inl[ioff[j] + imul[j] * pb];
+                const bool wr = mt * 16 + r16 < kS1 * kS1;
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = MFMA_16x16x32(w1f[nt], bfrag, acc);
+                    f16x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = (f16)(acc[q] >= 0.f ? acc[q] : acc[q] * a.slope);
+                    if (wr) *reinterpret_cast<f16x4 *>(s1l + p * kPix + (16 * nt + 4 * grp) * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // the next tile's input travels while conv2 runs
+        if (t + (int)gridDim.x < n_tiles) fetch_in(tmap(t + gridDim.x), pin);
+        // ---- 3. conv2: rows 2 wave, 2 wave + 1 of the tile; B fragments from the conv1 tile, W2 resident ---------------------
+        f32x4 acc[kNT2][2];
+#pragma unroll
+        for (int nt = 0; nt < kNT2; ++nt) {
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(b2l + 16 * nt + 4 * grp);
+            acc[nt][0] = bb;
+            acc[nt][1] = bb;
+        }
+        const unsigned char *bp0 = s1l + ((2 * wave) * kS1 + r16) * kPix;
+        const unsigned char *bp1 = bp0 + kS1 * kPix;
+#pragma unroll
+        for (int ks = 0; ks < kKS2; ++ks) {
+            const f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp0 + koff[ks]);
+            const f16x8 b1 = *reinterpret_cast<const f16x8 *>(bp1 + koff[ks]);
+#pragma unroll
+            for (int nt = 0; nt < kNT2; ++nt) {
+                const f16x8 w = w2l[(ks * kNT2 + nt) * 64 + lane];
+                acc[nt][0] = MFMA_16x16x32(w, b0, acc[nt][0]);
+                acc[nt][1] = MFMA_16x16x32(w, b1, acc[nt][1]);
+            }
+        }
+        const int ox = kTile * txt + r16;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int oy = kTile * tyt + 2 * wave + f;
+            const bool ok = oy < S && ox < S;
+            f16 *op = a.out + (((long)b * S + min(oy, S - 1)) * S + min(ox, S - 1)) * kC + pair_run_channel(grp);
+#pragma unroll
+            for (int p = 0; p < kNT2 / 2; ++p) {
+                f16x4 oa, ob;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float u = acc[2 * p][f][q], v = acc[2 * p + 1][f][q];
+                    oa[q] = (f16)(u >= 0.f ? u : u * a.slope);
+                    ob[q] = (f16)(v >= 0.f ? v : v * a.slope);
+                }
+                const f16x8 o = pair_to_run(oa, ob);
+                if (ok) *reinterpret_cast<f16x8 *>(op + 32 * p) = o;
+            }
+        }
+        __syncthreads();          // the conv1 tile and the input patch are rewritten by the next trip
+    }
+}
+
+bool stem_fused_supported(int C1, int C) { return C1 == kC1 && C == kC; }
+
+int launch_stem_fused(const StemFusedArgs &a, hipStream_t s) {
+    NUNIF_REQUIRE(a.T > 16, "stem: tile size %d too small", a.T);
+    const int S = a.T - 16;
+    const int ntx = (S + kTile - 1) / kTile;
+    const long n_tiles = (long)a.B * ntx * ntx;
+    if (n_tiles == 0) return NUNIF_HIP_OK;
+    const double px = (double)a.B * S * S;
+    ProfScope ps("stem_fused_kernel", s, 2.0 * px * (27.0 * kC1 + 9.0 * kC1 * kC), px * (12.0 + kC * 2.0));
+    static bool configured = false;
+    if (!configured) {
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)stem_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
+        configured = true;
+    }
+    const unsigned grid = (unsigned)std::min<long>(n_tiles, 256);
+    stem_fused_kernel<<<grid, kWaves * 64, kSmem, s>>>(a);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+}  // namespace nunif

@@ -69,6 +69,8 @@ struct nunif_swin_unet {
     float *stem1_w = nullptr, *stem1_b = nullptr;
     Linear stem2, down1, down2, up2, up1, proj2, to_image;
     f16 *to_image_chained = nullptr;  // ToImage weights in the chained k order, for the fused head of the last C = 96 block
+    f16 *stemf_w1 = nullptr, *stemf_w2 = nullptr;   // fused stem (swin_stem.hip)
+    int stem_fused = 1;               // NUNIF_STEM_FUSED=0: stem1_kernel + gather GEMM
     int snake = 1;                    // NUNIF_SNAKE=0: every kernel walks its tokens upwards
     int dir = 0;                      // direction of the next kernel; next_dir() flips it
     int fuse_to_image = 1;            // NUNIF_FUSE_TOIMAGE=0: separate gemm_kernel launch (A/B)
@@ -377,6 +379,20 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
     if ((rc = ensure_workspace(h, B, T))) return rc;
     f16 *s1 = (f16 *)h->s1.p, *f1 = (f16 *)h->f1.p, *f2 = (f16 *)h->f2.p, *f3 = (f16 *)h->f3.p;
 
+    if (h->stem_fused && h->stemf_w2 && stem_fused_supported(h->C1, (int)C)) {
+        StemFusedArgs sf;
+        memset(&sf, 0, sizeof(sf));
+        if (frame) {
+            sf.x = frame; sf.frame_mode = 1; sf.H = grid->x_h; sf.W = grid->x_w; sf.wb = grid->w_blocks;
+            sf.istep = grid->input_tile_step; sf.pad_t = grid->pad_t; sf.pad_l = grid->pad_l; sf.tile_begin = tile_begin;
+        } else {
+            sf.x = x;
+        }
+        sf.B = B; sf.T = T; sf.w1 = h->stemf_w1; sf.w2 = h->stemf_w2; sf.b2 = h->stem2.bias; sf.out = f1; sf.slope = 0.1f;
+        h->dir = 1;
+        if ((rc = launch_stem_fused(sf, s))) return rc;
+        goto stem_done;
+    }
     Stem1Args a1;
     memset(&a1, 0, sizeof(a1));
     if (frame) {
@@ -400,21 +416,22 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
     } else if ((rc = run_gemm(h->stem2, s1, B, T - 14, T - 14, h->C1P, S, S, 1, 0, 0, 3, 0, 2, 0.1f, nullptr, f1, C, 1, s,
                               "gemm_stem2", next_dir(h))))
         return rc;
+stem_done:
     if ((rc = tap(h, "stem", f1, (size_t)B * S * S * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[0], f1, B, S, C, s, "swin1"))) return rc;                          // swin1 -> x3
     if ((rc = run_gemm(h->down1, f1, B, S, S, C, S / 2, S / 2, 2, 0, 0, 2, 0, 0, 0.f, nullptr, f2, 2 * C, 1, s,
-                       "gemm_down", next_dir(h))))
+                       "gemm_down1", next_dir(h))))
         return rc;
     if ((rc = tap(h, "down1", f2, (size_t)B * (S / 2) * (S / 2) * 2 * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[1], f2, B, S / 2, 2 * C, s, "swin2"))) return rc;                  // swin2 -> x4
     if ((rc = run_gemm(h->down2, f2, B, S / 2, S / 2, 2 * C, S / 4, S / 4, 2, 0, 0, 2, 0, 0, 0.f, nullptr, f3,
-                       2 * C, 1, s, "gemm_down", next_dir(h))))
+                       2 * C, 1, s, "gemm_down2", next_dir(h))))
         return rc;
     if ((rc = tap(h, "down2", f3, (size_t)B * (S / 4) * (S / 4) * 2 * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[2], f3, B, S / 4, 2 * C, s, "swin3"))) return rc;                  // swin3
     // x = up2(x5) + x4, written in place over x4 (each lane reads then writes its own 8 bytes)
     if ((rc = run_gemm(h->up2, f3, B, S / 4, S / 4, 2 * C, S / 4, S / 4, 1, 0, 0, 1, 1, 0, 0.f, f2, f2, 2 * C, 1, s,
-                       "gemm_up", next_dir(h))))
+                       "gemm_up2", next_dir(h))))
         return rc;
     if ((rc = tap(h, "up2", f2, (size_t)B * (S / 2) * (S / 2) * 2 * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[3], f2, B, S / 2, 2 * C, s, "swin4"))) return rc;                  // swin4
@@ -425,7 +442,7 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
         if ((rc = run_linear(h->proj2, f1, B, S, S, 0, nullptr, top, s, "gemm_proj2", next_dir(h)))) return rc;
     }
     if ((rc = run_gemm(h->up1, f2, B, S / 2, S / 2, 2 * C, S / 2, S / 2, 1, 0, 0, 1, 1, 0, 0.f, top, top,
-                       h->top_dim, 1, s, "gemm_up", next_dir(h))))
+                       h->top_dim, 1, s, "gemm_up1", next_dir(h))))
         return rc;
     if ((rc = tap(h, "up1", top, (size_t)B * S * S * h->top_dim * 2, s))) return rc;
     // to_image + pixel_shuffle + clamp(0,1) (ToImage.forward :110-116, wrapper eval clamp :225-226): fused into the
@@ -468,6 +485,7 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
     if (const char *v = getenv("NUNIF_STEM2_CONV")) h->stem2_conv = atoi(v);
     if (const char *v = getenv("NUNIF_FUSE_TOIMAGE")) h->fuse_to_image = atoi(v);
     if (const char *v = getenv("NUNIF_SNAKE")) h->snake = atoi(v);
+    if (const char *v = getenv("NUNIF_STEM_FUSED")) h->stem_fused = atoi(v);
     h->scale_factor = scale_factor;
     const std::string P = "unet.";
     int rc = NUNIF_HIP_OK;
@@ -505,6 +523,21 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
                     std::copy(packed.begin() + ((size_t)nt * KS + ks) * 512, packed.begin() + ((size_t)nt * KS + ks + 1) * 512,
                               stream.begin() + ((size_t)ks * NT + nt) * 512);
             if ((rc = upload(h, stream, &h->stem2_stream))) break;
+        }
+        if (stem_fused_supported(C1, C)) {
+            const float *w0d = w0->data, *b0d = b0->data, *wd = w2->data;
+            std::vector<f16> p1 = pack_a_fragments(C1, 32, [=](int n, int k) {
+                return k < 27 ? w0d[(size_t)n * 27 + k] : (k == 27 ? b0d[n] : 0.0f); }, false);
+            const int K2 = 448, KS = K2 / 32, NT = C / 16;
+            std::vector<f16> p2 = pack_a_fragments(C, K2, [=](int n, int k) {
+                const int tap = k / C1, ci = k % C1;
+                return k < 9 * C1 ? wd[((size_t)n * C1 + ci) * 9 + tap] : 0.0f; }, false);
+            std::vector<f16> stream((size_t)KS * NT * 512, (f16)0.0f);
+            for (int ks = 0; ks < KS; ++ks)
+                for (int nt = 0; nt < NT; ++nt)
+                    std::copy(p2.begin() + ((size_t)nt * KS + ks) * 512, p2.begin() + ((size_t)nt * KS + ks + 1) * 512,
+                              stream.begin() + ((size_t)ks * NT + nt) * 512);
+            if ((rc = upload(h, p1, &h->stemf_w1)) || (rc = upload(h, stream, &h->stemf_w2))) break;
         }
         if ((rc = make_stage(h, m, P + "swin1", C, 2, &h->swin[0]))) break;
         if ((rc = make_stage(h, m, P + "swin2", 2 * C, 2, &h->swin[1]))) break;
