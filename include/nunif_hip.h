@@ -183,6 +183,14 @@ int nunif_hip_row_flow_delta(nunif_row_flow *handle, const float *x, float *delt
 int nunif_hip_delta_warp(const float *c, const float *delta, float *out, int32_t B, int32_t C, int32_t H, int32_t W,
                          int32_t dh, int32_t dw, double delta_scale, int32_t flip, void *stream);
 
+/* iw3 output formats.
+ * anaglyph: iw3/anaglyph.py apply_anaglyph_redcyan :96-110; left, right, out: [3,H,W] f32; mode 0 color, 1 gray, 2 half-color,
+ * 3 wimmer, 4 wimmer2, 5 dubois, 6 dubois2.
+ * equirectangular: iw3/equirectangular.py equirectangular_projection :7-40 (VR180); c: [C,h,w] f32 -> out: [C,Hp,Wp] with
+ * Hp = h + 2*((S - h)/2), Wp = w + 2*((S - w)/2), S = max(h,w) + max(h,w)/2 (the zero padding is folded into the sampler). */
+int nunif_hip_anaglyph(const float *left, const float *right, float *out, int32_t H, int32_t W, int32_t mode, void *stream);
+int nunif_hip_equirectangular(const float *c, float *out, int32_t C, int32_t h, int32_t w, void *stream);
+
 /* iw3 "sbs.mlbw" (iw3/models/mlbw.py :37-247; --method mlbw_l2 / mlbw_l4 / mlbw_l2s / mlbw_l4s): multi-layer backward
  * warp.  create() takes the reference state dict (lv1_in.1, lv2.N.*, lv1_out.1); the layer count (2 / 4) and the
  * small / full block stack are read from the tensor shapes.  x: [B,3,h,w] feature planes; delta, weight: [B,L,h,w] f32
@@ -193,6 +201,21 @@ void nunif_hip_mlbw_destroy(nunif_mlbw *handle);
 int32_t nunif_hip_mlbw_num_layers(const nunif_mlbw *handle);
 int nunif_hip_mlbw_delta(nunif_mlbw *handle, const float *x, float *delta, float *weight, int32_t B, int32_t h, int32_t w,
                          int32_t flip, void *stream);
+/* "sbs.mask_mlbw_l2" (mlbw.py:275-278; MLBW(hole_mask=True): lv1_out has 2L + 1 channels): the extra channel is the hole
+ * logit map.  mask_logits: [B,1,h,w] f32, already flipped back to image coordinates when flip != 0
+ * (backward_warp.py:325-327); NULL = skip it.  has_hole_mask: 1 when the loaded weights carry the extra channel. */
+int32_t nunif_hip_mlbw_has_hole_mask(const nunif_mlbw *handle);
+int nunif_hip_mlbw_delta_mask(nunif_mlbw *handle, const float *x, float *delta, float *weight, float *mask_logits, int32_t B,
+                              int32_t h, int32_t w, int32_t flip, void *stream);
+/* iw3/backward_warp.py postprocess_hole_mask :382-393 with iw3/dilation.py closing :64-71 (n_iter = 1, 3x3),
+ * dilate_inner :91-103 / dilate_outer :74-88: closing of the logits at model resolution, bilinear (align_corners) resize to
+ * H x W, sigmoid > threshold, then the horizontal OR-dilations.  logits: [B,1,h,w] f32; mask: [B,1,H,W] uint8 (0 / 1);
+ * work: 2*B*h*w floats followed by B*H*W bytes.  inner_iter / outer_iter are the FINAL iteration counts (the caller applies the reference's
+ * max(round(W / base_width * n), 1) scaling); mask[x] = OR of the thresholded map over [x - outer_iter, x + inner_iter].
+ * z (optional, [B,C,H,W] f32): the "hole fill for visualize" of apply_divergence_nn_delta_weight :333-339, z *= 1 - mask. */
+int nunif_hip_hole_mask_postprocess(const float *logits, uint8_t *mask, float *work, int32_t B, int32_t h, int32_t w,
+                                    int32_t H, int32_t W, float threshold, int32_t inner_iter, int32_t outer_iter, float *z,
+                                    int32_t C, void *stream);
 
 /* The composite of iw3/backward_warp.py apply_divergence_nn_delta_weight :300-321: out = clamp(sum_i
  * backward_warp(c, delta_i) * weight_i).  delta: [B,L,dh,dw]; weight: [B,L,H,W] already at image resolution (the

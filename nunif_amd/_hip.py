@@ -76,6 +76,13 @@ SIGNATURES = {
     "nunif_hip_mlbw_destroy": (None, [c_void_p]),
     "nunif_hip_mlbw_num_layers": (c_int32, [c_void_p]),
     "nunif_hip_mlbw_delta": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_anaglyph": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_equirectangular": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_mlbw_has_hole_mask": (c_int32, [c_void_p]),
+    "nunif_hip_mlbw_delta_mask": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                            c_void_p]),
+    "nunif_hip_hole_mask_postprocess": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_float, c_int32, c_int32,
+                                                  c_void_p, c_int32, c_void_p]),
     "nunif_hip_delta_weight_warp": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 7 +
                                     [c_double, c_int32, c_void_p]),
     "nunif_hip_depth_aa_create": (c_int32, [ctypes.POINTER(TensorDesc), c_int32, ctypes.POINTER(c_void_p)]),

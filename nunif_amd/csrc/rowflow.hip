@@ -353,12 +353,13 @@ struct MlbwOutArgs {
     const f16 *f, *x1;       // [B,Hp,Wq,C]
     const float *w;          // [Cs*9][2L] (k = ci*9 + tap) then bias[2L]
     float *delta, *weight;   // [B,L,h,w] each
-    int B, h, w_, Hp, Wp, ph1, pw1, Cs, L;
+    float *mask;             // hole-mask variant (2L + 1 outputs): [B,1,h,w] logits in IMAGE coordinates, else NULL
+    int B, h, w_, Hp, Wp, ph1, pw1, Cs, L, no, flip;
 };
 
 __global__ void __launch_bounds__(256) mlbw_out_kernel(MlbwOutArgs a) {
     __shared__ float sw[(16 * 9 + 1) * 8];
-    const int no = 2 * a.L;
+    const int no = a.no;         // 2L, or 2L + 1 with the hole-mask logit (mlbw.py:70-75, 104-106)
     for (int i = threadIdx.x; i < (a.Cs * 9 + 1) * no; i += 256) sw[i] = a.w[i];
     __syncthreads();
     const long total = (long)a.B * a.h * a.w_;
@@ -390,6 +391,9 @@ __global__ void __launch_bounds__(256) mlbw_out_kernel(MlbwOutArgs a) {
         a.delta[o0 + i * hw] = acc[i];
         a.weight[o0 + i * hw] = e[i] / sum;
     }
+    // the reference flips the logits back for the right eye (backward_warp.py:325-327); delta / weight stay in model
+    // coordinates because the warp kernel folds the flip
+    if (a.mask) a.mask[((long)b * a.h + y) * a.w_ + (a.flip ? a.w_ - 1 - x : x)] = acc[2 * a.L];
 }
 
 }  // namespace nunif
@@ -664,7 +668,7 @@ extern "C" int nunif_hip_delta_weight_warp(const float *c, const float *delta, c
 // ---- MLBW --------------------------------------------------------------------------------------------------------------
 struct nunif_mlbw {
     std::vector<void *> owned;
-    int L = 2, C = 64, n_blocks = 4;
+    int L = 2, C = 64, n_blocks = 4, hole_mask = 0;
     float *w_in = nullptr, *w_out = nullptr;
     WaBlock blk[4];
     int sy[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
@@ -690,8 +694,11 @@ extern "C" int nunif_hip_mlbw_create(const nunif_tensor_desc *tensors, int32_t n
             break;
         const int Cs = (int)bi->numel;                  // C / 8
         h->C = Cs * 8; h->L = h->C / 32;
-        if ((Cs != 8 && Cs != 16) || wi->numel != (int64_t)Cs * 27 || bo->numel != 2 * h->L || wo->numel != (int64_t)2 * h->L * Cs * 9) {
-            set_error("mlbw: unsupported shape (C/8 = %d, %lld outputs; hole-mask variants are not on the engine yet)", Cs,
+        h->hole_mask = bo->numel == 2 * h->L + 1 ? 1 : 0;             // sbs.mask_mlbw_l2 (mlbw.py:275-278)
+        const int no = 2 * h->L + h->hole_mask;
+        if ((Cs != 8 && Cs != 16) || wi->numel != (int64_t)Cs * 27 || bo->numel != no || no > 8 ||
+            wo->numel != (int64_t)no * Cs * 9) {
+            set_error("mlbw: unsupported shape (C/8 = %d, %lld outputs)", Cs,
                       (long long)bo->numel);
             rc = NUNIF_HIP_EUNSUPPORTED;
             break;
@@ -700,10 +707,9 @@ extern "C" int nunif_hip_mlbw_create(const nunif_tensor_desc *tensors, int32_t n
         // shifts (mlbw.py:57-68): full (T,T),(F,F),(T,T),(F,F); small (F,T),(F,F)
         if (h->n_blocks == 4) { h->sy[0] = h->sx[0] = 2; h->sy[2] = h->sx[2] = 2; }
         else { h->sx[0] = 2; }
-        std::vector<float> win(28 * Cs), wout((size_t)(Cs * 9 + 1) * 2 * h->L);
+        std::vector<float> win(28 * Cs), wout((size_t)(Cs * 9 + 1) * no);
         for (int k = 0; k < 27; ++k) for (int co = 0; co < Cs; ++co) win[k * Cs + co] = wi->data[co * 27 + k];
         for (int co = 0; co < Cs; ++co) win[27 * Cs + co] = bi->data[co];
-        const int no = 2 * h->L;
         for (int k = 0; k < Cs * 9; ++k) for (int o = 0; o < no; ++o) wout[(size_t)k * no + o] = wo->data[(size_t)o * Cs * 9 + k];
         for (int o = 0; o < no; ++o) wout[(size_t)Cs * 9 * no + o] = bo->data[o];
         if ((rc = upload(h, win, &h->w_in)) || (rc = upload(h, wout, &h->w_out))) break;
@@ -723,10 +729,17 @@ extern "C" void nunif_hip_mlbw_destroy(nunif_mlbw *h) {
 }
 
 extern "C" int32_t nunif_hip_mlbw_num_layers(const nunif_mlbw *h) { return h ? h->L : 0; }
+extern "C" int32_t nunif_hip_mlbw_has_hole_mask(const nunif_mlbw *h) { return h ? h->hole_mask : 0; }
 
 extern "C" int nunif_hip_mlbw_delta(nunif_mlbw *h, const float *x, float *delta, float *weight, int32_t B, int32_t hh,
                                     int32_t ww, int32_t flip, void *stream) {
+    return nunif_hip_mlbw_delta_mask(h, x, delta, weight, nullptr, B, hh, ww, flip, stream);
+}
+
+extern "C" int nunif_hip_mlbw_delta_mask(nunif_mlbw *h, const float *x, float *delta, float *weight, float *mask_logits,
+                                         int32_t B, int32_t hh, int32_t ww, int32_t flip, void *stream) {
     NUNIF_REQUIRE(h && x && delta && weight && B > 0 && hh > 0 && ww > 0, "mlbw_delta: bad argument");
+    NUNIF_REQUIRE(!mask_logits || h->hole_mask, "mlbw_delta_mask: this model has no hole-mask output");
     hipStream_t s = (hipStream_t)stream;
     const int pad_w = 32 - ww % 32, pad_h = 4 - hh % 4;                 // mlbw.py:78-93 (eval: centred)
     const int pw1 = pad_w / 2, ph1 = pad_h / 2;
@@ -777,7 +790,8 @@ extern "C" int nunif_hip_mlbw_delta(nunif_mlbw *h, const float *x, float *delta,
         ProfScope ps("mlbw_out_kernel", s, 2.0 * 9 * Cs * 2 * h->L * (double)px, (double)px * (8.0 * h->L + 36.0 * Cs));
         MlbwOutArgs a;
         a.f = cur; a.x1 = x1; a.w = h->w_out; a.delta = delta; a.weight = weight; a.B = B; a.h = hh; a.w_ = ww; a.Hp = Hp;
-        a.Wp = Wp; a.ph1 = ph1; a.pw1 = pw1; a.Cs = Cs; a.L = h->L;
+        a.Wp = Wp; a.ph1 = ph1; a.pw1 = pw1; a.Cs = Cs; a.L = h->L; a.no = 2 * h->L + h->hole_mask; a.flip = flip;
+        a.mask = mask_logits;
         mlbw_out_kernel<<<(unsigned)((px + 255) / 256), 256, 0, s>>>(a);
         NUNIF_LAUNCH_CHECK();
     }

@@ -202,3 +202,45 @@ def delta_weight_warp(c, delta, weight, delta_scale, flip=False):
                                                           delta.shape[3], layers, float(delta_scale), 1 if flip else 0,
                                                           _hip.current_stream_ptr(c.device)))
     return out
+
+
+def hole_mask_postprocess(mask_logits, target_size, threshold, inner_iter=0, outer_iter=0, z=None):
+    """``nunif_hip_hole_mask_postprocess``: closing + bilinear resize + sigmoid > threshold + horizontal OR-dilations.
+    mask_logits [B,1,h,w] f32 -> bool [B,1,H,W]; ``z`` ([B,C,H,W] f32, optional) is zeroed in place where the mask is set."""
+    x = _cuda_f32(mask_logits, "hole_mask_postprocess")
+    B, one, h, w = x.shape
+    assert one == 1
+    H, W = int(target_size[0]), int(target_size[1])
+    mask = torch.empty((B, 1, H, W), dtype=torch.uint8, device=x.device)
+    work = torch.empty((2 * B * h * w + (B * H * W + 3) // 4,), dtype=torch.float32, device=x.device)
+    if z is not None:
+        assert z.dtype == torch.float32 and z.is_contiguous() and z.shape[0] == B and tuple(z.shape[2:]) == (H, W)
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_hole_mask_postprocess(
+            _p(x), _p(mask), _p(work), B, h, w, H, W, float(threshold), int(inner_iter), int(outer_iter),
+            _p(z), int(z.shape[1]) if z is not None else 0,
+            _hip.current_stream_ptr(x.device)))
+    return mask.bool()
+
+
+def anaglyph(left, right, mode):
+    left, right = _cuda_f32(left, "anaglyph"), _cuda_f32(right, "anaglyph")
+    assert left.ndim == 3 and left.shape[0] == 3 and left.shape == right.shape
+    out = torch.empty_like(left)
+    with torch.cuda.device(left.device):
+        _hip.check(_hip.lib().nunif_hip_anaglyph(_p(left), _p(right), _p(out), left.shape[1], left.shape[2], int(mode),
+                                                 _hip.current_stream_ptr(left.device)))
+    return out
+
+
+def equirectangular(c):
+    c = _cuda_f32(c, "equirectangular")
+    assert c.ndim == 3
+    C, h, w = c.shape
+    max_edge = max(h, w)
+    size = max_edge + max_edge // 2
+    Hp, Wp = h + 2 * ((size - h) // 2), w + 2 * ((size - w) // 2)
+    out = torch.empty((C, Hp, Wp), dtype=torch.float32, device=c.device)
+    with torch.cuda.device(c.device):
+        _hip.check(_hip.lib().nunif_hip_equirectangular(_p(c), _p(out), C, h, w, _hip.current_stream_ptr(c.device)))
+    return out

@@ -2,7 +2,7 @@
 (``make_grid`` :86-93 and ``backward_warp`` :67-83 folded into ``nunif_hip_backward_warp``) and the NN-delta path the
 default ``--method row_flow_v3`` takes — ``make_divergence_feature_value`` :8-14, ``make_input_tensor`` :17-64 (c=None),
 ``apply_divergence_nn_LR`` :124-160, ``apply_divergence_nn`` :163-188, ``apply_divergence_nn_delta`` :191-236.
-and the multi-layer variant ``apply_divergence_nn_delta_weight`` :262-341 (MLBW).  Symmetric models and the hole-mask
+and the multi-layer variant ``apply_divergence_nn_delta_weight`` :262-341 (MLBW).  Symmetric models and the cycle
 output are not provided yet.
 """
 import torch
@@ -77,9 +77,8 @@ def apply_divergence_nn_delta_weight(model, c, depth, divergence, convergence, s
                                      enable_amp=True, return_mask=False):
     """MLBW: L flows + softmax layer weights; composite = clamp(sum_i backward_warp(c, delta_i) * w_i)."""
     assert model.delta_output
-    if return_mask or getattr(model, "hole_mask", False):
-        raise NotImplementedError("the hole-mask MLBW output is not on the HIP engine yet")
     flip = shift > 0
+    hole_mask = bool(getattr(model, "hole_mask", False))
     B, _, H, W = depth.shape
     base_size = max(H, W)
     if torch.is_tensor(convergence):
@@ -89,12 +88,56 @@ def apply_divergence_nn_delta_weight(model, c, depth, divergence, convergence, s
     x = torch.stack([make_input_tensor(None, depth[i], divergence=divergence, convergence=convergence[i],
                                        image_width=base_size, preserve_screen_border=preserve_screen_border)
                      for i in range(B)])
-    delta, layer_weight = model.infer_delta(x, flip=flip)
+    if hole_mask:
+        delta, layer_weight, hole_mask_logits = model.infer_delta(x, flip=flip)   # logits already in image coordinates
+    else:
+        delta, layer_weight = model.infer_delta(x, flip=flip)
+        hole_mask_logits = None
     if c.shape[2] != layer_weight.shape[2] or c.shape[3] != layer_weight.shape[3]:
         # F.interpolate(layer_weight, size, bilinear, align_corners=True, antialias=True)  :295-297
         layer_weight = _ops.resize_aa(layer_weight, c.shape[-2:], mode="bilinear", align_corners=True)
     delta_scale = 1.0 / (W // 2 - 1)
-    return _ops.delta_weight_warp(c, delta, layer_weight, delta_scale, flip=flip).to(c.dtype)
+    z = _ops.delta_weight_warp(c, delta, layer_weight, delta_scale, flip=flip)
+    if return_mask:
+        return z.to(c.dtype), hole_mask_logits
+    if hole_mask_logits is not None:
+        # "hole fill for visualize" :333-339: z = z * (1 - mask), fused into the mask kernel
+        _ops.hole_mask_postprocess(hole_mask_logits, c.shape[-2:], 0.15, z=z)
+    return z.to(c.dtype)
+
+
+def _scaled_iter(n_iter, width, base_width):
+    """dilate_inner / dilate_outer (iw3/dilation.py:74-103): n_iter <= 0 is a no-op, else max(round(W / base * n), 1)."""
+    if n_iter <= 0:
+        return 0
+    return max(round(width / base_width * n_iter), 1) if base_width is not None else n_iter
+
+
+def postprocess_hole_mask(mask_logits, target_size, threshold, inner_dilation=0, outer_dilation=0):
+    """Reference :382-393: closing(n_iter=1) -> bilinear resize (align_corners) -> sigmoid > threshold ->
+    dilate_inner / dilate_outer (horizontal OR-dilations scaled by target width / logit width).  Returns bool [B,1,H,W]."""
+    base_width = mask_logits.shape[-1]
+    width = int(target_size[1])
+    return _ops.hole_mask_postprocess(mask_logits, target_size, threshold,
+                                      inner_iter=_scaled_iter(inner_dilation, width, base_width),
+                                      outer_iter=_scaled_iter(outer_dilation, width, base_width))
+
+
+def nonwarp_mask(model, c, depth, divergence, convergence, mapper=None, threshold=0.15, inner_dilation=0, outer_dilation=0):
+    """Reference :396-422: warp the depth to the left, warp it back to the right with the hole-mask model and return
+    ``(c, mask)`` — the disocclusion mask of the un-warped view."""
+    disparity = get_mapper(mapper)(depth) if mapper is not None else depth
+    warped_depth, _ = apply_divergence_nn_delta_weight(model, depth, disparity, divergence=divergence,
+                                                       convergence=convergence, steps=1, shift=-1,
+                                                       preserve_screen_border=False, enable_amp=True, return_mask=True)
+    disparity = get_mapper(mapper)(warped_depth) if mapper is not None else depth
+    dummy = torch.zeros_like(c)
+    _, mask_logits = apply_divergence_nn_delta_weight(model, dummy, disparity, divergence=divergence,
+                                                      convergence=convergence, steps=1, shift=1,
+                                                      preserve_screen_border=False, enable_amp=True, return_mask=True)
+    mask = postprocess_hole_mask(mask_logits, c.shape[-2:], threshold=threshold, inner_dilation=inner_dilation,
+                                 outer_dilation=outer_dilation)
+    return c, mask
 
 
 def apply_divergence_nn(model, c, depth, divergence, convergence, steps, shift, preserve_screen_border=False,

@@ -5,7 +5,8 @@ Mirrors ``iw3/models/mlbw.py`` (reference) ``MLBW`` :37-247 — registry name + 
 offset 32, in_channels 8, blend_size 4), ``num_layers`` / ``delta_output`` / ``symmetric`` / ``hole_mask`` attributes and
 the ``state_dict`` key layout (``lv1_in.1``, ``lv2.N.*``, ``lv1_out.1``).  Only the inference path iw3 uses is on the
 engine: ``delta_output = True`` (``_forward_delta_only`` :238-247) -> ``(delta, layer_weight)``, consumed by
-``apply_divergence_nn_delta_weight``.  The ``cycle`` (training) and ``hole_mask`` variants are not provided.
+``apply_divergence_nn_delta_weight``.  ``hole_mask=True`` (``sbs.mask_mlbw_l2`` :275-278) adds the hole-logit channel
+(``_forward`` :104-106, ``_forward_delta_only`` :234-238).  The ``cycle`` (training) variant is not provided.
 """
 import ctypes
 import math
@@ -20,7 +21,7 @@ from .row_flow_v3 import _score_bias_input
 OFFSET = 32
 
 
-def _init_weights(num_layers, small):
+def _init_weights(num_layers, small, hole_mask=False):
     C = 32 * num_layers
     sd = OrderedDict()
 
@@ -41,7 +42,7 @@ def _init_weights(num_layers, small):
         sd[p + "bias.index"], sd[p + "bias.delta"] = _score_bias_input((4, 4))
         lin(p + "bias.to_bias.0", 8, 2)
         lin(p + "bias.to_bias.2", 1, 8)
-    lin("lv1_out.1", 2 * num_layers, C // 8, 1, 9)
+    lin("lv1_out.1", 2 * num_layers + (1 if hole_mask else 0), C // 8, 1, 9)
     return sd
 
 
@@ -67,6 +68,7 @@ class HipMLBWEngine:
             _hip.check(_hip.lib().nunif_hip_mlbw_create(arr, len(descs), ctypes.byref(handle)))
         self.handle = handle
         self.num_layers = _hip.lib().nunif_hip_mlbw_num_layers(handle)
+        self.hole_mask = bool(_hip.lib().nunif_hip_mlbw_has_hole_mask(handle))
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -81,10 +83,14 @@ class HipMLBWEngine:
         assert C == 3
         delta = torch.empty((B, self.num_layers, h, w), dtype=torch.float32, device=self.device)
         weight = torch.empty_like(delta)
+        mask = torch.empty((B, 1, h, w), dtype=torch.float32, device=self.device) if self.hole_mask else None
         with torch.cuda.device(self.device):
-            _hip.check(_hip.lib().nunif_hip_mlbw_delta(self.handle, ctypes.c_void_p(x.data_ptr()),
-                                                       ctypes.c_void_p(delta.data_ptr()), ctypes.c_void_p(weight.data_ptr()),
-                                                       B, h, w, 1 if flip else 0, _hip.current_stream_ptr(self.device)))
+            _hip.check(_hip.lib().nunif_hip_mlbw_delta_mask(
+                self.handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(delta.data_ptr()),
+                ctypes.c_void_p(weight.data_ptr()), ctypes.c_void_p(mask.data_ptr() if mask is not None else None),
+                B, h, w, 1 if flip else 0, _hip.current_stream_ptr(self.device)))
+        if self.hole_mask:
+            return delta, weight, mask          # mask logits are already flipped back to image coordinates
         return delta, weight
 
 
@@ -97,14 +103,16 @@ class MLBW(I2IBaseModel):
                          scale=1, offset=OFFSET, in_channels=8, blend_size=4)
         if base_dim != 32 or num_layers not in (2, 4):
             raise ValueError("the HIP mlbw engine supports base_dim = 32 with 2 or 4 layers (heads of 32 channels)")
-        if cycle or hole_mask:
-            raise NotImplementedError("cycle / hole_mask MLBW variants are not on the HIP engine yet")
+        if cycle:
+            raise NotImplementedError("the cycle (training) MLBW variant is not on the HIP engine")
+        if hole_mask and num_layers != 2:
+            raise ValueError("the hole-mask variant is registered for 2 layers only (sbs.mask_mlbw_l2)")
         self.register_buffer("_device_probe", torch.empty(0), persistent=False)
         self.num_layers = num_layers
         self.cycle, self.hole_mask = cycle, hole_mask
         self.delta_output = False
         self.symmetric = False
-        self._weights = _init_weights(num_layers, small)
+        self._weights = _init_weights(num_layers, small, hole_mask)
         self._engine = None
 
     def get_device(self):
@@ -158,5 +166,6 @@ class MLBW(I2IBaseModel):
 
 register_model_factory("sbs.mlbw_l2", lambda **kwargs: MLBW(num_layers=2, base_dim=32, **kwargs))
 register_model_factory("sbs.mlbw_l4", lambda **kwargs: MLBW(num_layers=4, base_dim=32, **kwargs))
+register_model_factory("sbs.mask_mlbw_l2", lambda **kwargs: MLBW(num_layers=2, base_dim=32, hole_mask=True, **kwargs))
 register_model_factory("sbs.mlbw_l2s", lambda **kwargs: MLBW(num_layers=2, base_dim=32, small=True, **kwargs))
 register_model_factory("sbs.mlbw_l4s", lambda **kwargs: MLBW(num_layers=4, base_dim=32, small=True, **kwargs))

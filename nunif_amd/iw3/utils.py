@@ -1,15 +1,17 @@
 """Per-frame stereo glue on the HIP engine.  Mirrors the hot-path functions of ``iw3/utils.py`` (reference):
 ``apply_divergence`` :292-391 (mapper + method dispatch; forward / forward_fill / grid_sample / backward / NULL),
-``postprocess_image`` :430-487 (IPD pad, half-SBS / half-TB bicubic-antialias resize, SBS / TB / cross-eyed compose,
-max-output resize) and ``nunif/utils/video.py`` ``to_tensor`` / ``to_frame`` :218-269 (``to_frame_tensor`` here returns
+``postprocess_image`` :430-487 (IPD pad, ``postprocess_padding`` :394-427, VR180 projection, half-SBS / half-TB / half-RGBD
+bicubic-antialias resize, anaglyph / SBS / TB / cross-eyed compose, max-output resize), ``apply_rgbd`` :74-88 and ``nunif/utils/video.py`` ``to_tensor`` / ``to_frame`` :218-269 (``to_frame_tensor`` here returns
 the quantised HWC tensor; wrapping it into an ``av.VideoFrame`` is the caller's codec business).
-``row_flow_v3`` (the default method) and ``mlbw_l2/l4/l2s/l4s`` run on the engine; inpaint side models, anaglyph and VR180 projection are
-"next" rows."""
+``row_flow_v3`` (the default method) and ``mlbw_l2/l4/l2s/l4s`` run on the engine; the inpaint side models are a
+"next" row."""
 import torch
 import torch.nn.functional as F
 
 from . import _ops
+from .anaglyph import apply_anaglyph_redcyan
 from .backward_warp import apply_divergence_grid_sample, apply_divergence_nn_LR
+from .equirectangular import equirectangular_projection
 from .forward_warp import apply_divergence_forward_warp
 from .mapper import get_mapper
 
@@ -55,28 +57,72 @@ def _zero_pad(x, left, top, right, bottom):
     return F.pad(x, (left, right, top, bottom), mode="constant", value=0.0)
 
 
+def apply_rgbd(im, depth, mapper):
+    """RGBD output (iw3/utils.py:74-88): left = image, right = the (mapped) depth resized bicubic-antialias, 3 channels."""
+    height, width = im.shape[-2:]
+    if mapper is not None:
+        depth = get_mapper(mapper)(depth)
+    batch = depth.ndim == 4
+    right = _ops.resize_aa(depth if batch else depth.unsqueeze(0), (height, width), mode="bicubic")
+    if not batch:
+        right = right.squeeze(0)
+    return im, right.expand_as(im)
+
+
+def postprocess_padding(left_eye, right_eye, pad, pad_mode):
+    """Zero padding of both eyes (iw3/utils.py:394-427): fractions of the frame (tblr / tb / lr / top) or fit to 16:9."""
+    assert pad_mode in {"tblr", "tb", "lr", "16:9", "top"}
+    pad_l = pad_t = pad_r = pad_b = 0
+    if pad_mode in {"tblr", "tb", "lr"}:
+        if "tb" in pad_mode:
+            pad_t = pad_b = round(left_eye.shape[1] * pad) // 2
+        if "lr" in pad_mode:
+            pad_l = pad_r = round(left_eye.shape[2] * pad) // 2
+    elif pad_mode == "top":
+        pad_t = round(left_eye.shape[1] * pad)
+    else:
+        target_ratio = 16 / 9
+        height, width = left_eye.shape[1:]
+        current_ratio = width / height
+        if abs(target_ratio - current_ratio) > 1e-3:
+            if current_ratio > target_ratio:
+                pad_t = pad_b = (round(width / target_ratio) - height) // 2
+            else:
+                pad_l = pad_r = (round(height * target_ratio) - width) // 2
+        else:
+            return left_eye, right_eye
+    return _zero_pad(left_eye, pad_l, pad_t, pad_r, pad_b), _zero_pad(right_eye, pad_l, pad_t, pad_r, pad_b)
+
+
 def postprocess_image(left_eye, right_eye, args):
     """CHW, CHW -> CHW float in [0,1]."""
     g = lambda k, d=None: getattr(args, k, d)     # noqa: E731
-    for unsupported in ("vr180", "anaglyph", "rgbd", "half_rgbd"):
-        if g(unsupported):
-            raise NotImplementedError(f"--{unsupported} is not on the HIP engine yet")
     ipd_pad = int(abs(g("ipd_offset", 0)) * 0.01 * max(left_eye.shape[-2:]))
     ipd_pad -= ipd_pad % 2
-    if ipd_pad > 0:
+    if ipd_pad > 0 and not (g("rgbd") or g("half_rgbd")):
         pad_o, pad_i = (ipd_pad * 2, ipd_pad) if g("ipd_offset", 0) > 0 else (ipd_pad, ipd_pad * 2)
         left_eye = _zero_pad(left_eye, pad_o, 0, pad_i, 0)
         right_eye = _zero_pad(right_eye, pad_i, 0, pad_o, 0)
     if g("pad") is not None or g("pad_mode") == "16:9":
-        raise NotImplementedError("--pad / --pad-mode is not on the HIP engine yet")
-    if g("half_sbs"):
+        left_eye, right_eye = postprocess_padding(left_eye, right_eye, pad=g("pad"), pad_mode=g("pad_mode"))
+    if g("vr180"):
+        left_eye, right_eye = equirectangular_projection(left_eye), equirectangular_projection(right_eye)
+    elif g("half_sbs") or g("half_rgbd"):
         size = (left_eye.shape[1], left_eye.shape[2] // 2)
         left_eye, right_eye = (_ops.resize_aa(e.unsqueeze(0), size, mode="bicubic")[0] for e in (left_eye, right_eye))
     elif g("half_tb"):
         size = (left_eye.shape[1] // 2, left_eye.shape[2])
         left_eye, right_eye = (_ops.resize_aa(e.unsqueeze(0), size, mode="bicubic")[0] for e in (left_eye, right_eye))
+    if g("anaglyph") is not None:
+        sbs = apply_anaglyph_redcyan(left_eye, right_eye, g("anaglyph"))
+        return _max_output_resize(sbs, args)
     layout = "tb" if (g("tb") or g("half_tb")) else ("cross_eyed" if g("cross_eyed") else "sbs")
-    sbs = _ops.stereo_compose(left_eye, right_eye, layout)
+    sbs = _ops.stereo_compose(left_eye.contiguous(), right_eye.contiguous(), layout)
+    return _max_output_resize(sbs, args)
+
+
+def _max_output_resize(sbs, args):
+    g = lambda k, d=None: getattr(args, k, d)     # noqa: E731
     h, w = sbs.shape[1:]
     new_w, new_h = w, h
     if g("max_output_height") is not None and new_h > args.max_output_height:

@@ -181,7 +181,7 @@ def row_flow_v3_state_dict(seed):
     return sd
 
 
-def mlbw_state_dict(seed, num_layers=2, small=False):
+def mlbw_state_dict(seed, num_layers=2, small=False, hole_mask=False):
     """Seeded weights in the reference's key layout (every bias non-zero); the output conv is scaled so that the layer
     deltas differ by a few depth pixels and the layer-weight logits really select between them."""
     g = torch.Generator().manual_seed(seed)
@@ -208,7 +208,10 @@ def mlbw_state_dict(seed, num_layers=2, small=False):
         lin(p + "bias.to_bias.0", 8, 2, std=1.0, bstd=0.3)
         lin(p + "bias.to_bias.2", 1, 8, std=1.0, bstd=0.3)
         sd[p + "bias.index"], sd[p + "bias.delta"] = window_score_bias_input((4, 4))
-    lin("lv1_out.1", 2 * num_layers, C // 8, 1, 9, std=2.0 * math.sqrt(1.0 / (9 * C // 8)), bstd=1.0)
+    lin("lv1_out.1", 2 * num_layers + (1 if hole_mask else 0), C // 8, 1, 9, std=2.0 * math.sqrt(1.0 / (9 * C // 8)),
+        bstd=1.0)
+    if hole_mask:
+        sd["lv1_out.1.bias"][2 * num_layers] = -1.7     # logit(0.15): the default threshold cuts through the map
     return sd
 
 

@@ -126,3 +126,127 @@ class EMAScaler:
         out = [self._norm(f, lo, hi) for f in self.queue]
         self.reset()
         return out
+
+
+# ---- output formats ---------------------------------------------------------------------------------------------------------
+# iw3/anaglyph.py :4-110 (seven red-cyan methods), iw3/equirectangular.py :7-40 (VR180), iw3/utils.py apply_rgbd :74-88,
+# postprocess_padding :394-427 and the full postprocess_image :430-487.
+def _luma(x):
+    return x[0:1] * 0.299 + x[1:2] * 0.587 + x[2:3] * 0.114
+
+
+def _srgb_decode(x):
+    return torch.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+
+
+def _srgb_encode(x):
+    return torch.where(x <= 0.0031308, x * 12.92, 1.055 * x ** (1.0 / 2.4) - 0.055)
+
+
+_DUBOIS_L = ((0.437, 0.449, 0.164), (-0.062, -0.062, -0.024), (-0.048, -0.050, -0.017))
+_DUBOIS_R = ((-0.011, -0.032, -0.007), (0.377, 0.761, 0.009), (-0.026, -0.093, 1.234))
+
+
+def anaglyph(left, right, kind):
+    if kind == "color":
+        return torch.cat([left[0:1], right[1:3]], 0)
+    if kind == "gray":
+        ry = _luma(right)
+        return torch.cat([_luma(left), ry, ry], 0).clamp(0, 1)
+    if kind == "half-color":
+        return torch.cat([_luma(left), right[1:3]], 0).clamp(0, 1)
+    if kind == "wimmer":
+        return torch.cat([left[1:2] * 0.7 + left[2:3] * 0.3, right[1:3]], 0).clamp(0, 1)
+    if kind == "wimmer2":
+        def gb(e):
+            return (e[1:2] + 0.45 * (e[0:1] - e[1:2]).clamp(min=0), e[2:3] + 0.25 * (e[0:1] - e[2:3]).clamp(min=0))
+        (gl, bl), (gr, br) = gb(left), gb(right)
+        return torch.cat([(0.75 * gl + 0.25 * bl) ** (1.0 / 1.6), gr, br], 0).clamp(0, 1)
+    if kind in ("dubois", "dubois2"):
+        ll, rl = _srgb_decode(left), _srgb_decode(right)
+        rows = []
+        for lm, rm in zip(_DUBOIS_L, _DUBOIS_R):
+            a = (ll * torch.tensor(lm).view(3, 1, 1)).sum(0, keepdim=True)
+            b = (rl * torch.tensor(rm).view(3, 1, 1)).sum(0, keepdim=True)
+            if kind == "dubois":
+                a, b = a.clamp(0, 1), b.clamp(0, 1)
+            rows.append(a + b)
+        return _srgb_encode(torch.cat(rows, 0).clamp(0, 1)).clamp(0, 1)
+    raise ValueError(kind)
+
+
+def equirectangular(c):
+    h, w = c.shape[1:]
+    edge = max(h, w)
+    size = edge + edge // 2
+    pw, ph = (size - w) // 2, (size - h) // 2
+    c = F.pad(c, (pw, pw, ph, ph))
+    H, W = c.shape[1:]
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    az, el = xs * (math.pi * 0.5), ys * (math.pi * 0.5)
+    k = edge / size
+    grid = torch.stack([k * torch.tan(az), k * (torch.tan(el) / torch.cos(az))], 2)
+    return F.grid_sample(c[None], grid[None], mode="bicubic", padding_mode="zeros", align_corners=True)[0].clamp(0, 1)
+
+
+def rgbd(im, depth):
+    right = F.interpolate(depth[None], im.shape[-2:], mode="bicubic", antialias=True)[0]
+    return im, right.expand_as(im)
+
+
+def padding(left, right, pad, pad_mode):
+    l = t = r = b = 0
+    H, W = left.shape[1:]
+    if pad_mode in ("tblr", "tb", "lr"):
+        if "tb" in pad_mode:
+            t = b = round(H * pad) // 2
+        if "lr" in pad_mode:
+            l = r = round(W * pad) // 2
+    elif pad_mode == "top":
+        t = round(H * pad)
+    elif abs(16 / 9 - W / H) > 1e-3:
+        if W / H > 16 / 9:
+            t = b = (round(W / (16 / 9)) - H) // 2
+        else:
+            l = r = (round(H * (16 / 9)) - W) // 2
+    return F.pad(left, (l, r, t, b)), F.pad(right, (l, r, t, b))
+
+
+def postprocess_image(left, right, ipd_offset=0, pad=None, pad_mode=None, vr180=False, half_sbs=False, half_tb=False,
+                      half_rgbd=False, rgbd_out=False, tb=False, cross_eyed=False, anaglyph_kind=None,
+                      max_output_height=None, max_output_width=None, keep_aspect_ratio=False):
+    ipd = int(abs(ipd_offset) * 0.01 * max(left.shape[-2:]))
+    ipd -= ipd % 2
+    if ipd > 0 and not (rgbd_out or half_rgbd):
+        o, i = (ipd * 2, ipd) if ipd_offset > 0 else (ipd, ipd * 2)
+        left, right = F.pad(left, (o, i, 0, 0)), F.pad(right, (i, o, 0, 0))
+    if pad is not None or pad_mode == "16:9":
+        left, right = padding(left, right, pad, pad_mode)
+    bic = lambda e, size: F.interpolate(e[None], size=size, mode="bicubic", align_corners=False, antialias=True)[0]  # noqa: E731
+    if vr180:
+        left, right = equirectangular(left), equirectangular(right)
+    elif half_sbs or half_rgbd:
+        left, right = (bic(e, (e.shape[1], e.shape[2] // 2)) for e in (left, right))
+    elif half_tb:
+        left, right = (bic(e, (e.shape[1] // 2, e.shape[2])) for e in (left, right))
+    if anaglyph_kind is not None:
+        out = anaglyph(left, right, anaglyph_kind)
+    elif tb or half_tb:
+        out = torch.cat([left, right], 1).clamp(0, 1)
+    elif cross_eyed:
+        out = torch.cat([right, left], 2).clamp(0, 1)
+    else:
+        out = torch.cat([left, right], 2).clamp(0, 1)
+    h, w = out.shape[1:]
+    nw, nh = w, h
+    if max_output_height is not None and nh > max_output_height:
+        if keep_aspect_ratio:
+            nw = int(max_output_height / nh * nw)
+        nh = max_output_height
+    if max_output_width is not None and nw > max_output_width:
+        if keep_aspect_ratio:
+            nh = int(max_output_width / nw * nh)
+        nw = max_output_width
+    if (nw, nh) != (w, h):
+        out = bic(out, (nh - nh % 2, nw - nw % 2)).clamp(0, 1)
+    return out

@@ -214,6 +214,89 @@ def gen_mlbw():
     save("mlbw", **out)
 
 
+def gen_hole_mask():
+    """sbs.mask_mlbw_l2 (MLBW(hole_mask=True)) + return_mask / hole fill / postprocess_hole_mask / nonwarp_mask on the reference."""
+    from iw3.models.mlbw import MLBW
+    from iw3 import backward_warp as RB
+    from oracle import mlbw as OM, row_flow_v3 as ORF
+    from oracle.forward_warp import synth_depth
+    out = {}
+    depth = synth_depth(9, 2, 58, 104, "smooth_edges")
+    c = torch.stack([synth_image(84, 3, 116, 208), synth_image(85, 3, 116, 208)])
+    out["depth"], out["c"] = depth, c
+    sd = OM.random_state_dict(431, 2, False, hole_mask=True)
+    m = MLBW(num_layers=2, base_dim=32, hole_mask=True).eval()
+    m.load_state_dict(sd, strict=True)
+    m.delta_output = True
+    out["sdsum"] = sd_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    d, w, lg = m(ORF.make_input(depth[:1], 2.0, 0.5, 104))
+    out["delta"], out["weight"], out["logits"] = d, w, lg
+    for tag, shift in (("l", -1), ("r", 1)):
+        z, lgs = RB.apply_divergence_nn_delta_weight(m, c, depth, 2.0, 0.5, steps=1, shift=shift, enable_amp=False,
+                                                     return_mask=True)
+        out["z_" + tag], out["logits_" + tag] = z, lgs
+        out["fill_" + tag] = RB.apply_divergence_nn_delta_weight(m, c, depth, 2.0, 0.5, steps=1, shift=shift, enable_amp=False)
+    lg_r = out["logits_r"]
+    out["mask_same"] = RB.postprocess_hole_mask(lg_r, (58, 104), 0.15)
+    out["mask_up"] = RB.postprocess_hole_mask(lg_r, (116, 208), 0.15)
+    out["mask_dil"] = RB.postprocess_hole_mask(lg_r, (116, 208), 0.15, inner_dilation=1, outer_dilation=2)
+    out["mask_odd"] = RB.postprocess_hole_mask(lg_r, (131, 259), 0.3, inner_dilation=0, outer_dilation=1)
+    _, out["nonwarp"] = RB.nonwarp_mask(m, c, depth, 4.0, 0.5, threshold=0.15, inner_dilation=1, outer_dilation=1)
+    for k in ("mask_same", "mask_up", "mask_dil", "mask_odd", "nonwarp"):
+        print(k, float(out[k].float().mean()))
+        out[k] = np.packbits(out[k].numpy().astype(np.uint8), axis=None)
+    for k in ("z_l", "z_r", "fill_l", "fill_r"):
+        out[k] = out[k].half()
+    save("hole_mask", **out)
+
+
+from make_golden_cases import FORMAT_CASES  # noqa: E402
+
+
+def format_args(**kw):
+    import argparse
+    base = dict(ipd_offset=0, rgbd=False, half_rgbd=False, pad=None, pad_mode="tblr", vr180=False, half_sbs=False, half_tb=False,
+                anaglyph=None, tb=False, cross_eyed=False, max_output_height=None, max_output_width=None,
+                keep_aspect_ratio=False)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def gen_formats():
+    """iw3 output formats on the reference: postprocess_image with padding modes, VR180, anaglyph, RGBD (iw3/utils.py)."""
+    import av
+    av.__version__ = "14.2.0"          # the import stub's version string does not parse; iw3.utils only compares it
+    import iw3.utils as U
+    from oracle.forward_warp import synth_depth
+
+    class TFShim:
+        """torchvision.transforms.functional is not installed: its two tensor functions postprocess_image uses, restated
+        (pad: F.pad with (left, top, right, bottom) order; resize: F.interpolate(bicubic, antialias) — what torchvision
+        0.22 does for tensors)."""
+        @staticmethod
+        def pad(img, padding, padding_mode="constant"):
+            l, t, r, b = padding
+            return torch.nn.functional.pad(img, (l, r, t, b), mode=padding_mode)
+
+        @staticmethod
+        def resize(img, size, interpolation=None, antialias=True):
+            return torch.nn.functional.interpolate(img[None], size=tuple(size), mode="bicubic", align_corners=False,
+                                                   antialias=antialias)[0]
+    U.TF = TFShim
+    out = {}
+    left, right = synth_image(91, 3, 54, 100), synth_image(92, 3, 54, 100)
+    out["left"], out["right"] = left, right
+    for name, kw in FORMAT_CASES.items():
+        out[name] = U.postprocess_image(left.clone(), right.clone(), format_args(**kw))
+        print(name, tuple(out[name].shape))
+    depth = synth_depth(12, 1, 30, 52, "smooth_edges")[0]
+    out["depth"] = depth
+    for name, kw in (("rgbd", dict(rgbd=True)), ("half_rgbd", dict(half_rgbd=True, ipd_offset=3.0))):
+        le, re = U.apply_rgbd(left.clone(), depth.clone(), mapper="pow2")
+        out[name] = U.postprocess_image(le, re, format_args(**kw))
+    save("formats", **out)
+
+
 def gen_depth_aa():
     """iw3.depth_aa (iw3/models/depth_aa.py) on the reference: forward (clamped / unclamped) and infer()."""
     from iw3.models.depth_aa import DepthAA
@@ -233,7 +316,7 @@ def gen_depth_aa():
 
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa}
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

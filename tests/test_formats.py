@@ -1,0 +1,80 @@
+"""iw3 output formats (postprocess_image: IPD / --pad modes, VR180, anaglyph, RGBD): oracle vs the reference fixture (CPU),
+HIP engine vs fixture (GPU)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, psnr
+from oracle import iw3_utils as OU
+
+sys.path.insert(0, GOLDEN)
+from make_golden_cases import FORMAT_CASES  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def g():
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "formats.npz")).items()}
+
+
+def _oracle_kwargs(kw):
+    kw = dict(kw)
+    if "anaglyph" in kw:
+        kw["anaglyph_kind"] = kw.pop("anaglyph")
+    if "rgbd" in kw:
+        kw["rgbd_out"] = kw.pop("rgbd")
+    return kw
+
+
+def _args(**kw):
+    base = dict(ipd_offset=0, rgbd=False, half_rgbd=False, pad=None, pad_mode="tblr", vr180=False, half_sbs=False, half_tb=False,
+                anaglyph=None, tb=False, cross_eyed=False, max_output_height=None, max_output_width=None,
+                keep_aspect_ratio=False)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+@pytest.mark.parametrize("name", sorted(FORMAT_CASES))
+def test_oracle_matches_reference_fixture(g, name):
+    out = OU.postprocess_image(g["left"].clone(), g["right"].clone(), **_oracle_kwargs(FORMAT_CASES[name]))
+    assert out.shape == g[name].shape
+    assert (out - g[name]).abs().max().item() < 2e-6, name
+
+
+def test_oracle_rgbd(g):
+    depth = OU.MAPPERS["pow2"](g["depth"])
+    for name, kw in (("rgbd", dict(rgbd_out=True)), ("half_rgbd", dict(half_rgbd=True, ipd_offset=3.0))):
+        le, re = OU.rgbd(g["left"], depth)
+        out = OU.postprocess_image(le, re, **kw)
+        assert out.shape == g[name].shape and (out - g[name]).abs().max().item() < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(FORMAT_CASES))
+def test_hip_postprocess_image(hiplib, g, name):
+    from nunif_amd.iw3.utils import postprocess_image
+    left, right = g["left"].to("cuda:0"), g["right"].to("cuda:0")
+    out = postprocess_image(left, right, _args(**FORMAT_CASES[name]))
+    assert out.shape == g[name].shape, (out.shape, g[name].shape)
+    p = psnr(out.cpu(), g[name])
+    assert p >= 50.0, (name, p)
+    if name.startswith("pad_") or name in ("ana_color", "sbs_ipd", "sbs_ipd_neg"):
+        assert torch.equal(out.cpu(), g[name]), name            # pure data movement: bit-exact
+
+
+@pytest.mark.gpu
+def test_hip_rgbd_and_errors(hiplib, g):
+    from nunif_amd.iw3.anaglyph import apply_anaglyph_redcyan
+    from nunif_amd.iw3.utils import apply_rgbd, postprocess_image
+    left, depth = g["left"].to("cuda:0"), g["depth"].to("cuda:0")
+    for name, kw in (("rgbd", dict(rgbd=True)), ("half_rgbd", dict(half_rgbd=True, ipd_offset=3.0))):
+        le, re = apply_rgbd(left, depth, mapper="pow2")
+        assert re.shape == le.shape
+        assert psnr(postprocess_image(le, re, _args(**kw)).cpu(), g[name]) >= 50.0
+    with pytest.raises(ValueError):
+        apply_anaglyph_redcyan(left, left, "nope")
+    with pytest.raises(RuntimeError):
+        apply_anaglyph_redcyan(g["left"], g["right"], "color")      # CPU tensors: no fallback

@@ -66,9 +66,10 @@ def test_frame_edge_and_compose_bit_exact(hiplib):
     ref = torch.nn.functional.interpolate(OU.compose(left, right)[None], size=(22, 60), mode="bicubic",
                                           align_corners=False, antialias=True)[0].clamp(0, 1)
     assert out.shape == ref.shape and (out - ref).abs().max().item() < 2e-6
-    args.vr180 = True
-    with pytest.raises(NotImplementedError):
-        postprocess_image(left.to(DEV), right.to(DEV), args)
+    args.vr180, args.max_output_height = True, None
+    out = postprocess_image(left.to(DEV), right.to(DEV), args).cpu()       # VR180 (tests/test_formats.py checks the values)
+    ref = OU.postprocess_image(left, right, vr180=True)
+    assert out.shape == ref.shape and (out - ref).abs().max().item() < 1e-3
 
 
 def test_ema_scaler_and_base_depth_model(hiplib):
