@@ -43,6 +43,10 @@ struct C3W { float *w = nullptr, *b = nullptr; int C = 0; };
 }  // namespace
 
 struct nunif_cunet {
+    // kind 0 / 1: CUNet / UpCUNet; 2: waifu2x.vgg_7 (vgg_7.py:6-30: seven 3x3 VALID convs, scale 1, offset 7);
+    // 3: waifu2x.upconv_7 (upconv_7.py:6-35: six 3x3 VALID convs + ConvTranspose2d(256, 3, 4, 2, 3), scale 2, offset 14)
+    int kind = 0;
+    C3W st_first; ConvW st_conv[6]; UpW st_deconv; int st_n = 0;      // the plain conv stacks
     int no_clip = 0;
     int up = 0;                 // 1: UpCUNet (unet1 ends in ConvTranspose2d(64, 3, 4, 2, 3); scale 2, offset 36)
     UpW u1bottom_up;            // that head as a 2x2-window gather GEMM (K = 4*64) with a pixel-shuffle store
@@ -80,11 +84,14 @@ int upload_f32(nunif_cunet *h, const HostT *t, float **dev) {
 }
 
 // Conv2d weight [Cout][Cin][k][k] -> MFMA A fragments in [k-step][n-tile] order, reduction index = tap*Cin + ci
-int make_conv(nunif_cunet *h, const TMap &m, const std::string &key, int cin, int cout, int k, int stride, ConvW *c) {
+// cin_real < cin: the producer stores its cin_real channels padded with zeros to cin (a multiple of 32)
+int make_conv(nunif_cunet *h, const TMap &m, const std::string &key, int cin, int cout, int k, int stride, ConvW *c,
+              int cin_real = 0) {
     const HostT *w, *b;
     int rc;
+    if (cin_real <= 0) cin_real = cin;
     if ((rc = find(m, key + ".weight", &w)) || (rc = find(m, key + ".bias", &b))) return rc;
-    NUNIF_REQUIRE(w->numel == (int64_t)cout * cin * k * k && b->numel == cout, "%s: unexpected shape", key.c_str());
+    NUNIF_REQUIRE(w->numel == (int64_t)cout * cin_real * k * k && b->numel == cout, "%s: unexpected shape", key.c_str());
     NUNIF_REQUIRE(cin % 32 == 0, "%s: Cin=%d must be a multiple of 32", key.c_str(), cin);
     const int N = (cout + 15) / 16 * 16, NT = N / 16, KS = k * k * cin / 32;
     std::vector<f16> stream((size_t)KS * NT * 512 + 8192, (f16)0.0f);
@@ -94,7 +101,7 @@ int make_conv(nunif_cunet *h, const TMap &m, const std::string &key, int cin, in
                 for (int j = 0; j < 8; ++j) {
                     const int n = nt * 16 + (l & 15), kk = ks * 32 + (l >> 4) * 8 + j;
                     const int tap = kk / cin, ci = kk % cin;
-                    const float v = n < cout ? w->data[((size_t)n * cin + ci) * k * k + tap] : 0.0f;
+                    const float v = (n < cout && ci < cin_real) ? w->data[((size_t)n * cin_real + ci) * k * k + tap] : 0.0f;
                     stream[(((size_t)ks * NT + nt) * 64 + l) * 8 + j] = (f16)v;
                 }
     std::vector<float> bias(N, 0.0f);
@@ -158,14 +165,23 @@ int make_deconv4(nunif_cunet *h, const TMap &m, const std::string &key, int cin,
     return upload(h, bias, &u->bias);
 }
 
-int make_c3(nunif_cunet *h, const TMap &m, const std::string &key, int cout, C3W *c) {
+// cout_pad > cout: the extra output channels get zero weights / bias (LeakyReLU(0) = 0), so the next conv sees Cin % 32 == 0
+int make_c3(nunif_cunet *h, const TMap &m, const std::string &key, int cout, C3W *c, int cout_pad = 0) {
     const HostT *w, *b;
     int rc;
     if ((rc = find(m, key + ".weight", &w)) || (rc = find(m, key + ".bias", &b))) return rc;
     NUNIF_REQUIRE(w->numel == (int64_t)cout * 27 && b->numel == cout, "%s: unexpected shape (3 input channels)", key.c_str());
-    c->C = cout;
-    if ((rc = upload_f32(h, w, &c->w))) return rc;
-    return upload_f32(h, b, &c->b);
+    if (cout_pad <= cout) {
+        c->C = cout;
+        if ((rc = upload_f32(h, w, &c->w))) return rc;
+        return upload_f32(h, b, &c->b);
+    }
+    std::vector<float> wp((size_t)cout_pad * 27, 0.0f), bp(cout_pad, 0.0f);
+    std::copy(w->data, w->data + (size_t)cout * 27, wp.begin());
+    std::copy(b->data, b->data + cout, bp.begin());
+    c->C = cout_pad;
+    if ((rc = upload(h, wp, &c->w))) return rc;
+    return upload(h, bp, &c->b);
 }
 
 int make_se(nunif_cunet *h, const TMap &m, const std::string &key, int C, SEW *s) {
@@ -214,9 +230,43 @@ int run_deconv4(const UpW &u, const f16 *a, int B, int Hi, float *out, int no_cl
     return launch_gemm(g, s, "upcunet_bottom");
 }
 
+// waifu2x.vgg_7 / waifu2x.upconv_7: first conv on the VALU (3 input channels), the 3x3 VALID convs on conv_kernel with
+// LeakyReLU(0.1), image head = last conv (fp32 planar, clamp) or the 4x4 s2 p3 ConvTranspose as a gather GEMM.
+// x: tile mode [B,3,T,T] or frame + grid; z: [B,3,T-14,T-14] (vgg_7) / [B,3,2T-28,2T-28] (upconv_7)
+int forward_stack(nunif_cunet *h, const float *x, const float *frame, const nunif_tile_grid *grid, int tile_begin, float *z,
+                  int B, int T, hipStream_t s) {
+    NUNIF_REQUIRE(T > 14, "tile_size %d is too small (7 convolutions of 3x3)", T);
+    int rc, cmax = 0;
+    for (int i = 0; i < h->st_n; ++i) cmax = std::max(cmax, h->st_conv[i].N);
+    const size_t bytes = (size_t)B * (T - 2) * (T - 2) * std::max(cmax, h->st_first.C) * sizeof(f16);
+    if ((rc = h->t[0].ensure(bytes)) || (rc = h->t[1].ensure(bytes))) return rc;
+    f16 *cur = (f16 *)h->t[0].p, *nxt = (f16 *)h->t[1].p;
+    C3ConvArgs c3;
+    memset(&c3, 0, sizeof(c3));
+    if (frame) {
+        c3.x = frame; c3.frame_mode = 1; c3.H = grid->x_h; c3.W = grid->x_w; c3.wb = grid->w_blocks;
+        c3.istep = grid->input_tile_step; c3.pad_t = grid->pad_t; c3.pad_l = grid->pad_l; c3.tile_begin = tile_begin;
+    } else {
+        c3.x = x;
+    }
+    c3.B = B; c3.T = T; c3.w = h->st_first.w; c3.bias = h->st_first.b; c3.C = h->st_first.C; c3.out = cur; c3.slope = 0.1f;
+    if ((rc = launch_c3_conv(c3, s))) return rc;
+    int side = T - 2;
+    const int n_mid = h->kind == 2 ? h->st_n - 1 : h->st_n;          // vgg_7: the last conv is the image head
+    for (int i = 0; i < n_mid; ++i) {
+        if ((rc = run_conv(h->st_conv[i], cur, nullptr, 0, 0, B, side, nxt, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+        std::swap(cur, nxt);
+        side -= 2;
+    }
+    if (h->kind == 2)
+        return run_conv(h->st_conv[h->st_n - 1], cur, nullptr, 0, 0, B, side, nullptr, z, nullptr, 0, 0, 1, 0, s);
+    return run_deconv4(h->st_deconv, cur, B, side, z, 0, s);
+}
+
 // x: tile mode [B,3,T,T] or (frame != NULL) frame + grid; z: [B,3,T-56,T-56] (CUNet) / [B,3,2T-72,2T-72] (UpCUNet)
 int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif_tile_grid *grid, int tile_begin,
                  float *z, int B, int T, hipStream_t s) {
+    if (h->kind >= 2) return forward_stack(h, x, frame, grid, tile_begin, z, B, T, s);
     NUNIF_REQUIRE(T % 4 == 0 && T >= 64, "tile_size %d is not valid for cunet (multiple of 4, >= 64)", T);
     const size_t b = B;
     const int a1 = T - 2, x1 = T - 4, d1 = x1 / 2, e1 = d1 - 2, f1 = d1 - 4, g1 = 2 * f1, h1 = g1 - 2;
@@ -312,8 +362,26 @@ extern "C" int nunif_hip_cunet_create(const nunif_tensor_desc *tensors, int32_t 
     int rc = NUNIF_HIP_OK;
     do {
         const HostT *bw;
+        if (m.count("net.12.weight")) {                  // nn.Sequential key layout of vgg_7 / upconv_7
+            bw = &m["net.12.weight"];
+            const bool upconv = bw->shape.size() == 4 && bw->shape[2] == 4;
+            h->kind = upconv ? 3 : 2;
+            static const int vgg_c[8] = {3, 32, 32, 64, 64, 128, 128, 3}, up_c[7] = {3, 16, 32, 64, 128, 128, 256};
+            const int *ch = upconv ? up_c : vgg_c;
+            const int first_pad = (ch[1] + 31) / 32 * 32;
+            if ((rc = make_c3(h, m, "net.0", ch[1], &h->st_first, first_pad))) break;
+            h->st_n = upconv ? 5 : 6;
+            for (int i = 0; i < h->st_n && !rc; ++i) {
+                const int cin = i == 0 ? first_pad : ch[i + 1];
+                rc = make_conv(h, m, "net." + std::to_string(2 * (i + 1)), cin, ch[i + 2], 3, 1, &h->st_conv[i], ch[i + 1]);
+            }
+            if (rc) break;
+            if (upconv && (rc = make_deconv4(h, m, "net.12", 256, 3, &h->st_deconv))) break;
+            break;
+        }
         if ((rc = find(m, "unet1.conv_bottom.weight", &bw))) break;
         h->up = (bw->shape.size() == 4 && bw->shape[2] == 4) ? 1 : 0;
+        h->kind = h->up;
         const std::string a = "unet1.", b = "unet2.";
         if ((rc = make_c3(h, m, a + "conv1.conv.0", 32, &h->u1c1a))) break;
         if ((rc = make_conv(h, m, a + "conv1.conv.2", 32, 64, 3, 1, &h->u1c1b))) break;
@@ -367,8 +435,10 @@ extern "C" int nunif_hip_cunet_render(nunif_cunet *h, const float *x, float *y, 
                                       int32_t tile_size, int32_t batch_size, void *stream) {
     NUNIF_REQUIRE(h && x && y && batch_size > 0, "cunet_render: bad argument");
     nunif_tile_grid g;
-    // CUNet: scale 1, offset 28; UpCUNet: scale 2, offset 36 (cunet.py:143,177); blend_size None -> plain overwrite
-    int rc = nunif_hip_tile_grid_init(x_h, x_w, h->up ? 2 : 1, h->up ? 36 : 28, tile_size, 0, &g);
+    // CUNet: scale 1, offset 28; UpCUNet: scale 2, offset 36 (cunet.py:143,177); vgg_7: 1, 7; upconv_7: 2, 14;
+    // blend_size None -> plain overwrite
+    static const int kScale[4] = {1, 2, 1, 2}, kOffset[4] = {28, 36, 7, 14};
+    int rc = nunif_hip_tile_grid_init(x_h, x_w, kScale[h->kind], kOffset[h->kind], tile_size, 0, &g);
     if (rc) return rc;
     const int n_tiles = g.h_blocks * g.w_blocks;
     const size_t To = g.out_tile_size;

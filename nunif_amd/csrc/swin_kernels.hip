@@ -441,6 +441,7 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
         case 18: return launch_gemm_t<18, 2>(g, s, "gemm_kernel<18,2>", "gemm_res_kernel<18,2>", flops, bytes);
         case 19: return launch_gemm_t<19, 1>(g, s, "gemm_kernel<19,1>", "gemm_res_kernel<19,1>", flops, bytes);
         case 24: return launch_gemm_t<24, 1>(g, s, "gemm_kernel<24,1>", "gemm_res_kernel<24,1>", flops, bytes);
+        case 32: return launch_gemm_t<32, 1>(g, s, "gemm_kernel<32,1>", "gemm_res_kernel<32,1>", flops, bytes);
         default:
             set_error("gemm %s: unsupported K=%d", tag, g.K);
             return NUNIF_HIP_EUNSUPPORTED;

@@ -2,8 +2,8 @@
 (``make_grid`` :86-93 and ``backward_warp`` :67-83 folded into ``nunif_hip_backward_warp``) and the NN-delta path the
 default ``--method row_flow_v3`` takes — ``make_divergence_feature_value`` :8-14, ``make_input_tensor`` :17-64 (c=None),
 ``apply_divergence_nn_LR`` :124-160, ``apply_divergence_nn`` :163-188, ``apply_divergence_nn_delta`` :191-236.
-and the multi-layer variant ``apply_divergence_nn_delta_weight`` :262-341 (MLBW).  Symmetric models and the cycle
-output are not provided yet.
+and the multi-layer variant ``apply_divergence_nn_delta_weight`` :262-341 (MLBW).  ``apply_divergence_nn_symmetric`` :343-379, the hole-mask output (``postprocess_hole_mask`` :382-393, ``nonwarp_mask``
+:396-422).  The cycle (training) output is not provided.
 """
 import torch
 
@@ -140,6 +140,27 @@ def nonwarp_mask(model, c, depth, divergence, convergence, mapper=None, threshol
     return c, mask
 
 
+def apply_divergence_nn_symmetric(model, c, depth, divergence, convergence, synthetic_view, enable_amp=True):
+    """Reference :343-379 (``row_flow_v3_sym``): ONE flow from the un-flipped planes (feature width = W, not max(H, W));
+    the left eye samples at grid + delta, the right eye at grid - delta."""
+    assert synthetic_view in {"both", "right", "left"}
+    assert model.delta_output and model.symmetric
+    B, _, H, W = depth.shape
+    if synthetic_view != "both":
+        divergence = divergence * 2
+    if torch.is_tensor(convergence):
+        convergence = convergence.flatten()
+    else:
+        convergence = [convergence] * B
+    x = torch.stack([make_input_tensor(None, depth[i], divergence=divergence, convergence=convergence[i], image_width=W)
+                     for i in range(B)])
+    delta = model.infer_delta(x, flip=False)
+    delta_scale = 1.0 / (W // 2 - 1)
+    left_eye = _ops.delta_warp(c, delta, delta_scale, flip=False).to(c.dtype) if synthetic_view != "right" else c
+    right_eye = _ops.delta_warp(c, delta, -delta_scale, flip=False).to(c.dtype) if synthetic_view != "left" else c
+    return left_eye, right_eye
+
+
 def apply_divergence_nn(model, c, depth, divergence, convergence, steps, shift, preserve_screen_border=False,
                         enable_amp=True):
     if model.name == "sbs.mlbw":
@@ -155,7 +176,8 @@ def apply_divergence_nn_LR(model, c, depth, divergence, convergence, steps, synt
     assert synthetic_view in {"both", "right", "left"}
     steps = 1 if steps is None else steps
     if getattr(model, "symmetric", False):
-        raise NotImplementedError("symmetric side models are not on the HIP engine yet")
+        return apply_divergence_nn_symmetric(model, c, depth, divergence, convergence, synthetic_view=synthetic_view,
+                                             enable_amp=enable_amp)
     kw = dict(preserve_screen_border=preserve_screen_border, enable_amp=enable_amp)
     if synthetic_view == "both":
         left_eye = apply_divergence_nn(model, c, depth, divergence, convergence, steps, shift=-1, **kw)

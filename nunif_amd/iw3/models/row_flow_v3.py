@@ -158,8 +158,7 @@ class RowFlowV3(I2IBaseModel):
         if not self.delta_output:
             raise NotImplementedError("the HIP engine implements the delta_output path (what iw3 inference uses); "
                                       "set model.delta_output = True")
-        if self.symmetric:
-            raise NotImplementedError("symmetric row_flow_v3 is not on the HIP engine yet")
+        # (symmetric only changes what the CALLER does with the flow: +delta for the left eye, -delta for the right)
         if x.shape[1] == 8:                     # training-style packed input: rgb | depth feat | grid
             x = x[:, 3:6]
         delta = self.infer_delta(x)

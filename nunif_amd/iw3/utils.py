@@ -31,7 +31,8 @@ def apply_divergence(depth, im, args, side_model=None, reset_pts=None):
         left, right = apply_divergence_forward_warp(im, depth, args.divergence, convergence=convergence,
                                                     method=args.method, synthetic_view=args.synthetic_view,
                                                     width_base=False)
-    elif args.method in {"row_flow_v3", "row_flow", "mlbw_l2", "mlbw_l4", "mlbw_l2s", "mlbw_l4s"}:
+    elif args.method in {"row_flow_v3", "row_flow", "row_flow_v3_sym", "row_flow_sym", "mlbw_l2", "mlbw_l4", "mlbw_l2s",
+                         "mlbw_l4s"}:
         # iw3/utils.py:369-387: optional --stereo-width resize of the depth, then the NN backward warp
         if side_model is None:
             raise ValueError(f"method={args.method} needs a side model (nunif_amd.iw3.models.row_flow_v3.RowFlowV3)")

@@ -181,6 +181,24 @@ def row_flow_v3_state_dict(seed):
     return sd
 
 
+def conv_stack_state_dict(seed, kind):
+    """Seeded weights of waifu2x.vgg_7 (``kind="vgg_7"``) / waifu2x.upconv_7 in the reference's ``net.N`` key layout; He-scaled
+    so that activations keep their range through the stack, non-zero biases, image head centred on 0.5."""
+    g = torch.Generator().manual_seed(seed)
+    ch = (3, 32, 32, 64, 64, 128, 128, 3) if kind == "vgg_7" else (3, 16, 32, 64, 128, 128, 256, 3)
+    sd, n = {}, len(ch) - 1
+    for i in range(n):
+        cin, cout, last = ch[i], ch[i + 1], i == n - 1
+        deconv = last and kind == "upconv_7"
+        k = 4 if deconv else 3
+        shape = (cin, cout, k, k) if deconv else (cout, cin, k, k)
+        fan_in = cin * (4 if deconv else 9)                 # a stride-2 4x4 transposed conv sums 2x2 taps per output pixel
+        gain = 0.25 if last else 1.0
+        sd[f"net.{2 * i}.weight"] = torch.randn(shape, generator=g) * (gain * math.sqrt(2.0 / (1.01 * fan_in)))
+        sd[f"net.{2 * i}.bias"] = torch.randn(cout, generator=g) * 0.05 + (0.5 if last else 0.0)
+    return sd
+
+
 def mlbw_state_dict(seed, num_layers=2, small=False, hole_mask=False):
     """Seeded weights in the reference's key layout (every bias non-zero); the output conv is scaled so that the layer
     deltas differ by a few depth pixels and the layer-weight logits really select between them."""

@@ -60,9 +60,15 @@ def _init_weights(in_channels, out_channels, up=False):
 
 
 class HipCUNetEngine:
-    def __init__(self, state_dict, no_clip, device):
+    """One ``nunif_cunet`` handle: CUNet / UpCUNet, or the plain conv stacks vgg_7 / upconv_7 (the C side tells them apart
+    by the state-dict keys); ``scale`` / ``offset`` are the model's i2i geometry (output side = T * scale - 2 * offset)."""
+
+    def __init__(self, state_dict, no_clip, device, scale=None, offset=None):
         self.device = torch.device(device)
-        self.up = state_dict["unet1.conv_bottom.weight"].shape[2] == 4
+        if scale is None:
+            up = state_dict["unet1.conv_bottom.weight"].shape[2] == 4
+            scale, offset = (2, 36) if up else (1, 28)
+        self.scale, self.offset = scale, offset
         if self.device.type != "cuda":
             raise RuntimeError("the cunet HIP engine needs a ROCm device (model.to('cuda:N')); no CPU fallback")
         keep, descs = [], []
@@ -91,7 +97,7 @@ class HipCUNetEngine:
     def forward(self, x):
         B, C, T, T2 = x.shape
         assert C == 3 and T == T2
-        To = 2 * T - 72 if self.up else T - 56
+        To = T * self.scale - 2 * self.offset
         z = torch.empty((B, 3, To, To), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _hip.check(_hip.lib().nunif_hip_cunet_forward(self.handle, ctypes.c_void_p(x.data_ptr()),
@@ -102,7 +108,7 @@ class HipCUNetEngine:
     def render(self, x, tile_size, batch_size):
         C, H, W = x.shape
         assert C == 3
-        sc = 2 if self.up else 1
+        sc = self.scale
         y = torch.empty((3, H * sc, W * sc), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _hip.check(_hip.lib().nunif_hip_cunet_render(self.handle, ctypes.c_void_p(x.data_ptr()),

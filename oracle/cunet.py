@@ -76,6 +76,22 @@ def model_forward(sd, x, no_clip=False):
 GEOMETRY = {"waifu2x.cunet": (1, 28, 0), "waifu2x.upcunet": (2, 36, 0)}
 
 
+def conv_stack_forward(sd, x):
+    """waifu2x.vgg_7 (vgg_7.py:11-30) / waifu2x.upconv_7 (upconv_7.py:11-35): ``net`` = 3x3 VALID convs with LeakyReLU(0.1)
+    between them; the last layer is a plain conv (vgg_7) or ConvTranspose2d(256, 3, 4, 2, 3) (upconv_7); eval clamp."""
+    keys = sorted({int(k.split(".")[1]) for k in sd if k.startswith("net.")})
+    for i in keys[:-1]:
+        x = F.leaky_relu(F.conv2d(x, sd[f"net.{i}.weight"], sd[f"net.{i}.bias"]), 0.1)
+    w, b = sd[f"net.{keys[-1]}.weight"], sd[f"net.{keys[-1]}.bias"]
+    x = F.conv_transpose2d(x, w, b, stride=2, padding=3) if w.shape[2] == 4 else F.conv2d(x, w, b)
+    return x.clamp(0., 1.)
+
+
+def conv_stack_state_dict(*args, **kwargs):
+    from nunif_amd.synthetic import conv_stack_state_dict as f
+    return f(*args, **kwargs)
+
+
 def valid_tile_size(size):
     return size % 4 == 0
 

@@ -136,6 +136,19 @@ def apply_divergence_nn_LR(sd, c, depth, divergence, convergence, synthetic_view
     return apply_divergence_nn_delta(sd, c, depth, divergence * 2, convergence, -1), c
 
 
+def apply_divergence_nn_symmetric(sd, c, depth, divergence, convergence, synthetic_view="both"):
+    """iw3/backward_warp.py:343-379 (model.symmetric): one un-flipped flow, +delta / -delta, no clamp beyond backward_warp's."""
+    B, _, H, W = depth.shape
+    if synthetic_view != "both":
+        divergence = divergence * 2
+    delta = delta_forward(sd, make_input(depth, divergence, convergence, W))
+    delta = torch.cat([delta, torch.zeros_like(delta)], dim=1)
+    grid, scale = make_grid(B, W, H), 1.0 / (W // 2 - 1)
+    left = backward_warp(c, grid, delta, scale) if synthetic_view != "right" else c
+    right = backward_warp(c, grid, -delta, scale) if synthetic_view != "left" else c
+    return left, right
+
+
 def random_state_dict(*args, **kwargs):
     """Seeded test weights: alias of ``nunif_amd.synthetic.row_flow_v3_state_dict`` (moved there so that bench.py and the tools do
     not import the oracle for their inputs)."""

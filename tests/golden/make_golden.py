@@ -190,6 +190,26 @@ def gen_row_flow():
     save("row_flow", **out)
 
 
+def gen_row_flow_sym():
+    """The symmetric use of sbs.row_flow_v3 (``row_flow_v3_sym``: model.symmetric = True, apply_divergence_nn_symmetric)."""
+    from iw3.models.row_flow_v3 import RowFlowV3
+    from iw3 import backward_warp as RB
+    from oracle import row_flow_v3 as ORF
+    from oracle.forward_warp import synth_depth
+    out = {}
+    sd = ORF.random_state_dict(311)
+    m = RowFlowV3().eval()
+    m.load_state_dict(sd, strict=True)
+    m.delta_output, m.symmetric = True, True
+    depth = synth_depth(5, 1, 58, 104, "smooth_edges")
+    c = synth_image(77, 3, 116, 208)[None]
+    out["depth"], out["c"] = depth, c
+    out["left"], out["right"] = RB.apply_divergence_nn_LR(m, c, depth, 2.0, 0.5, steps=1, synthetic_view="both", enable_amp=False)
+    _, out["right_only"] = RB.apply_divergence_nn_LR(m, c, depth, 2.0, 0.5, steps=1, synthetic_view="right", enable_amp=False)
+    out["left_only"], _ = RB.apply_divergence_nn_LR(m, c, depth, 2.0, 0.5, steps=1, synthetic_view="left", enable_amp=False)
+    save("row_flow_sym", **out)
+
+
 def gen_mlbw():
     """sbs.mlbw (iw3/models/mlbw.py) + apply_divergence_nn_delta_weight on the reference: l2, l4 and the small l2s."""
     from iw3.models.mlbw import MLBW
@@ -212,6 +232,28 @@ def gen_mlbw():
         out[tag + "_left"], out[tag + "_right"] = RB.apply_divergence_nn_LR(m, c[:nb], depth[:nb], 2.0, 0.5, steps=1,
                                                                             synthetic_view="both", enable_amp=False)
     save("mlbw", **out)
+
+
+def gen_convstack():
+    """waifu2x.vgg_7 / waifu2x.upconv_7 on the reference: one tile forward + a small tiled_render each."""
+    from waifu2x.models.vgg_7 import VGG7
+    from waifu2x.models.upconv_7 import UpConv7
+    from nunif.utils.render import tiled_render
+    from oracle import cunet as OC
+    out = {}
+    x = torch.stack([synth_image(101, 3, 64, 64), synth_image(102, 3, 64, 64)])
+    frame = synth_image(103, 3, 90, 130)
+    out["x"], out["frame"] = x, frame
+    for tag, cls, seed in (("vgg_7", VGG7, 601), ("upconv_7", UpConv7, 602)):
+        sd = OC.conv_stack_state_dict(seed, tag)
+        m = cls().eval()
+        m.load_state_dict(sd, strict=True)
+        out[tag + "_sdsum"] = sd_checksum(sd)
+        out[tag + "_z"] = m(x)
+        out[tag + "_render"] = tiled_render(frame, m, tile_size=64, batch_size=4)
+        print(tag, tuple(out[tag + "_z"].shape), tuple(out[tag + "_render"].shape), float(out[tag + "_z"].mean()),
+              float(out[tag + "_z"].std()), float((out[tag + "_z"] <= 0).float().mean()), float((out[tag + "_z"] >= 1).float().mean()))
+    save("convstack", **out)
 
 
 def gen_hole_mask():
@@ -316,7 +358,7 @@ def gen_depth_aa():
 
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats}
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

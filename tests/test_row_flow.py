@@ -92,3 +92,37 @@ def test_hip_row_flow_1080p_vs_oracle(hiplib):
     cpu_model.delta_output = True
     with pytest.raises(RuntimeError):
         cpu_model(torch.rand(1, 3, 64, 64))     # a CPU-resident model has no engine: no fallback
+
+
+# ---- symmetric use (row_flow_v3_sym: apply_divergence_nn_symmetric) -----------------------------------------------------
+@pytest.fixture(scope="module")
+def gs():
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "row_flow_sym.npz")).items()}
+
+
+def test_oracle_symmetric_matches_reference_fixture(gs):
+    sd = ORF.random_state_dict(311)
+    left, right = ORF.apply_divergence_nn_symmetric(sd, gs["c"], gs["depth"], 2.0, 0.5, "both")
+    assert (left - gs["left"]).abs().max().item() < 2e-4 and (right - gs["right"]).abs().max().item() < 2e-4
+    _, r = ORF.apply_divergence_nn_symmetric(sd, gs["c"], gs["depth"], 2.0, 0.5, "right")
+    l, c = ORF.apply_divergence_nn_symmetric(sd, gs["c"], gs["depth"], 2.0, 0.5, "left")
+    assert (r - gs["right_only"]).abs().max().item() < 2e-4 and (l - gs["left_only"]).abs().max().item() < 2e-4
+    assert c is gs["c"]
+
+
+@pytest.mark.gpu
+def test_hip_row_flow_symmetric(hiplib, gs):
+    from nunif_amd.nunif.models import create_model
+    from nunif_amd.iw3 import models  # noqa: F401
+    from nunif_amd.iw3.backward_warp import apply_divergence_nn_LR
+    m = create_model("sbs.row_flow_v3").eval()
+    m.load_state_dict(ORF.random_state_dict(311), strict=True)
+    m = m.to("cuda:0")
+    m.delta_output, m.symmetric = True, True
+    c, depth = gs["c"].to("cuda:0"), gs["depth"].to("cuda:0")
+    left, right = apply_divergence_nn_LR(m, c, depth, 2.0, 0.5, steps=1, synthetic_view="both")
+    assert psnr(left.cpu(), gs["left"]) >= 50.0 and psnr(right.cpu(), gs["right"]) >= 50.0
+    le, r = apply_divergence_nn_LR(m, c, depth, 2.0, 0.5, steps=1, synthetic_view="right")
+    assert le is c and psnr(r.cpu(), gs["right_only"]) >= 50.0
+    l, ri = apply_divergence_nn_LR(m, c, depth, 2.0, 0.5, steps=1, synthetic_view="left")
+    assert ri is c and psnr(l.cpu(), gs["left_only"]) >= 50.0
