@@ -183,6 +183,17 @@ int nunif_hip_row_flow_delta(nunif_row_flow *handle, const float *x, float *delt
 int nunif_hip_delta_warp(const float *c, const float *delta, float *out, int32_t B, int32_t C, int32_t H, int32_t W,
                          int32_t dh, int32_t dw, double delta_scale, int32_t flip, void *stream);
 
+/* iw3 "inpaint.light_inpaint_v1" (iw3/models/light_inpaint_v1.py LightInpaintV1 :53-161), the image inpaint net behind
+ * MLBWInpaintImage (iw3/mlbw_inpaint.py:78-157).  create() takes the reference state dict (mask_bias, patch.0, enc1.*, down,
+ * enc2.N.*, up, dec1.*, to_image.1).  infer = LightInpaintV1.infer :106-110: preprocess (optional mask_closing, horizontal
+ * dilations with FINAL iteration counts, x * (1 - mask), soft mask = clamp(gaussian15(mask) + mask)) + forward with
+ * skip_i2i_offset=True.  x, out: [B,3,H,W] f32 in [0,1]; mask: [B,1,H,W] uint8 (0 / 1 hole mask). */
+typedef struct nunif_light_inpaint nunif_light_inpaint;
+int nunif_hip_light_inpaint_create(const nunif_tensor_desc *tensors, int32_t n_tensors, nunif_light_inpaint **handle);
+void nunif_hip_light_inpaint_destroy(nunif_light_inpaint *handle);
+int nunif_hip_light_inpaint_infer(nunif_light_inpaint *handle, const float *x, const uint8_t *mask, float *out, int32_t B,
+                                  int32_t H, int32_t W, int32_t closing, int32_t inner_iter, int32_t outer_iter, void *stream);
+
 /* iw3 output formats.
  * anaglyph: iw3/anaglyph.py apply_anaglyph_redcyan :96-110; left, right, out: [3,H,W] f32; mode 0 color, 1 gray, 2 half-color,
  * 3 wimmer, 4 wimmer2, 5 dubois, 6 dubois2.

@@ -1,0 +1,650 @@
+// iw3 "inpaint.light_inpaint_v1" (the image inpaint net behind MLBWInpaintImage) for gfx950.
+//
+// Replaces iw3/models/light_inpaint_v1.py LightInpaintV1.infer :106-110 = preprocess :93-104 + forward(skip_i2i_offset) :130-161
+// (_forward :112-128, GMLPBlock :37-50, GLUConvMLP :15-34), nunif/modules/attention.py WindowGMLP2d :654-693 / GMLP :621-651,
+// nunif/modules/norm.py FastLayerNorm :78-101, nunif/modules/gaussian_filter.py SeparableGaussianFilter2d :52-73.
+//
+// Data layout: NHWC fp16 token maps (level 1: 1/4 resolution, C = 96, 16 x 16 windows; level 2: 1/8, C = 192, 8 x 8 windows).
+// Every Linear / 1x1 / 2x2-stride-2 conv is gemm_kernel, the 3x3 convs are conv_kernel (replicate padding folded into the
+// gather); what is new here is the glue a gMLP needs:
+//   * the token-mixing step contracts over the TOKENS of a window, i.e. over the strided axis of a token-major map: the
+//     LayerNorm of the gate half writes its result transposed per window ([window][channel][token], coalesced because the
+//     lanes of a wave walk consecutive tokens), the mixing is then a plain GEMM with K = tokens, and the gate kernel
+//     transposes back while it multiplies with the value half;
+//   * a shifted block works on the zero-padded map (half a window on every side): the padded tokens take part in the
+//     mixing (LayerNorm(0) = 0 but proj_in(0) = bias), so the padded map really exists between ln1 and proj_out.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "swin_kernels.h"
+
+namespace nunif {
+
+// ---- pre-processing -----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) li_u8_to_f32_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, long n) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id < n) out[id] = in[id] ? 1.f : 0.f;
+}
+
+__global__ void __launch_bounds__(256) li_morph_kernel(const float *__restrict__ in, float *__restrict__ out, int B, int H, int W,
+                                                        int is_min) {
+    const long n = (long)B * H * W, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const int x = (int)(id % W);
+    const long t = id / W;
+    const int y = (int)(t % H);
+    const float *p = in + (t / H) * (long)H * W;
+    float v = p[(long)y * W + x];
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const float u = p[(long)yy * W + xx];
+            v = is_min ? fminf(v, u) : fmaxf(v, u);
+        }
+    }
+    out[id] = v;
+}
+
+__global__ void __launch_bounds__(256) li_add_clamp_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                            float *__restrict__ out, long n) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id < n) out[id] = fminf(fmaxf(a[id] + b[id], 0.f), 1.f);
+}
+
+// mask[x] = max over [x - n_outer, x + n_inner] (dilate_inner then dilate_outer, iw3/dilation.py:74-103; zeros at the border)
+__global__ void __launch_bounds__(256) li_dilate_kernel(const float *__restrict__ in, float *__restrict__ out, long rows, int W,
+                                                         int n_inner, int n_outer) {
+    const long n = rows * W, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const int X = (int)(id % W);
+    const float *p = in + (id / W) * W;
+    float m = 0.f;
+    for (int x = max(X - n_outer, 0); x <= min(X + n_inner, W - 1); ++x) m = fmaxf(m, p[x]);
+    out[id] = m;
+}
+
+struct Gauss15 { float w[15]; };
+
+// one pass of the separable 15-tap gaussian with replicate padding; vertical pass: out = clamp(blur + hard mask, 0, 1)
+__global__ void __launch_bounds__(256) li_blur_kernel(const float *__restrict__ in, const float *__restrict__ hard,
+                                                       float *__restrict__ out, int B, int H, int W, int vertical, Gauss15 g) {
+    const long n = (long)B * H * W, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const int x = (int)(id % W);
+    const long t = id / W;
+    const int y = (int)(t % H);
+    const float *p = in + (t / H) * (long)H * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        const int yy = vertical ? min(max(y + k - 7, 0), H - 1) : y, xx = vertical ? x : min(max(x + k - 7, 0), W - 1);
+        acc += p[(long)yy * W + xx] * g.w[k];
+    }
+    out[id] = vertical ? fminf(fmaxf(acc + hard[id], 0.f), 1.f) : acc;
+}
+
+// ---- patch embedding input: (x (1 - m) - 0.5) / 0.5, replicate padding to the 64-pixel grid, pixel_unshuffle(4) -----------
+// out: [B,h1,w1,64] fp16 (48 real channels c*16 + iy*4 + ix, rest 0); mtok: the token is masked if any of its 16 pixels of the
+// soft mask exceeds 0.99 (light_inpaint_v1.py:116)
+__global__ void __launch_bounds__(256) li_patch_in_kernel(const float *__restrict__ x, const float *__restrict__ hard,
+                                                           const float *__restrict__ soft, f16 *__restrict__ out,
+                                                           uint8_t *__restrict__ mtok, int B, int H, int W, int h1, int w1) {
+    const long n = (long)B * h1 * w1, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const int tx = (int)(id % w1);
+    const long t = id / w1;
+    const int ty = (int)(t % h1), b = (int)(t / h1);
+    f16 v[64];
+#pragma unroll
+    for (int i = 48; i < 64; ++i) v[i] = (f16)0.f;
+    float mmax = 0.f;
+    for (int iy = 0; iy < 4; ++iy) {
+        const int yy = min(ty * 4 + iy, H - 1);
+        for (int ix = 0; ix < 4; ++ix) {
+            const int xx = min(tx * 4 + ix, W - 1);
+            const long pix = ((long)b * H + yy) * W + xx;
+            const float keep = 1.f - hard[pix];
+            mmax = fmaxf(mmax, soft[pix]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float px = x[(((long)b * 3 + c) * H + yy) * W + xx] * keep;
+                v[c * 16 + iy * 4 + ix] = (f16)((px - 0.5f) / 0.5f);
+            }
+        }
+    }
+    f16x8 *o = reinterpret_cast<f16x8 *>(out + id * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (f16x8){v[8 * i], v[8 * i + 1], v[8 * i + 2], v[8 * i + 3], v[8 * i + 4], v[8 * i + 5],
+                                               v[8 * i + 6], v[8 * i + 7]};
+    mtok[id] = mmax > 0.99f ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) li_mask_bias_kernel(f16 *__restrict__ x, const uint8_t *__restrict__ mtok,
+                                                            const f16 *__restrict__ bias, long tokens, int C) {
+    const int runs = C / 8;
+    const long n = tokens * runs, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const long tok = id / runs;
+    const int r = (int)(id - tok * runs);
+    if (mtok[tok]) reinterpret_cast<f16x8 *>(x)[id] = reinterpret_cast<const f16x8 *>(bias)[r];
+}
+
+// ---- gMLP glue --------------------------------------------------------------------------------------------------------------
+// LayerNorm(C, eps 1e-5, weight only) of every token, written into the zero-padded map (pad = half a window, or 0)
+template <int C>
+__global__ void __launch_bounds__(256) li_ln_pad_kernel(const f16 *__restrict__ x, const float *__restrict__ w,
+                                                         f16 *__restrict__ out, int B, int h, int wd, int pad) {
+    const int hp = h + 2 * pad, wp = wd + 2 * pad;
+    const long n = (long)B * hp * wp, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const int px = (int)(id % wp);
+    const long t = id / wp;
+    const int py = (int)(t % hp), b = (int)(t / hp);
+    const int y = py - pad, xx = px - pad;
+    f16x8 *o = reinterpret_cast<f16x8 *>(out + id * C);
+    if (y < 0 || y >= h || xx < 0 || xx >= wd) {
+        const f16x8 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+#pragma unroll
+        for (int i = 0; i < C / 8; ++i) o[i] = z;
+        return;
+    }
+    const f16x8 *p = reinterpret_cast<const f16x8 *>(x + (((long)b * h + y) * wd + xx) * C);
+    f16x8 v[C / 8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < C / 8; ++i) {
+        v[i] = p[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+    }
+    const float mean = sum / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < C / 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)v[i][j] - mean; var += d * d; }
+    const float rs = rsqrtf(var / (float)C + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < C / 8; ++i) {
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (f16)(((float)v[i][j] - mean) * rs * w[8 * i + j]);
+        o[i] = r;
+    }
+}
+
+// LayerNorm over the gate half v = a[:, C2:2*C2] of proj_in's output (C2 = 2C channels), written TRANSPOSED per window:
+// vt[window][channel][token].  Thread id = (window, token in window): the 64 lanes of a wave hold consecutive tokens, so each
+// channel's store is one contiguous 128-byte run.
+template <int C2>
+__global__ void __launch_bounds__(256) li_ln2_t_kernel(const f16 *__restrict__ a, const float *__restrict__ w, f16 *__restrict__ vt,
+                                                        int B, int hp, int wp, int ws) {
+    const int N = ws * ws, nwx = wp / ws, nwy = hp / ws;
+    const long n = (long)B * hp * wp, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const long win = id / N;
+    const int tn = (int)(id - win * N);
+    const int wx = (int)(win % nwx);
+    const long t2 = win / nwx;
+    const int wy = (int)(t2 % nwy), b = (int)(t2 / nwy);
+    const long tok = ((long)b * hp + wy * ws + tn / ws) * wp + wx * ws + tn % ws;
+    const f16x8 *p = reinterpret_cast<const f16x8 *>(a + tok * (2 * C2) + C2);
+    f16x8 v[C2 / 8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < C2 / 8; ++i) {
+        v[i] = p[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+    }
+    const float mean = sum / (float)C2;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < C2 / 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)v[i][j] - mean; var += d * d; }
+    const float rs = rsqrtf(var / (float)C2 + 1e-5f);
+    f16 *o = vt + (win * C2) * N + tn;
+#pragma unroll
+    for (int i = 0; i < C2 / 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[(long)(8 * i + j) * N] = (f16)(((float)v[i][j] - mean) * rs * w[8 * i + j]);
+}
+
+// g[token][c] = u[token][c] * st[window][c][token]  (u = first half of proj_in's output, st = the mixed gate, transposed)
+template <int C2>
+__global__ void __launch_bounds__(256) li_gate_kernel(const f16 *__restrict__ a, const f16 *__restrict__ st, f16 *__restrict__ g,
+                                                       int B, int hp, int wp, int ws) {
+    const int N = ws * ws, nwx = wp / ws, nwy = hp / ws;
+    const long n = (long)B * hp * wp, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const long win = id / N;
+    const int tn = (int)(id - win * N);
+    const int wx = (int)(win % nwx);
+    const long t2 = win / nwx;
+    const int wy = (int)(t2 % nwy), b = (int)(t2 / nwy);
+    const long tok = ((long)b * hp + wy * ws + tn / ws) * wp + wx * ws + tn % ws;
+    const f16x8 *u = reinterpret_cast<const f16x8 *>(a + tok * (2 * C2));
+    const f16 *s = st + (win * C2) * N + tn;
+    f16x8 *o = reinterpret_cast<f16x8 *>(g + tok * C2);
+#pragma unroll
+    for (int i = 0; i < C2 / 8; ++i) {
+        const f16x8 uv = u[i];
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (f16)((float)uv[j] * (float)s[(long)(8 * i + j) * N]);
+        o[i] = r;
+    }
+}
+
+// x = x + crop(proj_out(...) + shortcut) with shortcut = the (padded) block input: x <- 2 x + crop(po)
+__global__ void __launch_bounds__(256) li_crop_add_kernel(f16 *__restrict__ x, const f16 *__restrict__ po, int B, int h, int wd,
+                                                           int pad, int C) {
+    const int runs = C / 8, wp = wd + 2 * pad, hp = h + 2 * pad;
+    const long n = (long)B * h * wd * runs, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const long tok = id / runs;
+    const int r = (int)(id - tok * runs);
+    const int xx = (int)(tok % wd);
+    const long t = tok / wd;
+    const int y = (int)(t % h), b = (int)(t / h);
+    const long ptok = ((long)b * hp + y + pad) * wp + xx + pad;
+    const f16x8 a = reinterpret_cast<const f16x8 *>(x)[id], p = reinterpret_cast<const f16x8 *>(po + ptok * C)[r];
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)(2.f * (float)a[j] + (float)p[j]);
+    reinterpret_cast<f16x8 *>(x)[id] = o;
+}
+
+// F.glu(y, dim = channels): z[c] = y[c] * sigmoid(y[C/2 + c]); z is stored padded to Cz channels (zeros) for the 3x3 conv
+__global__ void __launch_bounds__(256) li_glu_kernel(const f16 *__restrict__ y, f16 *__restrict__ z, long tokens, int C, int Cz) {
+    const int runs = Cz / 8, half = C / 2;
+    const long n = tokens * runs, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const long tok = id / runs;
+    const int c0 = (int)(id - tok * runs) * 8;
+    f16x8 o = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    if (c0 < half) {
+        const f16x8 a = *reinterpret_cast<const f16x8 *>(y + tok * C + c0), g = *reinterpret_cast<const f16x8 *>(y + tok * C + half + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)a[j] * (1.f / (1.f + expf(-(float)g[j]))));
+    }
+    reinterpret_cast<f16x8 *>(z)[id] = o;
+}
+
+// out = clamp(src (1 - m) + y m, 0, 1): src = x (1 - hard mask), m = soft mask, y = pixel_shuffle(4) of the net's 48 channels
+__global__ void __launch_bounds__(256) li_compose_kernel(const float *__restrict__ x, const float *__restrict__ hard,
+                                                          const float *__restrict__ soft, const f16 *__restrict__ ti,
+                                                          float *__restrict__ out, int B, int H, int W, int h1, int w1) {
+    const long n = (long)B * H * W, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const int xx = (int)(id % W);
+    const long t = id / W;
+    const int yy = (int)(t % H), b = (int)(t / H);
+    const float keep = 1.f - hard[id], m = soft[id];
+    const f16 *tv = ti + (((long)b * h1 + yy / 4) * w1 + xx / 4) * 48 + (yy & 3) * 4 + (xx & 3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const long o = (((long)b * 3 + c) * H + yy) * W + xx;
+        const float src = x[o] * keep;
+        out[o] = fminf(fmaxf(src * (1.f - m) + (float)tv[c * 16] * m, 0.f), 1.f);
+    }
+}
+
+}  // namespace nunif
+
+using namespace nunif;
+
+// =====================================================================================================================
+// host side
+// =====================================================================================================================
+namespace {
+
+struct HostT { const float *data; std::vector<int64_t> shape; int64_t numel; };
+typedef std::map<std::string, HostT> TMap;
+
+int find(const TMap &m, const std::string &key, const HostT **out) {
+    auto it = m.find(key);
+    if (it == m.end()) { set_error("state_dict is missing '%s'", key.c_str()); return NUNIF_HIP_EMISSING; }
+    *out = &it->second;
+    return NUNIF_HIP_OK;
+}
+
+struct Buf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return NUNIF_HIP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) { set_error("hipMalloc(%zu) failed", bytes); return NUNIF_HIP_ENOMEM; }
+        cap = bytes;
+        return NUNIF_HIP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Lin { f16 *w = nullptr; float *bias = nullptr; int N = 0, K = 0; };                 // gemm_kernel packing [nt][ks]
+struct Conv3 { f16 *stream = nullptr; float *bias = nullptr; int N = 0, n_real = 0, Cin = 0; };   // conv_kernel stream [ks][nt]
+struct GBlock {
+    int C = 0, ws = 0, shift = 0;
+    float *ln1 = nullptr, *ln2 = nullptr;
+    Lin proj_in, spatial, proj_out, w1;
+    Conv3 w2;
+};
+
+}  // namespace
+
+struct nunif_light_inpaint {
+    std::vector<void *> owned;
+    f16 *mask_bias = nullptr;
+    Lin patch, down, up;
+    GBlock enc1, enc2[4], dec1;
+    Conv3 to_image;
+    Gauss15 gauss;
+    Buf x1, x2, a, pi, vt, st, g, po, y, z, ti, mtok, mf0, mf1, mf2, hard, soft;
+};
+
+namespace {
+
+template <typename T>
+int upload(nunif_light_inpaint *h, const std::vector<T> &host, T **dev) {
+    void *p = nullptr;
+    if (hipMalloc(&p, host.size() * sizeof(T)) != hipSuccess) { set_error("hipMalloc failed"); return NUNIF_HIP_ENOMEM; }
+    h->owned.push_back(p);
+    NUNIF_HIP_CHECK(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = reinterpret_cast<T *>(p);
+    return NUNIF_HIP_OK;
+}
+
+// W[n][k] (n < n_real, k < K) -> MFMA A fragments in [n-tile][k-step] order (+ 16 KiB of zeros for the ring prefetch)
+template <typename F>
+int make_lin(nunif_light_inpaint *h, int n_real, int K, F wt, const std::vector<float> &bias, Lin *L) {
+    const int N = (n_real + 31) / 32 * 32, KS = K / 32;
+    std::vector<f16> packed((size_t)N * K + 8192, (f16)0.f);
+    for (int nt = 0; nt < N / 16; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = nt * 16 + (l & 15), k = ks * 32 + (l >> 4) * 8 + j;
+                    packed[(((size_t)nt * KS + ks) * 64 + l) * 8 + j] = (f16)(n < n_real ? wt(n, k) : 0.f);
+                }
+    std::vector<float> b(N, 0.f);
+    std::copy(bias.begin(), bias.end(), b.begin());
+    L->N = N; L->K = K;
+    int rc = upload(h, packed, &L->w);
+    return rc ? rc : upload(h, b, &L->bias);
+}
+
+// 3x3 conv weight [cout][cin_real][3][3] -> conv_kernel stream [k-step][n-tile], k = tap * cin + ci (cin = cin_real padded)
+int make_conv3(nunif_light_inpaint *h, const TMap &m, const std::string &key, int cin_real, int cin, int cout, Conv3 *c) {
+    const HostT *w, *b;
+    int rc;
+    if ((rc = find(m, key + ".weight", &w)) || (rc = find(m, key + ".bias", &b))) return rc;
+    NUNIF_REQUIRE(w->numel == (int64_t)cout * cin_real * 9 && b->numel == cout, "%s: unexpected shape", key.c_str());
+    const int N = (cout + 31) / 32 * 32, NT = N / 16, KS = 9 * cin / 32;
+    std::vector<f16> stream((size_t)KS * NT * 512 + 8192, (f16)0.f);
+    for (int ks = 0; ks < KS; ++ks)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = nt * 16 + (l & 15), kk = ks * 32 + (l >> 4) * 8 + j;
+                    const int tap = kk / cin, ci = kk % cin;
+                    const float v = (n < cout && ci < cin_real) ? w->data[((size_t)n * cin_real + ci) * 9 + tap] : 0.f;
+                    stream[(((size_t)ks * NT + nt) * 64 + l) * 8 + j] = (f16)v;
+                }
+    std::vector<float> bias(N, 0.f);
+    std::copy(b->data, b->data + cout, bias.begin());
+    c->N = N; c->n_real = cout; c->Cin = cin;
+    if ((rc = upload(h, stream, &c->stream))) return rc;
+    return upload(h, bias, &c->bias);
+}
+
+int make_plain(nunif_light_inpaint *h, const TMap &m, const std::string &key, int n_real, int K, Lin *L) {
+    const HostT *w, *b;
+    int rc;
+    if ((rc = find(m, key + ".weight", &w)) || (rc = find(m, key + ".bias", &b))) return rc;
+    NUNIF_REQUIRE(w->numel == (int64_t)n_real * K && b->numel == n_real, "%s: unexpected shape", key.c_str());
+    const float *wd = w->data;
+    return make_lin(h, n_real, K, [=](int n, int k) { return wd[(size_t)n * K + k]; },
+                    std::vector<float>(b->data, b->data + n_real), L);
+}
+
+int make_gblock(nunif_light_inpaint *h, const TMap &m, const std::string &p, int C, int ws, int shift, GBlock *g) {
+    g->C = C; g->ws = ws; g->shift = shift;
+    const int N = ws * ws;
+    const HostT *n1, *n2;
+    int rc;
+    if ((rc = find(m, p + "norm1.weight", &n1)) || (rc = find(m, p + "norm2.weight", &n2))) return rc;
+    NUNIF_REQUIRE(n1->numel == C && n2->numel == 2 * C, "%s: LayerNorm shapes", p.c_str());
+    if ((rc = upload(h, std::vector<float>(n1->data, n1->data + C), &g->ln1)) ||
+        (rc = upload(h, std::vector<float>(n2->data, n2->data + 2 * C), &g->ln2)))
+        return rc;
+    if ((rc = make_plain(h, m, p + "gmlp.gmlp.proj_in", 4 * C, C, &g->proj_in)) ||
+        (rc = make_plain(h, m, p + "gmlp.gmlp.proj_spatial", N, N, &g->spatial)) ||       // Conv1d(N, N, 1): weight [N][N][1]
+        (rc = make_plain(h, m, p + "gmlp.gmlp.proj_out", C, 2 * C, &g->proj_out)) ||
+        (rc = make_plain(h, m, p + "glu_conv.w1", C, C, &g->w1)))
+        return rc;
+    return make_conv3(h, m, p + "glu_conv.w2", C / 2, (C / 2 + 31) / 32 * 32, C, &g->w2);
+}
+
+int lin(const Lin &L, const f16 *a, long rows, int n_real, int act, float slope, const f16 *res, f16 *out, hipStream_t s,
+        const char *tag) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = a; g.B = 1; g.Hi = 1; g.Wi = (int)rows; g.Cin = L.K; g.Ho = 1; g.Wo = (int)rows; g.stride = 1; g.kw = 1;
+    g.K = L.K; g.w = L.w; g.bias = L.bias; g.N = L.N; g.mode = 0; g.act = act; g.slope = slope; g.res = res; g.out = out;
+    g.ldo = n_real; g.n_real = n_real; g.ps = 1;
+    return launch_gemm(g, s, tag);
+}
+
+template <int C>
+int run_gblock(nunif_light_inpaint *h, const GBlock &g, f16 *x, int B, int hh, int ww, hipStream_t s) {
+    const int pad = g.shift ? g.ws / 2 : 0, hp = hh + 2 * pad, wp = ww + 2 * pad, N = g.ws * g.ws;
+    const long tok = (long)B * hh * ww, tokp = (long)B * hp * wp, wins = tokp / N;
+    f16 *a = (f16 *)h->a.p, *pi = (f16 *)h->pi.p, *vt = (f16 *)h->vt.p, *st = (f16 *)h->st.p, *gg = (f16 *)h->g.p;
+    f16 *po = (f16 *)h->po.p, *y = (f16 *)h->y.p, *z = (f16 *)h->z.p;
+    const unsigned bp = (unsigned)((tokp + 255) / 256);
+    int rc;
+    {
+        ProfScope ps("li_ln_pad_kernel", s, 0.0, (double)tokp * C * 4.0);
+        li_ln_pad_kernel<C><<<bp, 256, 0, s>>>(x, g.ln1, a, B, hh, ww, pad);
+    }
+    if ((rc = lin(g.proj_in, a, tokp, 4 * C, 1, 0.f, nullptr, pi, s, "li_proj_in"))) return rc;
+    {
+        ProfScope ps("li_ln2_t_kernel", s, 0.0, (double)tokp * C * 8.0);
+        li_ln2_t_kernel<2 * C><<<bp, 256, 0, s>>>(pi, g.ln2, vt, B, hp, wp, g.ws);
+    }
+    // token mixing: rows = (window, channel), K = tokens of the window
+    if ((rc = lin(g.spatial, vt, wins * 2 * C, N, 0, 0.f, nullptr, st, s, "li_spatial"))) return rc;
+    {
+        ProfScope ps("li_gate_kernel", s, 0.0, (double)tokp * C * 12.0);
+        li_gate_kernel<2 * C><<<bp, 256, 0, s>>>(pi, st, gg, B, hp, wp, g.ws);
+    }
+    if ((rc = lin(g.proj_out, gg, tokp, C, 0, 0.f, nullptr, po, s, "li_proj_out"))) return rc;
+    {
+        const long n = tok * (C / 8);
+        ProfScope ps("li_crop_add_kernel", s, 0.0, (double)tok * C * 6.0);
+        li_crop_add_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x, po, B, hh, ww, pad, C);
+    }
+    // GLUConvMLP: 1x1 -> GLU -> replicate pad + 3x3, residual
+    if ((rc = lin(g.w1, x, tok, C, 0, 0.f, nullptr, y, s, "li_glu_w1"))) return rc;
+    {
+        const long n = tok * (g.w2.Cin / 8);
+        ProfScope ps("li_glu_kernel", s, 0.0, (double)tok * C * 3.0);
+        li_glu_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(y, z, tok, C, g.w2.Cin);
+    }
+    ConvArgs cv;
+    memset(&cv, 0, sizeof(cv));
+    cv.a = z; cv.B = B; cv.Hi = hh; cv.Wi = ww; cv.Cin = g.w2.Cin; cv.Ho = hh; cv.Wo = ww; cv.stride = 1; cv.kh = 3; cv.kw = 3;
+    cv.wstream = g.w2.stream; cv.bias = g.w2.bias; cv.N = g.w2.N; cv.n_real = C; cv.act = 0; cv.out = x; cv.rpad = 1; cv.res = x;
+    if ((rc = launch_conv(cv, s))) return rc;
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" int nunif_hip_light_inpaint_create(const nunif_tensor_desc *tensors, int32_t n_tensors, nunif_light_inpaint **handle) {
+    NUNIF_REQUIRE(tensors && handle && n_tensors > 0, "light_inpaint_create: NULL argument");
+    TMap m;
+    for (int i = 0; i < n_tensors; ++i) {
+        HostT t;
+        t.data = tensors[i].data;
+        t.numel = 1;
+        for (int d = 0; d < tensors[i].ndim; ++d) { t.shape.push_back(tensors[i].shape[d]); t.numel *= tensors[i].shape[d]; }
+        m[tensors[i].name] = t;
+    }
+    nunif_light_inpaint *h = new nunif_light_inpaint();
+    int rc = NUNIF_HIP_OK;
+    do {
+        const HostT *mb, *pw, *pb, *dw, *db, *uw, *ub;
+        if ((rc = find(m, "mask_bias", &mb)) || (rc = find(m, "patch.0.weight", &pw)) || (rc = find(m, "patch.0.bias", &pb)) ||
+            (rc = find(m, "down.weight", &dw)) || (rc = find(m, "down.bias", &db)) || (rc = find(m, "up.weight", &uw)) ||
+            (rc = find(m, "up.bias", &ub)))
+            break;
+        if (mb->numel != 96 || pw->numel != 96 * 48 || dw->numel != (int64_t)192 * 96 * 4 || uw->numel != (int64_t)384 * 192) {
+            set_error("light_inpaint: unexpected shapes (C = 96 expected)");
+            rc = NUNIF_HIP_EUNSUPPORTED;
+            break;
+        }
+        std::vector<f16> mbh(96);
+        for (int i = 0; i < 96; ++i) mbh[i] = (f16)mb->data[i];
+        if ((rc = upload(h, mbh, &h->mask_bias))) break;
+        {   // patch: 1x1 conv 48 -> 96 on the pixel_unshuffle(4) channels (input padded to 64)
+            const float *wd = pw->data;
+            if ((rc = make_lin(h, 96, 64, [=](int n, int k) { return k < 48 ? wd[(size_t)n * 48 + k] : 0.f; },
+                               std::vector<float>(pb->data, pb->data + 96), &h->patch)))
+                break;
+        }
+        {   // down: Conv2d(96, 192, 2, 2): weight [192][96][2][2] -> k = (i*2 + j) * 96 + ci
+            const float *wd = dw->data;
+            if ((rc = make_lin(h, 192, 384, [=](int n, int k) { return wd[((size_t)n * 96 + k % 96) * 4 + k / 96]; },
+                               std::vector<float>(db->data, db->data + 192), &h->down)))
+                break;
+        }
+        {   // up: 1x1 conv 192 -> 384 + F.pixel_shuffle(2): rows c*4 + q -> q*96 + c (gemm mode 1 column order)
+            const float *wd = uw->data;
+            std::vector<float> bb(384);
+            for (int n = 0; n < 384; ++n) bb[n] = ub->data[(n % 96) * 4 + n / 96];
+            if ((rc = make_lin(h, 384, 192, [=](int n, int k) { return wd[(size_t)((n % 96) * 4 + n / 96) * 192 + k]; }, bb, &h->up)))
+                break;
+        }
+        if ((rc = make_gblock(h, m, "enc1.", 96, 16, 1, &h->enc1))) break;
+        for (int i = 0; i < 4 && !rc; ++i) rc = make_gblock(h, m, "enc2." + std::to_string(i) + ".", 192, 8, i & 1, &h->enc2[i]);
+        if (rc) break;
+        if ((rc = make_gblock(h, m, "dec1.", 96, 16, 0, &h->dec1))) break;
+        if ((rc = make_conv3(h, m, "to_image.1", 96, 96, 48, &h->to_image))) break;
+        // get_gaussian_kernel1d(15) (gaussian_filter.py:8-19): sigma = 15 * 0.15 + 0.35, normalised, computed in fp32 like torch
+        float g[15], sum = 0.f;
+        const float sigma = 15 * 0.15f + 0.35f;
+        for (int i = 0; i < 15; ++i) { const float xv = (float)(i - 7) / sigma; g[i] = expf(-0.5f * (xv * xv)); sum += g[i]; }
+        for (int i = 0; i < 15; ++i) h->gauss.w[i] = g[i] / sum;
+    } while (0);
+    if (rc) { nunif_hip_light_inpaint_destroy(h); return rc; }
+    *handle = h;
+    return NUNIF_HIP_OK;
+}
+
+extern "C" void nunif_hip_light_inpaint_destroy(nunif_light_inpaint *h) {
+    if (!h) return;
+    for (void *p : h->owned) (void)hipFree(p);
+    for (Buf *b : {&h->x1, &h->x2, &h->a, &h->pi, &h->vt, &h->st, &h->g, &h->po, &h->y, &h->z, &h->ti, &h->mtok, &h->mf0, &h->mf1,
+                   &h->mf2, &h->hard, &h->soft})
+        b->release();
+    delete h;
+}
+
+extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float *x, const uint8_t *mask, float *out, int32_t B,
+                                             int32_t H, int32_t W, int32_t closing, int32_t inner_iter, int32_t outer_iter,
+                                             void *stream) {
+    NUNIF_REQUIRE(h && x && mask && out && B > 0 && H > 0 && W > 0 && inner_iter >= 0 && outer_iter >= 0,
+                  "light_inpaint_infer: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int Hp = H + 64 - H % 64, Wp = W + 64 - W % 64;            // light_inpaint_v1.py:135-137: always pads (1..64)
+    const int h1 = Hp / 4, w1 = Wp / 4, h2 = h1 / 2, w2 = w1 / 2;
+    const long px = (long)B * H * W, t1 = (long)B * h1 * w1, t2 = (long)B * h2 * w2;
+    const long tp1 = (long)B * (h1 + 16) * (w1 + 16), tp2 = (long)B * (h2 + 8) * (w2 + 8);
+    const size_t big = (size_t)std::max(tp1 * 96, tp2 * 192) * sizeof(f16);
+    int rc;
+    if ((rc = h->x1.ensure((size_t)t1 * 96 * 2)) || (rc = h->x2.ensure((size_t)t2 * 192 * 2)) || (rc = h->a.ensure(big)) ||
+        (rc = h->pi.ensure(big * 4)) || (rc = h->vt.ensure(big * 2)) || (rc = h->st.ensure(big * 2)) ||
+        (rc = h->g.ensure(big * 2)) || (rc = h->po.ensure(big)) || (rc = h->y.ensure(big)) || (rc = h->z.ensure(big)) ||
+        (rc = h->ti.ensure((size_t)t1 * 64 * 2)) || (rc = h->mtok.ensure((size_t)t1)) || (rc = h->mf0.ensure((size_t)px * 4)) ||
+        (rc = h->mf1.ensure((size_t)px * 4)) || (rc = h->mf2.ensure((size_t)px * 4)) || (rc = h->hard.ensure((size_t)px * 4)) ||
+        (rc = h->soft.ensure((size_t)px * 4)))
+        return rc;
+    float *mf0 = (float *)h->mf0.p, *mf1 = (float *)h->mf1.p, *mf2 = (float *)h->mf2.p, *hard = (float *)h->hard.p;
+    float *soft = (float *)h->soft.p;
+    const unsigned pb = (unsigned)((px + 255) / 256);
+    {
+        ProfScope ps("li_preprocess", s, 0.0, (double)px * 40.0);
+        // preprocess :93-104: [mask_closing] -> dilate_inner / dilate_outer -> hard mask; soft = clamp(blur15(hard) + hard)
+        li_u8_to_f32_kernel<<<pb, 256, 0, s>>>(mask, mf0, px);
+        float *cur = mf0;
+        if (closing) {          // mask_closing (iw3/dilation.py:145-152): closing(3x3, n_iter = 2) + the original, clamp
+            li_morph_kernel<<<pb, 256, 0, s>>>(mf0, mf1, B, H, W, 0);
+            li_morph_kernel<<<pb, 256, 0, s>>>(mf1, mf2, B, H, W, 0);
+            li_morph_kernel<<<pb, 256, 0, s>>>(mf2, mf1, B, H, W, 1);
+            li_morph_kernel<<<pb, 256, 0, s>>>(mf1, mf2, B, H, W, 1);
+            li_add_clamp_kernel<<<pb, 256, 0, s>>>(mf2, mf0, mf1, px);
+            cur = mf1;
+        }
+        if (inner_iter > 0 || outer_iter > 0) li_dilate_kernel<<<pb, 256, 0, s>>>(cur, hard, (long)B * H, W, inner_iter, outer_iter);
+        else NUNIF_HIP_CHECK(hipMemcpyAsync(hard, cur, (size_t)px * 4, hipMemcpyDeviceToDevice, s));
+        li_blur_kernel<<<pb, 256, 0, s>>>(hard, hard, mf2, B, H, W, 0, h->gauss);
+        li_blur_kernel<<<pb, 256, 0, s>>>(mf2, hard, soft, B, H, W, 1, h->gauss);
+    }
+    f16 *x1 = (f16 *)h->x1.p, *x2 = (f16 *)h->x2.p, *a = (f16 *)h->a.p, *ti = (f16 *)h->ti.p;
+    uint8_t *mtok = (uint8_t *)h->mtok.p;
+    {
+        ProfScope ps("li_patch_in_kernel", s, 0.0, (double)px * 20.0);
+        li_patch_in_kernel<<<(unsigned)((t1 + 255) / 256), 256, 0, s>>>(x, hard, soft, a, mtok, B, H, W, h1, w1);
+    }
+    // NOTE: the replicate padding of the soft mask is the clamp of the pixel coordinate inside li_patch_in_kernel
+    if ((rc = lin(h->patch, a, t1, 96, 2, 0.2f, nullptr, x1, s, "li_patch"))) return rc;
+    {
+        const long n = t1 * 12;
+        li_mask_bias_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x1, mtok, h->mask_bias, t1, 96);
+    }
+    if ((rc = run_gblock<96>(h, h->enc1, x1, B, h1, w1, s))) return rc;
+    {   // down: 2x2 stride-2 conv as a gather GEMM
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.a = x1; g.B = B; g.Hi = h1; g.Wi = w1; g.Cin = 96; g.Ho = h2; g.Wo = w2; g.stride = 2; g.kw = 2;
+        g.K = 384; g.w = h->down.w; g.bias = h->down.bias; g.N = h->down.N; g.mode = 0; g.out = x2; g.ldo = 192; g.n_real = 192;
+        g.ps = 1;
+        if ((rc = launch_gemm(g, s, "li_down"))) return rc;
+    }
+    for (int i = 0; i < 4; ++i)
+        if ((rc = run_gblock<192>(h, h->enc2[i], x2, B, h2, w2, s))) return rc;
+    {   // x = x1 + pixel_shuffle(up(x2), 2), written over x1
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.a = x2; g.B = B; g.Hi = h2; g.Wi = w2; g.Cin = 192; g.Ho = h2; g.Wo = w2; g.stride = 1; g.kw = 1;
+        g.K = 192; g.w = h->up.w; g.bias = h->up.bias; g.N = h->up.N; g.mode = 1; g.res = x1; g.out = x1; g.ldo = 96; g.n_real = 384;
+        g.ps = 1;
+        if ((rc = launch_gemm(g, s, "li_up"))) return rc;
+    }
+    if ((rc = run_gblock<96>(h, h->dec1, x1, B, h1, w1, s))) return rc;
+    {
+        ConvArgs cv;
+        memset(&cv, 0, sizeof(cv));
+        cv.a = x1; cv.B = B; cv.Hi = h1; cv.Wi = w1; cv.Cin = 96; cv.Ho = h1; cv.Wo = w1; cv.stride = 1; cv.kh = 3; cv.kw = 3;
+        cv.wstream = h->to_image.stream; cv.bias = h->to_image.bias; cv.N = h->to_image.N; cv.n_real = 48; cv.act = 0; cv.out = ti;
+        cv.rpad = 1;
+        if ((rc = launch_conv(cv, s))) return rc;
+    }
+    {
+        ProfScope ps("li_compose_kernel", s, 0.0, (double)px * 36.0);
+        li_compose_kernel<<<pb, 256, 0, s>>>(x, hard, soft, ti, out, B, H, W, h1, w1);
+    }
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}

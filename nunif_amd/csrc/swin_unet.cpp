@@ -67,7 +67,7 @@ struct nunif_swin_unet {
     int C1 = 48, C1P = 64;            // stem conv1 channels (real / padded to a multiple of 32)
     int top_dim = 96;                 // channels of level 1 on the decoder side (C for 1x/2x, 2C for 4x)
     float *stem1_w = nullptr, *stem1_b = nullptr;
-    Linear stem2, down1, down2, up2, up1, proj2, to_image;
+    Linear stem2, down1, down2, up2, up1, proj2, to_image, to_image_pre;
     f16 *to_image_chained = nullptr;  // ToImage weights in the chained k order, for the fused head of the last C = 96 block
     f16 *stemf_w1 = nullptr, *stemf_w2 = nullptr;   // fused stem (swin_stem.hip)
     int stem_fused = 1;               // NUNIF_STEM_FUSED=0: stem1_kernel + gather GEMM
@@ -454,6 +454,13 @@ stem_done:
         return run_stage(h, h->swin[4], top, B, S, h->top_dim, s, "swin5", &ti);
     }
     if ((rc = run_stage(h, h->swin[4], top, B, S, h->top_dim, s, "swin5"))) return rc;                // swin5
+    if (h->scale_factor == 8) {
+        f16 *pre = (f16 *)h->att.p;                 // the attention scratch map is free again: [B,S,S,192]
+        if ((rc = run_gemm(h->to_image_pre, top, B, S, S, h->top_dim, S, S, 1, 0, 0, 1, 0, 2, 0.2f, nullptr, pre, 192, 1, s,
+                           "gemm_to_image_pre", next_dir(h))))
+            return rc;
+        top = pre;
+    }
     if ((rc = run_gemm(h->to_image, top, B, S, S, h->top_dim, S, S, 1, 0, 0, 1, 2, 0, 0.f, nullptr, z, 0,
                        h->scale_factor, s, "gemm_to_image", next_dir(h))))
         return rc;
@@ -466,8 +473,8 @@ stem_done:
 extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int32_t n_tensors,
                                           int32_t scale_factor, nunif_swin_unet **handle) {
     NUNIF_REQUIRE(tensors && handle && n_tensors > 0, "swin_unet_create: NULL argument");
-    NUNIF_REQUIRE(scale_factor == 1 || scale_factor == 2 || scale_factor == 4,
-                  "swin_unet_create: scale_factor %d unsupported (1, 2, 4)", scale_factor);
+    NUNIF_REQUIRE(scale_factor == 1 || scale_factor == 2 || scale_factor == 4 || scale_factor == 8,
+                  "swin_unet_create: scale_factor %d unsupported (1, 2, 4, 8)", scale_factor);
     TensorMap m;
     for (int i = 0; i < n_tensors; ++i) {
         HostTensor t;
@@ -501,7 +508,7 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
         const int C1 = (int)w0->shape[0];
         if (C % 96 != 0 || C1 * 2 != C) { set_error("base_dim %d unsupported", C); rc = NUNIF_HIP_EUNSUPPORTED; break; }
         h->C = C; h->heads = C / 16; h->C1 = C1; h->C1P = (C1 + 31) / 32 * 32;
-        h->has_proj2 = scale_factor == 4;
+        h->has_proj2 = scale_factor >= 4;
         h->top_dim = h->has_proj2 ? 2 * C : C;
         {
             std::vector<float> w(w0->data, w0->data + w0->numel), b(b0->data, b0->data + b0->numel);
@@ -573,8 +580,13 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
         if ((rc = make_up(P + "up2", 2 * C, 2 * C, &h->up2))) break;
         if ((rc = make_up(P + "up1", 2 * C, h->top_dim, &h->up1))) break;
         if (h->has_proj2 && (rc = make_plain_linear(h, m, P + "proj2", 2 * C, C, &h->proj2))) break;
-        if ((rc = make_plain_linear(h, m, P + "to_image.proj", 3 * scale_factor * scale_factor, h->top_dim,
-                                    &h->to_image)))
+        if (scale_factor == 8) {
+            // ToImage of the 8x net (swin_unet.py:96-101): Linear -> LeakyReLU(0.2) -> Linear, both 192 wide
+            if ((rc = make_plain_linear(h, m, P + "to_image.proj.0", 192, h->top_dim, &h->to_image_pre)) ||
+                (rc = make_plain_linear(h, m, P + "to_image.proj.2", 192, 192, &h->to_image)))
+                break;
+        } else if ((rc = make_plain_linear(h, m, P + "to_image.proj", 3 * scale_factor * scale_factor, h->top_dim,
+                                           &h->to_image)))
             break;
         if (h->top_dim == 96 && 3 * scale_factor * scale_factor <= 16) {
             const HostTensor *tw;
@@ -632,6 +644,9 @@ extern "C" int nunif_hip_swin_unet_forward(nunif_swin_unet *h, const float *x, f
 extern "C" int nunif_hip_swin_unet_render(nunif_swin_unet *h, const float *x, float *y, int32_t x_h, int32_t x_w,
                                           int32_t tile_size, int32_t batch_size, void *stream) {
     NUNIF_REQUIRE(h && x && y && batch_size > 0, "swin_unet_render: bad argument");
+    // (the reference registers its experimental 8x net with scale = 4 / offset = 64, swin_unet.py:309, which no tile grid
+    //  can serve: only the per-tile forward exists for it)
+    NUNIF_REQUIRE(h->scale_factor != 8, "swin_unet_render: the 8x net has no consistent tile geometry; use forward");
     const int s = h->scale_factor;
     nunif_tile_grid g;
     int rc = nunif_hip_tile_grid_init(x_h, x_w, s, 8 * s, tile_size, 4 * s, &g);   // offsets/blend: swin_unet.py:213,234,267

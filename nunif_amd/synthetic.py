@@ -100,8 +100,11 @@ def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_c
         lin(P + "proj2", c, c * 2)
         lin(P + "up1.proj", c * 2, c * 2 * 4)
         stage(P + "swin5", c * 2, h, 2)
-        assert scale_factor == 4, "8x head not generated here"
-        lin(P + "to_image.proj", c * 2, out_channels * scale_factor ** 2, HEAD_GAIN, 0.5)
+        if scale_factor == 8:        # ToImage :96-101: Linear, LeakyReLU(0.2), Linear
+            lin(P + "to_image.proj.0", c * 2, out_channels * 64)
+            lin(P + "to_image.proj.2", out_channels * 64, out_channels * 64, HEAD_GAIN, 0.5)
+        else:
+            lin(P + "to_image.proj", c * 2, out_channels * scale_factor ** 2, HEAD_GAIN, 0.5)
     return sd
 
 
@@ -196,6 +199,46 @@ def conv_stack_state_dict(seed, kind):
         gain = 0.25 if last else 1.0
         sd[f"net.{2 * i}.weight"] = torch.randn(shape, generator=g) * (gain * math.sqrt(2.0 / (1.01 * fan_in)))
         sd[f"net.{2 * i}.bias"] = torch.randn(cout, generator=g) * 0.05 + (0.5 if last else 0.0)
+    return sd
+
+
+def light_inpaint_state_dict(seed):
+    """Seeded weights of inpaint.light_inpaint_v1 in the reference's key layout: every bias non-zero, LayerNorm weights
+    around 1, the token-mixing matrices (proj_spatial) strong enough to matter (the reference initialises them ~1e-5 with
+    bias 1), to_image centred on 0.5 so that the net output sits in the image range."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def rnd(*shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    def lin(key, *shape, std=None, bstd=0.05, bmean=0.0):
+        fan = 1
+        for s in shape[1:]:
+            fan *= s
+        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
+        sd[key + ".bias"] = rnd(shape[0], std=bstd) + bmean
+
+    def block(p, C, ws):
+        N = ws * ws
+        lin(p + "gmlp.gmlp.proj_in", 4 * C, C, std=math.sqrt(2.0 / C))
+        sd[p + "gmlp.gmlp.proj_spatial.weight"] = rnd(N, N, 1, std=0.7 / math.sqrt(N))
+        sd[p + "gmlp.gmlp.proj_spatial.bias"] = rnd(N, std=0.3) + 0.5
+        lin(p + "gmlp.gmlp.proj_out", C, 2 * C, std=0.5 * math.sqrt(1.0 / (2 * C)))
+        sd[p + "norm1.weight"] = 1.0 + rnd(C, std=0.1)
+        sd[p + "norm2.weight"] = 1.0 + rnd(2 * C, std=0.1)
+        lin(p + "glu_conv.w1", C, C, 1, 1, std=math.sqrt(2.0 / C))
+        lin(p + "glu_conv.w2", C, C // 2, 3, 3, std=0.5 * math.sqrt(1.0 / (9 * C // 2)))
+
+    sd["mask_bias"] = rnd(1, 96, 1, 1, std=0.3)
+    lin("patch.0", 96, 48, 1, 1, std=math.sqrt(2.0 / 48))
+    block("enc1.", 96, 16)
+    lin("down", 192, 96, 2, 2)
+    for i in range(4):
+        block(f"enc2.{i}.", 192, 8)
+    lin("up", 384, 192, 1, 1)
+    block("dec1.", 96, 16)
+    lin("to_image.1", 48, 96, 3, 3, std=0.0028 * math.sqrt(1.0 / (9 * 96)), bstd=0.05, bmean=0.5)
     return sd
 
 

@@ -73,7 +73,11 @@ def _init_weights(scale_factor, base_dim, in_channels, out_channels):
     top = C if scale_factor in (1, 2) else C * 2
     linear(P + "up1.proj", C * 2, top * 4)
     stage(P + "swin5", top, 2)
-    linear(P + "to_image.proj", top, out_channels * scale_factor ** 2)
+    if scale_factor == 8:            # ToImage :96-101: Linear -> LeakyReLU(0.2) -> Linear
+        linear(P + "to_image.proj.0", top, out_channels * 64)
+        linear(P + "to_image.proj.2", out_channels * 64, out_channels * 64)
+    else:
+        linear(P + "to_image.proj", top, out_channels * scale_factor ** 2)
     return sd
 
 
@@ -263,6 +267,24 @@ class SwinUNet4x(_HipSwinUNetModel):
     def to_1x(self, shared=True):
         return SwinUNetDownscaled(in_channels=self.i2i_in_channels, out_channels=self.out_channels,
                                   downscale_factor=4, unet=self)
+
+
+@register_model
+class SwinUNet8x(_HipSwinUNetModel):
+    """Reference :303-321.  The registered geometry (scale 4, offset 64, blend 32) is the reference's; the net itself
+    returns 8 x (T - 16) pixels per side, so only the per-tile ``forward`` is meaningful (as in the reference)."""
+    name = "waifu2x.swin_unet_8x"
+    unet_scale_factor = 8
+
+    def __init__(self, in_channels=3, out_channels=3):
+        super().__init__(dict(in_channels=in_channels, out_channels=out_channels),
+                         scale=4, offset=64, in_channels=in_channels, blend_size=32)
+        self._setup(in_channels, out_channels)
+
+    def __getattribute__(self, name):
+        if name == "render_frame":             # no consistent tile grid exists for this net
+            raise AttributeError(name)
+        return super().__getattribute__(name)
 
 
 @register_model

@@ -1,0 +1,132 @@
+"""Oracle: iw3 ``inpaint.light_inpaint_v1`` (the image inpaint net behind ``MLBWInpaintImage``), torch CPU fp32.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows the reference: ``iw3/models/light_inpaint_v1.py`` — ``GLUConvMLP`` :15-34, ``GMLPBlock`` :37-50, ``LightInpaintV1``
+:53-150 (``preprocess`` :93-104, ``infer`` :106-110, ``_forward`` :112-128, ``forward`` :130-161);
+``nunif/modules/attention.py`` ``GMLP`` :621-651, ``WindowGMLP2d`` :654-693 (shift = ZERO padding by half a window, crop);
+``nunif/modules/norm.py`` ``FastLayerNorm`` :78-101 (LayerNorm, eps 1e-5, weight only); ``nunif/modules/gaussian_filter.py``
+``get_gaussian_kernel1d`` :8-19, ``SeparableGaussianFilter2d`` :52-73 (replicate pad, horizontal then vertical);
+``iw3/dilation.py`` ``mask_closing`` :145-152; ``iw3/mlbw_inpaint.py`` ``forward_right`` / ``forward_left`` :21-35,
+``apply_divergence`` :38-75, ``MLBWInpaintImage.forward`` :118-157.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import mlbw as OM
+
+
+def _ln(x, w):
+    return F.layer_norm(x, (x.shape[-1],), w, None, 1e-5)
+
+
+def _windows(x, ws):
+    B, C, H, W = x.shape
+    return x.reshape(B, C, H // ws, ws, W // ws, ws).permute(0, 2, 4, 3, 5, 1).reshape(-1, ws * ws, C)
+
+
+def _unwindows(t, shape, ws):
+    B, C, H, W = shape
+    return t.reshape(B, H // ws, W // ws, ws, ws, C).permute(0, 5, 1, 3, 2, 4).reshape(B, C, H, W)
+
+
+def window_gmlp(sd, p, x, ws, shift):
+    """WindowGMLP2d(norm1, norm2) INCLUDING the GMLP-internal shortcut (GMLP.forward returns proj_out(...) + its input)."""
+    pad = ws // 2 if shift else 0
+    if pad:
+        x = F.pad(x, (pad,) * 4)
+    shape = x.shape
+    t = _windows(x, ws)
+    a = F.gelu(F.linear(_ln(t, sd[p + "norm1.weight"]), sd[p + "gmlp.gmlp.proj_in.weight"], sd[p + "gmlp.gmlp.proj_in.bias"]))
+    u, v = a.chunk(2, dim=-1)
+    v = F.conv1d(_ln(v, sd[p + "norm2.weight"]), sd[p + "gmlp.gmlp.proj_spatial.weight"], sd[p + "gmlp.gmlp.proj_spatial.bias"])
+    t = F.linear(u * v, sd[p + "gmlp.gmlp.proj_out.weight"], sd[p + "gmlp.gmlp.proj_out.bias"]) + t
+    x = _unwindows(t, shape, ws)
+    return x[:, :, pad:x.shape[2] - pad, pad:x.shape[3] - pad] if pad else x
+
+
+def gmlp_block(sd, p, x, ws, shift):
+    x = x + window_gmlp(sd, p, x, ws, shift)
+    y = F.glu(F.conv2d(x, sd[p + "glu_conv.w1.weight"], sd[p + "glu_conv.w1.bias"]), dim=1)
+    y = F.conv2d(F.pad(y, (1, 1, 1, 1), mode="replicate"), sd[p + "glu_conv.w2.weight"], sd[p + "glu_conv.w2.bias"])
+    return x + y
+
+
+def gaussian_kernel1d(k):
+    sigma = k * 0.15 + 0.35
+    half = (k - 1) * 0.5
+    g = torch.exp(-0.5 * (torch.linspace(-half, half, steps=k) / sigma).pow(2))
+    return g / g.sum()
+
+
+def mask_blur(m, k=15):
+    g = gaussian_kernel1d(k)
+    m = F.pad(m, (k // 2,) * 4, mode="replicate")
+    m = F.conv2d(m, g.view(1, 1, 1, k))
+    return F.conv2d(m, g.view(1, 1, k, 1))
+
+
+def preprocess(x, mask, closing=False, inner_dilation=0, outer_dilation=0, base_width=None):
+    if closing:
+        m0 = mask.float()
+        mask = (OM.closing(m0, kernel_size=3, n_iter=2) + m0).clamp(0, 1)
+    else:
+        mask = mask.float()
+    mask = OM.dilate_inner(mask, inner_dilation, base_width).float()
+    mask = OM.dilate_outer(mask, outer_dilation, base_width).float()
+    x = x * (1 - mask)
+    return x, torch.clamp(mask_blur(mask) + mask, 0, 1)
+
+
+def net(sd, x, mask):
+    """_forward: x normalised [B,3,Hp,Wp] (multiples of 64), mask float [B,1,Hp,Wp] -> [B,3,Hp,Wp]."""
+    x = F.leaky_relu(F.conv2d(F.pixel_unshuffle(x, 4), sd["patch.0.weight"], sd["patch.0.bias"]), 0.2)
+    mtok = F.pixel_unshuffle(mask, 4).amax(dim=1, keepdim=True) > 0.99
+    x = torch.where(mtok, sd["mask_bias"], x)
+    x1 = gmlp_block(sd, "enc1.", x, 16, True)
+    x2 = F.conv2d(x1, sd["down.weight"], sd["down.bias"], stride=2)
+    for i, sh in enumerate((False, True, False, True)):
+        x2 = gmlp_block(sd, f"enc2.{i}.", x2, 8, sh)
+    x2 = F.pixel_shuffle(F.conv2d(x2, sd["up.weight"], sd["up.bias"]), 2)
+    x = gmlp_block(sd, "dec1.", x1 + x2, 16, False)
+    x = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), sd["to_image.1.weight"], sd["to_image.1.bias"])
+    return F.pixel_shuffle(x, 4)
+
+
+def forward(sd, x, mask, skip_i2i_offset=True):
+    src = x
+    H, W = x.shape[2:]
+    pad1, pad2 = 64 - W % 64, 64 - H % 64
+    xn = F.pad((x - 0.5) / 0.5, (0, pad1, 0, pad2), mode="replicate")
+    mp = F.pad(mask, (0, pad1, 0, pad2), mode="replicate")
+    y = net(sd, xn, mp)[:, :, :H, :W]
+    if not skip_i2i_offset:
+        src, mask, y = (t[:, :, 16:-16, 16:-16] for t in (src, mask, y))
+    return (src * (1 - mask) + y * mask).clamp(0, 1)
+
+
+def infer(sd, x, mask, closing=False, inner_dilation=0, outer_dilation=0, base_width=None):
+    x, mask = preprocess(x, mask, closing, inner_dilation, outer_dilation, base_width)
+    return forward(sd, x, mask, skip_i2i_offset=True)
+
+
+# ---- MLBWInpaintImage (iw3/mlbw_inpaint.py:78-157; max_width = None) ------------------------------------------------------
+def mlbw_inpaint_image(sd_mask_mlbw, sd_inpaint, x, depth, divergence, convergence, synthetic_view="both",
+                       inner_dilation=0, outer_dilation=0):
+    def eye(shift, div):
+        z, logits = OM.apply_divergence_nn_delta_weight(sd_mask_mlbw, x, depth, div, convergence, shift, 2, return_mask=True)
+        if shift < 0:
+            z, logits = z.flip(-1), logits.flip(-1)
+        m = OM.postprocess_hole_mask(logits, z.shape[-2:], 0.15, inner_dilation, outer_dilation)
+        z = infer(sd_inpaint, z, m)
+        return z.flip(-1) if shift < 0 else z
+    if synthetic_view == "both":
+        return eye(-1, divergence), eye(1, divergence)
+    if synthetic_view == "right":
+        return x, eye(1, divergence * 2)
+    return eye(-1, divergence * 2), x
+
+
+def random_state_dict(*args, **kwargs):
+    from nunif_amd.synthetic import light_inpaint_state_dict
+    return light_inpaint_state_dict(*args, **kwargs)

@@ -95,6 +95,60 @@ def gen_swin():
     save("swin_unet", **out)
 
 
+def gen_swin8x():
+    """waifu2x.swin_unet_8x (two-layer ToImage head, pixel_shuffle 8) on the reference; stored as fp16."""
+    from waifu2x.models.swin_unet import SwinUNet8x
+    from oracle import swin_unet as O
+    x = synth_image(14, 3, 64, 64).unsqueeze(0)
+    sd = O.random_state_dict(108, 8)
+    m = SwinUNet8x().eval()
+    m.load_state_dict(sd, strict=True)
+    y = m(x)
+    print(tuple(y.shape), float(y.mean()), float(y.std()), float((y <= 0).float().mean()), float((y >= 1).float().mean()))
+    save("swin_unet_8x", x=x, y=y.half(), sdsum=sd_checksum(sd))
+
+
+def gen_light_inpaint():
+    """inpaint.light_inpaint_v1 on the reference (infer / forward) + the MLBWInpaintImage flow (mask MLBW warp, hole mask,
+    inpaint, left eye processed flipped) assembled from the reference's own functions."""
+    from iw3.models.light_inpaint_v1 import LightInpaintV1
+    from iw3.models.mlbw import MLBW
+    from iw3 import mlbw_inpaint as RI
+    from oracle import light_inpaint as OL, mlbw as OM
+    from oracle.forward_warp import synth_depth
+    out = {}
+    sd = OL.random_state_dict(701)
+    m = LightInpaintV1().eval()
+    m.load_state_dict(sd, strict=True)
+    out["sdsum"] = sd_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    x = torch.stack([synth_image(111, 3, 70, 100), synth_image(112, 3, 70, 100)])
+    g = torch.Generator().manual_seed(113)
+    mask = torch.rand(2, 1, 70, 100, generator=g) > 0.93
+    mask[0, :, 20:42, 30:55] = True
+    mask[1, :, 5:12, 60:100] = True
+    out["x"], out["mask"] = x, mask
+    out["infer"] = m.infer(x, mask)
+    out["infer_close"] = m.infer(x, mask, closing=True, inner_dilation=1, outer_dilation=2, base_width=50)
+    out["forward_off"] = m(x, mask.float())                      # with the i2i offset crop (training-style call)
+    print("infer", float(out["infer"].std()), float((out["infer"] - x).abs().mean()),
+          float(((out["infer"] <= 0) | (out["infer"] >= 1)).float().mean()))
+    # MLBWInpaintImage.forward :118-157 without the model downloads
+    sdm = OM.random_state_dict(431, 2, False, hole_mask=True)
+    mm = MLBW(num_layers=2, base_dim=32, hole_mask=True).eval()
+    mm.load_state_dict(sdm, strict=True)
+    mm.delta_output = True
+    depth = synth_depth(9, 2, 58, 104, "smooth_edges")
+    c = torch.stack([synth_image(84, 3, 116, 208), synth_image(85, 3, 116, 208)])
+    out["depth"], out["c"] = depth, c
+    le, re, lm, rm = RI.apply_divergence(mm, c, depth, 2.0, 0.5, False, "both", False)
+    kw = dict(inner_dilation=1, outer_dilation=1, base_width=depth.shape[-1])
+    out["mi_left"] = RI.forward_left(m, le, lm, **kw).half()
+    out["mi_right"] = RI.forward_right(m, re, rm, **kw).half()
+    le, re, lm, rm = RI.apply_divergence(mm, c[:1], depth[:1], 2.0, 0.5, False, "right", False)
+    out["mi_right_only"] = RI.forward_right(m, re, rm, inner_dilation=0, outer_dilation=0, base_width=104).half()
+    save("light_inpaint", **out)
+
+
 def gen_iw3():
     from iw3.forward_warp import apply_divergence_forward_warp
     from iw3.backward_warp import apply_divergence_grid_sample
@@ -358,7 +412,7 @@ def gen_depth_aa():
 
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym}
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "light_inpaint": gen_light_inpaint}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

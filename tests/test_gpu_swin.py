@@ -249,3 +249,24 @@ def test_load_save_roundtrip_and_errors(hiplib, tmp_path):
         m(torch.rand(1, 3, 100, 100).to("cuda:0"))      # 100 is not a valid tile size
     with pytest.raises(RuntimeError):
         create_model("waifu2x.swin_unet_2x").eval()(torch.rand(1, 3, 64, 64))   # model on CPU: no fallback
+
+
+def test_swin_unet_8x(hiplib):
+    """waifu2x.swin_unet_8x (reference swin_unet.py:303-321): forward only — its registered tile geometry is inconsistent."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from nunif_amd.nunif.models import create_model
+    from nunif_amd.waifu2x.models import swin_unet as M  # noqa: F401
+    g = np.load(os.path.join(GOLDEN, "swin_unet_8x.npz"))
+    m = create_model("waifu2x.swin_unet_8x").eval()
+    assert (m.i2i_scale, m.i2i_offset, m.i2i_blend_size) == (4, 64, 32) and not hasattr(m, "render_frame")
+    sd = O.random_state_dict(108, 8)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda:0")
+    x = torch.from_numpy(g["x"])
+    y = m(x.to("cuda:0")).cpu()
+    ref = torch.from_numpy(g["y"]).float()
+    assert y.shape == ref.shape == (1, 3, 384, 384)
+    assert psnr(y, ref) >= PSNR_MIN, psnr(y, ref)
+    assert psnr(y, O.model_forward(sd, x, "waifu2x.swin_unet_8x")) >= PSNR_MIN

@@ -94,3 +94,16 @@ def test_stitch_identity_model_reproduces_nearest_upscale():
     out = OS.tiled_render(x, model, scale, offset, blend, tile, 4)
     expect = torch.nn.functional.interpolate(x[None], scale_factor=scale, mode="nearest")[0]
     assert (out - expect).abs().max().item() < 1e-6
+
+
+def test_swin_8x_matches_reference():
+    """waifu2x.swin_unet_8x: the two-layer ToImage head + pixel_shuffle(8) (fixture stored as fp16)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "swin_unet_8x.npz"))
+    sd = O.random_state_dict(108, 8)
+    assert sd_checksum(sd) == pytest.approx(float(g["sdsum"]), rel=1e-12)
+    y = O.model_forward(sd, torch.from_numpy(g["x"]), "waifu2x.swin_unet_8x")
+    ref = torch.from_numpy(g["y"]).float()
+    assert y.shape == ref.shape == (1, 3, 384, 384) and (y - ref).abs().max().item() < 1e-3
