@@ -17,7 +17,11 @@ from nunif_amd.iw3.base_depth_model import CallableDepthModel  # noqa: E402
 from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2  # noqa: E402
 from nunif_amd.iw3.models.row_flow_v3 import RowFlowV3  # noqa: E402
 from nunif_amd.iw3.utils import apply_divergence  # noqa: E402
-from nunif_amd.synthetic import depth_anything_v2_state_dict, row_flow_v3_state_dict  # noqa: E402
+from nunif_amd.iw3.mlbw_inpaint import MLBWInpaint  # noqa: E402
+from nunif_amd.iw3.models.light_inpaint_v1 import LightInpaintV1  # noqa: E402
+from nunif_amd.iw3.models.mlbw import MLBW  # noqa: E402
+from nunif_amd.synthetic import (depth_anything_v2_state_dict, light_inpaint_state_dict, mlbw_state_dict,  # noqa: E402
+                                 row_flow_v3_state_dict)
 
 DEV = "cuda:0"
 
@@ -54,7 +58,36 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         res[method] = {"ms_per_frame": round(dt * 1e3, 3), "fps": round(1 / dt, 1), "input_MPix_s": round(H * W / dt / 1e6, 1)}
+    # image-mode MLBW + inpaint (config 5 without the temporal queue): mask MLBW warp, hole masks, light_inpaint_v1 per eye
+    inp = LightInpaintV1().eval()
+    inp.load_state_dict(light_inpaint_state_dict(701))
+    mm = MLBW(num_layers=2, base_dim=32, hole_mask=True).eval()
+    mm.load_state_dict(mlbw_state_dict(431, 2, False, hole_mask=True))
+    inpaint = MLBWInpaint(inp.to(DEV), mm.to(DEV))
+
+    def step_inpaint(i):
+        x = frames[i % 3]
+        d = depth_model.minmax_normalize_chw(depth_model.infer(x, tta=False, edge_dilation=2))
+        left, right = inpaint.infer(x[None], d[None], divergence=2.0, convergence=0.5, synthetic_view="both",
+                                    inner_dilation=1, outer_dilation=1)
+        return _ops.stereo_to_frame(left[0], right[0], "sbs")
+
+    for i in range(2):
+        step_inpaint(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(10):
+        step_inpaint(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    res["mlbw_inpaint_image"] = {"ms_per_frame": round(dt * 1e3, 3), "fps": round(1 / dt, 1),
+                                 "input_MPix_s": round(H * W / dt / 1e6, 1)}
     _hip.profile_enable(True)
+    step_inpaint(0)
+    torch.cuda.synchronize()
+    recs = _hip.profile_read(reset=True)
+    res["kernel_classes_inpaint"] = [{"kernel": r["name"], "us": round(r["total_ms"] * 1e3, 1), "launches": r["launches"]}
+                                     for r in sorted(recs, key=lambda r: -r["total_ms"])[:16]]
     step(0)
     torch.cuda.synchronize()
     recs = _hip.profile_read()
