@@ -187,7 +187,11 @@ int nunif_hip_delta_warp(const float *c, const float *delta, float *out, int32_t
  * MLBWInpaintImage (iw3/mlbw_inpaint.py:78-157).  create() takes the reference state dict (mask_bias, patch.0, enc1.*, down,
  * enc2.N.*, up, dec1.*, to_image.1).  infer = LightInpaintV1.infer :106-110: preprocess (optional mask_closing, horizontal
  * dilations with FINAL iteration counts, x * (1 - mask), soft mask = clamp(gaussian15(mask) + mask)) + forward with
- * skip_i2i_offset=True.  x, out: [B,3,H,W] f32 in [0,1]; mask: [B,1,H,W] uint8 (0 / 1 hole mask). */
+ * skip_i2i_offset=True.  x, out: [B,3,H,W] f32 in [0,1]; mask: [B,1,H,W] uint8 (0 / 1 hole mask).
+ * The same entry points serve "inpaint.light_video_inpaint_v1" (iw3/models/light_video_inpaint_v1.py LightVideoInpaintV1
+ * :92-229, base_dim 96 / lv2_mlp_ratio 1; recognised by its `patch.weight` / `to_image.weight` keys): level 2 alternates
+ * 8x8-window gMLPs with temporal gMLPs over the 12 frames of each pixel, so infer takes EXACTLY B = 12 consecutive frames
+ * (the host pads shorter batches by repeating the first / last frame, :141-150). */
 typedef struct nunif_light_inpaint nunif_light_inpaint;
 int nunif_hip_light_inpaint_create(const nunif_tensor_desc *tensors, int32_t n_tensors, nunif_light_inpaint **handle);
 void nunif_hip_light_inpaint_destroy(nunif_light_inpaint *handle);

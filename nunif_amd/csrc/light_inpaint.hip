@@ -218,6 +218,73 @@ __global__ void __launch_bounds__(256) li_ln2_t_kernel(const f16 *__restrict__ a
         for (int j = 0; j < 8; ++j) o[(long)(8 * i + j) * N] = (f16)(((float)v[i][j] - mean) * rs * w[8 * i + j]);
 }
 
+// temporal block (light_video_inpaint_v1.py GMLP3DBlock, window (12,1,1)): LayerNorm over the gate half, token-major
+template <int V>
+__global__ void __launch_bounds__(256) li_ln2_kernel(const f16 *__restrict__ a, const float *__restrict__ w, f16 *__restrict__ vn,
+                                                      long tokens) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= tokens) return;
+    const f16x8 *p = reinterpret_cast<const f16x8 *>(a + id * (2 * V) + V);
+    f16x8 v[V / 8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < V / 8; ++i) {
+        v[i] = p[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+    }
+    const float mean = sum / (float)V;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < V / 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)v[i][j] - mean; var += d * d; }
+    const float rs = rsqrtf(var / (float)V + 1e-5f);
+    f16x8 *o = reinterpret_cast<f16x8 *>(vn + id * V);
+#pragma unroll
+    for (int i = 0; i < V / 8; ++i) {
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (f16)(((float)v[i][j] - mean) * rs * w[8 * i + j]);
+        o[i] = r;
+    }
+}
+
+// g[t][p][c] = u[t][p][c] * (b[t] + sum_s W[t][s] vn[s][p][c]) over the T = 12 frames of pixel p; thread = (pixel, 8 channels)
+struct TMix { float w[12][12]; float b[12]; };
+template <int V>
+__global__ void __launch_bounds__(256) li_tmix_gate_kernel(const f16 *__restrict__ a, const f16 *__restrict__ vn,
+                                                            f16 *__restrict__ g, long pixels, TMix m) {
+    constexpr int T = 12, runs = V / 8;
+    const long n = pixels * runs, id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const long p = id / runs;
+    const int c0 = (int)(id - p * runs) * 8;
+    float v[T][8];
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+        const f16x8 x = *reinterpret_cast<const f16x8 *>(vn + ((long)s * pixels + p) * V + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[s][j] = (float)x[j];
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = m.b[t];
+#pragma unroll
+        for (int s = 0; s < T; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(m.w[t][s], v[s][j], acc[j]);
+        const long tok = (long)t * pixels + p;
+        const f16x8 u = *reinterpret_cast<const f16x8 *>(a + tok * (2 * V) + c0);
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (f16)((float)u[j] * acc[j]);
+        *reinterpret_cast<f16x8 *>(g + tok * V + c0) = r;
+    }
+}
+
 // g[token][c] = u[token][c] * st[window][c][token]  (u = first half of proj_in's output, st = the mixed gate, transposed)
 template <int C2>
 __global__ void __launch_bounds__(256) li_gate_kernel(const f16 *__restrict__ a, const f16 *__restrict__ st, f16 *__restrict__ g,
@@ -282,14 +349,15 @@ __global__ void __launch_bounds__(256) li_glu_kernel(const f16 *__restrict__ y, 
 // out = clamp(src (1 - m) + y m, 0, 1): src = x (1 - hard mask), m = soft mask, y = pixel_shuffle(4) of the net's 48 channels
 __global__ void __launch_bounds__(256) li_compose_kernel(const float *__restrict__ x, const float *__restrict__ hard,
                                                           const float *__restrict__ soft, const f16 *__restrict__ ti,
-                                                          float *__restrict__ out, int B, int H, int W, int h1, int w1) {
+                                                          float *__restrict__ out, int B, int H, int W, int h1, int w1,
+                                                          int ti_stride) {
     const long n = (long)B * H * W, id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= n) return;
     const int xx = (int)(id % W);
     const long t = id / W;
     const int yy = (int)(t % H), b = (int)(t / H);
     const float keep = 1.f - hard[id], m = soft[id];
-    const f16 *tv = ti + (((long)b * h1 + yy / 4) * w1 + xx / 4) * 48 + (yy & 3) * 4 + (xx & 3);
+    const f16 *tv = ti + (((long)b * h1 + yy / 4) * w1 + xx / 4) * ti_stride + (yy & 3) * 4 + (xx & 3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const long o = (((long)b * 3 + c) * H + yy) * W + xx;
@@ -333,7 +401,8 @@ struct Buf {
 struct Lin { f16 *w = nullptr; float *bias = nullptr; int N = 0, K = 0; };                 // gemm_kernel packing [nt][ks]
 struct Conv3 { f16 *stream = nullptr; float *bias = nullptr; int N = 0, n_real = 0, Cin = 0; };   // conv_kernel stream [ks][nt]
 struct GBlock {
-    int C = 0, ws = 0, shift = 0;
+    int C = 0, V = 0, ws = 0, shift = 0, temporal = 0;      // V = gate / value width (mlp_ratio * C); temporal: window (12,1,1)
+    TMix tmix;
     float *ln1 = nullptr, *ln2 = nullptr;
     Lin proj_in, spatial, proj_out, w1;
     Conv3 w2;
@@ -345,8 +414,12 @@ struct nunif_light_inpaint {
     std::vector<void *> owned;
     f16 *mask_bias = nullptr;
     Lin patch, down, up;
-    GBlock enc1, enc2[4], dec1;
+    // video = inpaint.light_video_inpaint_v1: patch slope 0.1, enc1 unshifted, enc2 = [2-D, temporal, 2-D, temporal, 2-D] with
+    // mlp_ratio 1 in the 2-D blocks, 1x1 to_image; exactly 12 frames per call
+    int video = 0, n_enc2 = 4;
+    GBlock enc1, enc2[5], dec1;
     Conv3 to_image;
+    Lin to_image1;
     Gauss15 gauss;
     Buf x1, x2, a, pi, vt, st, g, po, y, z, ti, mtok, mf0, mf1, mf2, hard, soft;
 };
@@ -416,19 +489,32 @@ int make_plain(nunif_light_inpaint *h, const TMap &m, const std::string &key, in
                     std::vector<float>(b->data, b->data + n_real), L);
 }
 
-int make_gblock(nunif_light_inpaint *h, const TMap &m, const std::string &p, int C, int ws, int shift, GBlock *g) {
-    g->C = C; g->ws = ws; g->shift = shift;
-    const int N = ws * ws;
+int make_gblock(nunif_light_inpaint *h, const TMap &m, const std::string &p, int C, int ws, int shift, GBlock *g,
+                int ratio = 2, int temporal = 0) {
+    const int V = ratio * C;
+    g->C = C; g->V = V; g->ws = ws; g->shift = shift; g->temporal = temporal;
+    const int N = temporal ? 12 : ws * ws;
     const HostT *n1, *n2;
     int rc;
     if ((rc = find(m, p + "norm1.weight", &n1)) || (rc = find(m, p + "norm2.weight", &n2))) return rc;
-    NUNIF_REQUIRE(n1->numel == C && n2->numel == 2 * C, "%s: LayerNorm shapes", p.c_str());
+    NUNIF_REQUIRE(n1->numel == C && n2->numel == V, "%s: LayerNorm shapes", p.c_str());
     if ((rc = upload(h, std::vector<float>(n1->data, n1->data + C), &g->ln1)) ||
-        (rc = upload(h, std::vector<float>(n2->data, n2->data + 2 * C), &g->ln2)))
+        (rc = upload(h, std::vector<float>(n2->data, n2->data + V), &g->ln2)))
         return rc;
-    if ((rc = make_plain(h, m, p + "gmlp.gmlp.proj_in", 4 * C, C, &g->proj_in)) ||
-        (rc = make_plain(h, m, p + "gmlp.gmlp.proj_spatial", N, N, &g->spatial)) ||       // Conv1d(N, N, 1): weight [N][N][1]
-        (rc = make_plain(h, m, p + "gmlp.gmlp.proj_out", C, 2 * C, &g->proj_out)) ||
+    if (temporal) {
+        const HostT *sw, *sb;
+        if ((rc = find(m, p + "gmlp.gmlp.proj_spatial.weight", &sw)) || (rc = find(m, p + "gmlp.gmlp.proj_spatial.bias", &sb)))
+            return rc;
+        NUNIF_REQUIRE(sw->numel == 144 && sb->numel == 12, "%s: temporal mixing matrix must be 12 x 12", p.c_str());
+        for (int t = 0; t < 12; ++t) {
+            g->tmix.b[t] = sb->data[t];
+            for (int s2 = 0; s2 < 12; ++s2) g->tmix.w[t][s2] = sw->data[t * 12 + s2];
+        }
+    } else if ((rc = make_plain(h, m, p + "gmlp.gmlp.proj_spatial", N, N, &g->spatial))) {   // Conv1d(N, N, 1): weight [N][N][1]
+        return rc;
+    }
+    if ((rc = make_plain(h, m, p + "gmlp.gmlp.proj_in", 2 * V, C, &g->proj_in)) ||
+        (rc = make_plain(h, m, p + "gmlp.gmlp.proj_out", C, V, &g->proj_out)) ||
         (rc = make_plain(h, m, p + "glu_conv.w1", C, C, &g->w1)))
         return rc;
     return make_conv3(h, m, p + "glu_conv.w2", C / 2, (C / 2 + 31) / 32 * 32, C, &g->w2);
@@ -444,10 +530,10 @@ int lin(const Lin &L, const f16 *a, long rows, int n_real, int act, float slope,
     return launch_gemm(g, s, tag);
 }
 
-template <int C>
+template <int C, int V>
 int run_gblock(nunif_light_inpaint *h, const GBlock &g, f16 *x, int B, int hh, int ww, hipStream_t s) {
-    const int pad = g.shift ? g.ws / 2 : 0, hp = hh + 2 * pad, wp = ww + 2 * pad, N = g.ws * g.ws;
-    const long tok = (long)B * hh * ww, tokp = (long)B * hp * wp, wins = tokp / N;
+    const int pad = (g.shift && !g.temporal) ? g.ws / 2 : 0, hp = hh + 2 * pad, wp = ww + 2 * pad, N = g.ws * g.ws;
+    const long tok = (long)B * hh * ww, tokp = (long)B * hp * wp, wins = g.temporal ? 0 : tokp / N;
     f16 *a = (f16 *)h->a.p, *pi = (f16 *)h->pi.p, *vt = (f16 *)h->vt.p, *st = (f16 *)h->st.p, *gg = (f16 *)h->g.p;
     f16 *po = (f16 *)h->po.p, *y = (f16 *)h->y.p, *z = (f16 *)h->z.p;
     const unsigned bp = (unsigned)((tokp + 255) / 256);
@@ -456,16 +542,26 @@ int run_gblock(nunif_light_inpaint *h, const GBlock &g, f16 *x, int B, int hh, i
         ProfScope ps("li_ln_pad_kernel", s, 0.0, (double)tokp * C * 4.0);
         li_ln_pad_kernel<C><<<bp, 256, 0, s>>>(x, g.ln1, a, B, hh, ww, pad);
     }
-    if ((rc = lin(g.proj_in, a, tokp, 4 * C, 1, 0.f, nullptr, pi, s, "li_proj_in"))) return rc;
-    {
-        ProfScope ps("li_ln2_t_kernel", s, 0.0, (double)tokp * C * 8.0);
-        li_ln2_t_kernel<2 * C><<<bp, 256, 0, s>>>(pi, g.ln2, vt, B, hp, wp, g.ws);
-    }
-    // token mixing: rows = (window, channel), K = tokens of the window
-    if ((rc = lin(g.spatial, vt, wins * 2 * C, N, 0, 0.f, nullptr, st, s, "li_spatial"))) return rc;
-    {
-        ProfScope ps("li_gate_kernel", s, 0.0, (double)tokp * C * 12.0);
-        li_gate_kernel<2 * C><<<bp, 256, 0, s>>>(pi, st, gg, B, hp, wp, g.ws);
+    if ((rc = lin(g.proj_in, a, tokp, 2 * V, 1, 0.f, nullptr, pi, s, "li_proj_in"))) return rc;
+    if (g.temporal) {
+        NUNIF_REQUIRE(B == 12, "light_inpaint: the temporal block needs exactly 12 frames (got %d)", B);
+        const long pixels = (long)hh * ww;
+        {
+            ProfScope ps("li_ln2_kernel", s, 0.0, (double)tok * V * 4.0);
+            li_ln2_kernel<V><<<bp, 256, 0, s>>>(pi, g.ln2, vt, tok);
+        }
+        const long n = pixels * (V / 8);
+        ProfScope ps("li_tmix_gate_kernel", s, 2.0 * 144.0 * pixels * V, (double)tok * V * 6.0);
+        li_tmix_gate_kernel<V><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(pi, vt, gg, pixels, g.tmix);
+    } else {
+        {
+            ProfScope ps("li_ln2_t_kernel", s, 0.0, (double)tokp * V * 4.0);
+            li_ln2_t_kernel<V><<<bp, 256, 0, s>>>(pi, g.ln2, vt, B, hp, wp, g.ws);
+        }
+        // token mixing: rows = (window, channel), K = tokens of the window
+        if ((rc = lin(g.spatial, vt, wins * V, N, 0, 0.f, nullptr, st, s, "li_spatial"))) return rc;
+        ProfScope ps("li_gate_kernel", s, 0.0, (double)tokp * V * 6.0);
+        li_gate_kernel<V><<<bp, 256, 0, s>>>(pi, st, gg, B, hp, wp, g.ws);
     }
     if ((rc = lin(g.proj_out, gg, tokp, C, 0, 0.f, nullptr, po, s, "li_proj_out"))) return rc;
     {
@@ -505,7 +601,11 @@ extern "C" int nunif_hip_light_inpaint_create(const nunif_tensor_desc *tensors, 
     int rc = NUNIF_HIP_OK;
     do {
         const HostT *mb, *pw, *pb, *dw, *db, *uw, *ub;
-        if ((rc = find(m, "mask_bias", &mb)) || (rc = find(m, "patch.0.weight", &pw)) || (rc = find(m, "patch.0.bias", &pb)) ||
+        // inpaint.light_video_inpaint_v1 has `patch` = Conv2d(3, 96, 4, 4) (same k = c*16 + ky*4 + kx order as the
+        // pixel_unshuffle(4) + 1x1 conv of the image net) and a 1x1 `to_image`
+        h->video = m.count("patch.weight") ? 1 : 0;
+        const std::string pk = h->video ? "patch" : "patch.0";
+        if ((rc = find(m, "mask_bias", &mb)) || (rc = find(m, pk + ".weight", &pw)) || (rc = find(m, pk + ".bias", &pb)) ||
             (rc = find(m, "down.weight", &dw)) || (rc = find(m, "down.bias", &db)) || (rc = find(m, "up.weight", &uw)) ||
             (rc = find(m, "up.bias", &ub)))
             break;
@@ -536,11 +636,31 @@ extern "C" int nunif_hip_light_inpaint_create(const nunif_tensor_desc *tensors, 
             if ((rc = make_lin(h, 384, 192, [=](int n, int k) { return wd[(size_t)((n % 96) * 4 + n / 96) * 192 + k]; }, bb, &h->up)))
                 break;
         }
-        if ((rc = make_gblock(h, m, "enc1.", 96, 16, 1, &h->enc1))) break;
-        for (int i = 0; i < 4 && !rc; ++i) rc = make_gblock(h, m, "enc2." + std::to_string(i) + ".", 192, 8, i & 1, &h->enc2[i]);
-        if (rc) break;
-        if ((rc = make_gblock(h, m, "dec1.", 96, 16, 0, &h->dec1))) break;
-        if ((rc = make_conv3(h, m, "to_image.1", 96, 96, 48, &h->to_image))) break;
+        if (h->video) {
+            // light_video_inpaint_v1.py:109-119 (base_dim 96, lv2_mlp_ratio 1)
+            h->n_enc2 = 5;
+            if ((rc = make_gblock(h, m, "enc1.", 96, 16, 0, &h->enc1))) break;
+            static const int shift[5] = {1, 0, 0, 0, 1}, temporal[5] = {0, 1, 0, 1, 0};
+            for (int i = 0; i < 5 && !rc; ++i)
+                rc = make_gblock(h, m, "enc2." + std::to_string(i) + ".", 192, 8, shift[i], &h->enc2[i], temporal[i] ? 2 : 1,
+                                 temporal[i]);
+            if (rc) break;
+            if ((rc = make_gblock(h, m, "dec1.", 96, 16, 0, &h->dec1))) break;
+            const HostT *tw, *tb;
+            if ((rc = find(m, "to_image.weight", &tw)) || (rc = find(m, "to_image.bias", &tb))) break;
+            NUNIF_REQUIRE(tw->numel == 48 * 96 && tb->numel == 48, "to_image: unexpected shape");
+            const float *wd = tw->data;
+            std::vector<float> bb(64, 0.f);
+            std::copy(tb->data, tb->data + 48, bb.begin());
+            if ((rc = make_lin(h, 64, 96, [=](int n, int k) { return n < 48 ? wd[(size_t)n * 96 + k] : 0.f; }, bb, &h->to_image1)))
+                break;
+        } else {
+            if ((rc = make_gblock(h, m, "enc1.", 96, 16, 1, &h->enc1))) break;
+            for (int i = 0; i < 4 && !rc; ++i) rc = make_gblock(h, m, "enc2." + std::to_string(i) + ".", 192, 8, i & 1, &h->enc2[i]);
+            if (rc) break;
+            if ((rc = make_gblock(h, m, "dec1.", 96, 16, 0, &h->dec1))) break;
+            if ((rc = make_conv3(h, m, "to_image.1", 96, 96, 48, &h->to_image))) break;
+        }
         // get_gaussian_kernel1d(15) (gaussian_filter.py:8-19): sigma = 15 * 0.15 + 0.35, normalised, computed in fp32 like torch
         float g[15], sum = 0.f;
         const float sigma = 15 * 0.15f + 0.35f;
@@ -566,6 +686,7 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
                                              void *stream) {
     NUNIF_REQUIRE(h && x && mask && out && B > 0 && H > 0 && W > 0 && inner_iter >= 0 && outer_iter >= 0,
                   "light_inpaint_infer: bad argument");
+    NUNIF_REQUIRE(!h->video || B == 12, "light_inpaint_infer: the video net takes exactly 12 frames per call (got %d)", B);
     hipStream_t s = (hipStream_t)stream;
     const int Hp = H + 64 - H % 64, Wp = W + 64 - W % 64;            // light_inpaint_v1.py:135-137: always pads (1..64)
     const int h1 = Hp / 4, w1 = Wp / 4, h2 = h1 / 2, w2 = w1 / 2;
@@ -608,12 +729,12 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
         li_patch_in_kernel<<<(unsigned)((t1 + 255) / 256), 256, 0, s>>>(x, hard, soft, a, mtok, B, H, W, h1, w1);
     }
     // NOTE: the replicate padding of the soft mask is the clamp of the pixel coordinate inside li_patch_in_kernel
-    if ((rc = lin(h->patch, a, t1, 96, 2, 0.2f, nullptr, x1, s, "li_patch"))) return rc;
+    if ((rc = lin(h->patch, a, t1, 96, 2, h->video ? 0.1f : 0.2f, nullptr, x1, s, "li_patch"))) return rc;
     {
         const long n = t1 * 12;
         li_mask_bias_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x1, mtok, h->mask_bias, t1, 96);
     }
-    if ((rc = run_gblock<96>(h, h->enc1, x1, B, h1, w1, s))) return rc;
+    if ((rc = run_gblock<96, 192>(h, h->enc1, x1, B, h1, w1, s))) return rc;
     {   // down: 2x2 stride-2 conv as a gather GEMM
         GemmArgs g;
         memset(&g, 0, sizeof(g));
@@ -622,8 +743,11 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
         g.ps = 1;
         if ((rc = launch_gemm(g, s, "li_down"))) return rc;
     }
-    for (int i = 0; i < 4; ++i)
-        if ((rc = run_gblock<192>(h, h->enc2[i], x2, B, h2, w2, s))) return rc;
+    for (int i = 0; i < h->n_enc2; ++i) {
+        rc = h->enc2[i].V == 192 ? run_gblock<192, 192>(h, h->enc2[i], x2, B, h2, w2, s)
+                                 : run_gblock<192, 384>(h, h->enc2[i], x2, B, h2, w2, s);
+        if (rc) return rc;
+    }
     {   // x = x1 + pixel_shuffle(up(x2), 2), written over x1
         GemmArgs g;
         memset(&g, 0, sizeof(g));
@@ -632,8 +756,10 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
         g.ps = 1;
         if ((rc = launch_gemm(g, s, "li_up"))) return rc;
     }
-    if ((rc = run_gblock<96>(h, h->dec1, x1, B, h1, w1, s))) return rc;
-    {
+    if ((rc = run_gblock<96, 192>(h, h->dec1, x1, B, h1, w1, s))) return rc;
+    if (h->video) {
+        if ((rc = lin(h->to_image1, x1, t1, 64, 0, 0.f, nullptr, ti, s, "li_to_image"))) return rc;
+    } else {
         ConvArgs cv;
         memset(&cv, 0, sizeof(cv));
         cv.a = x1; cv.B = B; cv.Hi = h1; cv.Wi = w1; cv.Cin = 96; cv.Ho = h1; cv.Wo = w1; cv.stride = 1; cv.kh = 3; cv.kw = 3;
@@ -643,7 +769,7 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
     }
     {
         ProfScope ps("li_compose_kernel", s, 0.0, (double)px * 36.0);
-        li_compose_kernel<<<pb, 256, 0, s>>>(x, hard, soft, ti, out, B, H, W, h1, w1);
+        li_compose_kernel<<<pb, 256, 0, s>>>(x, hard, soft, ti, out, B, H, W, h1, w1, h->video ? 64 : 48);
     }
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;

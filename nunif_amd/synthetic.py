@@ -242,6 +242,45 @@ def light_inpaint_state_dict(seed):
     return sd
 
 
+def light_video_inpaint_state_dict(seed):
+    """Seeded weights of inpaint.light_video_inpaint_v1 (base_dim 96, lv2_mlp_ratio 1) in the reference's key layout; same
+    conventions as ``light_inpaint_state_dict``."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def rnd(*shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    def lin(key, *shape, std=None, bstd=0.05, bmean=0.0):
+        fan = 1
+        for s in shape[1:]:
+            fan *= s
+        sd[key + ".weight"] = rnd(*shape, std=std if std is not None else math.sqrt(1.0 / fan))
+        sd[key + ".bias"] = rnd(shape[0], std=bstd) + bmean
+
+    def block(p, C, N, ratio):
+        V = C * ratio
+        lin(p + "gmlp.gmlp.proj_in", 2 * V, C, std=math.sqrt(2.0 / C))
+        sd[p + "gmlp.gmlp.proj_spatial.weight"] = rnd(N, N, 1, std=0.7 / math.sqrt(N))
+        sd[p + "gmlp.gmlp.proj_spatial.bias"] = rnd(N, std=0.3) + 0.5
+        lin(p + "gmlp.gmlp.proj_out", C, V, std=0.5 * math.sqrt(1.0 / V))
+        sd[p + "norm1.weight"] = 1.0 + rnd(C, std=0.1)
+        sd[p + "norm2.weight"] = 1.0 + rnd(V, std=0.1)
+        lin(p + "glu_conv.w1", C, C, 1, 1, std=math.sqrt(2.0 / C))
+        lin(p + "glu_conv.w2", C, C // 2, 3, 3, std=0.5 * math.sqrt(1.0 / (9 * C // 2)))
+
+    sd["mask_bias"] = rnd(1, 96, 1, 1, std=0.3)
+    lin("patch", 96, 3, 4, 4, std=math.sqrt(2.0 / 48))
+    block("enc1.", 96, 256, 2)
+    lin("down", 192, 96, 2, 2)
+    for i, (n, r) in enumerate(((64, 1), (12, 2), (64, 1), (12, 2), (64, 1))):
+        block(f"enc2.{i}.", 192, n, r)
+    lin("up", 384, 192, 1, 1)
+    block("dec1.", 96, 256, 2)
+    lin("to_image", 48, 96, 1, 1, std=0.002 * math.sqrt(1.0 / 96), bstd=0.05, bmean=0.5)
+    return sd
+
+
 def mlbw_state_dict(seed, num_layers=2, small=False, hole_mask=False):
     """Seeded weights in the reference's key layout (every bias non-zero); the output conv is scaled so that the layer
     deltas differ by a few depth pixels and the layer-weight logits really select between them."""

@@ -47,9 +47,7 @@ def window_gmlp(sd, p, x, ws, shift):
 
 def gmlp_block(sd, p, x, ws, shift):
     x = x + window_gmlp(sd, p, x, ws, shift)
-    y = F.glu(F.conv2d(x, sd[p + "glu_conv.w1.weight"], sd[p + "glu_conv.w1.bias"]), dim=1)
-    y = F.conv2d(F.pad(y, (1, 1, 1, 1), mode="replicate"), sd[p + "glu_conv.w2.weight"], sd[p + "glu_conv.w2.bias"])
-    return x + y
+    return _glu_conv(sd, p, x)
 
 
 def gaussian_kernel1d(k):
@@ -127,6 +125,114 @@ def mlbw_inpaint_image(sd_mask_mlbw, sd_inpaint, x, depth, divergence, convergen
     return eye(-1, divergence * 2), x
 
 
+# ---- inpaint.light_video_inpaint_v1 (iw3/models/light_video_inpaint_v1.py:92-229) -------------------------------------------
+SEQ_LEN = 12
+
+
+def temporal_gmlp(sd, p, x):
+    """GMLP3DBlock.gmlp with window (12, 1, 1) (:62-80, attention.py WindowGMLP3d :696-736): the tokens of a window are the 12
+    frames of one pixel.  x: [12,C,H,W]; returns proj_out(...) + x."""
+    T, C, H, W = x.shape
+    t = x.permute(2, 3, 0, 1).reshape(H * W, T, C)
+    a = F.gelu(F.linear(_ln(t, sd[p + "norm1.weight"]), sd[p + "gmlp.gmlp.proj_in.weight"], sd[p + "gmlp.gmlp.proj_in.bias"]))
+    u, v = a.chunk(2, dim=-1)
+    v = F.conv1d(_ln(v, sd[p + "norm2.weight"]), sd[p + "gmlp.gmlp.proj_spatial.weight"], sd[p + "gmlp.gmlp.proj_spatial.bias"])
+    t = F.linear(u * v, sd[p + "gmlp.gmlp.proj_out.weight"], sd[p + "gmlp.gmlp.proj_out.bias"]) + t
+    return t.reshape(H, W, T, C).permute(2, 3, 0, 1)
+
+
+def _glu_conv(sd, p, x):
+    y = F.glu(F.conv2d(x, sd[p + "glu_conv.w1.weight"], sd[p + "glu_conv.w1.bias"]), dim=1)
+    return x + F.conv2d(F.pad(y, (1, 1, 1, 1), mode="replicate"), sd[p + "glu_conv.w2.weight"], sd[p + "glu_conv.w2.bias"])
+
+
+def video_net(sd, x, mask):
+    """_forward :166-197 (the micro-batching only chunks per-frame work): x [12,3,Hp,Wp] normalised, mask float."""
+    assert x.shape[0] == SEQ_LEN
+    mtok = F.pixel_unshuffle(mask, 4).amax(dim=1, keepdim=True) > 0.99
+    x0 = F.leaky_relu(F.conv2d(x, sd["patch.weight"], sd["patch.bias"], stride=4), 0.1)
+    x0 = torch.where(mtok, sd["mask_bias"], x0)
+    x1 = gmlp_block(sd, "enc1.", x0, 16, False)
+    x2 = F.conv2d(x1, sd["down.weight"], sd["down.bias"], stride=2)
+    for i, kind in enumerate(("s1", "t", "s0", "t", "s1")):
+        p = f"enc2.{i}."
+        if kind == "t":
+            x2 = _glu_conv(sd, p, x2 + temporal_gmlp(sd, p, x2))
+        else:
+            x2 = gmlp_block(sd, p, x2, 8, kind == "s1")
+    x3 = F.pixel_shuffle(F.conv2d(x2, sd["up.weight"], sd["up.bias"]), 2)
+    out = gmlp_block(sd, "dec1.", x1 + x3, 16, False)
+    return F.pixel_shuffle(F.conv2d(out, sd["to_image.weight"], sd["to_image.bias"]), 4)
+
+
+def video_infer(sd, x, mask, closing=False, inner_dilation=0, outer_dilation=0, base_width=None):
+    """infer :140-164: pad the batch to 12 frames by repeating the first / last frame, preprocess, forward, un-pad."""
+    n = x.shape[0]
+    b1 = b2 = 0
+    if n % SEQ_LEN != 0:
+        pad = SEQ_LEN - n % SEQ_LEN
+        b1, b2 = pad // 2, pad - pad // 2
+        x = torch.cat([x[0:1]] * b1 + [x] + [x[-1:]] * b2, dim=0)
+        mask = torch.cat([mask[0:1]] * b1 + [mask] + [mask[-1:]] * b2, dim=0)
+    xp, mp = preprocess(x, mask, closing, inner_dilation, outer_dilation, base_width)
+    H, W = x.shape[2:]
+    pad1, pad2 = 64 - W % 64, 64 - H % 64
+    xn = F.pad((xp - 0.5) / 0.5, (0, pad1, 0, pad2), mode="replicate")
+    mpp = F.pad(mp, (0, pad1, 0, pad2), mode="replicate")
+    y = video_net(sd, xn, mpp)[:, :, :H, :W]
+    out = (xp * (1 - mp) + y * mp).clamp(0, 1)
+    return out[b1:out.shape[0] - b2]
+
+
+def mlbw_inpaint_video(sd_mask_mlbw, sd_video, batches, divergence, convergence, inner_dilation=0, outer_dilation=0,
+                       pre_padding=3, post_padding=3):
+    """MLBWInpaintVideo (iw3/mlbw_inpaint.py:160-293, synthetic_view="both") over a list of (frames, depth) batches followed
+    by flush(); returns the list of (left, right) results (None while the 12-frame queue fills).  The queue is a plain list."""
+    queue, results = [], []
+
+    def run(flush):
+        le = torch.stack([q[0] for q in queue]); ri = torch.stack([q[1] for q in queue])
+        lm = torch.stack([q[2] for q in queue]); rm = torch.stack([q[3] for q in queue])
+        kw = dict(inner_dilation=inner_dilation, outer_dilation=outer_dilation)
+        H, W = le.shape[-2:]
+        base = lm.shape[-1]
+        m = postprocess_scaled(lm.flip(-1), (H, W), base, **kw)
+        left = video_infer(sd_video, le.flip(-1), m).flip(-1)
+        m = postprocess_scaled(rm, (H, W), base, **kw)
+        right = video_infer(sd_video, ri, m)
+        if flush:
+            del queue[:]
+            return left[pre_padding:], right[pre_padding:]
+        del queue[:SEQ_LEN - (pre_padding + post_padding)]
+        return left[pre_padding:SEQ_LEN - post_padding], right[pre_padding:SEQ_LEN - post_padding]
+
+    for frames, depth in batches:
+        for i in range(frames.shape[0]):
+            c, d = frames[i:i + 1], depth[i:i + 1]
+            zl, ll = OM.apply_divergence_nn_delta_weight(sd_mask_mlbw, c, d, divergence, convergence, -1, 2, return_mask=True)
+            zr, lr = OM.apply_divergence_nn_delta_weight(sd_mask_mlbw, c, d, divergence, convergence, 1, 2, return_mask=True)
+            for _ in range(pre_padding + 1 if not queue else 1):
+                queue.append((zl[0], zr[0], ll[0], lr[0]))
+        results.append(run(False) if len(queue) == SEQ_LEN else None)
+    if queue:
+        pad = SEQ_LEN - len(queue)
+        queue.extend([queue[-1]] * pad)
+        left, right = run(True)
+        results.append((left[:left.shape[0] - pad], right[:right.shape[0] - pad]))
+    else:
+        results.append(None)
+    return results
+
+
+def postprocess_scaled(logits, size, base_width, inner_dilation=0, outer_dilation=0):
+    return OM.postprocess_hole_mask(logits, size, 0.15, inner_dilation, outer_dilation)
+
+
 def random_state_dict(*args, **kwargs):
     from nunif_amd.synthetic import light_inpaint_state_dict
     return light_inpaint_state_dict(*args, **kwargs)
+
+
+def video_random_state_dict(*args, **kwargs):
+    from nunif_amd.synthetic import light_video_inpaint_state_dict
+    return light_video_inpaint_state_dict(*args, **kwargs)

@@ -149,6 +149,64 @@ def gen_light_inpaint():
     save("light_inpaint", **out)
 
 
+def gen_light_video_inpaint():
+    """inpaint.light_video_inpaint_v1 on the reference (12-frame infer, a 7-frame batch padded by infer itself) and the
+    MLBWInpaintVideo queue (pre / post padding 3, batches of 3 frames, flush) assembled around seeded models."""
+    from iw3.models.light_video_inpaint_v1 import LightVideoInpaintV1
+    from iw3.models.mlbw import MLBW
+    from iw3 import mlbw_inpaint as RI
+    from oracle import light_inpaint as OL, mlbw as OM
+    from oracle.forward_warp import synth_depth
+    out = {}
+    sd = OL.video_random_state_dict(801)
+    m = LightVideoInpaintV1().eval()
+    m.load_state_dict(sd, strict=True)
+    out["sdsum"] = sd_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    base = synth_image(121, 3, 40, 84)
+    x = torch.stack([base[:, :, i:i + 72] for i in range(12)])              # a panning shot
+    g = torch.Generator().manual_seed(123)
+    mask = torch.rand(12, 1, 40, 72, generator=g) > 0.94
+    for i in range(12):
+        mask[i, :, 10:26, 20 + i:44 + i] = True
+    out["x"], out["mask"] = x, mask
+    out["infer12"] = m.infer(x, mask)
+    out["infer7"] = m.infer(x[:7], mask[:7], closing=True, inner_dilation=1, outer_dilation=1, base_width=36)
+    y = out["infer12"]
+    print("infer12", float(y.std()), float((y - x).abs().mean()), float(((y <= 0) | (y >= 1)).float().mean()))
+    # MLBWInpaintVideo :160-293 without the downloads
+    sdm = OM.random_state_dict(431, 2, False, hole_mask=True)
+    mm = MLBW(num_layers=2, base_dim=32, hole_mask=True).eval()
+    mm.load_state_dict(sdm, strict=True)
+    mm.delta_output = True
+    vid = object.__new__(RI.MLBWInpaintVideo)
+    torch.nn.Module.__init__(vid)
+    vid.model, vid.mask_mlbw = m, mm
+    vid.model_seq, vid.pre_padding, vid.post_padding = 12, 3, 3
+    vid.frame_queue = vid.synthetic_view = vid.inner_dilation = vid.outer_dilation = vid.base_width = None
+    vid.device = torch.device("cpu")
+    n_frames = 18
+    wide = synth_image(131, 3, 44, 80 + n_frames)
+    frames = torch.stack([wide[:, :, i:i + 80] for i in range(n_frames)])
+    depth = synth_depth(15, 1, 22, 40, "smooth_edges").expand(n_frames, 1, 22, 40).clone()
+    depth = (depth + torch.linspace(0, 0.2, n_frames).view(-1, 1, 1, 1)).clamp(0, 1)
+    out["v_frames"], out["v_depth"] = frames, depth
+    lefts, rights, sizes = [], [], []
+    for i in range(0, n_frames, 3):          # the queue only lands exactly on 12 with batches of 1 or 3 (3 + 3k, then 6 + 3k)
+        le, ri = vid.infer(frames[i:i + 3], depth[i:i + 3], divergence=2.0, convergence=0.5, synthetic_view="both",
+                           inner_dilation=1, outer_dilation=1, enable_amp=False)
+        sizes.append(0 if le is None else le.shape[0])
+        if le is not None:
+            lefts.append(le.clone()); rights.append(ri.clone())
+    le, ri = vid.flush(enable_amp=False)
+    sizes.append(0 if le is None else le.shape[0])
+    if le is not None:
+        lefts.append(le.clone()); rights.append(ri.clone())
+    out["v_sizes"] = np.asarray(sizes)
+    out["v_left"], out["v_right"] = torch.cat(lefts).half(), torch.cat(rights).half()
+    print("video queue sizes", sizes, tuple(out["v_left"].shape))
+    save("light_video_inpaint", **out)
+
+
 def gen_iw3():
     from iw3.forward_warp import apply_divergence_forward_warp
     from iw3.backward_warp import apply_divergence_grid_sample
@@ -412,7 +470,7 @@ def gen_depth_aa():
 
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "light_inpaint": gen_light_inpaint}
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

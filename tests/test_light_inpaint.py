@@ -84,3 +84,78 @@ def test_hip_mlbw_inpaint_image(hiplib, g):
     assert side.flush() == (None, None)
     with pytest.raises(NotImplementedError):
         side.set_mode("video")
+
+
+# ---- inpaint.light_video_inpaint_v1 + MLBWInpaintVideo --------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gv():
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "light_video_inpaint.npz")).items()}
+
+
+def _video_batches(gv):
+    f, d = gv["v_frames"], gv["v_depth"]
+    return [(f[i:i + 3], d[i:i + 3]) for i in range(0, f.shape[0], 3)]
+
+
+def test_oracle_video_matches_reference_fixture(gv):
+    sd = OL.video_random_state_dict(801)
+    assert sd_checksum(sd) == pytest.approx(float(gv["sdsum"]), rel=1e-12)
+    assert (OL.video_infer(sd, gv["x"], gv["mask"]) - gv["infer12"]).abs().max().item() < 2e-5
+    y7 = OL.video_infer(sd, gv["x"][:7], gv["mask"][:7], True, 1, 1, 36)
+    assert y7.shape[0] == 7 and (y7 - gv["infer7"]).abs().max().item() < 2e-5
+
+
+def test_oracle_video_queue_flow(gv):
+    sdm, sdv = OM.random_state_dict(431, 2, False, hole_mask=True), OL.video_random_state_dict(801)
+    res = OL.mlbw_inpaint_video(sdm, sdv, _video_batches(gv)[:3], 2.0, 0.5, 1, 1)        # first output + flush (CPU time)
+    sizes = [0 if r is None else r[0].shape[0] for r in res]
+    assert sizes == [0, 0, 6, 3]
+    left = torch.cat([r[0] for r in res if r is not None])
+    assert (left[:6] - gv["v_left"][:6].float()).abs().max().item() < 2e-3             # fixture stored as fp16
+
+
+@pytest.mark.gpu
+def test_hip_light_video_inpaint(hiplib, gv):
+    from nunif_amd.nunif.models import create_model
+    from nunif_amd.iw3 import models  # noqa: F401
+    mv = create_model("inpaint.light_video_inpaint_v1").eval()
+    mv.load_state_dict(OL.video_random_state_dict(801), strict=True)
+    mv = mv.to("cuda:0")
+    x, mask = gv["x"].to("cuda:0"), gv["mask"].to("cuda:0")
+    y = mv.infer(x, mask)
+    p = psnr(y.cpu(), gv["infer12"])
+    assert y.shape == x.shape and p >= 50.0, p
+    y7 = mv.infer(x[:7], mask[:7], closing=True, inner_dilation=1, outer_dilation=1, base_width=36)
+    p = psnr(y7.cpu(), gv["infer7"])
+    assert y7.shape[0] == 7 and p >= 50.0, p
+    with pytest.raises(AssertionError):
+        mv.infer(torch.cat([x, x[:1]]), torch.cat([mask, mask[:1]]))
+
+
+@pytest.mark.gpu
+def test_hip_mlbw_inpaint_video_queue(hiplib, gv):
+    from nunif_amd.nunif.models import create_model
+    from nunif_amd.iw3.mlbw_inpaint import MLBWInpaint
+    mi, mm = _models()
+    mv = create_model("inpaint.light_video_inpaint_v1").eval()
+    mv.load_state_dict(OL.video_random_state_dict(801), strict=True)
+    side = MLBWInpaint(mi, mm, video_model=mv.to("cuda:0"))
+    side.set_mode("video")
+    sizes, lefts, rights = [], [], []
+    for f, d in _video_batches(gv):
+        le, ri = side.infer(f.to("cuda:0"), d.to("cuda:0"), divergence=2.0, convergence=0.5, synthetic_view="both",
+                            inner_dilation=1, outer_dilation=1)
+        sizes.append(0 if le is None else le.shape[0])
+        if le is not None:
+            lefts.append(le.clone()); rights.append(ri.clone())
+    le, ri = side.flush()
+    sizes.append(0 if le is None else le.shape[0])
+    lefts.append(le); rights.append(ri)
+    assert sizes == [int(v) for v in gv["v_sizes"]] == [0, 0, 6, 0, 6, 0, 6]
+    for got, key in ((torch.cat(lefts), "v_left"), (torch.cat(rights), "v_right")):
+        ref = gv[key].float()
+        assert got.shape == ref.shape
+        bad = ((got.cpu() - ref).abs() > 2e-2).float().mean().item()
+        assert bad < 0.03, (key, bad)
+    assert side.flush() == (None, None)
+    side.reset()
