@@ -262,6 +262,17 @@ int nunif_hip_dilate_edge(const float *x, float *y, float *work, int32_t B, int3
  * min/max, i.e. EMA off).  minmax: [B,2] device scratch that receives the order-keyed min/max. */
 int nunif_hip_minmax_normalize(const float *x, float *y, float *minmax, int32_t B, int64_t n_per, void *stream);
 
+/* VideoDepthAnything pre/post glue (iw3/video_depth_anything_model.py:51-91).
+ * reflection_pad2d: nunif/modules/reflection_pad2d.py reflection_pad2d_naive :13-48 on planar fp32 [planes,H,W] -> [planes,
+ *   H+top+bottom, W+left+right]; positive pads reflect without repeating the edge, negative pads crop (the F.pad(out, (-14,)*4)
+ *   of _postprocess :79).
+ * depth_postprocess: _postprocess :66-76 — nan_to_num, clamp(max=max_dist) when max_dist > 0, metric depth -> disparity
+ *   1/(d+eps) when to_disparity, optional sign flip (the "-out" for non-disparity outputs :88-90).  In place allowed. */
+int nunif_hip_reflection_pad2d(const float *x, float *y, int64_t planes, int32_t H, int32_t W, int32_t left, int32_t right,
+                               int32_t top, int32_t bottom, void *stream);
+int nunif_hip_depth_postprocess(const float *x, float *y, int64_t n, float max_dist, int32_t to_disparity, float eps,
+                                int32_t negate, void *stream);
+
 /* Frame edge.  frame: HWC [H,W,3] uint8 (bits=8) or uint16 (bits=16) device memory.
  * frame_to_tensor replaces nunif/utils/video.py to_tensor :218-223 (x.permute(2,0,1) / iinfo.max).
  * stereo_to_frame fuses iw3/utils.py postprocess_image :468-479 (cat + clamp) with video.py from_tensor :236-245

@@ -321,3 +321,59 @@ extern "C" int nunif_hip_minmax_normalize(const float *x, float *y, float *minma
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
+
+// ---- VideoDepthAnything pre/post glue (iw3/video_depth_anything_model.py:51-91) ---------------------------------------------
+// reflection_pad2d_naive (nunif/modules/reflection_pad2d.py:13-48): reflect WITHOUT repeating the edge pixel for positive
+// pads, crop for negative ones (F.pad(out, (-14,) * 4), video_depth_anything_model.py:79); one gather, planar fp32.
+__global__ void __launch_bounds__(256) reflection_pad_kernel(const float *__restrict__ x, float *__restrict__ y, long planes,
+                                                             int H, int W, int Ho, int Wo, int left, int top) {
+    const long n = planes * Ho * Wo;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int xo = (int)(i % Wo);
+    const long t = i / Wo;
+    const int yo = (int)(t % Ho);
+    const long p = t / Ho;
+    int sx = xo - left, sy = yo - top;
+    sx = sx < 0 ? -sx : (sx >= W ? 2 * (W - 1) - sx : sx);
+    sy = sy < 0 ? -sy : (sy >= H ? 2 * (H - 1) - sy : sy);
+    y[i] = x[(p * H + sy) * W + sx];
+}
+
+extern "C" int nunif_hip_reflection_pad2d(const float *x, float *y, int64_t planes, int32_t H, int32_t W, int32_t left,
+                                          int32_t right, int32_t top, int32_t bottom, void *stream) {
+    NUNIF_REQUIRE(x && y && planes > 0 && H > 0 && W > 0, "reflection_pad2d: bad argument");
+    // the reference asserts padding <= size (reflection_pad2d.py:15-16); a reflected index must stay inside the map
+    NUNIF_REQUIRE(left < W && right < W && top < H && bottom < H, "reflection_pad2d: padding must be smaller than the map");
+    const int Ho = H + top + bottom, Wo = W + left + right;
+    NUNIF_REQUIRE(Ho > 0 && Wo > 0, "reflection_pad2d: empty result");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)planes * Ho * Wo;
+    ProfScope ps("reflection_pad_kernel", s, 0.0, (double)n * 8.0);
+    reflection_pad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x, y, planes, H, W, Ho, Wo, left, top);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+// _postprocess :66-76: nan_to_num, optional clamp(max=max_dist), metric depth -> disparity 1 / (d + eps), optional sign flip
+__global__ void __launch_bounds__(256) depth_post_kernel(const float *__restrict__ x, float *__restrict__ y, long n,
+                                                         float max_dist, int to_disparity, float eps, int negate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i];
+    if (v != v) v = 0.0f;                                   // torch.nan_to_num defaults: nan -> 0, +-inf -> +-FLT_MAX
+    v = fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
+    if (max_dist > 0.0f) v = fminf(v, max_dist);
+    if (to_disparity) v = 1.0f / (v + eps);
+    y[i] = negate ? -v : v;
+}
+
+extern "C" int nunif_hip_depth_postprocess(const float *x, float *y, int64_t n, float max_dist, int32_t to_disparity,
+                                           float eps, int32_t negate, void *stream) {
+    NUNIF_REQUIRE(x && y && n > 0, "depth_postprocess: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("depth_post_kernel", s, 0.0, (double)n * 8.0);
+    depth_post_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x, y, (long)n, max_dist, to_disparity, eps, negate);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}

@@ -91,6 +91,9 @@ int launch_qkv_attn_w(const f16 *x, f16 *att, const f16 *wstream, const float *b
 int launch_window_attn(const f16 *qkv, f16 *out, const float *bias, int B, int H, int W, int heads, int hd,
                        int shift, hipStream_t s);
 
+// ---- LayerNormNoBias over the channels of an NHWC fp16 map (swin_unet_4xl blocks; C = 96 / 192 / 384) ----------------------
+int launch_layernorm_nobias(const f16 *x, f16 *y, const float *gamma, long M, int C, hipStream_t s);
+
 // ---- CUNet kernels (cunet_kernels.hip) ---------------------------------------------------------------------------------
 // K-looped implicit-GEMM conv, NHWC fp16.  Output pixel (y,x), tap (dy,dx) reads a[(y*stride+dy), (x*stride+dx)];
 // optional second input a2 is added element-wise at (y*stride+dy+crop2, x*stride+dx+crop2) (the cropped U-Net skip).

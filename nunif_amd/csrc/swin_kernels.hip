@@ -441,6 +441,7 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
         case 18: return launch_gemm_t<18, 2>(g, s, "gemm_kernel<18,2>", "gemm_res_kernel<18,2>", flops, bytes);
         case 19: return launch_gemm_t<19, 1>(g, s, "gemm_kernel<19,1>", "gemm_res_kernel<19,1>", flops, bytes);
         case 24: return launch_gemm_t<24, 1>(g, s, "gemm_kernel<24,1>", "gemm_res_kernel<24,1>", flops, bytes);
+        case 27: return launch_gemm_t<27, 1>(g, s, "gemm_kernel<27,1>", "gemm_res_kernel<27,1>", flops, bytes);
         case 32: return launch_gemm_t<32, 1>(g, s, "gemm_kernel<32,1>", "gemm_res_kernel<32,1>", flops, bytes);
         default:
             set_error("gemm %s: unsupported K=%d", tag, g.K);
@@ -523,6 +524,75 @@ int launch_stem1(const Stem1Args &a, hipStream_t s) {
     ProfScope ps("stem1_kernel", s, 2.0 * 27 * a.C1 * (double)total, (double)total * (a.C1P * 2.0 + 12.0));
     const size_t smem = (size_t)(28 * a.C1) * sizeof(float);
     stem1_kernel<<<(unsigned)((total + 255) / 256), 256, smem, s>>>(a);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+// =================================================================================================================
+// LayerNormNoBias over the channel axis of an NHWC fp16 map (nunif/modules/norm.py:17-22 = nn.LayerNorm(bias=False),
+// eps 1e-5; the norm1 / norm2 of swin_unet_4xl's blocks, swin_unet.py:390-391).  One wave per token, two-pass in
+// registers (mean, then the centred second moment, like ATen's CPU kernel), fp32 statistics, fp16 result.
+// =================================================================================================================
+template <int C>
+__global__ void __launch_bounds__(256) layernorm_nobias_kernel(const f16 *__restrict__ x, f16 *__restrict__ y,
+                                                               const float *__restrict__ gamma, long M, float eps) {
+    static_assert(C % 32 == 0, "C must be a multiple of 32");
+    constexpr int NP = (C / 2 + 63) / 64;            // half2 pieces per lane
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const f16 *px = x + m * C;
+    float v[NP][2];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c2 = i * 64 + lane;
+        if (c2 < C / 2) {
+            const __half2 h2 = *reinterpret_cast<const __half2 *>(px + 2 * c2);
+            v[i][0] = __low2float(h2); v[i][1] = __high2float(h2);
+        } else {
+            v[i][0] = 0.f; v[i][1] = 0.f;
+        }
+        sum += v[i][0] + v[i][1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.0f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c2 = i * 64 + lane;
+        if (c2 < C / 2) {
+            const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
+            sq += d0 * d0 + d1 * d1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq * (1.0f / C) + eps);
+    f16 *py = y + m * C;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c2 = i * 64 + lane;
+        if (c2 < C / 2) {
+            const float2 g2 = *reinterpret_cast<const float2 *>(gamma + 2 * c2);
+            *reinterpret_cast<__half2 *>(py + 2 * c2) =
+                __floats2half2_rn((v[i][0] - mean) * rstd * g2.x, (v[i][1] - mean) * rstd * g2.y);
+        }
+    }
+}
+
+int launch_layernorm_nobias(const f16 *x, f16 *y, const float *gamma, long M, int C, hipStream_t s) {
+    if (M == 0) return NUNIF_HIP_OK;
+    ProfScope ps("layernorm_nobias_kernel", s, 8.0 * (double)M * C, (double)M * C * 4.0);
+    const unsigned blocks = (unsigned)((M + 3) / 4);
+    if (C == 96) layernorm_nobias_kernel<96><<<blocks, 256, 0, s>>>(x, y, gamma, M, 1e-5f);
+    else if (C == 192) layernorm_nobias_kernel<192><<<blocks, 256, 0, s>>>(x, y, gamma, M, 1e-5f);
+    else if (C == 384) layernorm_nobias_kernel<384><<<blocks, 256, 0, s>>>(x, y, gamma, M, 1e-5f);
+    else {
+        set_error("layernorm: channel count %d unsupported (96, 192, 384)", C);
+        return NUNIF_HIP_EUNSUPPORTED;
+    }
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }

@@ -28,6 +28,11 @@ struct Linear {          // fragment-packed fp16 weight + fp32 bias, device memo
 
 struct Block {
     Linear qkv, proj, mlp0, mlp3;
+    // generic path (LayerNorm variants, head counts other than 6: swin_unet_4xl): mlp.0 / mlp.3 in the PLAIN k order for
+    // gemm_kernel, LayerNormNoBias weights (nunif/modules/norm.py:17-22)
+    Linear mlp0p, mlp3p;
+    float *norm1 = nullptr, *norm2 = nullptr;
+    bool fast = true;             // fused qkv+attention / register-chained tail kernels apply
     float *attn_bias = nullptr;   // [heads][36][48]
     f16 *tail_stream = nullptr;   // proj | mlp.0 | mlp.3 fragments in proj_mlp_kernel's consumption order
     f16 *qkv_stream = nullptr;    // per-head Wq | Wk | Wv fragments in qkv_attn_w_kernel's consumption order
@@ -68,6 +73,8 @@ struct nunif_swin_unet {
     int top_dim = 96;                 // channels of level 1 on the decoder side (C for 1x/2x, 2C for 4x)
     float *stem1_w = nullptr, *stem1_b = nullptr;
     Linear stem2, down1, down2, up2, up1, proj2, to_image, to_image_pre;
+    Linear down2b;                    // second tap row of down2 when 4 * Cin > 1024 (swin_unet_4xl: K = 1536 as two K = 768 passes)
+    bool down2_split = false;
     f16 *to_image_chained = nullptr;  // ToImage weights in the chained k order, for the fused head of the last C = 96 block
     f16 *stemf_w1 = nullptr, *stemf_w2 = nullptr;   // fused stem (swin_stem.hip)
     int stem_fused = 1;               // NUNIF_STEM_FUSED=0: stem1_kernel + gather GEMM
@@ -177,7 +184,24 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
         int rc;
         std::vector<f16> hq;
         if ((rc = make_plain_linear(h, m, p + "attn.qkv", 3 * dim, dim, &bl.qkv, false, &hq))) return rc;
-        {   // qkv weights in the order qkv_attn_w_kernel consumes them: per head Wq tiles, Wk tiles, Wv tiles
+        const bool has_norm = m.find(p + "norm1.weight") != m.end();
+        bl.fast = heads == 6 && (dim == 96 || dim == 192) && !has_norm;
+        if (has_norm) {
+            // LayerNormNoBias (swin_unet_4xl, swin_unet.py:390-391): x = x + attn(norm1(x)); x = x + mlp(norm2(x))
+            const HostTensor *n1, *n2;
+            if ((rc = find(m, p + "norm1.weight", &n1)) || (rc = find(m, p + "norm2.weight", &n2))) return rc;
+            NUNIF_REQUIRE(n1->numel == dim && n2->numel == dim, "%snorm: shape", p.c_str());
+            NUNIF_REQUIRE(m.find(p + "norm1.bias") == m.end(), "%snorm1: LayerNorm with bias is not a reference variant", p.c_str());
+            std::vector<float> g1(n1->data, n1->data + dim), g2(n2->data, n2->data + dim);
+            if ((rc = upload(h, g1, &bl.norm1)) || (rc = upload(h, g2, &bl.norm2))) return rc;
+        }
+        if (!bl.fast) {
+            if ((rc = make_plain_linear(h, m, p + "attn.proj", dim, dim, &bl.proj)) ||
+                (rc = make_plain_linear(h, m, p + "mlp.0", 2 * dim, dim, &bl.mlp0p)) ||
+                (rc = make_plain_linear(h, m, p + "mlp.3", dim, 2 * dim, &bl.mlp3p)))
+                return rc;
+        }
+        if (bl.fast) {   // qkv weights in the order qkv_attn_w_kernel consumes them: per head Wq tiles, Wk tiles, Wv tiles
             const int KS = dim / 32, NTH = (dim / heads) / 16, nf = qkv_attn_w_stream_frags(dim);
             std::vector<f16> stream((size_t)(nf + 7) / 8 * 8 * 512, (f16)0.0f);
             size_t fi = 0;
@@ -192,7 +216,7 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
             NUNIF_REQUIRE((int)fi == nf, "internal: qkv stream has %zu fragments, expected %d", fi, nf);
             if ((rc = upload(h, stream, &bl.qkv_stream))) return rc;
         }
-        {
+        if (bl.fast) {
             const HostTensor *w, *b;
             if ((rc = find(m, p + "attn.qkv.weight", &w)) || (rc = find(m, p + "attn.qkv.bias", &b))) return rc;
             const float qs = (1.0f / sqrtf((float)(dim / heads))) * 1.4426950408889634f;
@@ -216,10 +240,12 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
             if ((rc = upload(h, rb, &bl.qkv_rbias))) return rc;
         }
         std::vector<f16> hp, h0, h3;
+        if (bl.fast) {
         if ((rc = make_plain_linear(h, m, p + "attn.proj", dim, dim, &bl.proj, false, &hp))) return rc;
         if ((rc = make_plain_linear(h, m, p + "mlp.0", 2 * dim, dim, &bl.mlp0, true, &h0))) return rc;   // chained
         if ((rc = make_plain_linear(h, m, p + "mlp.3", dim, 2 * dim, &bl.mlp3, true, &h3))) return rc;   // chained
-        {   // one linear stream of 1-KiB fragments in the order proj_mlp_kernel consumes them (swin_block_tail.hip)
+        }
+        if (bl.fast) {   // one linear stream of 1-KiB fragments in the order proj_mlp_kernel consumes them (swin_block_tail.hip)
             const int KS = dim / 32, NT = dim / 16, SH = 2 * dim / 32;
             const int nf = proj_mlp_stream_frags(dim);
             std::vector<f16> stream((size_t)(nf + 15) / 16 * 16 * 512, (f16)0.0f);     // whole 16-fragment chunks
@@ -238,8 +264,6 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
             NUNIF_REQUIRE((int)fi == nf, "internal: tail stream has %zu fragments, expected %d", fi, nf);
             if ((rc = upload(h, stream, &bl.tail_stream))) return rc;
         }
-        NUNIF_REQUIRE(m.find(p + "norm1.weight") == m.end(), "%s: LayerNorm variants (swin_unet_4xl) unsupported",
-                      p.c_str());
         const HostTensor *tab;
         if ((rc = find(m, p + "attn.relative_position_bias_table", &tab))) return rc;
         NUNIF_REQUIRE(tab->numel == 121 * heads, "%s: bias table shape", p.c_str());
@@ -325,6 +349,30 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         // variant 3 (default): one window per wave, weights resident in LDS, no barrier in the window loop;
         // variant 2: one window per wave, weights through the LDS ring (both widths);
         // variant 1: one wave per head, 4 windows per workgroup (C = 96 only); variant 0: unfused GEMM + attention.
+        if (!bl.fast) {
+            // generic block (swin_unet_4xl: 12 heads, LayerNormNoBias): every Linear on gemm_kernel, attention on the
+            // fused-qkv-map kernel, the two LayerNorms as their own pass.  att / hid double as the normalised maps.
+            f16 *hid = (f16 *)h->hid.p;
+            const f16 *xin = x;
+            if (bl.norm1) {
+                if ((rc = launch_layernorm_nobias(x, hid, bl.norm1, (long)tok, dim, s))) return rc;
+                xin = hid;
+            }
+            if ((rc = run_linear(bl.qkv, xin, B, S, S, 0, nullptr, qkv, s, "gemm_qkv", next_dir(h)))) return rc;
+            if ((rc = tap(h, tn + ".qkv", qkv, tok * 3 * dim * 2, s))) return rc;
+            if ((rc = launch_window_attn(qkv, att, bl.attn_bias, B, S, S, h->heads, dim / h->heads, shift, s))) return rc;
+            if ((rc = tap(h, tn + ".attn", att, tok * dim * 2, s))) return rc;
+            if ((rc = run_linear(bl.proj, att, B, S, S, 0, x, x, s, "gemm_proj", next_dir(h)))) return rc;
+            xin = x;
+            if (bl.norm2) {
+                if ((rc = launch_layernorm_nobias(x, att, bl.norm2, (long)tok, dim, s))) return rc;
+                xin = att;
+            }
+            if ((rc = run_linear(bl.mlp0p, xin, B, S, S, 1, nullptr, hid, s, "gemm_mlp0", next_dir(h)))) return rc;
+            if ((rc = run_linear(bl.mlp3p, hid, B, S, S, 0, x, x, s, "gemm_mlp3", next_dir(h)))) return rc;
+            if ((rc = tap(h, tn + ".out", x, tok * dim * 2, s))) return rc;
+            continue;
+        }
         if (h->attn_variant == 3 && h->heads == 6 && (dim == 96 || dim == 192)) {
             if ((rc = launch_qkv_attn_r(x, att, bl.qkv_res, bl.qkv_rbias, bl.attn_btab, bl.attn_btab32, B, S, S, dim, h->heads, shift, s,
                                         next_dir(h))))
@@ -427,6 +475,9 @@ stem_done:
     if ((rc = run_gemm(h->down2, f2, B, S / 2, S / 2, 2 * C, S / 4, S / 4, 2, 0, 0, 2, 0, 0, 0.f, nullptr, f3,
                        2 * C, 1, s, "gemm_down2", next_dir(h))))
         return rc;
+    if (h->down2_split && (rc = run_gemm(h->down2b, f2, B, S / 2, S / 2, 2 * C, S / 4, S / 4, 2, 1, 0, 2, 0, 0, 0.f, f3, f3,
+                                         2 * C, 1, s, "gemm_down2b", next_dir(h))))
+        return rc;
     if ((rc = tap(h, "down2", f3, (size_t)B * (S / 4) * (S / 4) * 2 * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[2], f3, B, S / 4, 2 * C, s, "swin3"))) return rc;                  // swin3
     // x = up2(x5) + x4, written in place over x4 (each lane reads then writes its own 8 bytes)
@@ -447,7 +498,8 @@ stem_done:
     if ((rc = tap(h, "up1", top, (size_t)B * S * S * h->top_dim * 2, s))) return rc;
     // to_image + pixel_shuffle + clamp(0,1) (ToImage.forward :110-116, wrapper eval clamp :225-226): fused into the
     // last block's tail kernel when that block runs on the resident C = 96 kernel (1x / 2x nets)
-    if (h->fuse_to_image && h->top_dim == 96 && h->to_image_chained && !h->taps_on && !getenv("NUNIF_TAIL_RING")) {
+    if (h->fuse_to_image && h->top_dim == 96 && h->swin[4].back().fast && h->to_image_chained && !h->taps_on &&
+        !getenv("NUNIF_TAIL_RING")) {
         TailToImage ti;
         ti.w = h->to_image_chained; ti.bias = h->to_image.bias; ti.out = z; ti.H = S; ti.W = S; ti.ps = h->scale_factor;
         ti.n_real = h->to_image.n_real;
@@ -576,7 +628,22 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
             }, bb.data(), L);
         };
         if ((rc = make_down(P + "down1", C, 2 * C, &h->down1))) break;
-        if ((rc = make_down(P + "down2", 2 * C, 2 * C, &h->down2))) break;
+        if (4 * 2 * C > 1024) {
+            // gemm_kernel keeps a token's whole K extent in registers (K <= 1024): the 2x2 stride-2 conv over 2C = 384
+            // channels runs as its two tap ROWS, the second accumulating onto the first's output
+            const HostTensor *w, *b;
+            if ((rc = find(m, P + "down2.conv.weight", &w)) || (rc = find(m, P + "down2.conv.bias", &b))) break;
+            const int cin = 2 * C, cout = 2 * C;
+            if (w->numel != (int64_t)cout * cin * 4) { set_error("down2: shape"); rc = NUNIF_HIP_EINVAL; break; }
+            const float *wd = w->data;
+            std::vector<float> zero(cout, 0.0f);
+            if ((rc = make_linear(h, cout, 2 * cin, [=](int n, int k) {
+                    const int dx = k / cin, ci = k % cin; return wd[((size_t)n * cin + ci) * 4 + dx]; }, b->data, &h->down2)) ||
+                (rc = make_linear(h, cout, 2 * cin, [=](int n, int k) {
+                    const int dx = k / cin, ci = k % cin; return wd[((size_t)n * cin + ci) * 4 + 2 + dx]; }, zero.data(), &h->down2b)))
+                break;
+            h->down2_split = true;
+        } else if ((rc = make_down(P + "down2", 2 * C, 2 * C, &h->down2))) break;
         if ((rc = make_up(P + "up2", 2 * C, 2 * C, &h->up2))) break;
         if ((rc = make_up(P + "up1", 2 * C, h->top_dim, &h->up1))) break;
         if (h->has_proj2 && (rc = make_plain_linear(h, m, P + "proj2", 2 * C, C, &h->proj2))) break;

@@ -244,3 +244,28 @@ def equirectangular(c):
     with torch.cuda.device(c.device):
         _hip.check(_hip.lib().nunif_hip_equirectangular(_p(c), _p(out), C, h, w, _hip.current_stream_ptr(c.device)))
     return out
+
+
+def reflection_pad2d(x, padding):
+    """``reflection_pad2d_naive`` (nunif/modules/reflection_pad2d.py:13-48): (left, right, top, bottom); positive = reflect
+    (edge pixel not repeated), negative = crop.  x: [B,C,H,W] fp32."""
+    x = _cuda_f32(x, "reflection_pad2d")
+    assert x.dim() == 4 and len(padding) == 4
+    left, right, top, bottom = (int(p) for p in padding)
+    b, c, h, w = x.shape
+    y = torch.empty((b, c, h + top + bottom, w + left + right), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_reflection_pad2d(_p(x), _p(y), b * c, h, w, left, right, top, bottom,
+                                                         _hip.current_stream_ptr(x.device)))
+    return y
+
+
+def depth_postprocess(x, max_dist=None, to_disparity=False, eps=0.1, negate=False):
+    """nan_to_num -> clamp(max=max_dist) -> 1/(d+eps) -> optional sign flip (video_depth_anything_model.py:66-76,88-90)."""
+    x = _cuda_f32(x, "depth_postprocess")
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_depth_postprocess(_p(x), _p(y), x.numel(), float(max_dist) if max_dist else 0.0,
+                                                          int(bool(to_disparity)), float(eps), int(bool(negate)),
+                                                          _hip.current_stream_ptr(x.device)))
+    return y

@@ -1,0 +1,118 @@
+"""``VideoDepthAnythingStreamingModel`` on the HIP engine (config 5's depth stage).
+
+Mirrors ``iw3/video_depth_anything_streaming_model.py`` :45-119: per-frame ``model.infer_video_depth_one(frame, use_amp)``
+between ``batch_preprocess`` and ``postprocess`` (``video_depth_anything_model.py``), ``reset_state`` at scene cuts,
+``is_metric`` / ``force_disparity`` semantics, the ``VDA_Stream_*`` names, and ``prep_lower_bound`` rounding to a multiple of 14.
+
+The network is EXTERNAL to the reference tree (``torch.hub.load("nagadomi/Video-Depth-Anything_iw3:main",
+"VideoDepthAnythingStreaming")`` :59-67: DINOv2 encoder + a DPT head with temporal attention over cached frames); neither the
+repository nor its checkpoints are reachable offline, so its temporal head is NOT restated here.  ``load_model`` takes any
+object with the hub model's streaming interface —
+
+    net.infer_video_depth_one(frame[3,h,w] normalised, use_amp=True) -> [1,h,w]      net.reset_state()
+
+— and ``PerFrameStreamingBackbone`` adapts the engine's Depth-Anything-V2 ViT-S (``depth_anything_v2.HipDepthAnythingV2``,
+the same encoder family, no temporal modules) to it as a stand-in so that the whole config-5 path runs on the GPU.
+State is per instance and sequential: shard by scene segment or file across ranks, never by frame.
+"""
+import torch
+
+from . import _ops  # noqa: F401
+from .base_depth_model import BaseDepthModel
+from .video_depth_anything_model import batch_preprocess, postprocess
+
+NAME_MAP = {
+    "VDA_Stream_S": "vits", "VDA_Stream_B": "vitb", "VDA_Stream_L": "vitl",
+    "VDA_Stream_Metric_S": "vits", "VDA_Stream_Metric_B": "vitb", "VDA_Stream_Metric_L": "vitl",
+}
+AA_SUPPORT_MODELS = set(NAME_MAP)
+METRIC_DEPTH_TYPES = {"VDA_Stream_Metric_S", "VDA_Stream_Metric_B", "VDA_Stream_Metric_L"}
+
+
+class PerFrameStreamingBackbone:
+    """Adapter: a per-frame backbone ``net(x[B,3,h,w]) -> [B,h,w]`` behind the hub model's streaming interface.  It keeps the
+    frame counter the hub model keeps, but no temporal cache (the stand-in has no temporal attention)."""
+
+    def __init__(self, net):
+        self.net = net
+        self.prep_lower_bound = 392
+        self.frame_id = 0
+
+    def reset_state(self):
+        self.frame_id = 0
+
+    def infer_video_depth_one(self, frame, use_amp=True):
+        self.frame_id += 1
+        return self.net(frame.unsqueeze(0))
+
+    def eval(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        return self
+
+
+class VideoDepthAnythingStreamingModel(BaseDepthModel):
+    def __init__(self, model_type, backbone=None, depth_aa=None):
+        super().__init__(model_type)
+        if model_type not in NAME_MAP:
+            raise ValueError(f"unknown model_type {model_type}")
+        self.metric_depth = model_type in METRIC_DEPTH_TYPES
+        self.force_disparity = True          # :50 — use 1 / depth, is_metric() == False
+        self._backbone = backbone
+        self.depth_aa = depth_aa             # nunif_amd.iw3.models.DepthAA (weights loaded, on the device) or None
+
+    def load_model(self, model_type, resolution=None, device=None, backbone=None, **kwargs):
+        model = backbone if backbone is not None else self._backbone
+        if model is None:
+            raise RuntimeError("VideoDepthAnythingStreamingModel: the streaming network lives in an external torch.hub "
+                               "repository; pass backbone=<object with infer_video_depth_one / reset_state>")
+        if not hasattr(model, "infer_video_depth_one"):
+            model = PerFrameStreamingBackbone(model)
+        model.prep_lower_bound = resolution or 392
+        if model.prep_lower_bound % 14 != 0:         # from the GUI: 512 -> 518 (:70-72)
+            model.prep_lower_bound += 14 - model.prep_lower_bound % 14
+        return model
+
+    def reset_state(self):
+        self.model.reset_state()
+
+    @torch.inference_mode()
+    def infer(self, x, enable_amp=True, edge_dilation=0, depth_aa=False, **kwargs):
+        if not torch.is_tensor(x):
+            raise ValueError("infer expects a CHW or BCHW float tensor in [0,1]")
+        aa = None
+        if depth_aa:
+            aa = self.depth_aa
+            if aa is None:
+                raise ValueError("depth_aa=True needs model.depth_aa = nunif_amd.iw3.models.DepthAA")
+        batch = x.ndim != 3
+        if not batch:
+            x = x.unsqueeze(0)
+        x = batch_preprocess(x.to(self.device), self.model.prep_lower_bound, metric_depth=self.metric_depth,
+                             limit_resolution=self.limit_resolution)
+        outputs = [self.model.infer_video_depth_one(frame, use_amp=enable_amp).to(torch.float32) for frame in x]
+        depth = torch.stack(outputs).squeeze(1)          # (B, 1, H, W) -> (B, H, W)
+        depth = postprocess(depth, edge_dilation=edge_dilation, depth_aa=aa, metric_depth=self.metric_depth,
+                            force_disparity=self.force_disparity, enable_amp=enable_amp)
+        return depth if batch else depth.squeeze(0)
+
+    @classmethod
+    def get_name(cls):
+        return "VideoDepthAnythingStreaming"
+
+    def is_image_supported(self):
+        return False
+
+    @classmethod
+    def supported(cls, model_type):
+        return model_type in NAME_MAP
+
+    def is_metric(self):
+        if not self.metric_depth:
+            return False
+        return not self.force_disparity
+
+    @classmethod
+    def multi_gpu_supported(cls, model_type):
+        return False

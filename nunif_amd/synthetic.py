@@ -47,7 +47,7 @@ def window_score_bias_input(window):
     return index, ud / ud.abs().max()
 
 
-def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_channels=3):
+def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_channels=3, layer_norm=False):
     """Seeded random weights in the reference's key layout and shapes.
 
     Magnitudes follow the reference initialisers (kaiming/xavier) but every bias and relative-position
@@ -80,6 +80,9 @@ def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_c
             sd[p + "attn.relative_position_index"] = relative_position_index(*WINDOW)
             lin(p + "mlp.0", dim, dim * 2)
             lin(p + "mlp.3", dim * 2, dim, BRANCH_GAIN)
+            if layer_norm:      # LayerNormNoBias (swin_unet_4xl): weight only, drawn around 1 so that it is exercised
+                sd[p + "norm1.weight"] = 1.0 + normal((dim,), 0.1)
+                sd[p + "norm2.weight"] = 1.0 + normal((dim,), 0.1)
 
     c, h = base_dim, base_dim // 16
     P = "unet."

@@ -12,7 +12,7 @@ from collections import OrderedDict
 
 import torch
 
-from ...nunif.models import I2IBaseModel, register_model
+from ...nunif.models import I2IBaseModel, register_model, register_model_factory
 from ... import _hip
 
 WINDOW = 6
@@ -28,7 +28,7 @@ def _relative_position_index():
     return ((ys[:, None] - ys[None, :] + WINDOW - 1) * (2 * WINDOW - 1) + xs[:, None] - xs[None, :] + WINDOW - 1).reshape(-1)
 
 
-def _init_weights(scale_factor, base_dim, in_channels, out_channels):
+def _init_weights(scale_factor, base_dim, in_channels, out_channels, layer_norm=False):
     """Fresh weights in the reference's key layout (SwinUNetBase.__init__ :119-178; torchvision block init)."""
     sd = OrderedDict()
     C = base_dim
@@ -57,6 +57,9 @@ def _init_weights(scale_factor, base_dim, in_channels, out_channels):
             sd[p + "attn.relative_position_index"] = _relative_position_index()
             linear(p + "mlp.0", dim, dim * 2, 1e-6)
             linear(p + "mlp.3", dim * 2, dim, 1e-6)
+            if layer_norm:      # LayerNormNoBias: weight only (nunif/modules/norm.py:17-22)
+                sd[p + "norm1.weight"] = torch.ones(dim)
+                sd[p + "norm2.weight"] = torch.ones(dim)
 
     P = "unet."
     conv(P + "patch.0", in_channels, C // 2, 3)
@@ -147,11 +150,11 @@ class _HipSwinUNetModel(I2IBaseModel):
     def _setup(self, in_channels, out_channels, base_dim=96, layer_norm=False):
         if in_channels != 3 or out_channels != 3:
             raise ValueError("the HIP swin_unet engine supports in_channels = out_channels = 3")
-        if base_dim != 96 or layer_norm:
-            raise ValueError("the HIP swin_unet engine supports base_dim=96 without LayerNorm (not swin_unet_4xl)")
+        if base_dim not in (96, 192):
+            raise ValueError("the HIP swin_unet engine supports base_dim 96 and 192 (swin_unet_4xl)")
         self.register_tile_size_validator(tile_size_validator)
         self.register_buffer("_device_probe", torch.empty(0), persistent=False)
-        self._weights = _init_weights(self.unet_scale_factor, base_dim, in_channels, out_channels)
+        self._weights = _init_weights(self.unet_scale_factor, base_dim, in_channels, out_channels, layer_norm)
         self._engine = None
 
     # -- nn.Module surface ------------------------------------------------------------------------------------
@@ -267,6 +270,15 @@ class SwinUNet4x(_HipSwinUNetModel):
     def to_1x(self, shared=True):
         return SwinUNetDownscaled(in_channels=self.i2i_in_channels, out_channels=self.out_channels,
                                   downscale_factor=4, unet=self)
+
+
+def swin_unet_4xl(**kwargs):
+    """Reference :390-394: the 4x net at base_dim 192 (12 heads of 16 / 32) with LayerNormNoBias in every block.  Runs on the
+    engine's generic block path (gemm_kernel Linears + window_attn_kernel + layernorm_nobias_kernel)."""
+    return SwinUNet4x(base_dim=192, layer_norm=True, **kwargs)
+
+
+register_model_factory("waifu2x.swin_unet_4xl", swin_unet_4xl)
 
 
 @register_model

@@ -108,6 +108,61 @@ def gen_swin8x():
     save("swin_unet_8x", x=x, y=y.half(), sdsum=sd_checksum(sd))
 
 
+def gen_swin4xl():
+    """waifu2x.swin_unet_4xl (base_dim 192, 12 heads, LayerNormNoBias; swin_unet.py:390-394) and the LayerNorm variant of the
+    2x net at base_dim 96 on the reference; outputs stored as fp16."""
+    from waifu2x.models.swin_unet import swin_unet_4xl, SwinUNet2x
+    from oracle import swin_unet as O
+    x = synth_image(15, 3, 64, 64).unsqueeze(0)
+    sd = O.random_state_dict(204, 4, base_dim=192, layer_norm=True)
+    m = swin_unet_4xl().eval()
+    m.load_state_dict(sd, strict=True)
+    y = m(x)
+    print(tuple(y.shape), float(y.mean()), float(y.std()), float((y <= 0).float().mean()), float((y >= 1).float().mean()))
+    sd2 = O.random_state_dict(205, 2, base_dim=96, layer_norm=True)
+    m2 = SwinUNet2x(layer_norm=True).eval()
+    m2.load_state_dict(sd2, strict=True)
+    y2 = m2(x)
+    print(tuple(y2.shape), float(y2.mean()), float(y2.std()), float((y2 <= 0).float().mean()), float((y2 >= 1).float().mean()))
+    save("swin_unet_4xl", x=x, y=y.half(), sdsum=sd_checksum(sd), y2_ln=y2.half(), sdsum2=sd_checksum(sd2))
+
+
+def fake_vda_net(frame):
+    """Deterministic stand-in for the external streaming net: a smooth positive 'metric depth' of the frame (0.3 .. 12)."""
+    g = frame.mean(dim=0, keepdim=True)
+    g = torch.nn.functional.avg_pool2d(g.unsqueeze(0), 5, stride=1, padding=2)[0]
+    return 0.3 + 6.0 * torch.sigmoid(g) ** 2 + 0.002 * torch.arange(g.shape[-1]).view(1, 1, -1)
+
+
+def gen_vda():
+    """VideoDepthAnything pre/post-processing on the reference (video_depth_anything_model.py batch_preprocess / postprocess,
+    the streaming wrapper's per-frame loop) around a deterministic fake network; relative + metric, DepthAA on / off."""
+    from iw3 import video_depth_anything_model as RV
+    from iw3.models.depth_aa import DepthAA
+    from oracle import depth_aa as ODA
+    out = {}
+    x = torch.stack([synth_image(31 + i, 3, 54, 96) for i in range(5)]).half().float()     # stored as fp16, exactly
+    out["x"] = x
+    sd = ODA.random_state_dict(501)
+    aa = DepthAA().eval()
+    aa.load_state_dict(sd, strict=True)
+    for tag, metric, lb in (("rel", False, 56), ("met", True, 84)):
+        pre = RV.batch_preprocess(x.clone(), lb, metric_depth=metric)
+        out["pre_" + tag] = pre
+        raw = torch.stack([fake_vda_net(f) for f in pre]).squeeze(1)
+        raw[0, 3, 5] = float("nan")
+        if metric:              # (+inf in a relative map becomes FLT_MAX and overflows the reference's own dilation to NaN)
+            raw[1, 7, 9] = float("inf")
+        out["raw_" + tag] = raw
+        out["post_" + tag] = RV.postprocess(raw.clone(), edge_dilation=2, depth_aa=None, metric_depth=metric, force_disparity=True)
+        out["post_aa_" + tag] = RV.postprocess(raw.clone(), edge_dilation=[2, 1], depth_aa=aa, metric_depth=metric,
+                                                force_disparity=True, enable_amp=False)
+        print(tag, tuple(pre.shape), tuple(out["post_" + tag].shape), float(out["post_" + tag].min()), float(out["post_" + tag].max()))
+    out["post_met_nodisp"] = RV.postprocess(out["raw_met"].clone(), edge_dilation=1, depth_aa=None, metric_depth=True,
+                                            force_disparity=False, max_dist=5.0)
+    save("video_depth_anything", **{k: (v.half() if k.startswith("x") else v) for k, v in out.items()})
+
+
 def gen_light_inpaint():
     """inpaint.light_inpaint_v1 on the reference (infer / forward) + the MLBWInpaintImage flow (mask MLBW warp, hole mask,
     inpaint, left eye processed flipped) assembled from the reference's own functions."""
@@ -470,7 +525,7 @@ def gen_depth_aa():
 
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint}
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "vda": gen_vda, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -270,3 +270,36 @@ def test_swin_unet_8x(hiplib):
     assert y.shape == ref.shape == (1, 3, 384, 384)
     assert psnr(y, ref) >= PSNR_MIN, psnr(y, ref)
     assert psnr(y, O.model_forward(sd, x, "waifu2x.swin_unet_8x")) >= PSNR_MIN
+
+
+def test_swin_unet_4xl(hiplib):
+    """waifu2x.swin_unet_4xl (reference swin_unet.py:390-394: base_dim 192, 12 heads of 16 / 32, LayerNormNoBias) and
+    SwinUNet2x(layer_norm=True) on the engine's generic block path, against the reference's own outputs."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from nunif_amd.nunif.models import create_model
+    from nunif_amd.waifu2x.models import swin_unet as M
+    g = np.load(os.path.join(GOLDEN, "swin_unet_4xl.npz"))
+    x = torch.from_numpy(g["x"])
+    m = create_model("waifu2x.swin_unet_4xl").eval()
+    assert (m.i2i_scale, m.i2i_offset, m.i2i_blend_size) == (4, 32, 16)
+    sd = O.random_state_dict(204, 4, base_dim=192, layer_norm=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda:0")
+    y = m(x.to("cuda:0")).cpu()
+    ref = torch.from_numpy(g["y"]).float()
+    assert y.shape == ref.shape == (1, 3, 192, 192)
+    assert psnr(y, ref) >= PSNR_MIN, psnr(y, ref)
+    # whole-frame tiled render through the same handle (2 x 2 tiles of 64) against the oracle's per-tile render
+    m2 = M.SwinUNet2x(layer_norm=True).eval()
+    sd2 = O.random_state_dict(205, 2, base_dim=96, layer_norm=True)
+    m2.load_state_dict(sd2, strict=True)
+    m2 = m2.to("cuda:0")
+    y2 = m2(x.to("cuda:0")).cpu()
+    ref2 = torch.from_numpy(g["y2_ln"]).float()
+    assert psnr(y2, ref2) >= PSNR_MIN, psnr(y2, ref2)
+    from nunif_amd.nunif.utils.render import tiled_render
+    img = x[0, :, :50, :60].contiguous()
+    out = tiled_render(img.to("cuda:0"), m, tile_size=64, batch_size=4).cpu()
+    assert out.shape == (3, 200, 240) and torch.isfinite(out).all()

@@ -107,3 +107,23 @@ def test_swin_8x_matches_reference():
     y = O.model_forward(sd, torch.from_numpy(g["x"]), "waifu2x.swin_unet_8x")
     ref = torch.from_numpy(g["y"]).float()
     assert y.shape == ref.shape == (1, 3, 384, 384) and (y - ref).abs().max().item() < 1e-3
+
+
+def test_swin_4xl_matches_reference():
+    """waifu2x.swin_unet_4xl (base_dim 192, 12 heads, LayerNormNoBias; reference swin_unet.py:390-394) and the LayerNorm variant of
+    the 2x net: the oracle's norm1 / norm2 handling against the reference's own outputs (fixtures stored as fp16)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "swin_unet_4xl.npz"))
+    x = torch.from_numpy(g["x"])
+    sd = O.random_state_dict(204, 4, base_dim=192, layer_norm=True)
+    assert sd_checksum(sd) == pytest.approx(float(g["sdsum"]), rel=1e-12)
+    y = O.model_forward(sd, x, "waifu2x.swin_unet_4x")
+    ref = torch.from_numpy(g["y"]).float()
+    assert y.shape == ref.shape == (1, 3, 192, 192) and (y - ref).abs().max().item() < 1e-3
+    sd2 = O.random_state_dict(205, 2, base_dim=96, layer_norm=True)
+    assert sd_checksum(sd2) == pytest.approx(float(g["sdsum2"]), rel=1e-12)
+    y2 = O.model_forward(sd2, x, "waifu2x.swin_unet_2x")
+    ref2 = torch.from_numpy(g["y2_ln"]).float()
+    assert y2.shape == ref2.shape == (1, 3, 96, 96) and (y2 - ref2).abs().max().item() < 1e-3
