@@ -262,6 +262,13 @@ int nunif_hip_dilate_edge(const float *x, float *y, float *work, int32_t B, int3
  * min/max, i.e. EMA off).  minmax: [B,2] device scratch that receives the order-keyed min/max. */
 int nunif_hip_minmax_normalize(const float *x, float *y, float *minmax, int32_t B, int64_t n_per, void *stream);
 
+/* Stand-alone mask morphology on fp32 0/1 masks [B,H,W] (iw3/dilation.py dilate :41-46, erode :49-54, closing :57-64,
+ * mask_closing :145-153, dilate_outer :67-81, dilate_inner :84-98).  op: 0 dilate x n_a (3x3 max, window clipped at the border),
+ * 1 erode x n_a, 2 closing(n_iter = n_a), 3 mask_closing(n_iter = n_a) = clamp(closing + mask), 4 horizontal OR-dilation with
+ * n_a steps of dilate_inner (pixel x takes x+1) and n_b steps of dilate_outer (pixel x takes x-1).  work: B*H*W floats. */
+int nunif_hip_mask_morphology(const float *in, float *out, float *work, int32_t B, int32_t H, int32_t W, int32_t op,
+                              int32_t n_a, int32_t n_b, void *stream);
+
 /* VideoDepthAnything pre/post glue (iw3/video_depth_anything_model.py:51-91).
  * reflection_pad2d: nunif/modules/reflection_pad2d.py reflection_pad2d_naive :13-48 on planar fp32 [planes,H,W] -> [planes,
  *   H+top+bottom, W+left+right]; positive pads reflect without repeating the edge, negative pads crop (the F.pad(out, (-14,)*4)

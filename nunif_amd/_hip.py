@@ -101,6 +101,7 @@ SIGNATURES = {
                             [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
     "nunif_hip_dilate_edge": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
     "nunif_hip_minmax_normalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "nunif_hip_mask_morphology": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p]),
     "nunif_hip_reflection_pad2d": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                              c_void_p]),
     "nunif_hip_depth_postprocess": (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_int32, c_float, c_int32, c_void_p]),

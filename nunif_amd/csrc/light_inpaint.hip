@@ -774,3 +774,45 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
+
+// ---- stand-alone mask morphology (iw3/dilation.py dilate :41-46, erode :49-54, closing :57-64, mask_closing :145-153,
+//      dilate_outer :67-81, dilate_inner :84-98) on fp32 0/1 masks [B,H,W]; the same kernels the inpaint pre-processing uses ----
+// op: 0 dilate x n_a, 1 erode x n_a, 2 closing(n_iter = n_a), 3 mask_closing(n_iter = n_a), 4 horizontal OR-dilation: n_a steps
+// towards +x sources (dilate_inner) and n_b steps towards -x sources (dilate_outer).  work: B*H*W floats.  in != out.
+extern "C" int nunif_hip_mask_morphology(const float *in, float *out, float *work, int32_t B, int32_t H, int32_t W, int32_t op,
+                                         int32_t n_a, int32_t n_b, void *stream) {
+    using namespace nunif;
+    NUNIF_REQUIRE(in && out && work && B > 0 && H > 0 && W > 0 && n_a >= 0 && n_b >= 0 && op >= 0 && op <= 4 && in != out,
+                  "mask_morphology: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)B * H * W;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    ProfScope ps("mask_morphology", s, 0.0, (double)n * 8.0 * (op == 4 ? 1 : (op >= 2 ? 2 * n_a : n_a) + 1));
+    if (op == 4) {
+        li_dilate_kernel<<<blocks, 256, 0, s>>>(in, out, (long)B * H, W, n_a, n_b);
+        NUNIF_LAUNCH_CHECK();
+        return NUNIF_HIP_OK;
+    }
+    // passes: list of (is_min); ping-pong between out and work so that the last pass lands in out
+    int passes[64];
+    int np = 0;
+    NUNIF_REQUIRE(n_a <= 16, "mask_morphology: at most 16 iterations");
+    if (op == 0 || op >= 2) for (int i = 0; i < n_a; ++i) passes[np++] = 0;
+    if (op == 1 || op >= 2) for (int i = 0; i < n_a; ++i) passes[np++] = 1;
+    if (np == 0) {
+        NUNIF_HIP_CHECK(hipMemcpyAsync(out, in, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return NUNIF_HIP_OK;
+    }
+    const float *src = in;
+    // op 3 adds the original mask at the end (elementwise, in place on out), so the last morph pass must land in `work`
+    const bool last_in_out = op != 3;
+    for (int i = 0; i < np; ++i) {
+        const bool to_out = ((np - 1 - i) % 2 == 0) == last_in_out;
+        float *dst = to_out ? out : work;
+        li_morph_kernel<<<blocks, 256, 0, s>>>(src, dst, B, H, W, passes[i]);
+        src = dst;
+    }
+    if (op == 3) li_add_clamp_kernel<<<blocks, 256, 0, s>>>(src, in, out, n);      // (closing + original).clamp(0, 1)
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}

@@ -269,3 +269,18 @@ def depth_postprocess(x, max_dist=None, to_disparity=False, eps=0.1, negate=Fals
                                                           int(bool(to_disparity)), float(eps), int(bool(negate)),
                                                           _hip.current_stream_ptr(x.device)))
     return y
+
+
+def mask_morphology(mask, op, n_a, n_b=0):
+    """Stand-alone mask morphology (see ``nunif_hip_mask_morphology``).  mask: [B,1,H,W] (bool / float) -> fp32 0/1."""
+    assert mask.dim() == 4 and mask.shape[1] == 1
+    if mask.device.type != "cuda":
+        raise RuntimeError("mask_morphology: expected a ROCm tensor; there is no CPU path")
+    x = mask.to(torch.float32).contiguous()
+    b, _, h, w = x.shape
+    y = torch.empty_like(x)
+    work = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_mask_morphology(_p(x), _p(y), _p(work), b, h, w, op, int(n_a), int(n_b),
+                                                        _hip.current_stream_ptr(x.device)))
+    return y

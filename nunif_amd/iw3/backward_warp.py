@@ -17,6 +17,35 @@ def apply_divergence_grid_sample(c, depth, divergence, convergence, synthetic_vi
     return (c if left is None else left.to(c.dtype)), (c if right is None else right.to(c.dtype))
 
 
+def make_grid(batch, width, height, device):
+    """The identity sampling grid of ``backward_warp`` (reference :86-93): x, y planes of linspace(-1, 1).  The HIP warps build
+    this grid on the fly, so the tensor only carries a marker that ``backward_warp`` recognises."""
+    mesh_y, mesh_x = torch.meshgrid(torch.linspace(-1, 1, height, device=device), torch.linspace(-1, 1, width, device=device),
+                                    indexing="ij")
+    grid = torch.cat((mesh_x.reshape(1, 1, height, width).expand(batch, 1, height, width),
+                      mesh_y.reshape(1, 1, height, width).expand(batch, 1, height, width)), dim=1)
+    grid._nunif_identity_grid = True
+    return grid
+
+
+def pad_delta_y(delta_x):
+    """[B,C,H,W] x-displacements -> [B,2C,H,W] with zero y planes interleaved (reference :239-243)."""
+    B, C, H, W = delta_x.shape
+    return torch.stack([delta_x, torch.zeros_like(delta_x)], dim=2).reshape(B, C * 2, H, W)
+
+
+def backward_warp(c, grid, delta, delta_scale):
+    """``clamp(grid_sample(c, grid + delta * delta_scale, bilinear, border, align_corners=True), 0, 1)`` with the grid resized
+    bilinearly (align_corners) to the image when the delta map is smaller (reference :67-83).  ``grid`` must come from
+    ``make_grid`` and ``delta`` from ``pad_delta_y`` (x displacement, zero y) — what every call site in the reference passes;
+    one launch of ``nunif_hip_delta_warp``."""
+    if not getattr(grid, "_nunif_identity_grid", False):
+        raise NotImplementedError("backward_warp on the HIP engine takes the identity grid of make_grid()")
+    if delta.shape[1] != 2:
+        raise ValueError("delta must be [B,2,h,w] (x, y) as built by pad_delta_y")
+    return _ops.delta_warp(c, delta[:, 0:1].contiguous(), delta_scale).to(c.dtype)
+
+
 def make_divergence_feature_value(divergence, convergence, image_width):
     divergence_pix = divergence * 0.5 * 0.01 * image_width
     divergence_feature_value = divergence_pix / 32.0

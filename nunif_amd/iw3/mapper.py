@@ -11,6 +11,27 @@ _SHIFT = {"shift_30": 3.0, "shift_20": 2.0, "shift_14": 1.4, "shift_08": 0.8, "s
 _DIV = {"div_25": 2.5, "div_10": 1, "div_6": 0.6, "div_4": 0.4, "div_2": 0.2, "div_1": 0.1}
 
 
+# named elementary mappers (reference :7-61), each one launch of nunif_hip_map_depth
+def softplus01_legacy(depth, c=6):
+    return _ops.map_depth(depth, 2, c)
+
+
+def softplus01(x, bias, scale):
+    return _ops.map_depth(x, 3, bias, scale)
+
+
+def inv_softplus01(x, bias, scale):
+    return _ops.map_depth(x, 4, bias, scale)
+
+
+def distance_to_disparity(x, c):
+    return _ops.map_depth(x, 5, c)
+
+
+def shift_relative_depth(x, min_distance, max_distance=16):
+    return _ops.map_depth(x, 6, min_distance, max_distance)
+
+
 def resolve_mapper_function(name):
     if name == "none":
         return lambda x: x

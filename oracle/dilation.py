@@ -52,3 +52,49 @@ def dilate_edge(x, n):
     for _ in range(nx - both):
         x = one_iteration(x, 1, 3)
     return x
+
+
+# ---- mask morphology (iw3/dilation.py dilate :41-46, erode :49-54, closing :57-64, mask_closing :145-153,
+#      dilate_outer :67-81, dilate_inner :84-98) -------------------------------------------------------------------------
+def dilate(mask, kernel_size=3):
+    return F.max_pool2d(mask, kernel_size=kernel_size, stride=1, padding=kernel_size // 2)
+
+
+def erode(mask, kernel_size=3):
+    return -F.max_pool2d(-mask, kernel_size=kernel_size, stride=1, padding=kernel_size // 2)
+
+
+def closing(mask, kernel_size=3, n_iter=2):
+    mask = mask.float()
+    for _ in range(n_iter):
+        mask = dilate(mask, kernel_size)
+    for _ in range(n_iter):
+        mask = erode(mask, kernel_size)
+    return mask
+
+
+def mask_closing(mask, kernel_size=3, n_iter=2):
+    org = mask.float()
+    return (closing(org, kernel_size, n_iter) + org).clamp(0, 1)
+
+
+def dilate_outer(mask, n_iter, base_width=None):
+    if n_iter <= 0:
+        return mask
+    dt, m = mask.dtype, mask.bool()
+    if base_width is not None:
+        n_iter = max(round(mask.shape[-1] / base_width * n_iter), 1)
+    for _ in range(n_iter):
+        m = m | F.pad(m, (1, 0, 0, 0))[:, :, :, :-1]
+    return m.to(dt)
+
+
+def dilate_inner(mask, n_iter, base_width=None):
+    if n_iter <= 0:
+        return mask
+    dt, m = mask.dtype, mask.bool()
+    if base_width is not None:
+        n_iter = max(round(mask.shape[-1] / base_width * n_iter), 1)
+    for _ in range(n_iter):
+        m = m | F.pad(m, (0, 1, 0, 0))[:, :, :, 1:]
+    return m.to(dt)

@@ -144,3 +144,24 @@ def synth_depth(*args, **kwargs):
     """Alias of ``nunif_amd.synthetic.synth_depth``."""
     from nunif_amd.synthetic import synth_depth as f
     return f(*args, **kwargs)
+
+
+def nonwarp_mask(c, depth, divergence, convergence, view="right"):
+    """``iw3/forward_warp.py`` ``nonwarp_mask`` :259-295 on top of this module's ``forward_warp`` restatement."""
+    divergence = divergence * 0.5
+    if c.shape[-2:] != depth.shape[-2:]:
+        depth = F.interpolate(depth, size=c.shape[-2:], mode="bilinear", align_corners=True, antialias=True)
+    depth3 = depth.repeat(1, 3, 1, 1)
+    if view == "right":
+        wd, _ = forward_warp(depth3, depth, divergence, convergence, fill=True, synthetic_view="left")
+        wd = wd.mean(dim=1, keepdim=True)
+        _, _, _, mask = forward_warp(torch.zeros_like(c), wd, divergence, convergence, fill=False, synthetic_view="right",
+                                     return_mask=True)
+    else:
+        c, depth, depth3 = c.flip(-1), depth.flip(-1), depth3.flip(-1)
+        _, wd = forward_warp(depth3, depth, divergence, convergence, fill=True, synthetic_view="right")
+        wd = wd.mean(dim=1, keepdim=True)
+        _, _, mask, _ = forward_warp(torch.zeros_like(c), wd, divergence, convergence, fill=False, synthetic_view="left",
+                                     return_mask=True)
+        c, mask = c.flip(-1), mask.flip(-1)
+    return c, mask

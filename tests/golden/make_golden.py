@@ -163,6 +163,42 @@ def gen_vda():
     save("video_depth_anything", **{k: (v.half() if k.startswith("x") else v) for k, v in out.items()})
 
 
+def gen_morph():
+    """iw3/dilation.py mask morphology + iw3/mapper.py named mappers on the reference (tiny, exact)."""
+    from iw3 import dilation as RD
+    from iw3 import mapper as RM
+    g = torch.Generator().manual_seed(77)
+    m = (torch.rand(3, 1, 23, 37, generator=g) > 0.8)
+    mf = m.float()
+    out = {"mask": m.numpy()}
+    out["dilate"], out["erode"] = RD.dilate(mf), RD.erode(mf)
+    out["closing2"], out["closing1"] = RD.closing(m), RD.closing(m, n_iter=1)
+    out["mask_closing2"] = RD.mask_closing(m)
+    out["outer3"], out["inner2"] = RD.dilate_outer(m, 3), RD.dilate_inner(m, 2)
+    out["outer_bw"] = RD.dilate_outer(m, 4, base_width=74)         # round(37 / 74 * 4) = 2
+    x = torch.rand(2, 1, 9, 11, generator=g)
+    out["x"] = x
+    out["softplus01"], out["inv_softplus01"] = RM.softplus01(x, 0.343, 12), RM.inv_softplus01(x, -0.002102, 7.8788)
+    out["softplus01_legacy"] = RM.softplus01_legacy(x, 6)
+    out["distance_to_disparity"], out["shift_relative_depth"] = RM.distance_to_disparity(x, 0.6), RM.shift_relative_depth(x, 1.4)
+    # forward_warp.nonwarp_mask (:259-295) and backward_warp / make_grid / pad_delta_y (:67-93, :239-243)
+    from iw3 import forward_warp as RF
+    from iw3 import backward_warp as RB
+    from oracle.forward_warp import synth_depth
+    c = synth_image(81, 3, 40, 64).unsqueeze(0)
+    depth = synth_depth(13, 1, 40, 64, "smooth_edges")
+    out["fw_c"], out["fw_depth"] = c, depth
+    for view in ("right", "left"):
+        cc, mask = RF.nonwarp_mask(c.clone(), depth.clone(), 16.0, 0.5, view=view)
+        out["fw_mask_" + view] = mask
+        assert torch.equal(cc, c)
+    delta_x = (torch.rand(1, 1, 20, 32, generator=g) - 0.5) * 6.0
+    grid = RB.make_grid(1, 32, 20, delta_x.device)
+    out["bw_delta_x"] = delta_x
+    out["bw_out"] = RB.backward_warp(c, grid, RB.pad_delta_y(delta_x), 1.0 / (64 // 2 - 1))
+    save("morph", **out)
+
+
 def gen_light_inpaint():
     """inpaint.light_inpaint_v1 on the reference (infer / forward) + the MLBWInpaintImage flow (mask MLBW warp, hole mask,
     inpaint, left eye processed flipped) assembled from the reference's own functions."""
@@ -525,7 +561,7 @@ def gen_depth_aa():
 
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "vda": gen_vda, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint}
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

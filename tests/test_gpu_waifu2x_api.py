@@ -191,3 +191,37 @@ def test_hip_alpha_border_padding(hiplib):
         assert (got - ref).abs().max().item() < 1e-5, offset
     # pixels deeper than `offset` inside the hole stay zero
     assert float(pad(rgb.to("cuda:0"), alpha.to("cuda:0"), 4)[:, 30:34, 42:48].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_concurrent_renderer_matches_single_stream(hiplib):
+    """nunif_amd.parallel.ConcurrentRenderer: frames dealt over 2 / 3 engine replicas on their own HIP streams come back in
+    submission order and bit-identical to the single-stream render (results do not depend on what shares the GPU)."""
+    from nunif_amd.nunif.utils.render import tiled_render
+    from nunif_amd.parallel import ConcurrentRenderer
+    from nunif_amd.synthetic import swin_unet_state_dict
+    from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x
+    sd = swin_unet_state_dict(102, 2)
+
+    def make():
+        m = SwinUNet2x().eval()
+        m.load_state_dict(sd)
+        return m
+
+    g = torch.Generator().manual_seed(5)
+    frames = [torch.rand(3, 150 + 10 * i, 200, generator=g).to("cuda:0") for i in range(7)]
+
+    def render(m, f):
+        return tiled_render(f, m, tile_size=64, batch_size=4)
+
+    ref_model = make().to("cuda:0")
+    ref = [render(ref_model, f).cpu() for f in frames]
+    for n in (2, 3):
+        pool = ConcurrentRenderer(make, n, "cuda:0")
+        outs = [o.cpu() for o in pool.map(render, frames)]
+        assert len(outs) == len(ref)
+        for a, b in zip(outs, ref):
+            assert a.shape == b.shape and torch.equal(a, b)
+        pool.synchronize()
+    with pytest.raises(RuntimeError):
+        ConcurrentRenderer(make, 2, "cpu")

@@ -88,3 +88,75 @@ def test_hip_mask_mlbw(hiplib, g):
         assert bad < 0.02, (tag, bad)            # pixels whose logit sits within the fp16 error of the threshold may flip
     _, mask = nonwarp_mask(m, c, depth, 4.0, 0.5, threshold=0.15, inner_dilation=1, outer_dilation=1)
     assert mask.dtype == torch.bool and (mask.cpu() != g["nonwarp"]).float().mean().item() < 0.02
+
+
+def _morph_golden():
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "morph.npz")).items()}
+
+
+def test_oracle_mask_morphology_matches_reference():
+    """oracle.dilation mask morphology == the reference's iw3/dilation.py outputs (tests/golden/morph.npz), exactly."""
+    from oracle import dilation as OD
+    g = _morph_golden()
+    m = g["mask"]
+    mf = m.float()
+    assert torch.equal(OD.dilate(mf), g["dilate"]) and torch.equal(OD.erode(mf), g["erode"])
+    assert torch.equal(OD.closing(m), g["closing2"]) and torch.equal(OD.closing(m, n_iter=1), g["closing1"])
+    assert torch.equal(OD.mask_closing(m), g["mask_closing2"])
+    assert torch.equal(OD.dilate_outer(m, 3), g["outer3"]) and torch.equal(OD.dilate_inner(m, 2), g["inner2"])
+    assert torch.equal(OD.dilate_outer(m, 4, base_width=74), g["outer_bw"])
+
+
+@pytest.mark.gpu
+def test_hip_mask_morphology_and_named_mappers(hiplib):
+    """nunif_amd.iw3.dilation mask helpers (bit-exact) and nunif_amd.iw3.mapper named mappers vs the reference fixture."""
+    from nunif_amd.iw3 import dilation as D
+    from nunif_amd.iw3 import mapper as M
+    g = _morph_golden()
+    m = g["mask"].to("cuda:0")
+    mf = m.float()
+    assert torch.equal(D.dilate(mf).cpu(), g["dilate"]) and torch.equal(D.erode(mf).cpu(), g["erode"])
+    assert torch.equal(D.closing(m).cpu(), g["closing2"]) and torch.equal(D.closing(m, n_iter=1).cpu(), g["closing1"])
+    assert torch.equal(D.mask_closing(m).cpu(), g["mask_closing2"])
+    o3, i2 = D.dilate_outer(m, 3), D.dilate_inner(m, 2)
+    assert o3.dtype == torch.bool and torch.equal(o3.cpu(), g["outer3"]) and torch.equal(i2.cpu(), g["inner2"])
+    assert torch.equal(D.dilate_outer(m, 4, base_width=74).cpu(), g["outer_bw"])
+    assert D.dilate_outer(m, 0) is m
+    x = g["x"].to("cuda:0")
+    for name, got in (("softplus01", M.softplus01(x, 0.343, 12)), ("inv_softplus01", M.inv_softplus01(x, -0.002102, 7.8788)),
+                      ("softplus01_legacy", M.softplus01_legacy(x, 6)), ("distance_to_disparity", M.distance_to_disparity(x, 0.6)),
+                      ("shift_relative_depth", M.shift_relative_depth(x, 1.4))):
+        assert (got.cpu() - g[name]).abs().max().item() < 2e-6, name
+
+
+def test_oracle_forward_nonwarp_mask_matches_reference():
+    from oracle import forward_warp as OF
+    g = _morph_golden()
+    for view in ("right", "left"):
+        cc, mask = OF.nonwarp_mask(g["fw_c"], g["fw_depth"], 16.0, 0.5, view=view)
+        assert torch.equal(cc, g["fw_c"]) and torch.equal(mask, g["fw_mask_" + view]), view
+        assert 0.0 < float(mask.mean()) < 0.5
+
+
+@pytest.mark.gpu
+def test_hip_forward_nonwarp_mask_and_backward_warp(hiplib):
+    """iw3.forward_warp.nonwarp_mask (bit-exact, two forward-warp launches) and the generic backward_warp / make_grid /
+    pad_delta_y entry points vs the reference fixture."""
+    from nunif_amd.iw3 import backward_warp as B
+    from nunif_amd.iw3 import forward_warp as FW
+    g = _morph_golden()
+    c, depth = g["fw_c"].to("cuda:0"), g["fw_depth"].to("cuda:0")
+    for view in ("right", "left"):
+        cc, mask = FW.nonwarp_mask(c, depth, 16.0, 0.5, view=view)
+        assert torch.equal(cc.cpu(), g["fw_c"])
+        assert torch.equal(mask.cpu(), g["fw_mask_" + view]), view
+    delta_x = g["bw_delta_x"].to("cuda:0")
+    grid = B.make_grid(1, 32, 20, "cuda:0")
+    assert grid.shape == (1, 2, 20, 32)
+    out = B.backward_warp(c, grid, B.pad_delta_y(delta_x), 1.0 / (64 // 2 - 1)).cpu()
+    assert (out - g["bw_out"]).abs().max().item() < 1e-5
+    with pytest.raises(NotImplementedError):
+        B.backward_warp(c, grid.clone(), B.pad_delta_y(delta_x), 1.0)
