@@ -377,14 +377,14 @@ static thread_local const char *g_prof_tag = nullptr;
 
 template <int KS, int MF>
 static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym, const char *res_sym, double flops,
-                         double bytes) {
+                         double bytes, bool ring_only = false) {
     const long M = (long)g.B * g.Ho * g.Wo;
     const size_t wbytes = (size_t)(g.N / 16) * KS * 1024;
     // resident weights pay where the ring's one-chunk-ahead prefetch is too short (MF = 2: K = 384, 576); measured
     // slower for the MF = 4 shapes (K = 96, 192), which keep the ring.  NUNIF_GEMM_RING=1 / NUNIF_GEMM_RES=1 force one.
     static const bool force_ring = getenv("NUNIF_GEMM_RING") != nullptr, force_res = getenv("NUNIF_GEMM_RES") != nullptr;
     const bool fits = wbytes <= 144 * 1024 && M >= 8 * MF * 16 * 64;
-    const bool res = fits && !force_ring && (MF == 2 || force_res);
+    const bool res = fits && !force_ring && !ring_only && (MF == 2 || force_res);
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
     // (NUNIF_PROF_TAGS=1 names the class after the call site instead: separates e.g. the two gemm_kernel<6,4> users)
     ProfScope ps(g_prof_tag ? g_prof_tag : res ? res_sym : ring_sym, s, flops, bytes);
@@ -435,7 +435,16 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
         case 2: return launch_gemm_t<2, 4>(g, s, "gemm_kernel<2,4>", "gemm_res_kernel<2,4>", flops, bytes);
         case 4: return launch_gemm_t<4, 4>(g, s, "gemm_kernel<4,4>", "gemm_res_kernel<4,4>", flops, bytes);
         case 3: return launch_gemm_t<3, 4>(g, s, "gemm_kernel<3,4>", "gemm_res_kernel<3,4>", flops, bytes);
-        case 6: return launch_gemm_t<6, 4>(g, s, "gemm_kernel<6,4>", "gemm_res_kernel<6,4>", flops, bytes);
+        case 6: {
+            // PatchUp (mode 1 with the skip as residual) is HBM-bound and exposes the latency of its residual reads: with 2 token
+            // tiles per wave the kernel needs 156 instead of 252 registers, so 3 workgroups per CU are resident and hide it
+            // (measured, both PatchUps of the 2x net: 604 -> 529 us; the resident-weight form of the same shape was slower: 381 vs
+            // 340 us on PatchUp 1).  NUNIF_GEMM6_MF=4 restores the 4-tile form.
+            static const int mf6 = getenv("NUNIF_GEMM6_MF") ? atoi(getenv("NUNIF_GEMM6_MF")) : 2;
+            if (mf6 == 2 && g.mode == 1 && g.res)
+                return launch_gemm_t<6, 2>(g, s, "gemm_kernel<6,2>", "gemm_res_kernel<6,2>", flops, bytes, true);
+            return launch_gemm_t<6, 4>(g, s, "gemm_kernel<6,4>", "gemm_res_kernel<6,4>", flops, bytes);
+        }
         case 8: return launch_gemm_t<8, 4>(g, s, "gemm_kernel<8,4>", "gemm_res_kernel<8,4>", flops, bytes);
         case 12: return launch_gemm_t<12, 2>(g, s, "gemm_kernel<12,2>", "gemm_res_kernel<12,2>", flops, bytes);
         case 18: return launch_gemm_t<18, 2>(g, s, "gemm_kernel<18,2>", "gemm_res_kernel<18,2>", flops, bytes);

@@ -628,7 +628,12 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
             }, bb.data(), L);
         };
         if ((rc = make_down(P + "down1", C, 2 * C, &h->down1))) break;
-        if (4 * 2 * C > 1024) {
+        // the base_dim-96 nets' down2 runs the same way (K = 768, one token tile per wave on gemm_kernel<24,1>)
+        // as two K = 384 passes on the resident-weight gemm_res_kernel<12,2>
+        // (measured on the 2x net: gemm_kernel<24,1> 172 us -> 2 x 114 us - the 200 us of down1 stay = 30 us less per frame;
+        //  NUNIF_DOWN2_SPLIT=0 restores the single K = 768 pass)
+        static const bool split768 = !getenv("NUNIF_DOWN2_SPLIT") || atoi(getenv("NUNIF_DOWN2_SPLIT")) != 0;
+        if (4 * 2 * C > 1024 || split768) {
             // gemm_kernel keeps a token's whole K extent in registers (K <= 1024): the 2x2 stride-2 conv over 2C = 384
             // channels runs as its two tap ROWS, the second accumulating onto the first's output
             const HostTensor *w, *b;
