@@ -20,8 +20,10 @@ from nunif_amd.iw3.utils import apply_divergence  # noqa: E402
 from nunif_amd.iw3.mlbw_inpaint import MLBWInpaint  # noqa: E402
 from nunif_amd.iw3.models.light_inpaint_v1 import LightInpaintV1  # noqa: E402
 from nunif_amd.iw3.models.mlbw import MLBW  # noqa: E402
-from nunif_amd.synthetic import (depth_anything_v2_state_dict, light_inpaint_state_dict, mlbw_state_dict,  # noqa: E402
-                                 row_flow_v3_state_dict)
+from nunif_amd.iw3.models.light_video_inpaint_v1 import LightVideoInpaintV1  # noqa: E402
+from nunif_amd.iw3.video_depth_anything_streaming_model import VideoDepthAnythingStreamingModel  # noqa: E402
+from nunif_amd.synthetic import (depth_anything_v2_state_dict, light_inpaint_state_dict, light_video_inpaint_state_dict,  # noqa: E402
+                                 mlbw_state_dict, row_flow_v3_state_dict)
 
 DEV = "cuda:0"
 
@@ -82,6 +84,46 @@ def main():
     dt = (time.perf_counter() - t0) / 10
     res["mlbw_inpaint_image"] = {"ms_per_frame": round(dt * 1e3, 3), "fps": round(1 / dt, 1),
                                  "input_MPix_s": round(H * W / dt / 1e6, 1)}
+    # ---- BASELINE config 5 shape: 4K frames, VideoDepthAnythingStreaming wrapper (per-frame ViT-S stand-in for the external
+    #      streaming net) -> min-max -> mask-MLBW warp -> 12-frame queue -> light_video_inpaint_v1 on both eyes -> SBS u8 ----
+    if "--no-cfg5" not in sys.argv:
+        H5, W5 = 2160, 3840
+        vda = VideoDepthAnythingStreamingModel("VDA_Stream_S", backbone=depth_model.model).load(gpu=0)
+        vid = LightVideoInpaintV1().eval()
+        vid.load_state_dict(light_video_inpaint_state_dict(801))
+        inpaint_v = MLBWInpaint(inp.to(DEV), mm.to(DEV), video_model=vid.to(DEV))
+        inpaint_v.set_mode("video")
+        frames5 = [torch.rand(3, H5, W5, device=DEV) for _ in range(3)]
+        n_out = [0]
+
+        def step5(i, batch=3):
+            x = torch.stack([frames5[(i + k) % 3] for k in range(batch)])
+            d = vda.infer(x, edge_dilation=2)                                     # [B,1,h,w] raw
+            d = torch.stack(vda.minmax_normalize(d))
+            left, right = inpaint_v.infer(x, d, divergence=2.0, convergence=0.5, synthetic_view="both",
+                                          inner_dilation=1, outer_dilation=1)
+            if left is None:                      # the 12-frame queue is still filling
+                return
+            for k in range(left.shape[0]):
+                _ops.stereo_to_frame(left[k], right[k], "sbs")
+                n_out[0] += 1
+
+        for i in range(4):                       # fills the 12-frame queue (first outputs appear after 3 calls)
+            step5(i)
+        torch.cuda.synchronize()
+        n_out[0] = 0
+        t0 = time.perf_counter()
+        n_in = 0
+        for i in range(8):
+            step5(i)
+            n_in += 3
+        torch.cuda.synchronize()
+        dt5 = time.perf_counter() - t0
+        res["cfg5_4k_vda_stream_mlbw_video_inpaint"] = {
+            "frames_in": n_in, "frames_out": n_out[0], "ms_per_frame": round(1e3 * dt5 / n_in, 2), "fps": round(n_in / dt5, 1),
+            "input_MPix_s": round(H5 * W5 * n_in / dt5 / 1e6, 1),
+            "note": "streaming depth net = per-frame ViT-S stand-in (the external temporal head is not restated)"}
+        inpaint_v.reset()
     _hip.profile_enable(True)
     step_inpaint(0)
     torch.cuda.synchronize()
