@@ -134,6 +134,50 @@ def fake_vda_net(frame):
     return 0.3 + 6.0 * torch.sigmoid(g) ** 2 + 0.002 * torch.arange(g.shape[-1]).view(1, 1, -1)
 
 
+class FakeOnlineVDA:
+    """Stand-in for the external ``VideoDepthAnythingOnline``: buffers frames and emits them 4 at a time (so outputs lag the inputs
+    and a drain with ``infer(None)`` pads with copies of the last frame, as the windowed model does)."""
+    metric_depth = False
+
+    def __init__(self, net):
+        self.net, self.buf, self.last, self.prep_lower_bound = net, [], None, None
+
+    def reset_state(self):
+        self.buf, self.last = [], None
+
+    def infer(self, frame, use_amp=True):
+        if frame is None:
+            frame = self.last
+        self.last = frame
+        self.buf.append(frame)
+        if len(self.buf) < 4:
+            return None
+        out, self.buf = [self.net(f)[0] for f in self.buf], []
+        return out
+
+
+def gen_vda_online():
+    """The non-streaming ``VideoDepthAnythingModel`` wrapper (frame counting, drain / unpad at a scene cut, EMA normalisation)
+    on the reference, around ``FakeOnlineVDA``: 11 frames in batches of 3, a scene cut after frame 5, final flush."""
+    from iw3 import video_depth_anything_model as RV
+    x = torch.stack([synth_image(51 + i, 3, 54, 96) for i in range(11)]).half().float()
+    m = RV.VideoDepthAnythingModel("VDA_S")
+    m.model, m.device = FakeOnlineVDA(fake_vda_net), torch.device("cpu")
+    m.model.prep_lower_bound = 56
+    m.enable_ema(0.75, buffer_size=2)
+    outs, counts = [], []
+    for i in range(0, 11, 3):
+        got = m.infer_with_normalize(x[i:i + 3], list(range(i, min(i + 3, 11))), reset_pts={5}, edge_dilation=2)
+        counts.append(len(got))
+        outs += got
+    tail = m.flush_with_normalize(edge_dilation=2)
+    counts.append(len(tail))
+    outs += tail
+    assert len(outs) == 11, (len(outs), counts)
+    print("vda_online counts", counts)
+    save("video_depth_anything_online", x=x.half(), out=torch.stack(outs), counts=np.asarray(counts))
+
+
 def gen_vda():
     """VideoDepthAnything pre/post-processing on the reference (video_depth_anything_model.py batch_preprocess / postprocess,
     the streaming wrapper's per-frame loop) around a deterministic fake network; relative + metric, DepthAA on / off."""
@@ -561,7 +605,7 @@ def gen_depth_aa():
 
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint}
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "vda_online": gen_vda_online, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)
