@@ -156,26 +156,34 @@ __global__ void __launch_bounds__(256) li_ln_pad_kernel(const f16 *__restrict__ 
         return;
     }
     const f16x8 *p = reinterpret_cast<const f16x8 *>(x + (((long)b * h + y) * wd + xx) * C);
-    f16x8 v[C / 8];
+    // HOLD: the token's channel vector stays in registers between the three passes; wider tokens (the medium / large video
+    // nets) are re-read from the cache instead of spilling
+    constexpr bool HOLD = C <= 256;
+    constexpr int UNR = HOLD ? C / 8 : 8;          // HOLD needs the loops fully unrolled (register array)
+    f16x8 v[HOLD ? C / 8 : 1];
     float sum = 0.f;
-#pragma unroll
+#pragma unroll UNR
     for (int i = 0; i < C / 8; ++i) {
-        v[i] = p[i];
+        const f16x8 t = p[i];
+        if constexpr (HOLD) v[i] = t;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+        for (int j = 0; j < 8; ++j) sum += (float)t[j];
     }
     const float mean = sum / (float)C;
     float var = 0.f;
-#pragma unroll
-    for (int i = 0; i < C / 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = (float)v[i][j] - mean; var += d * d; }
-    const float rs = rsqrtf(var / (float)C + 1e-5f);
-#pragma unroll
+#pragma unroll UNR
     for (int i = 0; i < C / 8; ++i) {
+        const f16x8 t = HOLD ? v[HOLD ? i : 0] : p[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)t[j] - mean; var += d * d; }
+    }
+    const float rs = rsqrtf(var / (float)C + 1e-5f);
+#pragma unroll UNR
+    for (int i = 0; i < C / 8; ++i) {
+        const f16x8 t = HOLD ? v[HOLD ? i : 0] : p[i];
         f16x8 r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (f16)(((float)v[i][j] - mean) * rs * w[8 * i + j]);
+        for (int j = 0; j < 8; ++j) r[j] = (f16)(((float)t[j] - mean) * rs * w[8 * i + j]);
         o[i] = r;
     }
 }
@@ -196,26 +204,33 @@ __global__ void __launch_bounds__(256) li_ln2_t_kernel(const f16 *__restrict__ a
     const int wy = (int)(t2 % nwy), b = (int)(t2 / nwy);
     const long tok = ((long)b * hp + wy * ws + tn / ws) * wp + wx * ws + tn % ws;
     const f16x8 *p = reinterpret_cast<const f16x8 *>(a + tok * (2 * C2) + C2);
-    f16x8 v[C2 / 8];
+    constexpr bool HOLD = C2 <= 256;
+    constexpr int UNR = HOLD ? C2 / 8 : 8;
+    f16x8 v[HOLD ? C2 / 8 : 1];
     float sum = 0.f;
-#pragma unroll
+#pragma unroll UNR
     for (int i = 0; i < C2 / 8; ++i) {
-        v[i] = p[i];
+        const f16x8 t = p[i];
+        if constexpr (HOLD) v[i] = t;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+        for (int j = 0; j < 8; ++j) sum += (float)t[j];
     }
     const float mean = sum / (float)C2;
     float var = 0.f;
+#pragma unroll UNR
+    for (int i = 0; i < C2 / 8; ++i) {
+        const f16x8 t = HOLD ? v[HOLD ? i : 0] : p[i];
 #pragma unroll
-    for (int i = 0; i < C2 / 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = (float)v[i][j] - mean; var += d * d; }
+        for (int j = 0; j < 8; ++j) { const float d = (float)t[j] - mean; var += d * d; }
+    }
     const float rs = rsqrtf(var / (float)C2 + 1e-5f);
     f16 *o = vt + (win * C2) * N + tn;
+#pragma unroll UNR
+    for (int i = 0; i < C2 / 8; ++i) {
+        const f16x8 t = HOLD ? v[HOLD ? i : 0] : p[i];
 #pragma unroll
-    for (int i = 0; i < C2 / 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[(long)(8 * i + j) * N] = (f16)(((float)v[i][j] - mean) * rs * w[8 * i + j]);
+        for (int j = 0; j < 8; ++j) o[(long)(8 * i + j) * N] = (f16)(((float)t[j] - mean) * rs * w[8 * i + j]);
+    }
 }
 
 // temporal block (light_video_inpaint_v1.py GMLP3DBlock, window (12,1,1)): LayerNorm over the gate half, token-major
@@ -225,27 +240,33 @@ __global__ void __launch_bounds__(256) li_ln2_kernel(const f16 *__restrict__ a, 
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= tokens) return;
     const f16x8 *p = reinterpret_cast<const f16x8 *>(a + id * (2 * V) + V);
-    f16x8 v[V / 8];
+    constexpr bool HOLD = V <= 256;
+    constexpr int UNR = HOLD ? V / 8 : 8;
+    f16x8 v[HOLD ? V / 8 : 1];
     float sum = 0.f;
-#pragma unroll
+#pragma unroll UNR
     for (int i = 0; i < V / 8; ++i) {
-        v[i] = p[i];
+        const f16x8 t = p[i];
+        if constexpr (HOLD) v[i] = t;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+        for (int j = 0; j < 8; ++j) sum += (float)t[j];
     }
     const float mean = sum / (float)V;
     float var = 0.f;
+#pragma unroll UNR
+    for (int i = 0; i < V / 8; ++i) {
+        const f16x8 t = HOLD ? v[HOLD ? i : 0] : p[i];
 #pragma unroll
-    for (int i = 0; i < V / 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = (float)v[i][j] - mean; var += d * d; }
+        for (int j = 0; j < 8; ++j) { const float d = (float)t[j] - mean; var += d * d; }
+    }
     const float rs = rsqrtf(var / (float)V + 1e-5f);
     f16x8 *o = reinterpret_cast<f16x8 *>(vn + id * V);
-#pragma unroll
+#pragma unroll UNR
     for (int i = 0; i < V / 8; ++i) {
+        const f16x8 t = HOLD ? v[HOLD ? i : 0] : p[i];
         f16x8 r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (f16)(((float)v[i][j] - mean) * rs * w[8 * i + j]);
+        for (int j = 0; j < 8; ++j) r[j] = (f16)(((float)t[j] - mean) * rs * w[8 * i + j]);
         o[i] = r;
     }
 }
@@ -417,6 +438,7 @@ struct nunif_light_inpaint {
     // video = inpaint.light_video_inpaint_v1: patch slope 0.1, enc1 unshifted, enc2 = [2-D, temporal, 2-D, temporal, 2-D] with
     // mlp_ratio 1 in the 2-D blocks, 1x1 to_image; exactly 12 frames per call
     int video = 0, n_enc2 = 4;
+    int C = 96;               // base_dim: 96 (image net, video small), 128 (video medium), 192 (video large)
     GBlock enc1, enc2[5], dec1;
     Conv3 to_image;
     Lin to_image1;
@@ -491,13 +513,14 @@ int make_plain(nunif_light_inpaint *h, const TMap &m, const std::string &key, in
 
 int make_gblock(nunif_light_inpaint *h, const TMap &m, const std::string &p, int C, int ws, int shift, GBlock *g,
                 int ratio = 2, int temporal = 0) {
-    const int V = ratio * C;
-    g->C = C; g->V = V; g->ws = ws; g->shift = shift; g->temporal = temporal;
-    const int N = temporal ? 12 : ws * ws;
     const HostT *n1, *n2;
     int rc;
     if ((rc = find(m, p + "norm1.weight", &n1)) || (rc = find(m, p + "norm2.weight", &n2))) return rc;
-    NUNIF_REQUIRE(n1->numel == C && n2->numel == V, "%s: LayerNorm shapes", p.c_str());
+    // ratio <= 0: take the gate width from the checkpoint (lv2_mlp_ratio of the video nets: 1 small, 2 medium / large)
+    const int V = ratio > 0 ? ratio * C : (int)n2->numel;
+    g->C = C; g->V = V; g->ws = ws; g->shift = shift; g->temporal = temporal;
+    const int N = temporal ? 12 : ws * ws;
+    NUNIF_REQUIRE(n1->numel == C && n2->numel == V && (V == C || V == 2 * C), "%s: LayerNorm shapes", p.c_str());
     if ((rc = upload(h, std::vector<float>(n1->data, n1->data + C), &g->ln1)) ||
         (rc = upload(h, std::vector<float>(n2->data, n2->data + V), &g->ln2)))
         return rc;
@@ -585,6 +608,23 @@ int run_gblock(nunif_light_inpaint *h, const GBlock &g, f16 *x, int B, int hh, i
     return NUNIF_HIP_OK;
 }
 
+// (C, V) pairs of the registered nets: image / video-small 96: (96,192) (192,192) (192,384); video-medium 128: (128,256)
+// (256,512); video-large 192: (192,384) (384,768)
+int run_gblock_any(nunif_light_inpaint *h, const GBlock &g, f16 *x, int B, int hh, int ww, hipStream_t s) {
+    const int key = g.C * 1000 + g.V;
+    switch (key) {
+        case 96192: return run_gblock<96, 192>(h, g, x, B, hh, ww, s);
+        case 192192: return run_gblock<192, 192>(h, g, x, B, hh, ww, s);
+        case 192384: return run_gblock<192, 384>(h, g, x, B, hh, ww, s);
+        case 128256: return run_gblock<128, 256>(h, g, x, B, hh, ww, s);
+        case 256512: return run_gblock<256, 512>(h, g, x, B, hh, ww, s);
+        case 384768: return run_gblock<384, 768>(h, g, x, B, hh, ww, s);
+        default:
+            set_error("light_inpaint: block with C = %d, V = %d is not a registered variant", g.C, g.V);
+            return NUNIF_HIP_EUNSUPPORTED;
+    }
+}
+
 }  // namespace
 
 extern "C" int nunif_hip_light_inpaint_create(const nunif_tensor_desc *tensors, int32_t n_tensors, nunif_light_inpaint **handle) {
@@ -609,50 +649,53 @@ extern "C" int nunif_hip_light_inpaint_create(const nunif_tensor_desc *tensors, 
             (rc = find(m, "down.weight", &dw)) || (rc = find(m, "down.bias", &db)) || (rc = find(m, "up.weight", &uw)) ||
             (rc = find(m, "up.bias", &ub)))
             break;
-        if (mb->numel != 96 || pw->numel != 96 * 48 || dw->numel != (int64_t)192 * 96 * 4 || uw->numel != (int64_t)384 * 192) {
-            set_error("light_inpaint: unexpected shapes (C = 96 expected)");
+        const int C = (int)mb->numel, C2 = 2 * C;
+        if ((C != 96 && !(h->video && (C == 128 || C == 192))) || pw->numel != (int64_t)C * 48 ||
+            dw->numel != (int64_t)C2 * C * 4 || uw->numel != (int64_t)4 * C * C2) {
+            set_error("light_inpaint: unexpected shapes (base_dim 96; 128 / 192 for the video net)");
             rc = NUNIF_HIP_EUNSUPPORTED;
             break;
         }
-        std::vector<f16> mbh(96);
-        for (int i = 0; i < 96; ++i) mbh[i] = (f16)mb->data[i];
+        h->C = C;
+        std::vector<f16> mbh(C);
+        for (int i = 0; i < C; ++i) mbh[i] = (f16)mb->data[i];
         if ((rc = upload(h, mbh, &h->mask_bias))) break;
-        {   // patch: 1x1 conv 48 -> 96 on the pixel_unshuffle(4) channels (input padded to 64)
+        {   // patch: 1x1 conv 48 -> C on the pixel_unshuffle(4) channels (input padded to 64)
             const float *wd = pw->data;
-            if ((rc = make_lin(h, 96, 64, [=](int n, int k) { return k < 48 ? wd[(size_t)n * 48 + k] : 0.f; },
-                               std::vector<float>(pb->data, pb->data + 96), &h->patch)))
+            if ((rc = make_lin(h, C, 64, [=](int n, int k) { return k < 48 ? wd[(size_t)n * 48 + k] : 0.f; },
+                               std::vector<float>(pb->data, pb->data + C), &h->patch)))
                 break;
         }
-        {   // down: Conv2d(96, 192, 2, 2): weight [192][96][2][2] -> k = (i*2 + j) * 96 + ci
+        {   // down: Conv2d(C, 2C, 2, 2): weight [2C][C][2][2] -> k = (i*2 + j) * C + ci
             const float *wd = dw->data;
-            if ((rc = make_lin(h, 192, 384, [=](int n, int k) { return wd[((size_t)n * 96 + k % 96) * 4 + k / 96]; },
-                               std::vector<float>(db->data, db->data + 192), &h->down)))
+            if ((rc = make_lin(h, C2, 4 * C, [=](int n, int k) { return wd[((size_t)n * C + k % C) * 4 + k / C]; },
+                               std::vector<float>(db->data, db->data + C2), &h->down)))
                 break;
         }
-        {   // up: 1x1 conv 192 -> 384 + F.pixel_shuffle(2): rows c*4 + q -> q*96 + c (gemm mode 1 column order)
+        {   // up: 1x1 conv 2C -> 4C + F.pixel_shuffle(2): rows c*4 + q -> q*C + c (gemm mode 1 column order)
             const float *wd = uw->data;
-            std::vector<float> bb(384);
-            for (int n = 0; n < 384; ++n) bb[n] = ub->data[(n % 96) * 4 + n / 96];
-            if ((rc = make_lin(h, 384, 192, [=](int n, int k) { return wd[(size_t)((n % 96) * 4 + n / 96) * 192 + k]; }, bb, &h->up)))
+            std::vector<float> bb(4 * C);
+            for (int n = 0; n < 4 * C; ++n) bb[n] = ub->data[(n % C) * 4 + n / C];
+            if ((rc = make_lin(h, 4 * C, C2, [=](int n, int k) { return wd[(size_t)((n % C) * 4 + n / C) * C2 + k]; }, bb, &h->up)))
                 break;
         }
         if (h->video) {
-            // light_video_inpaint_v1.py:109-119 (base_dim 96, lv2_mlp_ratio 1)
+            // light_video_inpaint_v1.py:109-119; lv2_mlp_ratio (1 small, 2 medium / large) is read off the checkpoint
             h->n_enc2 = 5;
-            if ((rc = make_gblock(h, m, "enc1.", 96, 16, 0, &h->enc1))) break;
+            if ((rc = make_gblock(h, m, "enc1.", C, 16, 0, &h->enc1))) break;
             static const int shift[5] = {1, 0, 0, 0, 1}, temporal[5] = {0, 1, 0, 1, 0};
             for (int i = 0; i < 5 && !rc; ++i)
-                rc = make_gblock(h, m, "enc2." + std::to_string(i) + ".", 192, 8, shift[i], &h->enc2[i], temporal[i] ? 2 : 1,
+                rc = make_gblock(h, m, "enc2." + std::to_string(i) + ".", C2, 8, shift[i], &h->enc2[i], temporal[i] ? 2 : 0,
                                  temporal[i]);
             if (rc) break;
-            if ((rc = make_gblock(h, m, "dec1.", 96, 16, 0, &h->dec1))) break;
+            if ((rc = make_gblock(h, m, "dec1.", C, 16, 0, &h->dec1))) break;
             const HostT *tw, *tb;
             if ((rc = find(m, "to_image.weight", &tw)) || (rc = find(m, "to_image.bias", &tb))) break;
-            NUNIF_REQUIRE(tw->numel == 48 * 96 && tb->numel == 48, "to_image: unexpected shape");
+            NUNIF_REQUIRE(tw->numel == (int64_t)48 * C && tb->numel == 48, "to_image: unexpected shape");
             const float *wd = tw->data;
             std::vector<float> bb(64, 0.f);
             std::copy(tb->data, tb->data + 48, bb.begin());
-            if ((rc = make_lin(h, 64, 96, [=](int n, int k) { return n < 48 ? wd[(size_t)n * 96 + k] : 0.f; }, bb, &h->to_image1)))
+            if ((rc = make_lin(h, 64, C, [=](int n, int k) { return n < 48 ? wd[(size_t)n * C + k] : 0.f; }, bb, &h->to_image1)))
                 break;
         } else {
             if ((rc = make_gblock(h, m, "enc1.", 96, 16, 1, &h->enc1))) break;
@@ -692,9 +735,10 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
     const int h1 = Hp / 4, w1 = Wp / 4, h2 = h1 / 2, w2 = w1 / 2;
     const long px = (long)B * H * W, t1 = (long)B * h1 * w1, t2 = (long)B * h2 * w2;
     const long tp1 = (long)B * (h1 + 16) * (w1 + 16), tp2 = (long)B * (h2 + 8) * (w2 + 8);
-    const size_t big = (size_t)std::max(tp1 * 96, tp2 * 192) * sizeof(f16);
+    const int C = h->C, C2 = 2 * C;
+    const size_t big = (size_t)std::max(tp1 * C, tp2 * C2) * sizeof(f16);
     int rc;
-    if ((rc = h->x1.ensure((size_t)t1 * 96 * 2)) || (rc = h->x2.ensure((size_t)t2 * 192 * 2)) || (rc = h->a.ensure(big)) ||
+    if ((rc = h->x1.ensure((size_t)t1 * C * 2)) || (rc = h->x2.ensure((size_t)t2 * C2 * 2)) || (rc = h->a.ensure(big)) ||
         (rc = h->pi.ensure(big * 4)) || (rc = h->vt.ensure(big * 2)) || (rc = h->st.ensure(big * 2)) ||
         (rc = h->g.ensure(big * 2)) || (rc = h->po.ensure(big)) || (rc = h->y.ensure(big)) || (rc = h->z.ensure(big)) ||
         (rc = h->ti.ensure((size_t)t1 * 64 * 2)) || (rc = h->mtok.ensure((size_t)t1)) || (rc = h->mf0.ensure((size_t)px * 4)) ||
@@ -729,34 +773,32 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
         li_patch_in_kernel<<<(unsigned)((t1 + 255) / 256), 256, 0, s>>>(x, hard, soft, a, mtok, B, H, W, h1, w1);
     }
     // NOTE: the replicate padding of the soft mask is the clamp of the pixel coordinate inside li_patch_in_kernel
-    if ((rc = lin(h->patch, a, t1, 96, 2, h->video ? 0.1f : 0.2f, nullptr, x1, s, "li_patch"))) return rc;
+    if ((rc = lin(h->patch, a, t1, C, 2, h->video ? 0.1f : 0.2f, nullptr, x1, s, "li_patch"))) return rc;
     {
-        const long n = t1 * 12;
-        li_mask_bias_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x1, mtok, h->mask_bias, t1, 96);
+        const long n = t1 * (C / 8);
+        li_mask_bias_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x1, mtok, h->mask_bias, t1, C);
     }
-    if ((rc = run_gblock<96, 192>(h, h->enc1, x1, B, h1, w1, s))) return rc;
+    if ((rc = run_gblock_any(h, h->enc1, x1, B, h1, w1, s))) return rc;
     {   // down: 2x2 stride-2 conv as a gather GEMM
         GemmArgs g;
         memset(&g, 0, sizeof(g));
-        g.a = x1; g.B = B; g.Hi = h1; g.Wi = w1; g.Cin = 96; g.Ho = h2; g.Wo = w2; g.stride = 2; g.kw = 2;
-        g.K = 384; g.w = h->down.w; g.bias = h->down.bias; g.N = h->down.N; g.mode = 0; g.out = x2; g.ldo = 192; g.n_real = 192;
+        g.a = x1; g.B = B; g.Hi = h1; g.Wi = w1; g.Cin = C; g.Ho = h2; g.Wo = w2; g.stride = 2; g.kw = 2;
+        g.K = 4 * C; g.w = h->down.w; g.bias = h->down.bias; g.N = h->down.N; g.mode = 0; g.out = x2; g.ldo = C2; g.n_real = C2;
         g.ps = 1;
         if ((rc = launch_gemm(g, s, "li_down"))) return rc;
     }
     for (int i = 0; i < h->n_enc2; ++i) {
-        rc = h->enc2[i].V == 192 ? run_gblock<192, 192>(h, h->enc2[i], x2, B, h2, w2, s)
-                                 : run_gblock<192, 384>(h, h->enc2[i], x2, B, h2, w2, s);
-        if (rc) return rc;
+        if ((rc = run_gblock_any(h, h->enc2[i], x2, B, h2, w2, s))) return rc;
     }
     {   // x = x1 + pixel_shuffle(up(x2), 2), written over x1
         GemmArgs g;
         memset(&g, 0, sizeof(g));
-        g.a = x2; g.B = B; g.Hi = h2; g.Wi = w2; g.Cin = 192; g.Ho = h2; g.Wo = w2; g.stride = 1; g.kw = 1;
-        g.K = 192; g.w = h->up.w; g.bias = h->up.bias; g.N = h->up.N; g.mode = 1; g.res = x1; g.out = x1; g.ldo = 96; g.n_real = 384;
+        g.a = x2; g.B = B; g.Hi = h2; g.Wi = w2; g.Cin = C2; g.Ho = h2; g.Wo = w2; g.stride = 1; g.kw = 1;
+        g.K = C2; g.w = h->up.w; g.bias = h->up.bias; g.N = h->up.N; g.mode = 1; g.res = x1; g.out = x1; g.ldo = C; g.n_real = 4 * C;
         g.ps = 1;
         if ((rc = launch_gemm(g, s, "li_up"))) return rc;
     }
-    if ((rc = run_gblock<96, 192>(h, h->dec1, x1, B, h1, w1, s))) return rc;
+    if ((rc = run_gblock_any(h, h->dec1, x1, B, h1, w1, s))) return rc;
     if (h->video) {
         if ((rc = lin(h->to_image1, x1, t1, 64, 0, 0.f, nullptr, ti, s, "li_to_image"))) return rc;
     } else {

@@ -447,6 +447,7 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
         }
         case 8: return launch_gemm_t<8, 4>(g, s, "gemm_kernel<8,4>", "gemm_res_kernel<8,4>", flops, bytes);
         case 12: return launch_gemm_t<12, 2>(g, s, "gemm_kernel<12,2>", "gemm_res_kernel<12,2>", flops, bytes);
+        case 16: return launch_gemm_t<16, 2>(g, s, "gemm_kernel<16,2>", "gemm_res_kernel<16,2>", flops, bytes);
         case 18: return launch_gemm_t<18, 2>(g, s, "gemm_kernel<18,2>", "gemm_res_kernel<18,2>", flops, bytes);
         case 19: return launch_gemm_t<19, 1>(g, s, "gemm_kernel<19,1>", "gemm_res_kernel<19,1>", flops, bytes);
         case 24: return launch_gemm_t<24, 1>(g, s, "gemm_kernel<24,1>", "gemm_res_kernel<24,1>", flops, bytes);

@@ -4,7 +4,8 @@ Mirrors ``iw3/models/light_video_inpaint_v1.py`` ``LightVideoInpaintV1`` :92-229
 name + alias, i2i geometry (scale 1, offset 16, blend 8), the ``state_dict`` key layout and ``infer`` :140-164 — the batch is
 padded to ``SEQ_LEN`` = 12 frames by repeating the first / last frame, pre-processed and run through the net whose level-2
 stack alternates 8x8 window gMLPs with temporal gMLPs over the 12 frames of each pixel.  One C call per 12 frames
-(``nunif_hip_light_inpaint_infer``, nunif_amd/csrc/light_inpaint.hip).  The medium / large variants are not provided.
+(``nunif_hip_light_inpaint_infer``, nunif_amd/csrc/light_inpaint.hip).  ``LightVideoInpaintV1Medium`` (base_dim 128) and
+``LightVideoInpaintV1Large`` (base_dim 192), both with lv2_mlp_ratio 2 (:230-246), run on the same engine.
 """
 import math
 from collections import OrderedDict
@@ -18,8 +19,9 @@ SEQ_LEN = 12
 OFFSET = 16
 
 
-def _init_weights():
+def _init_weights(base_dim=96, lv2_mlp_ratio=1):
     sd = OrderedDict()
+    C, r2 = base_dim, lv2_mlp_ratio
 
     def lin(key, *shape):
         fan_in = 1
@@ -39,15 +41,15 @@ def _init_weights():
         lin(p + "glu_conv.w1", C, C, 1, 1)
         lin(p + "glu_conv.w2", C, C // 2, 3, 3)
 
-    sd["mask_bias"] = torch.randn(1, 96, 1, 1) * 0.01
-    lin("patch", 96, 3, 4, 4)
-    block("enc1.", 96, 256, 2)
-    lin("down", 192, 96, 2, 2)
-    for i, (n, r) in enumerate(((64, 1), (SEQ_LEN, 2), (64, 1), (SEQ_LEN, 2), (64, 1))):
-        block(f"enc2.{i}.", 192, n, r)
-    lin("up", 384, 192, 1, 1)
-    block("dec1.", 96, 256, 2)
-    lin("to_image", 48, 96, 1, 1)
+    sd["mask_bias"] = torch.randn(1, C, 1, 1) * 0.01
+    lin("patch", C, 3, 4, 4)
+    block("enc1.", C, 256, 2)
+    lin("down", 2 * C, C, 2, 2)
+    for i, (n, r) in enumerate(((64, r2), (SEQ_LEN, 2), (64, r2), (SEQ_LEN, 2), (64, r2))):
+        block(f"enc2.{i}.", 2 * C, n, r)
+    lin("up", 4 * C, 2 * C, 1, 1)
+    block("dec1.", C, 256, 2)
+    lin("to_image", 48, C, 1, 1)
     return sd
 
 
@@ -59,11 +61,12 @@ class LightVideoInpaintV1(I2IBaseModel):
     def __init__(self, base_dim=96, lv2_mlp_ratio=1):
         super().__init__(dict(base_dim=base_dim, lv2_mlp_ratio=lv2_mlp_ratio), scale=1, offset=OFFSET, in_channels=3,
                          blend_size=8)
-        if base_dim != 96 or lv2_mlp_ratio != 1:
-            raise ValueError("the HIP engine supports base_dim = 96, lv2_mlp_ratio = 1 (not the medium / large variants)")
+        if (base_dim, lv2_mlp_ratio) not in ((96, 1), (128, 2), (192, 2)):
+            raise ValueError("the HIP engine implements the registered variants: (base_dim, lv2_mlp_ratio) = (96, 1) small, "
+                             "(128, 2) medium, (192, 2) large")
         self.register_buffer("_device_probe", torch.empty(0), persistent=False)
         self.sequence_offset, self.downscaling_factor, self.mod = 0, 4, 16
-        self._weights = _init_weights()
+        self._weights = _init_weights(base_dim, lv2_mlp_ratio)
         self._engine = None
 
     def get_device(self):
@@ -131,3 +134,21 @@ class LightVideoInpaintV1(I2IBaseModel):
 
     def forward(self, x, mask, skip_i2i_offset=False, micro_batch_size=SEQ_LEN):
         raise NotImplementedError("the HIP engine implements LightVideoInpaintV1.infer; the training-style forward is not provided")
+
+
+@register_model
+class LightVideoInpaintV1Medium(LightVideoInpaintV1):
+    name = "inpaint.light_video_inpaint_v1_medium"
+    name_alias = ()
+
+    def __init__(self, base_dim=128, lv2_mlp_ratio=2):
+        super().__init__(base_dim=base_dim, lv2_mlp_ratio=lv2_mlp_ratio)
+
+
+@register_model
+class LightVideoInpaintV1Large(LightVideoInpaintV1):
+    name = "inpaint.light_video_inpaint_v1_large"
+    name_alias = ()
+
+    def __init__(self, base_dim=192, lv2_mlp_ratio=2):
+        super().__init__(base_dim=base_dim, lv2_mlp_ratio=lv2_mlp_ratio)

@@ -245,9 +245,9 @@ def light_inpaint_state_dict(seed):
     return sd
 
 
-def light_video_inpaint_state_dict(seed):
-    """Seeded weights of inpaint.light_video_inpaint_v1 (base_dim 96, lv2_mlp_ratio 1) in the reference's key layout; same
-    conventions as ``light_inpaint_state_dict``."""
+def light_video_inpaint_state_dict(seed, base_dim=96, lv2_mlp_ratio=1):
+    """Seeded weights of inpaint.light_video_inpaint_v1 (small: base_dim 96, lv2_mlp_ratio 1; medium 128 / 2; large 192 / 2) in
+    the reference's key layout; same conventions as ``light_inpaint_state_dict``."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
@@ -272,15 +272,16 @@ def light_video_inpaint_state_dict(seed):
         lin(p + "glu_conv.w1", C, C, 1, 1, std=math.sqrt(2.0 / C))
         lin(p + "glu_conv.w2", C, C // 2, 3, 3, std=0.5 * math.sqrt(1.0 / (9 * C // 2)))
 
-    sd["mask_bias"] = rnd(1, 96, 1, 1, std=0.3)
-    lin("patch", 96, 3, 4, 4, std=math.sqrt(2.0 / 48))
-    block("enc1.", 96, 256, 2)
-    lin("down", 192, 96, 2, 2)
-    for i, (n, r) in enumerate(((64, 1), (12, 2), (64, 1), (12, 2), (64, 1))):
-        block(f"enc2.{i}.", 192, n, r)
-    lin("up", 384, 192, 1, 1)
-    block("dec1.", 96, 256, 2)
-    lin("to_image", 48, 96, 1, 1, std=0.002 * math.sqrt(1.0 / 96), bstd=0.05, bmean=0.5)
+    C, r2 = base_dim, lv2_mlp_ratio
+    sd["mask_bias"] = rnd(1, C, 1, 1, std=0.3)
+    lin("patch", C, 3, 4, 4, std=math.sqrt(2.0 / 48))
+    block("enc1.", C, 256, 2)
+    lin("down", 2 * C, C, 2, 2)
+    for i, (n, r) in enumerate(((64, r2), (12, 2), (64, r2), (12, 2), (64, r2))):
+        block(f"enc2.{i}.", 2 * C, n, r)
+    lin("up", 4 * C, 2 * C, 1, 1)
+    block("dec1.", C, 256, 2)
+    lin("to_image", 48, C, 1, 1, std=0.002 * math.sqrt(1.0 / C), bstd=0.05, bmean=0.5)
     return sd
 
 

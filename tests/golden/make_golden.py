@@ -284,6 +284,29 @@ def gen_light_inpaint():
     save("light_inpaint", **out)
 
 
+def gen_light_video_inpaint_ml():
+    """inpaint.light_video_inpaint_v1_medium / _large (base_dim 128 / 192, lv2_mlp_ratio 2; light_video_inpaint_v1.py:230-246)
+    on the reference: one 12-frame infer each; outputs stored as fp16."""
+    from iw3.models.light_video_inpaint_v1 import LightVideoInpaintV1Medium, LightVideoInpaintV1Large
+    from oracle import light_inpaint as OL
+    base = synth_image(141, 3, 40, 84)
+    x = torch.stack([base[:, :, i:i + 72] for i in range(12)]).half().float()
+    g = torch.Generator().manual_seed(125)
+    mask = torch.rand(12, 1, 40, 72, generator=g) > 0.94
+    for i in range(12):
+        mask[i, :, 8:24, 22 + i:46 + i] = True
+    out = {"x": x.half(), "mask": mask.numpy()}
+    for tag, cls, seed, dim in (("medium", LightVideoInpaintV1Medium, 811, 128), ("large", LightVideoInpaintV1Large, 812, 192)):
+        sd = OL.video_random_state_dict(seed, base_dim=dim, lv2_mlp_ratio=2)
+        m = cls().eval()
+        m.load_state_dict(sd, strict=True)
+        y = m.infer(x, mask, inner_dilation=1)
+        print(tag, float(y.std()), float((y - x).abs().mean()), float(((y <= 0) | (y >= 1)).float().mean()))
+        out["y_" + tag] = y.half()
+        out["sdsum_" + tag] = sd_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    save("light_video_inpaint_ml", **out)
+
+
 def gen_light_video_inpaint():
     """inpaint.light_video_inpaint_v1 on the reference (12-frame infer, a 7-frame batch padded by infer itself) and the
     MLBWInpaintVideo queue (pre / post padding 3, batches of 3 frames, flush) assembled around seeded models."""
@@ -605,7 +628,7 @@ def gen_depth_aa():
 
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "vda_online": gen_vda_online, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint}
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "vda_online": gen_vda_online, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint, "light_video_inpaint_ml": gen_light_video_inpaint_ml}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

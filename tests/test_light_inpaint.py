@@ -159,3 +159,38 @@ def test_hip_mlbw_inpaint_video_queue(hiplib, gv):
         assert bad < 0.03, (key, bad)
     assert side.flush() == (None, None)
     side.reset()
+
+
+# ---- inpaint.light_video_inpaint_v1_medium / _large (base_dim 128 / 192, lv2_mlp_ratio 2) -----------------------------------
+VARIANTS = (("medium", "inpaint.light_video_inpaint_v1_medium", 811, 128), ("large", "inpaint.light_video_inpaint_v1_large", 812, 192))
+
+
+def _gml():
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "light_video_inpaint_ml.npz")).items()}
+
+
+def test_oracle_video_medium_large_match_reference_fixture():
+    g = _gml()
+    x, mask = g["x"].float(), g["mask"]
+    for tag, _, seed, dim in VARIANTS:
+        sd = OL.video_random_state_dict(seed, base_dim=dim, lv2_mlp_ratio=2)
+        assert sd_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point}) == pytest.approx(float(g["sdsum_" + tag]),
+                                                                                                        rel=1e-12)
+        y = OL.video_infer(sd, x, mask, inner_dilation=1)
+        assert (y - g["y_" + tag].float()).abs().max().item() < 1e-3, tag        # fixture stored as fp16
+
+
+@pytest.mark.gpu
+def test_hip_light_video_inpaint_medium_large(hiplib):
+    from nunif_amd.nunif.models import create_model
+    from nunif_amd.iw3 import models  # noqa: F401
+    g = _gml()
+    x, mask = g["x"].float().to("cuda:0"), g["mask"].to("cuda:0")
+    for tag, name, seed, dim in VARIANTS:
+        mv = create_model(name).eval()
+        mv.load_state_dict(OL.video_random_state_dict(seed, base_dim=dim, lv2_mlp_ratio=2), strict=True)
+        y = mv.to("cuda:0").infer(x, mask, inner_dilation=1)
+        p = psnr(y.cpu(), g["y_" + tag].float())
+        assert y.shape == x.shape and p >= 50.0, (tag, p)
+    with pytest.raises(ValueError):
+        create_model("inpaint.light_video_inpaint_v1", base_dim=64)
