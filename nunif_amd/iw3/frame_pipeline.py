@@ -1,0 +1,432 @@
+"""Frame scheduler of the iw3 video path: batching, depth -> normalise -> stereo -> quantise, ordered output.
+
+What it replaces in the reference:
+
+* ``VU.FrameCallbackPool`` (``nunif/utils/video.py:1622-1757``) — batches decoded frames and hands them to a thread
+  pool, one worker per device replica;
+* ``iw3.utils.bind_batch_frame_callback`` (``iw3/utils.py:709-831``) — the per-batch body: ``preprocess_image`` ->
+  ``depth_model.infer`` -> ``minmax_normalize`` (EMA look-ahead, flush at scene cuts) -> ``apply_divergence`` /
+  ``apply_rgbd`` -> ``postprocess_image`` -> ``VU.to_frame``; four locks (``depth_lock``, ``sbs_lock`` and two
+  ``TicketLock`` s, ``nunif/utils/ticket_lock.py``) put the worker threads back in frame order.
+
+Here nothing is threaded, so there is nothing to re-order and no lock exists:
+
+* inside one GPU the two halves of a batch run on two HIP streams as a software pipeline — the depth stage of batch
+  k+1 (stream D: preprocess, depth net, the sequential min-max state) overlaps the stereo stage of batch k (stream S:
+  warp / side model, output format, quantise); hand-over is one HIP event per batch (`_StagePipeline`);
+* across GPUs it is one process per GPU (``stereo_frames_sharded``): batch b belongs to rank ``b mod world``.  Frames are
+  independent except for the EMA min-max recurrence, which only needs two scalars per frame: every round the ranks
+  all-gather their frames' (min, max) — 8 bytes per frame over RCCL — and each rank replays the *same* recurrence
+  (``EMAMinMaxScaler`` itself, fed with two-element tensors) to obtain the (lo, hi) of its own frames.  The output is
+  bit-identical to a single process walking the frames in order.  Finished, already-quantised frames go to the I/O rank
+  with one gather.  Models with temporal state (VideoDepthAnything, the video inpaint queue) do not shard by frame:
+  shard those by scene segment — this function refuses them.
+
+The reference call signatures are kept: ``bind_batch_frame_callback(depth_model, side_model, segment_pts, args)``
+returns ``(frame_callback, preprocess_callback)`` and ``FrameCallbackPool`` takes the reference's constructor
+arguments, so ``iw3/utils.py:1137-1153`` reads the same.  A decoded frame is anything with ``.pts`` and either
+``.to_ndarray()`` (PyAV) or ``.data`` (``HostFrame``); results are quantised HWC uint8 / uint16 tensors (what
+``VU.to_frame`` wraps into an ``av.VideoFrame``), left on the device unless ``to_host=True``.
+
+The device functions are looked up in a ``PipelineOps`` table whose defaults are the HIP engine (no CPU fallback: they
+raise for CPU tensors).  The ``-m "not gpu"`` tests pass torch-CPU stand-ins to exercise the host logic against the
+reference's own scheduler (``tests/golden/frame_pool.npz``).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from ..parallel import shard_indices
+from .depth_scaler import EMAMinMaxScaler
+
+
+class HostFrame:
+    """Minimal stand-in for ``av.VideoFrame`` at this boundary: HWC uint8 / uint16 pixels + presentation time stamp."""
+
+    def __init__(self, data, pts):
+        self.data, self.pts = data, pts
+
+    def to_ndarray(self, format=None):
+        return self.data
+
+
+def chunks(array, n):
+    """iw3/utils.py:62-64."""
+    for i in range(0, len(array), n):
+        yield array[i:i + n]
+
+
+class PipelineOps:
+    """Device functions used by the scheduler.  Defaults: the HIP engine (``nunif_amd.iw3.utils``)."""
+
+    def __init__(self, to_tensor=None, preprocess_image=None, apply_divergence=None, apply_rgbd=None,
+                 postprocess_image=None, to_frame=None):
+        from . import utils as U
+        self.to_tensor = to_tensor or (lambda frame, device=None: U.to_tensor(_frame_pixels(frame), device=device))
+        self.preprocess_image = preprocess_image or U.preprocess_image
+        self.apply_divergence = apply_divergence or U.apply_divergence
+        self.apply_rgbd = apply_rgbd or U.apply_rgbd
+        self.postprocess_image = postprocess_image or U.postprocess_image
+        self.to_frame = to_frame or U.to_frame_tensor
+
+
+def _frame_pixels(frame):
+    if hasattr(frame, "data") and not callable(frame.data):
+        return frame.data
+    if hasattr(frame, "format") and hasattr(frame.format, "components"):     # PyAV: nunif/utils/video.py:226-233
+        return frame.to_ndarray(format="rgb48le" if frame.format.components[0].bits > 8 else "rgb24")
+    return frame.to_ndarray()
+
+
+def pix_fmt_requires_16bit(pix_fmt):
+    """nunif/utils/video.py:272-279."""
+    return pix_fmt in {"yuv420p10le", "p010le", "yuv422p10le", "yuv444p10le", "yuv420p12le", "yuv422p12le",
+                       "yuv444p12le", "yuv444p16le", "gbrp16le", "gbrp12le", "gbrp10le", "rgb48le"}
+
+
+class _StagePipeline:
+    """Two HIP streams per device: D (depth stage) and S (stereo stage).  ``to_stereo`` publishes tensors made on D to
+    S with one event; ``record_stream`` keeps the caching allocator from recycling them while S still reads them."""
+
+    def __init__(self, device, enabled):
+        self.enabled = bool(enabled) and torch.device(device).type == "cuda"
+        self.device = torch.device(device)
+        if self.enabled:
+            self.depth_stream = torch.cuda.Stream(self.device)
+            self.stereo_stream = torch.cuda.Stream(self.device)
+
+    def depth_stage(self, inputs=()):
+        if not self.enabled:
+            return _NullContext()
+        cur = torch.cuda.current_stream(self.device)
+        self.depth_stream.wait_stream(cur)             # the batch was uploaded on the caller's stream
+        for t in inputs:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.depth_stream)
+        return torch.cuda.stream(self.depth_stream)
+
+    def stereo_stage(self, inputs=()):
+        if not self.enabled:
+            return _NullContext()
+        self.stereo_stream.wait_stream(self.depth_stream)
+        for t in inputs:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.stereo_stream)
+        return torch.cuda.stream(self.stereo_stream)
+
+    def stereo_done(self):
+        """Event after everything queued on S so far (None without streams).  The consumer waits on THIS, so the caller's
+        stream — which only uploads frames — never waits for the stereo stage and batch k+1's depth stage can start."""
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.stereo_stream)
+        return ev
+
+
+class FrameList(list):
+    """A list of output frames + the HIP event after which they are complete (None: complete on the current stream)."""
+    event = None
+
+
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=None):
+    """``iw3/utils.py:709-831``.  Returns ``(frame_callback, preprocess_callback)``:
+    ``preprocess_callback(x, pts, flush) -> call_args`` and ``frame_callback(call_args) -> [quantised frames]``.
+
+    ``x`` is a B x 3 x H x W float batch (None for the final flush), ``pts`` its time stamps.  Output frames come out in
+    input order; with an EMA look-ahead of N frames (``depth_model.get_ema_buffer_size()``) they lag by N - 1 frames
+    until a scene cut (``pts in segment_pts``) or the final flush releases them.  Source frames wait in HBM next to
+    their depth (the reference parks them in host memory as uint8, :769-775 — 288 GB make that unnecessary; for 8 / 16
+    bit sources the values are the same)."""
+    ops = ops or PipelineOps()
+    segment_pts = set(segment_pts or ())
+    src_queue = []                      # (CHW source frame, pts), in frame order
+    use_16bit = pix_fmt_requires_16bit(getattr(args, "pix_fmt", None))
+    stages = {}                         # device -> _StagePipeline
+    tickets = [0]
+
+    def _stage(device):
+        key = str(device)
+        if key not in stages:
+            # (the reference's --cuda-stream flag selects per-THREAD streams, :806-815; there are no threads here, the two
+            #  stage streams are always on for a ROCm device unless NUNIF_IW3_STAGE_STREAMS=0)
+            stages[key] = _StagePipeline(device, os.environ.get("NUNIF_IW3_STAGE_STREAMS", "1") != "0")
+        return stages[key]
+
+    def _stereo(depth_list, device, st):
+        results = FrameList()
+        for depths in chunks(depth_list, args.batch_size):
+            depths = [d.to(device) for d in depths]
+            pairs = [src_queue.pop(0) for _ in range(len(depths))]
+            reset_pts = [t in segment_pts for _, t in pairs]
+            with st.stereo_stage(depths + [x for x, _ in pairs]):
+                depths = torch.stack(depths)
+                x_srcs = torch.stack([x for x, _ in pairs])
+                if getattr(args, "rgbd", False) or getattr(args, "half_rgbd", False):
+                    left, right = ops.apply_rgbd(x_srcs, depths, mapper=args.mapper)
+                else:
+                    left, right = ops.apply_divergence(depths, x_srcs, args, side_model, reset_pts=reset_pts)
+                frames = [ops.postprocess_image(left[i], right[i], args) for i in range(left.shape[0])]
+                results += [ops.to_frame(f, use_16bit=use_16bit) for f in frames]
+        results.event = st.stereo_done()
+        return results
+
+    @torch.inference_mode()
+    def frame_callback(call_args):
+        x, pts, flush, _ticket = call_args
+        if flush:
+            device = _flush_device()
+            st = _stage(device)
+            with st.depth_stage():
+                depth_list = depth_model.flush_minmax_normalize()
+            return _stereo(depth_list, device, st)
+        device = x.device
+        st = _stage(device)
+        reset_ema = [t in segment_pts for t in pts]
+        with st.depth_stage([x]):
+            x = ops.preprocess_image(x, args)
+            for x_, pts_ in zip(x, pts):
+                src_queue.append((x_, pts_))
+            depth_batch = depth_model.infer(x, tta=getattr(args, "tta", False), low_vram=getattr(args, "low_vram", False),
+                                            enable_amp=not getattr(args, "disable_amp", False),
+                                            edge_dilation=getattr(args, "edge_dilation", 0),
+                                            depth_aa=getattr(args, "depth_aa", False))
+            depth_list = depth_model.minmax_normalize(depth_batch, reset_ema=reset_ema)
+        return _stereo(depth_list, device, st)
+
+    def _flush_device():
+        state = getattr(args, "state", None) or {}
+        if "device" in state:
+            return torch.device(state["device"])
+        return torch.device(depth_model.device) if getattr(depth_model, "device", None) is not None else torch.device("cpu")
+
+    def preprocess_callback(x, pts, flush):
+        tickets[0] += 1                 # kept for signature parity (the reference's enqueue ticket); order is inherent here
+        return (x, pts, flush, tickets[0] - 1)
+
+    return frame_callback, preprocess_callback
+
+
+class _Pending:
+    def __init__(self, frames, device):
+        self.frames = frames
+        self.event = getattr(frames, "event", None)
+        if self.event is None and torch.device(device).type == "cuda":
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(device))
+
+    def done(self):
+        return self.event is None or self.event.query()
+
+    def result(self):
+        if self.event is not None:
+            self.event.synchronize()
+        return self.frames
+
+
+class FrameCallbackPool:
+    """``nunif/utils/video.py:1622-1757`` with the reference's constructor arguments.
+
+    ``max_workers`` is the number of *batches in flight on the GPU* (their kernels are queued asynchronously; a batch is
+    handed back when its HIP event has fired, or when more than ``max_workers`` are pending); ``max_workers <= 0`` hands a
+    batch back in the call that completed it, exactly like the reference's ``_DummyThreadPool`` path.  ``device`` is ONE
+    device (one process per GPU; ``stereo_frames_sharded`` spans GPUs) — a list with several devices raises."""
+
+    def __init__(self, frame_callback, batch_size, device, max_workers=1, max_batch_queue=2, require_pts=False,
+                 skip_pts=-1, require_flush=False, preprocess_callback=None, postprocess_callback=None, use_16bit=False,
+                 ops=None, to_host=False):
+        devices = list(device) if isinstance(device, (tuple, list)) else [device]
+        if len(devices) != 1:
+            raise ValueError("FrameCallbackPool drives ONE device per process; shard frames across ranks with "
+                             "nunif_amd.iw3.frame_pipeline.stereo_frames_sharded")
+        self.device = torch.device(devices[0])
+        self.ops = ops or PipelineOps()
+        self.frame_callback, self.preprocess_callback = frame_callback, preprocess_callback
+        self.postprocess_callback = postprocess_callback
+        self.batch_size, self.max_workers, self.max_batch_queue = batch_size, max_workers, max_batch_queue
+        self.require_pts, self.require_flush, self.skip_pts = require_pts, require_flush, skip_pts
+        self.use_16bit, self.to_host = use_16bit, to_host
+        self.frame_queue, self.pts_queue, self.pending = [], [], []
+
+    def make_args(self, batch, pts_batch, flush):
+        if self.require_pts and self.require_flush:
+            return (batch, pts_batch, flush)
+        if self.require_pts:
+            return (batch, pts_batch)
+        if self.require_flush:
+            return (batch, flush)
+        return (batch,)
+
+    def submit(self, *call_args):
+        if self.preprocess_callback is not None:
+            frames = self.frame_callback(self.preprocess_callback(*call_args))
+        else:
+            frames = self.frame_callback(*call_args)
+        return _Pending(frames, self.device)
+
+    def get_results(self, pending):
+        frames = pending.result()
+        if self.postprocess_callback is not None:
+            frames = self.postprocess_callback(frames)
+        if frames is None:
+            return []
+        out = []
+        for f in frames:
+            if torch.is_tensor(f) and f.is_floating_point():       # a callback that returns CHW float images
+                f = self.ops.to_frame(f, use_16bit=self.use_16bit)
+            out.append(f.cpu().numpy() if (self.to_host and torch.is_tensor(f)) else f)
+        return out
+
+    def _close_batch(self):
+        batch = torch.stack(self.frame_queue)
+        pts = list(self.pts_queue)
+        self.frame_queue.clear()
+        self.pts_queue.clear()
+        self.pending.append(self.submit(*self.make_args(batch, pts, False)))
+
+    def __call__(self, frame):
+        if frame is None:
+            return self.finish()
+        if frame.pts <= self.skip_pts:
+            return None
+        self.pts_queue.append(frame.pts)
+        self.frame_queue.append(self.ops.to_tensor(frame, device=self.device))
+        if len(self.frame_queue) == self.batch_size:
+            self._close_batch()
+        if self.pending and (self.max_workers <= 0 or len(self.pending) > self.max_workers or self.pending[0].done()):
+            return self.get_results(self.pending.pop(0))
+        return None
+
+    def finish(self):
+        if self.frame_queue:
+            self._close_batch()
+        remains = []
+        while self.pending:
+            remains += self.get_results(self.pending.pop(0))
+        if self.require_flush:
+            remains += self.get_results(self.submit(*self.make_args(None, None, True)))
+        return remains
+
+    def shutdown(self):
+        self.pending = []
+
+
+# ---- across GPUs: one process per GPU ----------------------------------------------------------------------------------
+def _replay_scaler(depth_model):
+    decay, buffer_size = depth_model.get_ema_state()
+    return EMAMinMaxScaler(decay=decay, buffer_size=buffer_size)
+
+
+def stereo_frames_sharded(frames, pts, segment_pts, depth_model, stereo_fn, batch_size, group=None, dst=0,
+                          infer_kwargs=None):
+    """Depth + stereo over ``frames`` (sequence of CHW float tensors on the rank's device; entries a rank does not own may
+    be None), batch ``b`` on rank ``b mod world``.  ``stereo_fn(x_srcs[B,3,H,W], depths[B,1,h,w], reset_pts) -> list of
+    quantised HWC frames``.  Returns the ordered list on ``dst`` (None elsewhere).
+
+    Normalisation is the sequential EMA of ``depth_model``'s scaler over ALL frames (module docstring): per round, one
+    all-gather of ``[batch_size, 2]`` floats per rank."""
+    if getattr(depth_model, "has_temporal_state", False):
+        raise ValueError("a depth model with temporal state cannot be sharded by frame; shard by scene segment")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = len(frames)
+    segment_pts = set(segment_pts or ())
+    infer_kwargs = infer_kwargs or {}
+    batches = list(chunks(list(range(n)), batch_size))
+    replay = _replay_scaler(depth_model)
+    replay_order = []                     # global frame indices waiting inside ``replay``, oldest first
+    raw = {}                              # my frames: index -> (source, raw depth)
+    ready = []                            # my frames with their range: (index, lo, hi), in frame order
+    out_local = {}
+
+    def assign(results):
+        for _, lo, hi in results:
+            idx = replay_order.pop(0)
+            if idx in raw:
+                ready.append((idx, lo, hi))
+
+    def feed(idx, mn, mx):
+        replay_order.append(idx)
+        _, lo, hi = replay.update(torch.stack([mn, mx]), return_minmax=True)
+        if lo is not None:
+            assign([(None, lo, hi)])
+        if pts[idx] in segment_pts:
+            assign(replay.flush(return_minmax=True))
+            replay.reset()
+
+    def run_ready():
+        for group_ in chunks(list(ready), batch_size):
+            xs = torch.stack([raw[i][0] for i, _, _ in group_])
+            ds = torch.stack([replay.normalize(raw[i][1], lo, hi) for i, lo, hi in group_])
+            outs = stereo_fn(xs, ds, [pts[i] in segment_pts for i, _, _ in group_])
+            for (i, _, _), o in zip(group_, outs):
+                out_local[i] = o
+                del raw[i]
+        ready.clear()
+
+    for r0 in range(0, len(batches), world):
+        round_batches = batches[r0:r0 + world]
+        mine = round_batches[rank] if rank < len(round_batches) else []
+        local = torch.zeros(batch_size, 2, dtype=torch.float32)
+        if mine:
+            x = torch.stack([frames[i] for i in mine])
+            d = depth_model.infer(x, **infer_kwargs)
+            mm = torch.stack([d.flatten(1).amin(dim=1), d.flatten(1).amax(dim=1)], dim=1).float()
+            local[:len(mine)] = mm.cpu()
+            for k, i in enumerate(mine):
+                raw[i] = (x[k], d[k])
+        if world > 1:
+            dev = frames[mine[0]].device if mine else _any_device(frames)
+            buf = [torch.empty_like(local, device=dev) for _ in range(world)]
+            dist.all_gather(buf, local.to(dev), group=group)
+            table = [b.cpu() for b in buf]
+        else:
+            table = [local]
+        for r, b in enumerate(round_batches):
+            for k, i in enumerate(b):
+                feed(i, table[r][k, 0], table[r][k, 1])
+        run_ready()
+    assign(replay.flush(return_minmax=True))
+    run_ready()
+    assert not raw, "frames left without a range"
+
+    if world == 1:
+        return [out_local[i] for i in range(n)]
+    mine_all = [i for bi in shard_indices(len(batches), rank, world) for i in batches[bi]]
+    per_rank = max(len([i for bi in shard_indices(len(batches), r, world) for i in batches[bi]]) for r in range(world))
+    probe = out_local[mine_all[0]] if mine_all else None
+    meta = [None] * world
+    dist.all_gather_object(meta, None if probe is None else (tuple(probe.shape), str(probe.dtype)), group=group)
+    shape, dtype = next(m for m in meta if m is not None)
+    dtype = getattr(torch, dtype.split(".")[-1])
+    dev = probe.device if probe is not None else _any_device(frames)
+    block = torch.zeros((per_rank, *shape), dtype=dtype, device=dev)
+    for k, i in enumerate(mine_all):
+        block[k] = out_local[i]
+    if rank == dst:
+        parts = [torch.empty_like(block) for _ in range(world)]
+        dist.gather(block, parts, dst=dst, group=group)
+        out = [None] * n
+        for r in range(world):
+            idxs = [i for bi in shard_indices(len(batches), r, world) for i in batches[bi]]
+            for k, i in enumerate(idxs):
+                out[i] = parts[r][k]
+        return out
+    dist.gather(block, None, dst=dst, group=group)
+    return None
+
+
+def _any_device(frames):
+    for f in frames:
+        if f is not None:
+            return f.device
+    return torch.device("cpu")

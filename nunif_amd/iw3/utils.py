@@ -54,6 +54,28 @@ def apply_divergence(depth, im, args, side_model=None, reset_pts=None):
     return left, right
 
 
+def preprocess_image(x, args):
+    """iw3/utils.py:247-271: optional 90-degree rotation, then the --max-output-height cap (bicubic antialias,
+    align_corners=True, even sizes) on CHW or BCHW."""
+    g = lambda k, d=None: getattr(args, k, d)     # noqa: E731
+    if g("rotate_left"):
+        x = torch.rot90(x, 1, (-2, -1)).contiguous()
+    elif g("rotate_right"):
+        x = torch.rot90(x, 3, (-2, -1)).contiguous()
+    h, w = x.shape[-2:]
+    new_w, new_h = w, h
+    if g("max_output_height") is not None and new_h > args.max_output_height:
+        new_w = int(args.max_output_height / new_h * new_w)
+        new_h = args.max_output_height
+    if new_w != w or new_h != h:
+        new_h -= new_h % 2
+        new_w -= new_w % 2
+        single = x.ndim == 3
+        y = _ops.resize_aa(x.unsqueeze(0) if single else x, (new_h, new_w), mode="bicubic", align_corners=True, clamp01=True)
+        x = y[0] if single else y
+    return x
+
+
 def _zero_pad(x, left, top, right, bottom):
     return F.pad(x, (left, right, top, bottom), mode="constant", value=0.0)
 

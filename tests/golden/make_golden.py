@@ -609,6 +609,99 @@ def gen_formats():
     save("formats", **out)
 
 
+def frame_pool_args(**kw):
+    """Reference argparse names read by bind_batch_frame_callback / apply_divergence / postprocess_image."""
+    import argparse
+    base = dict(batch_size=2, tta=False, low_vram=False, disable_amp=True, edge_dilation=0, depth_aa=False, rgbd=False,
+                half_rgbd=False, method="grid_sample", mapper="none", divergence=2.0, convergence=0.5, synthetic_view="both",
+                cuda_stream=False, pix_fmt="yuv420p", rotate_left=False, rotate_right=False, debug_depth=False,
+                state={"device": torch.device("cpu"), "convergence_model": None})
+    base.update(vars(format_args()))
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+from make_golden_cases import FRAME_POOL_CASES, fake_depth_net, frame_pool_frames  # noqa: E402
+
+
+def gen_frame_pool():
+    """The reference's frame scheduler on CPU: VU.FrameCallbackPool driving iw3.utils.bind_batch_frame_callback (batching,
+    EMA min-max look-ahead, flush at scene cuts, ordered output) around a fake depth net and the real grid_sample warp."""
+    import av
+    av.__version__ = "14.2.0"
+    import iw3.utils as U
+    import nunif.utils.video as VU
+    from iw3.base_depth_model import BaseDepthModel
+
+    class Frame:
+        def __init__(self, x, pts):
+            self.x, self.pts = x, pts
+
+    VU.to_tensor = lambda frame, device=None: frame.x.to(device) if device is not None else frame.x
+    VU.to_frame = lambda x, use_16bit=False: x
+
+    class FakeDepth(BaseDepthModel):
+        def load_model(self, model_type, resolution, device):
+            return None
+
+        def is_metric(self):
+            return False
+
+        @classmethod
+        def supported(cls, name):
+            return True
+
+        @classmethod
+        def get_name(cls):
+            return "fake"
+
+        @classmethod
+        def multi_gpu_supported(cls, name):
+            return True
+
+        @classmethod
+        def force_update(cls):
+            pass
+
+        @classmethod
+        def get_model_path(cls, name):
+            return None
+
+        @classmethod
+        def has_checkpoint_file(cls, name):
+            return True
+
+        def infer(self, x, **kw):
+            return fake_depth_net(x)
+
+    out = {}
+    for name, (n, bs, cuts, ema, workers) in FRAME_POOL_CASES.items():
+        dm = FakeDepth("fake")
+        if ema is not None:
+            dm.enable_ema(ema[0], buffer_size=ema[1])
+        args = frame_pool_args(batch_size=bs)
+        cb, pre = U.bind_batch_frame_callback(dm, None, set(cuts), args)
+        pool = VU.FrameCallbackPool(frame_callback=cb, preprocess_callback=pre, batch_size=bs, device=[torch.device("cpu")],
+                                    max_workers=workers, max_batch_queue=workers + 1, require_pts=True, require_flush=True)
+        counts, frames = [], []
+        for i, x in enumerate(frame_pool_frames(n)):
+            r = pool(Frame(x, i)) or []
+            counts.append(len(r))
+            frames += r
+        r = pool(None)
+        counts.append(len(r))
+        frames += r
+        pool.shutdown()
+        assert len(frames) == n, (name, len(frames))
+        out[name + "_counts"] = torch.tensor(counts)
+        if name == "ema_threads":          # worker threads change WHEN frames are handed back, never the frames
+            assert torch.equal(torch.stack(frames), out["ema_frames"])
+            continue
+        out[name + "_frames"] = torch.stack(frames)
+        print(name, counts)
+    save("frame_pool", **out)
+
+
 def gen_depth_aa():
     """iw3.depth_aa (iw3/models/depth_aa.py) on the reference: forward (clamped / unclamped) and infer()."""
     from iw3.models.depth_aa import DepthAA
@@ -628,7 +721,8 @@ def gen_depth_aa():
 
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "vda_online": gen_vda_online, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint, "light_video_inpaint_ml": gen_light_video_inpaint_ml}
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "vda_online": gen_vda_online, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint, "light_video_inpaint_ml": gen_light_video_inpaint_ml,
+          "frame_pool": gen_frame_pool}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

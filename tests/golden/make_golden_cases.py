@@ -10,3 +10,39 @@ FORMAT_CASES = {
     "ana_wimmer": dict(anaglyph="wimmer"), "ana_wimmer2": dict(anaglyph="wimmer2"), "ana_dubois": dict(anaglyph="dubois"),
     "ana_dubois2": dict(anaglyph="dubois2", ipd_offset=2.0),
 }
+
+
+# ---- frame scheduler (gen_frame_pool / tests/test_frame_pipeline.py) -------------------------------------------------
+import torch  # noqa: E402
+
+
+def _synth_image(seed, c, h, w):
+    """Same generator as make_golden.synth_image / conftest.synth_image."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(1, c, max(2, h // 16 + 1), max(2, w // 16 + 1), generator=g)
+    up = torch.nn.functional.interpolate(low, size=(h, w), mode="bilinear", align_corners=False)[0]
+    return torch.clamp(up * 0.8 + 0.2 * torch.rand(c, h, w, generator=g), 0, 1)
+
+
+def fake_depth_net(x):
+    """Deterministic stand-in for a depth net: BCHW in [0,1] -> B1HW whose range differs from frame to frame."""
+    w = torch.tensor([0.5, 0.3, 0.2]).view(1, 3, 1, 1)
+    d = (x * w).sum(dim=1, keepdim=True)
+    gain = 0.5 + x.mean(dim=(1, 2, 3), keepdim=True)
+    return d * gain + 0.1 * gain
+
+
+FRAME_POOL_CASES = {
+    # name: (n_frames, batch_size, scene-cut pts, (ema decay, buffer) or None, max_workers)
+    "plain": (11, 2, (5,), None, 0),
+    "ema": (13, 3, (6,), (0.75, 4), 0),
+    "ema_threads": (13, 3, (6,), (0.75, 4), 2),
+    "cut_last_of_batch": (8, 2, (3, 7), (0.5, 2), 0),
+}
+
+
+def frame_pool_frames(n, h=24, w=40):
+    """uint8-derived frames (what a decoder hands over): CHW float = u8 / 255."""
+    return [(_synth_image(700 + i, 3, h, w) * (0.6 + 0.04 * i) * 255).round().clamp(0, 255) / 255 for i in range(n)]
+
+

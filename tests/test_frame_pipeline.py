@@ -1,0 +1,171 @@
+"""Host logic of the iw3 frame scheduler (nunif_amd/iw3/frame_pipeline.py) on CPU.
+
+The fixture ``tests/golden/frame_pool.npz`` holds what the REFERENCE's ``VU.FrameCallbackPool`` +
+``iw3.utils.bind_batch_frame_callback`` hand back, call by call, around a fake depth net and the real grid-sample warp
+(``tests/golden/make_golden.py::gen_frame_pool``).  Here the same frames go through the product scheduler with torch-CPU
+stand-ins for the device functions (the HIP ops refuse CPU tensors): the schedule (frames per call) must be identical and
+the frames equal.  The N > 1 path (``stereo_frames_sharded``) runs on 2 gloo ranks and must be bit-identical to the single
+process.
+"""
+import argparse
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from make_golden_cases import FRAME_POOL_CASES, fake_depth_net, frame_pool_frames  # noqa: E402
+
+from nunif_amd.iw3.base_depth_model import BaseDepthModel  # noqa: E402
+from nunif_amd.iw3.frame_pipeline import (FrameCallbackPool, PipelineOps, bind_batch_frame_callback,  # noqa: E402
+                                          stereo_frames_sharded)
+from oracle.backward_warp import grid_sample_warp  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frame_pool.npz")
+
+
+class Frame:
+    def __init__(self, x, pts):
+        self.x, self.pts = x, pts
+
+
+class FakeDepth(BaseDepthModel):
+    def load_model(self, model_type, resolution=None, device=None, **kw):
+        return None
+
+    def is_metric(self):
+        return False
+
+    def infer(self, x, **kw):
+        return fake_depth_net(x)
+
+
+def _args(batch_size):
+    return argparse.Namespace(batch_size=batch_size, tta=False, low_vram=False, disable_amp=True, edge_dilation=0,
+                              depth_aa=False, rgbd=False, half_rgbd=False, method="grid_sample", mapper="none",
+                              divergence=2.0, convergence=0.5, synthetic_view="both", pix_fmt="yuv420p",
+                              state={"device": torch.device("cpu")})
+
+
+def _cpu_ops():
+    """torch-CPU stand-ins with the reference's semantics for this configuration (mapper "none", grid_sample, full SBS)."""
+    def apply_divergence(depths, x, args, side_model=None, reset_pts=None):
+        return grid_sample_warp(x, depths, args.divergence, args.convergence, args.synthetic_view)
+
+    return PipelineOps(to_tensor=lambda frame, device=None: frame.x,
+                       preprocess_image=lambda x, args: x,
+                       apply_divergence=apply_divergence,
+                       postprocess_image=lambda le, re, args: torch.clamp(torch.cat([le, re], dim=2), 0, 1),
+                       to_frame=lambda x, use_16bit=False: x)
+
+
+def _model(ema):
+    dm = FakeDepth("fake")
+    if ema is not None:
+        dm.enable_ema(ema[0], buffer_size=ema[1])
+    return dm
+
+
+def _run_pool(n, bs, cuts, ema, workers):
+    ops = _cpu_ops()
+    cb, pre = bind_batch_frame_callback(_model(ema), None, set(cuts), _args(bs), ops=ops)
+    pool = FrameCallbackPool(frame_callback=cb, preprocess_callback=pre, batch_size=bs, device=[torch.device("cpu")],
+                             max_workers=workers, max_batch_queue=workers + 1, require_pts=True, require_flush=True, ops=ops)
+    counts, frames = [], []
+    for i, x in enumerate(frame_pool_frames(n)):
+        r = pool(Frame(x, i)) or []
+        counts.append(len(r))
+        frames += r
+    r = pool(None)
+    counts.append(len(r))
+    frames += r
+    pool.shutdown()
+    return counts, frames
+
+
+@pytest.mark.parametrize("name", sorted(FRAME_POOL_CASES))
+def test_pool_matches_reference_scheduler(name):
+    g = np.load(GOLDEN)
+    n, bs, cuts, ema, workers = FRAME_POOL_CASES[name]
+    counts, frames = _run_pool(n, bs, cuts, ema, workers)
+    assert len(frames) == n
+    ref = torch.from_numpy(g[("ema" if name == "ema_threads" else name) + "_frames"])
+    assert torch.equal(torch.stack(frames), ref)          # same torch ops in the same order: bit-identical
+    if workers <= 0:                                       # the synchronous schedule is deterministic: frames per call
+        assert counts == g[name + "_counts"].tolist()
+    else:                                                  # (on CPU a batch is complete when its call returns)
+        assert sum(counts) == n
+
+
+def test_pool_refuses_several_devices_and_skips_pts():
+    ops = _cpu_ops()
+    with pytest.raises(ValueError):
+        FrameCallbackPool(lambda *a: [], 2, device=["cuda:0", "cuda:1"], ops=ops)
+    seen = []
+    pool = FrameCallbackPool(lambda batch, pts: (seen.append(list(pts)) or [b for b in batch]), 2, device="cpu",
+                             max_workers=0, require_pts=True, skip_pts=1, ops=ops)
+    out = []
+    for i, x in enumerate(frame_pool_frames(5)):
+        out += pool(Frame(x, i)) or []
+    out += pool(None)
+    assert seen == [[2, 3], [4]] and len(out) == 3         # pts 0 and 1 skipped; the partial batch is flushed at the end
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _stereo_fn(args):
+    def fn(xs, ds, reset_pts):
+        le, re = grid_sample_warp(xs, ds, args.divergence, args.convergence, "both")
+        return [torch.clamp(torch.cat([le[i], re[i]], dim=2), 0, 1) for i in range(xs.shape[0])]
+    return fn
+
+
+def _worker(rank, world, port, case, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, bs, cuts, ema, _ = FRAME_POOL_CASES[case]
+    frames = frame_pool_frames(n)
+    mine = {i for b in range(rank, (n + bs - 1) // bs, world) for i in range(b * bs, min(n, (b + 1) * bs))}
+    frames = [f if i in mine else None for i, f in enumerate(frames)]      # a rank only holds the frames it owns
+    with torch.inference_mode():
+        out = stereo_frames_sharded(frames, list(range(n)), set(cuts), _model(ema), _stereo_fn(_args(bs)), bs, dst=0)
+    if rank == 0:
+        torch.save(torch.stack(out), path)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["plain", "ema", "cut_last_of_batch"])
+def test_sharded_two_ranks_bit_identical_to_sequential(name, tmp_path):
+    g = np.load(GOLDEN)
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_worker, args=(2, _free_port(), name, path), nprocs=2, join=True)
+    got = torch.load(path)
+    assert torch.equal(got, torch.from_numpy(g[name + "_frames"]))
+
+
+@pytest.mark.parametrize("name", ["plain", "ema", "cut_last_of_batch"])
+def test_sharded_single_process(name):
+    g = np.load(GOLDEN)
+    n, bs, cuts, ema, _ = FRAME_POOL_CASES[name]
+    out = stereo_frames_sharded(frame_pool_frames(n), list(range(n)), set(cuts), _model(ema), _stereo_fn(_args(bs)), bs)
+    assert torch.equal(torch.stack(out), torch.from_numpy(g[name + "_frames"]))
+
+
+def test_sharded_refuses_temporal_models():
+    dm = _model(None)
+    dm.has_temporal_state = True
+    with pytest.raises(ValueError):
+        stereo_frames_sharded(frame_pool_frames(2), [0, 1], set(), dm, lambda *a: [], 2)
