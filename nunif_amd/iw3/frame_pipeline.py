@@ -184,7 +184,7 @@ def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=No
     def frame_callback(call_args):
         x, pts, flush, _ticket = call_args
         if flush:
-            device = _flush_device()
+            device = _device_of(args, depth_model)
             st = _stage(device)
             with st.depth_stage():
                 depth_list = depth_model.flush_minmax_normalize()
@@ -203,17 +203,124 @@ def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=No
             depth_list = depth_model.minmax_normalize(depth_batch, reset_ema=reset_ema)
         return _stereo(depth_list, device, st)
 
-    def _flush_device():
-        state = getattr(args, "state", None) or {}
-        if "device" in state:
-            return torch.device(state["device"])
-        return torch.device(depth_model.device) if getattr(depth_model, "device", None) is not None else torch.device("cpu")
-
     def preprocess_callback(x, pts, flush):
         tickets[0] += 1                 # kept for signature parity (the reference's enqueue ticket); order is inherent here
         return (x, pts, flush, tickets[0] - 1)
 
     return frame_callback, preprocess_callback
+
+
+def _side_flush(side_model, args, ops, use_16bit):
+    """Frames still inside a side model with a temporal queue (the video inpaint ``FrameQueue``), iw3/utils.py:658-663."""
+    out = []
+    if hasattr(side_model, "flush"):
+        left, right = side_model.flush(enable_amp=not getattr(args, "disable_amp", False))
+        if left is not None:
+            out = [ops.to_frame(ops.postprocess_image(le, re, args), use_16bit=use_16bit) for le, re in zip(left, right)]
+    return out
+
+
+def bind_single_frame_callback(depth_model, side_model, segment_pts, args, ops=None):
+    """``iw3/utils.py:618-709`` (``--batch-size 1`` / ``--max-workers 0`` route): ``frame_callback(frame) -> [frames]``,
+    ``frame_callback(None)`` flushes the scaler and the side model."""
+    ops = ops or PipelineOps()
+    segment_pts = set(segment_pts or ())
+    src_queue = []
+    use_16bit = pix_fmt_requires_16bit(getattr(args, "pix_fmt", None))
+    infer_kw = lambda: dict(tta=getattr(args, "tta", False), low_vram=getattr(args, "low_vram", False),     # noqa: E731
+                            enable_amp=not getattr(args, "disable_amp", False),
+                            edge_dilation=getattr(args, "edge_dilation", 0), depth_aa=getattr(args, "depth_aa", False))
+
+    def _postprocess(depths, flush):
+        frames = []
+        for depth in depths:
+            x, t = src_queue.pop(0)
+            if getattr(args, "rgbd", False) or getattr(args, "half_rgbd", False):
+                left, right = ops.apply_rgbd(x, depth, mapper=args.mapper)
+            else:
+                left, right = ops.apply_divergence(depth, x, args, side_model, reset_pts=[t in segment_pts])
+            if left is None:                  # a side model that is still filling its queue
+                continue
+            pairs = [(left, right)] if left.ndim == 3 else list(zip(left, right))
+            frames += [ops.to_frame(ops.postprocess_image(le, re, args), use_16bit=use_16bit) for le, re in pairs]
+        if flush:
+            frames += _side_flush(side_model, args, ops, use_16bit)
+        return frames
+
+    @torch.inference_mode()
+    def frame_callback(frame):
+        if frame is None:
+            return _postprocess(depth_model.flush_minmax_normalize(), flush=True)
+        x = ops.preprocess_image(ops.to_tensor(frame, device=_device_of(args, depth_model)), args)
+        src_queue.append((x, frame.pts))
+        depth = depth_model.minmax_normalize_chw(depth_model.infer(x, **infer_kw()))
+        depths = [depth] if depth is not None else []
+        flush = frame.pts in segment_pts
+        if flush:
+            depths += depth_model.flush_minmax_normalize()
+            depth_model.reset_state()
+        return _postprocess(depths, flush=flush)
+
+    depth_model.reset()
+    return frame_callback
+
+
+def bind_vda_frame_callback(depth_model, side_model, segment_pts, args, ops=None):
+    """``iw3/utils.py:834-926``: the route of depth models that normalise themselves over a window of frames
+    (``VideoDepthAnythingModel.infer_with_normalize`` / ``flush_with_normalize``): batches of ``args.batch_size`` frames,
+    outputs lag the inputs by the model's window; ``frame_callback(None)`` drains model, scaler and side model."""
+    ops = ops or PipelineOps()
+    segment_pts = set(segment_pts or ())
+    src_queue, batch_queue, pts_queue = [], [], []
+    use_16bit = pix_fmt_requires_16bit(getattr(args, "pix_fmt", None))
+    kw = lambda: dict(enable_amp=not getattr(args, "disable_amp", False), edge_dilation=getattr(args, "edge_dilation", 0),   # noqa: E731
+                      depth_aa=getattr(args, "depth_aa", False))
+
+    def _postprocess(depth_list, flush=False):
+        results = []
+        for depths in chunks(depth_list, args.batch_size):
+            depths = torch.stack(depths)
+            pairs = [src_queue.pop(0) for _ in range(depths.shape[0])]
+            x_srcs = torch.stack([x for x, _ in pairs])
+            if getattr(args, "rgbd", False) or getattr(args, "half_rgbd", False):
+                left, right = ops.apply_rgbd(x_srcs, depths, mapper=args.mapper)
+            else:
+                left, right = ops.apply_divergence(depths, x_srcs, args, side_model,
+                                                   reset_pts=[t in segment_pts for _, t in pairs])
+            if left is not None:
+                results += [ops.to_frame(ops.postprocess_image(left[i], right[i], args), use_16bit=use_16bit)
+                            for i in range(left.shape[0])]
+        if flush:
+            results += _side_flush(side_model, args, ops, use_16bit)
+        return results
+
+    def _batch_infer():
+        x = ops.preprocess_image(torch.stack(batch_queue), args)
+        for x_, t in zip(x, pts_queue):
+            src_queue.append((x_, t))
+        depth_list = depth_model.infer_with_normalize(x, list(pts_queue), segment_pts, **kw())
+        pts_queue.clear()
+        batch_queue.clear()
+        return _postprocess(depth_list)
+
+    @torch.inference_mode()
+    def frame_callback(frame):
+        if frame is None:
+            results = _batch_infer() if batch_queue else []
+            return results + _postprocess(depth_model.flush_with_normalize(**kw()), flush=True)
+        batch_queue.append(ops.to_tensor(frame, device=_device_of(args, depth_model)))
+        pts_queue.append(frame.pts)
+        return _batch_infer() if len(batch_queue) == args.batch_size else None
+
+    depth_model.reset()
+    return frame_callback
+
+
+def _device_of(args, depth_model):
+    state = getattr(args, "state", None) or {}
+    if "device" in state:
+        return torch.device(state["device"])
+    return torch.device(depth_model.device) if getattr(depth_model, "device", None) is not None else torch.device("cpu")
 
 
 class _Pending:

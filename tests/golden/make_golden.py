@@ -621,7 +621,8 @@ def frame_pool_args(**kw):
     return argparse.Namespace(**base)
 
 
-from make_golden_cases import FRAME_POOL_CASES, fake_depth_net, frame_pool_frames  # noqa: E402
+from make_golden_cases import (FRAME_CALLBACK_CASES, FRAME_POOL_CASES, FakeSide, FakeWindowDepth, fake_depth_net,  # noqa: E402
+                                frame_pool_frames)
 
 
 def gen_frame_pool():
@@ -672,9 +673,30 @@ def gen_frame_pool():
             return True
 
         def infer(self, x, **kw):
-            return fake_depth_net(x)
+            return fake_depth_net(x) if x.ndim == 4 else fake_depth_net(x[None])[0]
 
     out = {}
+    # the single-frame route (:618-709) and the windowed-depth route (:834-926); frames arrive as HWC uint8 ndarrays
+    VU.to_ndarray = lambda frame: (frame.x * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().numpy()
+    for name, (n, bs, cuts, ema) in FRAME_CALLBACK_CASES.items():
+        args = frame_pool_args(batch_size=bs)
+        if name == "single":
+            dm = FakeDepth("fake")
+            dm.enable_ema(ema[0], buffer_size=ema[1])
+            cb = U.bind_single_frame_callback(dm, FakeSide(), set(cuts), args)
+        else:
+            cb = U.bind_vda_frame_callback(FakeWindowDepth(), FakeSide(), set(cuts), args)
+        counts, frames = [], []
+        for i, x in enumerate(frame_pool_frames(n)):
+            r = cb(Frame(x, i)) or []
+            counts.append(len(r))
+            frames += r
+        r = cb(None)
+        counts.append(len(r))
+        frames += r
+        out[name + "_counts"] = torch.tensor(counts)
+        out[name + "_frames"] = torch.stack(frames)
+        print(name, counts, len(frames))
     for name, (n, bs, cuts, ema, workers) in FRAME_POOL_CASES.items():
         dm = FakeDepth("fake")
         if ema is not None:

@@ -46,3 +46,45 @@ def frame_pool_frames(n, h=24, w=40):
     return [(_synth_image(700 + i, 3, h, w) * (0.6 + 0.04 * i) * 255).round().clamp(0, 255) / 255 for i in range(n)]
 
 
+
+
+class FakeSide:
+    """Side model with a temporal queue as far as the schedulers care: ``flush`` hands back one more stereo pair."""
+
+    def flush(self, enable_amp=True):
+        return torch.full((1, 3, 24, 40), 0.25), torch.full((1, 3, 24, 40), 0.75)
+
+
+class FakeWindowDepth:
+    """Duck-typed stand-in for ``VideoDepthAnythingModel`` on the ``bind_vda_frame_callback`` route: outputs lag the inputs by
+    two frames, every frame is normalised by its own range, a scene cut / the final flush drains the window."""
+
+    def __init__(self):
+        self.buf = []
+
+    def reset(self):
+        self.buf = []
+
+    @staticmethod
+    def _emit(d):
+        return (d - d.amin()) / (d.amax() - d.amin())
+
+    def infer_with_normalize(self, x, pts, reset_pts, **kw):
+        out = []
+        for i in range(x.shape[0]):
+            self.buf.append(fake_depth_net(x[i:i + 1].cpu())[0].to(x.device))
+            if len(self.buf) > 2:
+                out.append(self._emit(self.buf.pop(0)))
+            if pts[i] in reset_pts:
+                out += [self._emit(d) for d in self.buf]
+                self.buf = []
+        return out
+
+    def flush_with_normalize(self, **kw):
+        out = [self._emit(d) for d in self.buf]
+        self.buf = []
+        return out
+
+
+# route -> (n_frames, batch_size, scene-cut pts, (ema decay, buffer) or None)
+FRAME_CALLBACK_CASES = {"single": (7, 1, (3,), (0.75, 3)), "vda": (11, 3, (4,), None)}

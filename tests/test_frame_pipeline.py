@@ -19,11 +19,12 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-from make_golden_cases import FRAME_POOL_CASES, fake_depth_net, frame_pool_frames  # noqa: E402
+from make_golden_cases import (FRAME_CALLBACK_CASES, FRAME_POOL_CASES, FakeSide, FakeWindowDepth, fake_depth_net,  # noqa: E402
+                                frame_pool_frames)
 
 from nunif_amd.iw3.base_depth_model import BaseDepthModel  # noqa: E402
 from nunif_amd.iw3.frame_pipeline import (FrameCallbackPool, PipelineOps, bind_batch_frame_callback,  # noqa: E402
-                                          stereo_frames_sharded)
+                                          bind_single_frame_callback, bind_vda_frame_callback, stereo_frames_sharded)
 from oracle.backward_warp import grid_sample_warp  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frame_pool.npz")
@@ -42,7 +43,7 @@ class FakeDepth(BaseDepthModel):
         return False
 
     def infer(self, x, **kw):
-        return fake_depth_net(x)
+        return fake_depth_net(x) if x.ndim == 4 else fake_depth_net(x[None])[0]
 
 
 def _args(batch_size):
@@ -55,6 +56,9 @@ def _args(batch_size):
 def _cpu_ops():
     """torch-CPU stand-ins with the reference's semantics for this configuration (mapper "none", grid_sample, full SBS)."""
     def apply_divergence(depths, x, args, side_model=None, reset_pts=None):
+        if depths.ndim == 3:
+            le, re = grid_sample_warp(x[None], depths[None], args.divergence, args.convergence, args.synthetic_view)
+            return le[0], re[0]
         return grid_sample_warp(x, depths, args.divergence, args.convergence, args.synthetic_view)
 
     return PipelineOps(to_tensor=lambda frame, device=None: frame.x,
@@ -114,6 +118,30 @@ def test_pool_refuses_several_devices_and_skips_pts():
         out += pool(Frame(x, i)) or []
     out += pool(None)
     assert seen == [[2, 3], [4]] and len(out) == 3         # pts 0 and 1 skipped; the partial batch is flushed at the end
+
+
+@pytest.mark.parametrize("name", sorted(FRAME_CALLBACK_CASES))
+def test_single_and_windowed_routes_match_reference(name):
+    """bind_single_frame_callback (per-frame + EMA look-ahead + side-model flush at a cut) and bind_vda_frame_callback
+    (a depth model that lags and normalises by itself) against the reference's own callbacks, call by call."""
+    g = np.load(GOLDEN)
+    n, bs, cuts, ema = FRAME_CALLBACK_CASES[name]
+    if name == "single":
+        cb = bind_single_frame_callback(_model(ema), FakeSide(), set(cuts), _args(bs), ops=_cpu_ops())
+    else:
+        cb = bind_vda_frame_callback(FakeWindowDepth(), FakeSide(), set(cuts), _args(bs), ops=_cpu_ops())
+    counts, frames = [], []
+    for i, x in enumerate(frame_pool_frames(n)):
+        r = cb(Frame(x, i)) or []
+        counts.append(len(r))
+        frames += r
+    r = cb(None)
+    counts.append(len(r))
+    frames += r
+    assert counts == g[name + "_counts"].tolist()
+    # (the reference feeds its depth net a permuted HWC view on these routes, so the fake net's mean() sums in another order:
+    #  last-bit differences in the depth, nothing to do with the scheduler)
+    assert (torch.stack(frames) - torch.from_numpy(g[name + "_frames"])).abs().max().item() < 1e-5
 
 
 def _free_port():

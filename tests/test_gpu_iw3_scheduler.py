@@ -12,7 +12,8 @@ import torch
 from conftest import psnr
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-from make_golden_cases import FRAME_POOL_CASES, fake_depth_net, frame_pool_frames  # noqa: E402
+from make_golden_cases import (FRAME_CALLBACK_CASES, FRAME_POOL_CASES, FakeSide, FakeWindowDepth, fake_depth_net,  # noqa: E402
+                                frame_pool_frames)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -27,9 +28,8 @@ def _args(batch_size, **kw):
     return argparse.Namespace(**base)
 
 
-def _run(name, monkeypatch, stage_streams, **kw):
+def _fake_depth():
     from nunif_amd.iw3.base_depth_model import BaseDepthModel
-    from nunif_amd.iw3.frame_pipeline import FrameCallbackPool, HostFrame, bind_batch_frame_callback
 
     class FakeDepth(BaseDepthModel):
         def load_model(self, model_type, resolution=None, device=None, **kw):
@@ -38,13 +38,24 @@ def _run(name, monkeypatch, stage_streams, **kw):
         def is_metric(self):
             return False
 
-        def infer(self, x, **kw):
-            return fake_depth_net(x.cpu()).to(x.device)      # the stand-in net is not under test: same values as the fixture
+        def infer(self, x, **kw):                            # the stand-in net is not under test: same values as the fixture
+            y = fake_depth_net(x.cpu() if x.ndim == 4 else x[None].cpu()).to(x.device)
+            return y if x.ndim == 4 else y[0]
 
-    monkeypatch.setenv("NUNIF_IW3_STAGE_STREAMS", "1" if stage_streams else "0")
-    n, bs, cuts, ema, workers = FRAME_POOL_CASES[name]
     dm = FakeDepth("fake")
     dm.device = torch.device(DEV)
+    return dm
+
+
+def _u8(x):
+    return (x * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().numpy()       # what a decoder hands over
+
+
+def _run(name, monkeypatch, stage_streams, **kw):
+    from nunif_amd.iw3.frame_pipeline import FrameCallbackPool, HostFrame, bind_batch_frame_callback
+    monkeypatch.setenv("NUNIF_IW3_STAGE_STREAMS", "1" if stage_streams else "0")
+    n, bs, cuts, ema, workers = FRAME_POOL_CASES[name]
+    dm = _fake_depth()
     if ema is not None:
         dm.enable_ema(ema[0], buffer_size=ema[1])
     cb, pre = bind_batch_frame_callback(dm, None, set(cuts), _args(bs, **kw))
@@ -52,8 +63,7 @@ def _run(name, monkeypatch, stage_streams, **kw):
                              max_workers=workers, max_batch_queue=workers + 1, require_pts=True, require_flush=True)
     counts, frames = [], []
     for i, x in enumerate(frame_pool_frames(n)):
-        u8 = (x * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().numpy()      # what a decoder hands over
-        r = pool(HostFrame(u8, i)) or []
+        r = pool(HostFrame(_u8(x), i)) or []
         counts.append(len(r))
         frames += r
     r = pool(None)
@@ -88,3 +98,36 @@ def test_stage_streams_do_not_change_the_frames(hiplib, monkeypatch, method):
         _, a = _run("ema", monkeypatch, True, method=method)
         _, b = _run("ema", monkeypatch, False, method=method)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", sorted(FRAME_CALLBACK_CASES))
+def test_single_and_windowed_routes(hiplib, name):
+    """bind_single_frame_callback / bind_vda_frame_callback on the HIP ops against the reference's own callbacks."""
+    from nunif_amd.iw3.frame_pipeline import HostFrame, bind_single_frame_callback, bind_vda_frame_callback
+
+    class Side(FakeSide):
+        def flush(self, enable_amp=True):
+            le, re = super().flush(enable_amp)
+            return le.to(DEV), re.to(DEV)
+
+    g = np.load(GOLDEN)
+    n, bs, cuts, ema = FRAME_CALLBACK_CASES[name]
+    if name == "single":
+        dm = _fake_depth()
+        dm.enable_ema(ema[0], buffer_size=ema[1])
+        cb = bind_single_frame_callback(dm, Side(), set(cuts), _args(bs))
+    else:
+        cb = bind_vda_frame_callback(FakeWindowDepth(), Side(), set(cuts), _args(bs))
+    counts, frames = [], []
+    for i, x in enumerate(frame_pool_frames(n)):
+        r = cb(HostFrame(_u8(x), i)) or []
+        counts.append(len(r))
+        frames += r
+    r = cb(None)
+    counts.append(len(r))
+    frames += r
+    assert counts == g[name + "_counts"].tolist()
+    got = torch.stack([f.cpu() for f in frames])
+    ref = (torch.from_numpy(g[name + "_frames"]) * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+    assert got.shape == ref.shape and int((got.int() - ref.int()).abs().max()) <= 1
+    assert psnr(got.float() / 255, ref.float() / 255) >= 50.0
