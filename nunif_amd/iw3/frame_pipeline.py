@@ -175,6 +175,8 @@ def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=No
                     left, right = ops.apply_rgbd(x_srcs, depths, mapper=args.mapper)
                 else:
                     left, right = ops.apply_divergence(depths, x_srcs, args, side_model, reset_pts=reset_pts)
+                if left is None:              # an inpaint side model whose 12-frame queue is still filling
+                    continue
                 frames = [ops.postprocess_image(left[i], right[i], args) for i in range(left.shape[0])]
                 results += [ops.to_frame(f, use_16bit=use_16bit) for f in frames]
         results.event = st.stereo_done()

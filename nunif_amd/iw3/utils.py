@@ -3,8 +3,9 @@
 ``postprocess_image`` :430-487 (IPD pad, ``postprocess_padding`` :394-427, VR180 projection, half-SBS / half-TB / half-RGBD
 bicubic-antialias resize, anaglyph / SBS / TB / cross-eyed compose, max-output resize), ``apply_rgbd`` :74-88 and ``nunif/utils/video.py`` ``to_tensor`` / ``to_frame`` :218-269 (``to_frame_tensor`` here returns
 the quantised HWC tensor; wrapping it into an ``av.VideoFrame`` is the caller's codec business).
-``row_flow_v3`` (the default method) and ``mlbw_l2/l4/l2s/l4s`` run on the engine; the inpaint side models are a
-"next" row."""
+``row_flow_v3`` (the default method), ``mlbw_l2/l4/l2s/l4s`` and the inpaint side models (``forward_inpaint`` ->
+``nunif_amd.iw3.forward_inpaint.ForwardInpaint``, ``mlbw_l2_inpaint`` -> ``nunif_amd.iw3.mlbw_inpaint.MLBWInpaint``) run on the
+engine."""
 import torch
 import torch.nn.functional as F
 
@@ -47,6 +48,33 @@ def apply_divergence(depth, im, args, side_model=None, reset_pts=None):
                                              getattr(args, "warp_steps", None), synthetic_view=args.synthetic_view,
                                              preserve_screen_border=getattr(args, "preserve_screen_border", False),
                                              enable_amp=not getattr(args, "disable_amp", False))
+    elif args.method in {"forward_inpaint", "mlbw_l2_inpaint"}:
+        # iw3/utils.py:333-365: one side_model.infer per frame (the video mode keeps a 12-frame queue and answers None until
+        # it is full), a flush where a scene ends; whatever came out is concatenated
+        if side_model is None:
+            raise ValueError(f"method={args.method} needs a side model (nunif_amd.iw3.forward_inpaint.ForwardInpaint / "
+                             "nunif_amd.iw3.mlbw_inpaint.MLBWInpaint)")
+        g = lambda k, d=None: getattr(args, k, d)     # noqa: E731
+        lefts, rights = [], []
+        reset_pts = reset_pts if reset_pts is not None else [False] * depth.shape[0]
+        for i in range(depth.shape[0]):
+            conv_i = convergence[i:i + 1] if torch.is_tensor(convergence) else convergence
+            le, ri = side_model.infer(im[i:i + 1], depth[i:i + 1], divergence=args.divergence, convergence=conv_i,
+                                      preserve_screen_border=g("preserve_screen_border", False),
+                                      synthetic_view=args.synthetic_view, inner_dilation=g("mask_inner_dilation", 0),
+                                      outer_dilation=g("mask_outer_dilation", 0), max_width=g("inpaint_max_width"),
+                                      enable_amp=not g("disable_amp", False))
+            if le is not None:
+                lefts.append(le)
+                rights.append(ri)
+            if reset_pts[i]:
+                le, ri = side_model.flush(enable_amp=not g("disable_amp", False))
+                if le is not None:
+                    lefts.append(le)
+                    rights.append(ri)
+        if not lefts:
+            return None, None
+        return (lefts[0], rights[0]) if len(lefts) == 1 else (torch.cat(lefts, dim=0), torch.cat(rights, dim=0))
     else:
         raise NotImplementedError(f"method={args.method}: this side model is not on the HIP engine yet")
     if not batch:

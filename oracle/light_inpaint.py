@@ -236,3 +236,75 @@ def random_state_dict(*args, **kwargs):
 def video_random_state_dict(*args, **kwargs):
     from nunif_amd.synthetic import light_video_inpaint_state_dict
     return light_video_inpaint_state_dict(*args, **kwargs)
+
+
+# ---- ForwardInpaint (iw3/forward_inpaint.py: forward_right / forward_left :18-40, ForwardInpaintImage :43-103,
+#      ForwardInpaintVideo :106-232) ---------------------------------------------------------------------------------------
+def _forward_hole_mask(mask, inner_dilation, outer_dilation, base_width):
+    from . import dilation as OD
+    m = OD.mask_closing(mask > 0)
+    m = OD.dilate_outer(m, outer_dilation, base_width)
+    return OD.dilate_inner(m, inner_dilation, base_width)
+
+
+def _limit_width(x, max_width):
+    if max_width is not None and x.shape[-1] > max_width:
+        if max_width % 2 != 0:
+            max_width += 1
+        new_h = int((max_width / x.shape[-1]) * x.shape[-2])
+        if new_h % 2 != 0:
+            new_h += 1
+        x = F.interpolate(x, size=(new_h, max_width), mode="bilinear", antialias=True, align_corners=False)
+    return x
+
+
+def forward_inpaint_image(sd_inpaint, x, depth, divergence, convergence, synthetic_view="both", inner_dilation=0,
+                          outer_dilation=0, max_width=None, infer_fn=None):
+    from . import forward_warp as OF
+    infer_fn = infer_fn or (lambda z, m: infer(sd_inpaint, z, m))
+    x = _limit_width(x, max_width)
+    left, right, lmask, rmask = OF.forward_warp(x, depth, divergence, convergence, fill=False, synthetic_view=synthetic_view,
+                                                return_mask=True, width_base=False)
+    kw = dict(inner_dilation=inner_dilation, outer_dilation=outer_dilation, base_width=depth.shape[-1])
+    if synthetic_view in ("both", "left"):
+        left = infer_fn(left.flip(-1), _forward_hole_mask(lmask.flip(-1), **kw)).flip(-1)
+    if synthetic_view in ("both", "right"):
+        right = infer_fn(right, _forward_hole_mask(rmask, **kw))
+    return left, right
+
+
+def forward_inpaint_video(sd_video, batches, divergence, convergence, inner_dilation=0, outer_dilation=0, pre_padding=3,
+                          post_padding=3):
+    """ForwardInpaintVideo (synthetic_view="both") over a list of (frames, depth) batches followed by flush(); returns the list
+    of (left, right) results (None while the 12-frame queue fills).  The queue is a plain list."""
+    from . import forward_warp as OF
+    queue, results = [], []
+
+    def run(flush):
+        le = torch.stack([q[0] for q in queue]); ri = torch.stack([q[1] for q in queue])
+        lm = torch.stack([q[2] for q in queue]); rm = torch.stack([q[3] for q in queue])
+        kw = dict(inner_dilation=inner_dilation, outer_dilation=outer_dilation, base_width=base_width[0])
+        left = video_infer(sd_video, le.flip(-1), _forward_hole_mask(lm.flip(-1), **kw)).flip(-1)
+        right = video_infer(sd_video, ri, _forward_hole_mask(rm, **kw))
+        if flush:
+            del queue[:]
+            return left[pre_padding:], right[pre_padding:]
+        del queue[:SEQ_LEN - (pre_padding + post_padding)]
+        return left[pre_padding:SEQ_LEN - post_padding], right[pre_padding:SEQ_LEN - post_padding]
+
+    base_width = [None]
+    for frames, depth in batches:
+        base_width[0] = depth.shape[-1]
+        le, ri, lm, rm = OF.forward_warp(frames, depth, divergence, convergence, fill=False, return_mask=True, width_base=False)
+        for i in range(frames.shape[0]):
+            for _ in range(pre_padding + 1 if not queue else 1):
+                queue.append((le[i], ri[i], lm[i], rm[i]))
+        results.append(run(False) if len(queue) == SEQ_LEN else None)
+    if queue:
+        pad = SEQ_LEN - len(queue)
+        queue.extend([queue[-1]] * pad)
+        left, right = run(True)
+        results.append((left[:left.shape[0] - pad], right[:right.shape[0] - pad]))
+    else:
+        results.append(None)
+    return results

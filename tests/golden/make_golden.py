@@ -284,6 +284,62 @@ def gen_light_inpaint():
     save("light_inpaint", **out)
 
 
+def gen_forward_inpaint():
+    """iw3/forward_inpaint.py on the reference (``--method forward_inpaint``): un-filled forward warp + hole masks, mask closing /
+    directional dilation, light_inpaint_v1 per eye (left eye mirrored) — image mode (both eyes, right only, max_width) — and
+    the 12-frame ForwardInpaintVideo queue (batches of 3, flush) around seeded models."""
+    from iw3.models.light_inpaint_v1 import LightInpaintV1
+    from iw3.models.light_video_inpaint_v1 import LightVideoInpaintV1
+    from iw3 import forward_inpaint as RF
+    from oracle import light_inpaint as OL
+    from oracle.forward_warp import synth_depth
+    out = {}
+    m = LightInpaintV1().eval()
+    m.load_state_dict(OL.random_state_dict(701), strict=True)
+    img = object.__new__(RF.ForwardInpaintImage)
+    torch.nn.Module.__init__(img)
+    img.model = m
+    depth = synth_depth(19, 2, 58, 104, "smooth_edges")
+    c = torch.stack([synth_image(184, 3, 116, 208), synth_image(185, 3, 116, 208)])
+    out["depth"], out["c"] = depth, c
+    le, re = img.infer(c, depth, divergence=2.5, convergence=0.5, synthetic_view="both", inner_dilation=1, outer_dilation=2)
+    out["fi_left"], out["fi_right"] = le.half(), re.half()
+    le, re = img.infer(c[:1], depth[:1], divergence=2.0, convergence=0.3, synthetic_view="right")
+    assert torch.equal(le, c[:1])
+    out["fi_right_only"] = re.half()
+    le, re = img.infer(c[1:], depth[1:], divergence=2.0, convergence=0.5, synthetic_view="left", max_width=150)
+    out["fi_left_mw"], out["fi_right_mw"] = le.half(), re.half()
+    print("image", float((out["fi_left"].float() - c).abs().mean()), tuple(out["fi_left_mw"].shape))
+    # video queue
+    mv = LightVideoInpaintV1().eval()
+    mv.load_state_dict(OL.video_random_state_dict(801), strict=True)
+    vid = object.__new__(RF.ForwardInpaintVideo)
+    torch.nn.Module.__init__(vid)
+    vid.model, vid.model_seq, vid.pre_padding, vid.post_padding = mv, 12, 3, 3
+    vid.frame_queue = vid.synthetic_view = vid.inner_dilation = vid.outer_dilation = vid.base_width = None
+    n_frames = 15
+    wide = synth_image(231, 3, 44, 80 + n_frames)
+    frames = torch.stack([wide[:, :, i:i + 80] for i in range(n_frames)])
+    vdepth = synth_depth(25, 1, 22, 40, "smooth_edges").expand(n_frames, 1, 22, 40).clone()
+    vdepth = (vdepth + torch.linspace(0, 0.2, n_frames).view(-1, 1, 1, 1)).clamp(0, 1)
+    out["v_frames"], out["v_depth"] = frames, vdepth
+    lefts, rights, sizes = [], [], []
+    for i in range(0, n_frames, 3):
+        le, ri = vid.infer(frames[i:i + 3], vdepth[i:i + 3], divergence=2.0, convergence=0.5, synthetic_view="both",
+                           inner_dilation=1, outer_dilation=1)
+        sizes.append(0 if le is None else le.shape[0])
+        if le is not None:
+            lefts.append(le.clone()); rights.append(ri.clone())
+    le, ri = vid.flush()
+    sizes.append(0 if le is None else le.shape[0])
+    if le is not None:
+        lefts.append(le.clone()); rights.append(ri.clone())
+    out["v_sizes"] = np.asarray(sizes)
+    out["v_left"], out["v_right"] = torch.cat(lefts).half(), torch.cat(rights).half()
+    print("video queue sizes", sizes, tuple(out["v_left"].shape))
+    save("forward_inpaint", **out)
+
+
 def gen_light_video_inpaint_ml():
     """inpaint.light_video_inpaint_v1_medium / _large (base_dim 128 / 192, lv2_mlp_ratio 2; light_video_inpaint_v1.py:230-246)
     on the reference: one 12-frame infer each; outputs stored as fp16."""
@@ -744,7 +800,7 @@ def gen_depth_aa():
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
           "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "vda_online": gen_vda_online, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint, "light_video_inpaint_ml": gen_light_video_inpaint_ml,
-          "frame_pool": gen_frame_pool}
+          "frame_pool": gen_frame_pool, "forward_inpaint": gen_forward_inpaint}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)
