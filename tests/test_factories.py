@@ -1,0 +1,110 @@
+"""Model factories (host plumbing): ``create_stereo_model`` / ``create_depth_model`` resolve the reference's checkpoint FILE
+NAMES in a local model directory (no downloads), read the reference's ``.pth`` container and hand back the engine classes
+with the attributes ``iw3/stereo_model_factory.py`` / ``iw3/depth_model_factory.py`` set."""
+import os
+
+import pytest
+import torch
+
+from oracle import light_inpaint as OL
+from oracle import mlbw as OM
+
+
+def _save(name, sd, path, **kw):
+    from nunif_amd.nunif.models import create_model, save_model
+    from nunif_amd.iw3 import models  # noqa: F401
+    m = create_model(name, **kw)
+    m.load_state_dict(sd, strict=True)
+    save_model(m, path)
+
+
+@pytest.fixture(scope="module")
+def model_dir(tmp_path_factory):
+    from nunif_amd.iw3 import stereo_model_factory as F
+    from nunif_amd.synthetic import row_flow_v3_state_dict
+    d = str(tmp_path_factory.mktemp("hub"))
+    ck = os.path.join(d, "checkpoints")
+    os.makedirs(ck)
+    _save("sbs.row_flow_v3", row_flow_v3_state_dict(301), os.path.join(ck, F.ROW_FLOW_V3))
+    _save("sbs.row_flow_v3", row_flow_v3_state_dict(302), os.path.join(ck, F.ROW_FLOW_V3_SYM))
+    _save("sbs.mlbw_l2", OM.random_state_dict(411, 2, False), os.path.join(ck, F.MLBW[("l2", 2)]))
+    _save("sbs.mlbw_l2s", OM.random_state_dict(412, 2, True), os.path.join(ck, F.MLBW[("l2s", 1)]))
+    _save("sbs.mask_mlbw_l2", OM.random_state_dict(431, 2, False, hole_mask=True), os.path.join(ck, F.MASK_MLBW_L2_D1))
+    _save("inpaint.light_inpaint_v1", OL.random_state_dict(701), os.path.join(ck, F.INPAINT_MODELS["light_inpaint_v1"]["image"]))
+    _save("inpaint.light_video_inpaint_v1", OL.video_random_state_dict(801),
+          os.path.join(ck, F.INPAINT_MODELS["light_inpaint_v1"]["video"]))
+    return d
+
+
+def test_create_stereo_model_resolves_names_levels_and_flags(model_dir):
+    from nunif_amd.iw3 import stereo_model_factory as F
+    from nunif_amd.iw3.forward_inpaint import ForwardInpaint
+    from nunif_amd.iw3.mlbw_inpaint import MLBWInpaint
+    assert [F.get_mlbw_divergence_level(d) for d in (1, 4, 4.5, 7, 7.1, 10)] == [1, 1, 2, 2, 3, 3]
+    m = F.create_stereo_model("row_flow_v3", 2.0, -1, model_dir=model_dir)
+    assert (m.name, m.symmetric, m.delta_output) == ("sbs.row_flow_v3", False, True)
+    assert F.create_stereo_model("row_flow_sym", 2.0, -1, model_dir=model_dir).symmetric is True
+    m = F.create_stereo_model("mlbw_l2", 5.0, -1, model_dir=model_dir)                     # divergence 5 -> the d2 file
+    assert m.delta_output is True and m.name.startswith("sbs.mlbw")
+    assert F.create_stereo_model("mlbw_l2s", 5.0, -1, model_dir=model_dir).name == m.name   # the small net exists for d1 only
+    assert F.create_stereo_model("mlbw_l2s", 3.0, -1, model_dir=model_dir) is not None
+    with pytest.raises(FileNotFoundError, match="iw3_mlbw_l2_d3_weak"):
+        F.create_stereo_model("mlbw_l2", 9.0, -1, use_weak_convergence_model=True, model_dir=model_dir)
+    for method in ("forward", "forward_fill", "backward", "NULL"):
+        assert F.create_stereo_model(method, 2.0, -1, model_dir=model_dir) is None
+    side = F.create_stereo_model("forward_inpaint", 2.0, -1, model_dir=model_dir)
+    assert isinstance(side, ForwardInpaint)
+    side.set_mode("video")
+    side = F.create_stereo_model("mlbw_l2_inpaint", 2.0, -1, model_dir=model_dir)
+    assert isinstance(side, MLBWInpaint)
+    side.set_mode("video")
+    with pytest.raises(ValueError):
+        F.create_stereo_model("bogus", 2.0, -1, model_dir=model_dir)
+    with pytest.raises(NotImplementedError):
+        F.create_stereo_model("row_flow_v2", 2.0, -1, model_dir=model_dir)
+    with pytest.raises(ValueError):
+        F.load_image_inpaint_model("unknown_net", -1, model_dir)
+
+
+def test_create_depth_model_names():
+    from nunif_amd.iw3.depth_model_factory import create_depth_model
+    from nunif_amd.iw3.named_depth_models import MODEL_FILE_NAMES, NAME_MAP
+    assert set(NAME_MAP) == set(MODEL_FILE_NAMES)
+    kinds = {n: type(create_depth_model(n)).__name__ for n in ("Any_V2_S", "Distill_Any_S", "Any_V2_K_L", "NULL", "VDA_S", "VDA_Stream_S")}
+    assert kinds == {"Any_V2_S": "DepthAnythingModel", "Distill_Any_S": "DepthAnythingModel", "Any_V2_K_L": "DepthAnythingModel",
+                     "NULL": "NullDepthModel", "VDA_S": "VideoDepthAnythingModel", "VDA_Stream_S": "VideoDepthAnythingStreamingModel"}
+    assert create_depth_model("Any_V2_K_L").is_metric() and not create_depth_model("Any_V2_S").is_metric()
+    with pytest.raises(ValueError):
+        create_depth_model("ZoeD_N")                                   # external hub nets that are not restated
+    with pytest.raises(NotImplementedError):
+        create_depth_model("Any_V2_L").load(gpu=-1)                    # known name, geometry not instantiated: loud
+    with pytest.raises(FileNotFoundError):
+        m = create_depth_model("Any_V2_S")
+        m.model_dir = "/nonexistent"
+        m.load(gpu=-1)
+    null = create_depth_model("NULL").load(gpu=-1, resolution=64)
+    assert null.infer(torch.rand(2, 3, 50, 60)).shape == (2, 1, 64, 64) and null.infer(torch.rand(3, 50, 60)).shape == (1, 64, 64)
+
+
+@pytest.mark.gpu
+def test_named_depth_model_on_the_engine(hiplib, tmp_path):
+    """``create_depth_model("Any_V2_S")`` reads a checkpoint FILE in the published key layout and equals the engine driven
+    directly; tta / edge dilation / EMA plumbing come from BaseDepthModel."""
+    from nunif_amd.iw3.base_depth_model import CallableDepthModel
+    from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+    from nunif_amd.iw3.depth_model_factory import create_depth_model
+    from nunif_amd.synthetic import depth_anything_v2_state_dict
+    sd = depth_anything_v2_state_dict(601)
+    os.makedirs(tmp_path / "checkpoints")
+    torch.save(sd, tmp_path / "checkpoints" / "depth_anything_v2_vits.pth")
+    m = create_depth_model("Any_V2_S")
+    m.model_dir = str(tmp_path)
+    m.load(gpu=0, resolution=200)                                   # -> 210 (multiple of 14)
+    assert m.lower_bound == 210 and m.get_name() == "DepthAnything"
+    x = torch.rand(2, 3, 120, 200, generator=torch.Generator().manual_seed(4)).to("cuda:0")
+    ref = CallableDepthModel(HipDepthAnythingV2(sd, "cuda:0"), lower_bound=210).load(gpu=0)
+    for kw in (dict(), dict(tta=True, edge_dilation=2)):
+        assert torch.equal(m.infer(x, **kw), ref.infer(x, **kw))
+    assert m.infer(x[0]).shape[0] == 1
+    with pytest.raises(ValueError):
+        m.infer(x, depth_aa=True)                                     # no DepthAA checkpoint next to it
