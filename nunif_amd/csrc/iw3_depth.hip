@@ -9,6 +9,8 @@
 // All HBM-bound.  dilate_edge: the reference runs ~12 full-frame ATen ops per iteration; here an iteration is one
 // statistics pass (range mean / variance / min / max per image, fp64 block-reduced atomics) and one apply pass that
 // recomputes the 3x3 range, the Gaussian and the max-pool from a 5x5 neighbourhood in registers.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace nunif {
@@ -270,6 +272,8 @@ extern "C" int nunif_hip_resize_aa(const float *x, float *y, float *tmp, int64_t
     return NUNIF_HIP_OK;
 }
 
+static const long kStatBlocks = []() { const char *e = getenv("NUNIF_STAT_BLOCKS"); return e ? atol(e) : 96L; }();
+
 extern "C" int nunif_hip_dilate_edge(const float *x, float *y, float *work, int32_t B, int32_t H, int32_t W,
                                      int32_t n_x, int32_t n_y, void *stream) {
     NUNIF_REQUIRE(x && y && work && B > 0 && H > 0 && W > 0 && n_x >= 0 && n_y >= 0, "dilate_edge: bad argument");
@@ -291,7 +295,10 @@ extern "C" int nunif_hip_dilate_edge(const float *x, float *y, float *work, int3
     int dst_i = (total_iters % 2 == 1) ? 0 : 1;
     auto run = [&](int ky, int kx) -> int {
         range_stats_init_kernel<<<(B + 63) / 64, 64, 0, s>>>(stats, B);   // rmin starts at the largest uint key
-        dim3 g1((unsigned)std::min<long>(((long)H * W + 255) / 256, 512), B);
+        // every workgroup ends in 4 atomics on ONE cache line (stats[b]); they serialise in L2 at ~25 ns each, so the
+        // grid is kept small: with 512 workgroups the 2048 atomics WERE the kernel (56 us for a 392 x 686 map,
+        // profiles/r01d_kernel_stats_iw3_sched.csv); 96 workgroups leave ~3 px x 9 taps x 10 rounds per thread
+        dim3 g1((unsigned)std::min<long>(((long)H * W + 255) / 256, kStatBlocks), B);
         range_stats_kernel<<<g1, 256, 0, s>>>(src, stats, H, W);
         dim3 g2((unsigned)((W + kDilTW - 1) / kDilTW), (unsigned)((H + kDilTH - 1) / kDilTH), B);
         dilate_apply_kernel<<<g2, 256, 0, s>>>(src, bufs[dst_i], stats, H, W, ky, kx);
@@ -314,7 +321,7 @@ extern "C" int nunif_hip_minmax_normalize(const float *x, float *y, float *minma
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("minmax_normalize", s, 0.0, (double)B * n_per * 12.0);
     minmax_init_kernel<<<(B + 63) / 64, 64, 0, s>>>(reinterpret_cast<unsigned int *>(minmax), B);
-    dim3 g1((unsigned)std::min<long>((n_per + 255) / 256, 512), B);
+    dim3 g1((unsigned)std::min<long>((n_per + 255) / 256, kStatBlocks), B);       // same-address atomics: see dilate_edge
     minmax_stats_kernel<<<g1, 256, 0, s>>>(x, minmax, n_per);
     dim3 g2((unsigned)((n_per + 255) / 256), B);
     minmax_apply_kernel<<<g2, 256, 0, s>>>(x, y, minmax, n_per);

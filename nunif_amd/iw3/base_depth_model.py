@@ -64,6 +64,40 @@ class BaseDepthModel(metaclass=ABCMeta):
     def get_model(self):
         return self.model
 
+    # -- lifecycle parity (iw3/base_depth_model.py:43-49,56-96,140-149).  The engine's kernels are already native: compiling
+    #    is a no-op, so the context manager the CLI wraps around video processing costs nothing.
+    def compile_context(self, enabled=True):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def compile(self):
+        pass
+
+    def clear_compiled_model(self):
+        pass
+
+    @classmethod
+    def supported(cls, model_type):
+        return False
+
+    @classmethod
+    def has_checkpoint_file(cls, model_type):
+        return False
+
+    @classmethod
+    def get_model_path(cls, model_type):
+        return None
+
+    @classmethod
+    def force_update(cls):
+        pass
+
+    def is_image_supported(self):
+        return True
+
+    def is_video_supported(self):
+        return True
+
     @abstractmethod
     def infer(self, x, **kwargs):
         pass
