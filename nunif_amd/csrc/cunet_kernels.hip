@@ -10,36 +10,53 @@
 // channels of one pixel).  Cout <= 256, so ALL output-channel tiles of a pixel group stay in accumulators while the
 // kernel walks K = taps x Cin: activations stream from HBM exactly once (next k-step prefetched into registers),
 // weights stream [k-step][n-tile] through the 2 x 8 KiB LDS ring shared by the 4 waves.
+#include <cstdlib>
+
 #include "swin_kernels.h"
 
 namespace nunif {
 
 #define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
-template <int NT, int MF>
+// RES = true: the WHOLE weight stream (ksteps x NT fragments <= 80 KiB) is copied into LDS once and the workgroup is persistent
+// over pixel groups — no barrier and no weight latency inside the k loop.  With NT x MF <= 16 MFMAs per k-step the ring's
+// one-chunk prefetch distance (2 k-steps, ~500 cycles) is shorter than an L2 round trip and every chunk boundary stalled
+// all four waves (DPT-head 64 -> 64 3x3 convs: 81 TFLOP/s, profiles/r01d_kernel_stats_iw3_sched.csv).
+template <int NT, int MF, bool RES>
 __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
     constexpr int CH = 8;
-    __shared__ __attribute__((aligned(16))) f16x8 ring[2][CH * 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_conv[];
+    f16x8 *ring = reinterpret_cast<f16x8 *>(smem_conv);                  // ring form: [2][CH * 64]; RES: [ksteps * NT][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int r16 = lane & 15;
     const int grp = lane >> 4;
     const long M = (long)g.B * g.Ho * g.Wo;
-    const long m_base = ((long)blockIdx.x * 4 + wave) * (MF * 16);
-
+    const long n_groups = (M + 4 * MF * 16 - 1) / (4 * MF * 16);
     const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.wstream);      // zero-padded by 16 KiB on the host
-    f16x8 st0 = gsrc[tid], st1 = gsrc[tid + 256];
+    if (RES) {
+        const int nfrag = g.kh * g.kw * (g.Cin >> 5) * NT;
+        for (int i = tid; i < nfrag * 64; i += 256) ring[i] = gsrc[i];
+        __syncthreads();
+    }
+    int gi = blockIdx.x;                                                 // ring form: gridDim.x == n_groups, ONE trip (the
+    do {                                                                 // loop condition folds to false at compile time)
+    const long m_base = ((long)gi * 4 + wave) * (MF * 16);
+
+    f16x8 st0, st1;
+    if (!RES) { st0 = gsrc[tid]; st1 = gsrc[tid + 256]; }
     auto wfrag = [&](int fi) -> f16x8 {
+        if (RES) return ring[fi * 64 + lane];
         const int c = fi / CH;
         if (fi % CH == 0) {
-            ring[c & 1][tid] = st0;
-            ring[c & 1][tid + 256] = st1;
+            ring[(c & 1) * (CH * 64) + tid] = st0;
+            ring[(c & 1) * (CH * 64) + tid + 256] = st1;
             __syncthreads();
             st0 = gsrc[(c + 1) * (CH * 64) + tid];
             st1 = gsrc[(c + 1) * (CH * 64) + tid + 256];
         }
-        return ring[c & 1][(fi % CH) * 64 + lane];
+        return ring[(c & 1) * (CH * 64) + (fi % CH) * 64 + lane];
     };
 
     // per-lane pixel bases (element offsets) of the MF tiles
@@ -161,13 +178,31 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
             }
         }
     }
+    gi += gridDim.x;
+    } while (RES && gi < (int)n_groups);   // pixel groups
 }
+
+// read per launch (a getenv is noise next to a launch) so that a test can compare both forms inside one process
+static inline int conv_res_enabled() { const char *e = getenv("NUNIF_CONV_RES"); return e ? atoi(e) : 1; }
 
 template <int NT, int MF>
 static int launch_conv_t(const ConvArgs &g, hipStream_t s) {
     const long M = (long)g.B * g.Ho * g.Wo;
     const long rows = 4 * MF * 16;
-    conv_kernel<NT, MF><<<(unsigned)((M + rows - 1) / rows), 256, 0, s>>>(g);
+    const long n_groups = (M + rows - 1) / rows;
+    const size_t res_bytes = (size_t)g.kh * g.kw * (g.Cin >> 5) * NT * 1024;
+    // resident weights pay when the ring cannot hide its refills (few MFMAs per k-step) and there is enough work per workgroup
+    if (conv_res_enabled() && NT * MF <= 16 && res_bytes <= 80 * 1024 && n_groups >= 512) {
+        static bool configured = false;
+        if (!configured) {
+            NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv_kernel<NT, MF, true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            configured = true;
+        }
+        conv_kernel<NT, MF, true><<<512, 256, res_bytes, s>>>(g);
+    } else {
+        conv_kernel<NT, MF, false><<<(unsigned)n_groups, 256, 16 * 1024, s>>>(g);
+    }
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }

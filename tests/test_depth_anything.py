@@ -61,3 +61,17 @@ def test_hip_backbone_full_size_in_the_pipeline(hiplib):
     frame = synth_image(96, 3, 1080, 1920)
     d = model.infer(frame.to("cuda:0"), tta=False, edge_dilation=2)
     assert d.shape == (1, 392, 686) and torch.isfinite(d).all() and float(d.std()) > 0
+
+
+@pytest.mark.gpu
+def test_resident_weight_conv_is_bit_identical_to_the_ring_form(hiplib, monkeypatch):
+    """conv_kernel<NT,MF,RES>: the LDS-resident persistent form (taken for >= 512 pixel groups, i.e. the large DPT-head maps
+    at batch 2) issues the same MFMAs in the same order as the ring form."""
+    from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+    net = HipDepthAnythingV2(ODA.random_state_dict(602), "cuda:0")
+    x = _norm(torch.stack([synth_image(95, 3, 392, 686), synth_image(97, 3, 392, 686)])).to("cuda:0")
+    monkeypatch.setenv("NUNIF_CONV_RES", "1")
+    a = net(x).cpu()
+    monkeypatch.setenv("NUNIF_CONV_RES", "0")
+    b = net(x).cpu()
+    assert float(a.std()) > 0 and torch.equal(a, b)
