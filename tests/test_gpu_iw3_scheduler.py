@@ -131,3 +131,27 @@ def test_single_and_windowed_routes(hiplib, name):
     ref = (torch.from_numpy(g[name + "_frames"]) * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
     assert got.shape == ref.shape and int((got.int() - ref.int()).abs().max()) <= 1
     assert psnr(got.float() / 255, ref.float() / 255) >= 50.0
+
+
+def test_sharded_entry_point_on_one_gpu(hiplib, monkeypatch):
+    """``stereo_frames_sharded`` (the N-GPU entry, here world = 1) on the HIP ops == the pool on the same frames: the scalar
+    replay of the EMA recurrence on the host gives the ranges the device-side scaler gives."""
+    from nunif_amd.iw3 import utils as U
+    from nunif_amd.iw3.frame_pipeline import stereo_frames_sharded
+    name = "ema"
+    n, bs, cuts, ema, _ = FRAME_POOL_CASES[name]
+    _, pooled = _run(name, monkeypatch, True)
+    args = _args(bs)
+    dm = _fake_depth()
+    dm.enable_ema(ema[0], buffer_size=ema[1])
+
+    def stereo_fn(xs, ds, reset_pts):
+        le, ri = U.apply_divergence(ds, xs, args)
+        return [U.to_frame_tensor(U.postprocess_image(le[i], ri[i], args)) for i in range(xs.shape[0])]
+
+    frames = [U.to_tensor(_u8(x), device=DEV) for x in frame_pool_frames(n)]
+    out = stereo_frames_sharded(frames, list(range(n)), set(cuts), dm, stereo_fn, bs)
+    got = torch.stack([f.cpu() for f in out])
+    assert got.shape == pooled.shape
+    diff = (got.int() - pooled.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
