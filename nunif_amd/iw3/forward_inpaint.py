@@ -163,6 +163,24 @@ class ForwardInpaint:
     def reset(self):
         self.model[self.mode].reset()
 
+    # torch.compile plumbing of the reference (compile / clear_compiled_model / compile_context, CompileContext in
+    # iw3/inpaint_utils.py:191-203): the engine's nets are already native, so these cost nothing and change nothing
+    def compile(self):
+        pass
+
+    def clear_compiled_model(self):
+        pass
+
+    def compile_context(self, enabled=True):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def train(self, mode=True):
+        return self                      # inference only (the reference pins eval() the same way)
+
+    def eval(self):
+        return self
+
     @torch.inference_mode()
     def infer(self, x, depth, divergence, convergence, synthetic_view="both", inner_dilation=0, outer_dilation=0,
               max_width=None, enable_amp=True, **_kwargs):

@@ -52,6 +52,13 @@ def resolve_mapper_function(name):
     raise NotImplementedError(f"mapper={name}")
 
 
+def chain(x, functions):
+    """iw3/mapper.py:123-126."""
+    for f in functions:
+        x = f(x)
+    return x
+
+
 def get_mapper(name):
     functions = []
     for part in name.split(":"):

@@ -57,6 +57,14 @@ class Waifu2xImageModel():
     def cuda(self):
         return self.to("cuda")
 
+    def cpu(self):
+        """hub.py:80-81.  The model can be parked on the CPU (weights only); ``infer`` raises there: no CPU fallback."""
+        return self.to("cpu")
+
+    def __call__(self, x, tta=False, output_type="pil", **kwargs):
+        """hub.py:163: ``model(x)`` == ``model.infer(x)``."""
+        return self.infer(x, tta=tta, output_type=output_type, **kwargs)
+
     def half(self):
         self.ctx.half()
         return self

@@ -21,6 +21,11 @@ from .models import cunet, swin_unet, vgg_7  # noqa: F401  (registers waifu2x.sw
 METHODS = ("scale", "scale4x", "noise_scale", "noise_scale4x", "noise")
 
 
+
+def can_compile(model):
+    """waifu2x/utils.py:25-40 decides whether ``torch.compile`` may wrap a model.  Engine models are already native."""
+    return False
+
 class Waifu2x():
     def __init__(self, model_dir, gpus):
         self.scale_model = None
