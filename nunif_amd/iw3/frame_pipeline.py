@@ -494,7 +494,7 @@ def stereo_frames_sharded(frames, pts, segment_pts, depth_model, stereo_fn, batc
             for k, i in enumerate(mine):
                 raw[i] = (x[k], d[k])
         if world > 1:
-            dev = frames[mine[0]].device if mine else _any_device(frames)
+            dev = frames[mine[0]].device if mine else _any_device(frames, depth_model)
             buf = [torch.empty_like(local, device=dev) for _ in range(world)]
             dist.all_gather(buf, local.to(dev), group=group)
             table = [b.cpu() for b in buf]
@@ -517,7 +517,7 @@ def stereo_frames_sharded(frames, pts, segment_pts, depth_model, stereo_fn, batc
     dist.all_gather_object(meta, None if probe is None else (tuple(probe.shape), str(probe.dtype)), group=group)
     shape, dtype = next(m for m in meta if m is not None)
     dtype = getattr(torch, dtype.split(".")[-1])
-    dev = probe.device if probe is not None else _any_device(frames)
+    dev = probe.device if probe is not None else _any_device(frames, depth_model)
     block = torch.zeros((per_rank, *shape), dtype=dtype, device=dev)
     for k, i in enumerate(mine_all):
         block[k] = out_local[i]
@@ -534,8 +534,9 @@ def stereo_frames_sharded(frames, pts, segment_pts, depth_model, stereo_fn, batc
     return None
 
 
-def _any_device(frames):
+def _any_device(frames, depth_model=None):
     for f in frames:
         if f is not None:
             return f.device
-    return torch.device("cpu")
+    dev = getattr(depth_model, "device", None)          # a rank that owns no frame at all still joins the collectives
+    return torch.device(dev) if dev is not None else torch.device("cpu")

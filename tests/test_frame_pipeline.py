@@ -192,6 +192,27 @@ def test_sharded_single_process(name):
     assert torch.equal(torch.stack(out), torch.from_numpy(g[name + "_frames"]))
 
 
+def _worker_idle(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = frame_pool_frames(2)
+    frames = frames if rank == 0 else [None, None]                     # one batch only: rank 1 owns nothing
+    with torch.inference_mode():
+        out = stereo_frames_sharded(frames, [0, 1], set(), _model((0.5, 2)), _stereo_fn(_args(2)), 2, dst=0)
+    if rank == 0:
+        torch.save(torch.stack(out), path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_rank_without_frames_still_joins(tmp_path):
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_worker_idle, args=(2, _free_port(), path), nprocs=2, join=True)
+    ref = stereo_frames_sharded(frame_pool_frames(2), [0, 1], set(), _model((0.5, 2)), _stereo_fn(_args(2)), 2)
+    assert torch.equal(torch.load(path), torch.stack(ref))
+
+
 def test_sharded_refuses_temporal_models():
     dm = _model(None)
     dm.has_temporal_state = True
