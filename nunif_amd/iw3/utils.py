@@ -191,6 +191,40 @@ def _max_output_resize(sbs, args):
     return sbs
 
 
+def debug_depth_image(depth, args):
+    """iw3/utils.py:489-502 (``--debug-depth``): raw | mapped depth side by side as a grey 3-channel image."""
+    depth = depth.float()
+    out = torch.cat([depth, get_mapper(args.mapper)(depth.unsqueeze(0))[0]], dim=2)
+    return out.repeat((3, 1, 1))
+
+
+def process_image(x, args, depth_model, side_model=None, skip_autocrop=None, autocrop_uncrop=False):
+    """The image-mode entry (iw3/utils.py:505-548): ``preprocess_image`` -> depth -> per-image min-max -> stereo method ->
+    ``postprocess_image``; CHW float in, CHW float SBS (or the chosen format) out.  ``--autocrop`` (border detection,
+    ``nunif/utils/autocrop.py``) is not on the engine and is refused rather than ignored."""
+    assert depth_model.get_ema_buffer_size() == 1
+    g = lambda k, d=None: getattr(args, k, d)     # noqa: E731
+    if g("autocrop") is not None and not skip_autocrop:
+        raise NotImplementedError("--autocrop is outside the HIP engine's scope; crop the frame before process_image")
+    with torch.inference_mode():
+        x = preprocess_image(x, args)
+        depth = depth_model.infer(x, tta=g("tta", False), low_vram=g("low_vram", False), enable_amp=not g("disable_amp", False),
+                                  edge_dilation=g("edge_dilation", 0), depth_aa=g("depth_aa", False))
+        depth = depth_model.minmax_normalize_chw(depth)
+        if g("debug_depth"):
+            return debug_depth_image(depth, args)
+        if g("rgbd") or g("half_rgbd"):
+            left_eye, right_eye = apply_rgbd(x, depth, mapper=args.mapper)
+            return postprocess_image(left_eye, right_eye, args)
+        while True:                                   # a video inpaint side model answers None until its queue is full
+            left_eye, right_eye = apply_divergence(depth, x, args, side_model)
+            if left_eye is not None:
+                break
+        if left_eye.ndim == 4:
+            left_eye, right_eye = left_eye[0], right_eye[0]
+        return postprocess_image(left_eye, right_eye, args)
+
+
 def to_tensor(frame_hwc, device=None):
     """uint8/uint16 HWC (numpy array or tensor) -> CHW float on the device (video.py:218-223)."""
     if not torch.is_tensor(frame_hwc):

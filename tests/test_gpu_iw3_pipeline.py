@@ -185,3 +185,25 @@ def test_frame_ring_roundtrip_order_and_values(hiplib):
         o = [ring.submit(f) for f in frames[:3]] + ring.drain()
         got = [v for v in o if v is not None]
         assert all(np.array_equal(a, b) for a, b in zip(frames[:3], got))
+
+
+@pytest.mark.gpu
+def test_process_image_entry(hiplib):
+    """iw3.utils.process_image (image mode): the same kernels in the same order as the hand-assembled pipeline."""
+    from nunif_amd.iw3.base_depth_model import CallableDepthModel
+    from nunif_amd.iw3.utils import apply_divergence, postprocess_image, process_image
+    net = lambda t: t.mean(1) + 0.3 * t[:, 0]                              # noqa: E731
+    model = CallableDepthModel(net, lower_bound=56).load(gpu=0)
+    x = synth_image(97, 3, 120, 200).to(DEV)
+    args = SimpleNamespace(mapper="mul_1", convergence=0.5, divergence=3.0, method="forward_fill", synthetic_view="both",
+                           edge_dilation=2, tta=False)
+    out = process_image(x, args, model)
+    depth = model.minmax_normalize_chw(model.infer(x, edge_dilation=2))
+    ref = postprocess_image(*apply_divergence(depth, x, args), args)
+    assert out.shape == (3, 120, 400) and torch.equal(out, ref)
+    rgbd = process_image(x, SimpleNamespace(**{**vars(args), "rgbd": True}), model)
+    assert rgbd.shape == (3, 120, 400) and torch.equal(rgbd[:, :, :200], x)
+    dbg = process_image(x, SimpleNamespace(**{**vars(args), "debug_depth": True}), model)
+    assert dbg.shape[0] == 3 and dbg.shape[2] == 2 * depth.shape[2]
+    with pytest.raises(NotImplementedError):
+        process_image(x, SimpleNamespace(**{**vars(args), "autocrop": "black"}), model)
