@@ -10,6 +10,7 @@
 // channels of one pixel).  Cout <= 256, so ALL output-channel tiles of a pixel group stay in accumulators while the
 // kernel walks K = taps x Cin: activations stream from HBM exactly once (next k-step prefetched into registers),
 // weights stream [k-step][n-tile] through the 2 x 8 KiB LDS ring shared by the 4 waves.
+#include <algorithm>
 #include <cstdlib>
 
 #include "swin_kernels.h"
@@ -183,6 +184,7 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
 }
 
 // read per launch (a getenv is noise next to a launch) so that a test can compare both forms inside one process
+static inline long conv_res_min_groups() { const char *e = getenv("NUNIF_CONV_RES_MIN_GROUPS"); return e ? atol(e) : 512L; }
 static inline int conv_res_enabled() { const char *e = getenv("NUNIF_CONV_RES"); return e ? atoi(e) : 1; }
 
 template <int NT, int MF>
@@ -191,15 +193,18 @@ static int launch_conv_t(const ConvArgs &g, hipStream_t s) {
     const long rows = 4 * MF * 16;
     const long n_groups = (M + rows - 1) / rows;
     const size_t res_bytes = (size_t)g.kh * g.kw * (g.Cin >> 5) * NT * 1024;
-    // resident weights pay when the ring cannot hide its refills (few MFMAs per k-step) and there is enough work per workgroup
-    if (conv_res_enabled() && NT * MF <= 16 && res_bytes <= 80 * 1024 && n_groups >= 512) {
+    // resident weights pay when the ring cannot hide its refills (few MFMAs per k-step) AND every workgroup has many pixel groups
+    // to amortise its 36-72 KiB copy over.  Measured (profiles/r01d_ab_conv_res.txt, whole iw3 frame, same box): >= 512 groups
+    // only: -0.8 %; all launch sizes (NUNIF_CONV_RES_MIN_GROUPS=1): +3.8 % — for the small DPT-head maps one trip per workgroup
+    // does not pay for the copy, although both forms are bit-identical on every size (the conv tests pass either way).
+    if (conv_res_enabled() && NT * MF <= 16 && res_bytes <= 80 * 1024 && n_groups >= conv_res_min_groups()) {
         static bool configured = false;
         if (!configured) {
             NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv_kernel<NT, MF, true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             configured = true;
         }
-        conv_kernel<NT, MF, true><<<512, 256, res_bytes, s>>>(g);
+        conv_kernel<NT, MF, true><<<(unsigned)std::min<long>(n_groups, 512), 256, res_bytes, s>>>(g);
     } else {
         conv_kernel<NT, MF, false><<<(unsigned)n_groups, 256, 16 * 1024, s>>>(g);
     }
