@@ -340,6 +340,27 @@ def gen_forward_inpaint():
     save("forward_inpaint", **out)
 
 
+def gen_swin_v2():
+    """waifu2x.swin_unet_v2_{1x,2x,4x} on the reference (waifu2x/models/swin_unet_v2.py): constructor weights under a seed with
+    every bias / norm weight re-drawn (oracle.swin_unet_v2.randomize), one 64 x 64 tile batch each; stored: state-dict checksum,
+    input, output.  The HIP engine does not carry this family yet — the fixture pins the oracle the kernels will be held to."""
+    from waifu2x.models import swin_unet_v2 as RV
+    from oracle import swin_unet_v2 as OV
+    out = {}
+    x = torch.stack([synth_image(301, 3, 64, 64), synth_image(302, 3, 64, 64)])
+    out["x"] = x
+    for tag, cls, seed in (("1x", RV.SwinUNet1xV2, 11), ("2x", RV.SwinUNet2xV2, 12), ("4x", RV.SwinUNet4xV2, 13)):
+        torch.manual_seed(seed)
+        m = cls().eval()
+        sd = OV.randomize(m.state_dict(), seed + 100)
+        m.load_state_dict(sd, strict=True)
+        y = m(x)
+        print(tag, tuple(y.shape), float(y.std()), float(((y <= 0) | (y >= 1)).float().mean()), m.i2i_offset, m.i2i_scale)
+        out["y_" + tag], out["raw_" + tag] = y, m.unet(x)          # clamped model output, un-clamped network output
+        out["sdsum_" + tag] = sd_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    save("swin_unet_v2", **out)
+
+
 def gen_light_video_inpaint_ml():
     """inpaint.light_video_inpaint_v1_medium / _large (base_dim 128 / 192, lv2_mlp_ratio 2; light_video_inpaint_v1.py:230-246)
     on the reference: one 12-frame infer each; outputs stored as fp16."""
@@ -800,7 +821,7 @@ def gen_depth_aa():
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
           "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "vda_online": gen_vda_online, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint, "light_video_inpaint_ml": gen_light_video_inpaint_ml,
-          "frame_pool": gen_frame_pool, "forward_inpaint": gen_forward_inpaint}
+          "frame_pool": gen_frame_pool, "forward_inpaint": gen_forward_inpaint, "swin_v2": gen_swin_v2}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)
