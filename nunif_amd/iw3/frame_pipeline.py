@@ -86,8 +86,10 @@ def pix_fmt_requires_16bit(pix_fmt):
 
 
 class _StagePipeline:
-    """Two HIP streams per device: D (depth stage) and S (stereo stage).  ``to_stereo`` publishes tensors made on D to
-    S with one event; ``record_stream`` keeps the caching allocator from recycling them while S still reads them."""
+    """Two HIP streams per device: D (depth stage) and S (stereo stage).  ``depth_stage`` / ``stereo_stage`` are context managers
+    that order the stage behind its producer (D waits for the caller's upload stream, S waits for D) and ``record_stream`` every
+    tensor that crosses, so the caching allocator cannot recycle it while the other stream still reads it; ``stereo_done`` is the
+    event a consumer waits on."""
 
     def __init__(self, device, enabled):
         self.enabled = bool(enabled) and torch.device(device).type == "cuda"
