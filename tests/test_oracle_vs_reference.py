@@ -47,3 +47,69 @@ def test_forward_2x_random_tile(ref):
     m.load_state_dict(sd)
     x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(3))
     assert (m(x) - O.model_forward(sd, x)).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("view", ["both", "left", "right"])
+def test_frame_queue_matches_reference_under_random_operations(view):
+    """The 12-frame inpaint queue (iw3/inpaint_utils.py:98-188) is pure torch: the product class against the reference class,
+    state for state, under the operation pattern MLBWInpaintVideo / ForwardInpaintVideo produce (adds, remove(6), fill, clear)."""
+    refstub.install()
+    import av
+    av.__version__ = "14.2.0"
+    from iw3.inpaint_utils import FrameQueue as RefQueue
+    from nunif_amd.iw3.inpaint_utils import FrameQueue
+    kw = dict(synthetic_view=view, seq=12, height=6, width=10, dtype=torch.float32, device="cpu", mask_height=3, mask_width=5)
+    a, b = RefQueue(**kw), FrameQueue(**kw)
+    g = torch.Generator().manual_seed(17)
+
+    def same():
+        assert (a.index, a.full(), a.empty()) == (b.index, b.full(), b.empty())
+        for x, y in zip(a.get(), b.get()):
+            assert torch.equal(x[:a.index], y[:b.index])
+
+    for step in range(60):
+        if a.full():
+            op = int(torch.randint(0, 3, (1,), generator=g))
+            if op == 0:
+                a.remove(6); b.remove(6)
+            elif op == 1:
+                a.clear(); b.clear()
+            else:
+                a.remove(6); b.remove(6)
+        elif not a.empty() and int(torch.randint(0, 6, (1,), generator=g)) == 0:
+            assert a.fill() == b.fill()
+        else:
+            le, ri = torch.rand(3, 6, 10, generator=g), torch.rand(3, 6, 10, generator=g)
+            masks = {}
+            if view in ("both", "left"):
+                masks["left_mask"] = torch.rand(1, 3, 5, generator=g)
+            if view in ("both", "right"):
+                masks["right_mask"] = torch.rand(1, 3, 5, generator=g)
+            a.add(le, ri, **masks); b.add(le, ri, **masks)
+        same()
+
+
+@pytest.mark.parametrize("decay,buffer_size,mode", [(0.0, 1, "minmax"), (0.75, 4, "minmax"), (0.9, 2, "max"), (0.5, 22, "minmax")])
+def test_ema_minmax_scaler_matches_reference(decay, buffer_size, mode):
+    """EMAMinMaxScaler / MinMaxBuffer (iw3/depth_scaler.py:33-142): the product class against the reference class over a frame
+    sequence with flushes at scene cuts, output for output (both are torch-CPU here; on the device the same tensor ops run)."""
+    refstub.install()
+    from iw3.depth_scaler import EMAMinMaxScaler as RefScaler
+    from nunif_amd.iw3.depth_scaler import EMAMinMaxScaler
+    a, b = RefScaler(decay=decay, buffer_size=buffer_size, mode=mode), EMAMinMaxScaler(decay=decay, buffer_size=buffer_size, mode=mode)
+    g = torch.Generator().manual_seed(23)
+    n_out = 0
+    for i in range(70):
+        frame = torch.rand(1, 5, 7, generator=g) * (0.5 + 0.05 * (i % 9)) + 0.01 * i
+        ra, rb = a.update(frame, return_minmax=True), b.update(frame, return_minmax=True)
+        assert (ra[0] is None) == (rb[0] is None)
+        if ra[0] is not None:
+            n_out += 1
+            assert torch.equal(ra[0], rb[0]) and float(ra[1]) == float(rb[1]) and float(ra[2]) == float(rb[2])
+        if i in (24, 25, 60):                                   # scene cuts (one right after another, one late)
+            fa, fb = a.flush(), b.flush()
+            assert len(fa) == len(fb) and all(torch.equal(x, y) for x, y in zip(fa, fb))
+            n_out += len(fa)
+    fa, fb = a.flush(return_minmax=True), b.flush(return_minmax=True)
+    assert len(fa) == len(fb) and all(torch.equal(x[0], y[0]) for x, y in zip(fa, fb))
+    assert n_out + len(fa) == 70
