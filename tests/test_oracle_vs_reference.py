@@ -113,3 +113,39 @@ def test_ema_minmax_scaler_matches_reference(decay, buffer_size, mode):
     fa, fb = a.flush(return_minmax=True), b.flush(return_minmax=True)
     assert len(fa) == len(fb) and all(torch.equal(x[0], y[0]) for x, y in zip(fa, fb))
     assert n_out + len(fa) == 70
+
+
+def test_host_tables_match_reference():
+    """Pure host logic compared with the reference functions over their whole argument range: mapper name resolution
+    (iw3/mapper.py:154-232), MLBW divergence levels (stereo_model_factory.py:36-42), 16-bit pixel formats (video.py:272-279),
+    the depth pre-processing size rule (depth_anything_model.py:69-100)."""
+    refstub.install()
+    import av
+    av.__version__ = "14.2.0"
+    import iw3.mapper as RM
+    import iw3.stereo_model_factory as RS
+    import nunif.utils.video as RVU
+    from nunif_amd.iw3 import mapper as M
+    from nunif_amd.iw3 import stereo_model_factory as S
+    from nunif_amd.iw3.depth_anything_model import preprocess_size
+    from nunif_amd.iw3.frame_pipeline import pix_fmt_requires_16bit
+    for metric in (False, True):
+        for mtype in ((None, "div") if metric else (None, "mul", "shift")):
+            assert M.get_mapper_levels(metric, mtype) == RM.get_mapper_levels(metric, mtype)
+            for k in range(-12, 13):
+                fs = k / 4.0
+                assert M.resolve_mapper_name(None, fs, metric, mtype) == RM.resolve_mapper_name(None, fs, metric, mtype), (fs, metric, mtype)
+        assert M.resolve_mapper_name("auto", 0, metric) == RM.resolve_mapper_name("auto", 0, metric)
+    for d in [x / 4.0 for x in range(0, 50)]:
+        assert S.get_mlbw_divergence_level(d) == RS.get_mlbw_divergence_level(d)
+    for fmt in ("yuv420p", "yuv420p10le", "p010le", "yuv444p16le", "gbrp12le", "rgb48le", "rgb24", None):
+        assert pix_fmt_requires_16bit(fmt) == RVU.pix_fmt_requires_16bit(fmt)
+    # size rule: the reference computes it inside batch_preprocess; run it on zero frames and read the shape back
+    from iw3.depth_anything_model import batch_preprocess
+    g = torch.Generator().manual_seed(31)
+    for _ in range(60):
+        h, w = (int(v) for v in torch.randint(40, 900, (2,), generator=g))
+        lb = int(torch.randint(16, 40, (1,), generator=g)) * 14
+        for limit in (False, True):
+            out = batch_preprocess(torch.zeros(1, 3, h, w), lower_bound=lb, limit_resolution=limit)
+            assert tuple(out.shape[-2:]) == tuple(preprocess_size(h, w, lb, limit_resolution=limit)), (h, w, lb, limit)
