@@ -149,3 +149,28 @@ def test_host_tables_match_reference():
         for limit in (False, True):
             out = batch_preprocess(torch.zeros(1, 3, h, w), lower_bound=lb, limit_resolution=limit)
             assert tuple(out.shape[-2:]) == tuple(preprocess_size(h, w, lb, limit_resolution=limit)), (h, w, lb, limit)
+
+
+def test_postprocess_padding_matches_reference():
+    """``postprocess_padding`` (iw3/utils.py:394-427) is integer arithmetic + zero padding: product vs reference over random sizes."""
+    refstub.install()
+    import av
+    av.__version__ = "14.2.0"
+    import iw3.utils as RU
+    from nunif_amd.iw3.utils import postprocess_padding
+
+    class TFShim:                      # torchvision's tensor pad: (left, top, right, bottom)
+        @staticmethod
+        def pad(img, padding, padding_mode="constant"):
+            le, t, r, b = padding
+            return torch.nn.functional.pad(img, (le, r, t, b), mode=padding_mode)
+    RU.TF = TFShim
+    g = torch.Generator().manual_seed(41)
+    for _ in range(80):
+        h, w = (int(v) for v in torch.randint(8, 200, (2,), generator=g))
+        pad = float(torch.rand(1, generator=g)) * 0.4
+        mode = ["tblr", "tb", "lr", "top", "16:9"][int(torch.randint(0, 5, (1,), generator=g))]
+        le, ri = torch.rand(3, h, w, generator=g), torch.rand(3, h, w, generator=g)
+        a = RU.postprocess_padding(le, ri, pad, mode)
+        b = postprocess_padding(le, ri, pad, mode)
+        assert a[0].shape == b[0].shape and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (h, w, pad, mode)
