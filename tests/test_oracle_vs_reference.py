@@ -174,3 +174,38 @@ def test_postprocess_padding_matches_reference():
         a = RU.postprocess_padding(le, ri, pad, mode)
         b = postprocess_padding(le, ri, pad, mode)
         assert a[0].shape == b[0].shape and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (h, w, pad, mode)
+
+
+@pytest.mark.parametrize("name", ["waifu2x.cunet", "waifu2x.upcunet", "waifu2x.vgg_7", "waifu2x.upconv_7", "waifu2x.swin_unet_1x",
+                                  "waifu2x.swin_unet_2x", "waifu2x.swin_unet_4x", "waifu2x.swin_unet_8x", "waifu2x.swin_unet_4xl",
+                                  "sbs.row_flow_v3", "sbs.mlbw_l2", "sbs.mlbw_l4", "sbs.mlbw_l2s", "sbs.mlbw_l4s", "sbs.mask_mlbw_l2",
+                                  "iw3.depth_aa", "inpaint.light_inpaint_v1", "inpaint.light_video_inpaint_v1",
+                                  "inpaint.light_video_inpaint_v1_medium", "inpaint.light_video_inpaint_v1_large"])
+def test_pth_container_round_trips_between_the_two_trees(name, tmp_path):
+    """The ``.pth`` container (nunif/models/utils.py:15-74) is the drop-in boundary for weights: a file written by the reference
+    loads into the engine's class of the same registered name and a file written by the engine loads into the reference's, key for
+    key."""
+    refstub.install()
+    import av
+    av.__version__ = "14.2.0"
+    import nunif.models as RNM
+    import waifu2x.models  # noqa: F401  (registers the reference's waifu2x.*)
+    import iw3.models  # noqa: F401
+    from nunif_amd.nunif import models as PNM
+    import nunif_amd.waifu2x.models.cunet, nunif_amd.waifu2x.models.swin_unet, nunif_amd.iw3.models  # noqa: F401,E401
+    import nunif_amd.waifu2x.models.vgg_7, nunif_amd.waifu2x.models.upconv_7  # noqa: F401,E401
+    torch.manual_seed(5)
+    ref_model = RNM.create_model(name).eval()
+    p1 = str(tmp_path / "from_reference.pth")
+    RNM.save_model(ref_model, p1)
+    ours, meta = PNM.load_model(p1, weights_only=True)
+    assert ours.name == ref_model.name == meta["name"]        # (factory names such as sbs.mlbw_l2 build a model named sbs.mlbw)
+    ref_sd = ref_model.state_dict()
+    our_sd = ours.state_dict()
+    assert set(our_sd) == set(ref_sd)
+    assert all(torch.equal(our_sd[k].cpu(), ref_sd[k]) for k in ref_sd)
+    assert (ours.i2i_scale, ours.i2i_offset) == (ref_model.i2i_scale, ref_model.i2i_offset)
+    p2 = str(tmp_path / "from_engine.pth")
+    PNM.save_model(ours, p2)
+    back, _ = RNM.load_model(p2, weights_only=True)
+    assert all(torch.equal(back.state_dict()[k], ref_sd[k]) for k in ref_sd)
