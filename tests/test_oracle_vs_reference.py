@@ -209,3 +209,32 @@ def test_pth_container_round_trips_between_the_two_trees(name, tmp_path):
     PNM.save_model(ours, p2)
     back, _ = RNM.load_model(p2, weights_only=True)
     assert all(torch.equal(back.state_dict()[k], ref_sd[k]) for k in ref_sd)
+
+
+def test_i2i_contract_attributes_match_for_every_registered_model():
+    """Contract B1 (nunif/models/model.py:65-86): scale / offset / blend size / default tile and batch sizes and the tile-size
+    validators (``find_valid_tile_size`` over 8 .. 1024) of every registered model, engine class vs reference class."""
+    refstub.install()
+    import av
+    av.__version__ = "14.2.0"
+    import nunif.models as RNM
+    import waifu2x.models  # noqa: F401
+    import iw3.models  # noqa: F401
+    from nunif_amd.nunif import models as PNM
+    import nunif_amd.waifu2x.models.cunet, nunif_amd.waifu2x.models.swin_unet, nunif_amd.iw3.models  # noqa: F401,E401
+    import nunif_amd.waifu2x.models.vgg_7, nunif_amd.waifu2x.models.upconv_7  # noqa: F401,E401
+    names = ["waifu2x.cunet", "waifu2x.upcunet", "waifu2x.vgg_7", "waifu2x.upconv_7", "waifu2x.swin_unet_1x", "waifu2x.swin_unet_2x",
+             "waifu2x.swin_unet_4x", "waifu2x.swin_unet_8x", "waifu2x.swin_unet_4xl", "sbs.row_flow_v3", "sbs.mlbw_l2", "sbs.mask_mlbw_l2",
+             "iw3.depth_aa", "inpaint.light_inpaint_v1", "inpaint.light_video_inpaint_v1"]
+    for name in names:
+        a, b = RNM.create_model(name), PNM.create_model(name)
+        for attr in ("name", "i2i_scale", "i2i_offset", "i2i_in_channels", "i2i_blend_size", "i2i_default_tile_size",
+                     "i2i_default_batch_size"):
+            assert getattr(a, attr, None) == getattr(b, attr, None), (name, attr, getattr(a, attr, None), getattr(b, attr, None))
+        def valid(m, t):
+            try:
+                return m.find_valid_tile_size(t)
+            except ValueError:
+                return "ValueError"              # below the smallest valid tile both raise
+        for t in list(range(8, 1025, 4)) + [None]:
+            assert valid(a, t) == valid(b, t), (name, t, valid(a, t), valid(b, t))
