@@ -70,6 +70,12 @@ struct TailToImage { const f16 *w; const float *bias; float *out; int H, W, ps, 
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
                     long M, int C, hipStream_t s, const TailToImage *to_image = nullptr, int rev = 0);
 
+// ---- the same tail at C = 192 with the weights stationary on chip (swin_block_tail_ws.hip) --------------------------
+// wws: Wp [slice 4][nt 3][ks 6] (plain k order) | W0 [4][nt 6][ks 6] | W3 [4][nt 3][ks 12] (chained k order), 1-KiB fragments
+int proj_mlp_ws_stream_frags();
+int launch_proj_mlp_ws(const f16 *att, f16 *x, const f16 *wws, const float *bp, const float *b0, const float *b3, long M,
+                       hipStream_t s, int rev = 0);
+
 // ---- fused qkv Linear + (shifted) window attention, C = 96 / 6 heads of 16 (swin_qkv_attn.hip) ---------------------
 // x: [B,H,W,C] -> att: [B,H,W,C] (pre-projection attention output at the un-rolled positions)
 int launch_qkv_attn(const f16 *x, f16 *att, const f16 *wqkv, const float *bqkv, const float *bias, int B, int H,

@@ -35,6 +35,7 @@ struct Block {
     bool fast = true;             // fused qkv+attention / register-chained tail kernels apply
     float *attn_bias = nullptr;   // [heads][36][48]
     f16 *tail_stream = nullptr;   // proj | mlp.0 | mlp.3 fragments in proj_mlp_kernel's consumption order
+    f16 *tail_ws = nullptr;       // C = 192: per-slice fragments of the weight-stationary tail (swin_block_tail_ws.hip)
     f16 *qkv_stream = nullptr;    // per-head Wq | Wk | Wv fragments in qkv_attn_w_kernel's consumption order
     // LDS-resident variant (swin_qkv_attn_r.hip): same fragment order, q rows / q bias pre-multiplied by
     // head_dim^-0.5 * log2(e); bias table fp16 [heads][36][48] * log2(e) with the "real key" column 36 = 1000
@@ -81,6 +82,7 @@ struct nunif_swin_unet {
     int snake = 1;                    // NUNIF_SNAKE=0: every kernel walks its tokens upwards
     int dir = 0;                      // direction of the next kernel; next_dir() flips it
     int fuse_to_image = 1;            // NUNIF_FUSE_TOIMAGE=0: separate gemm_kernel launch (A/B)
+    int tail_ws = 1;                  // NUNIF_TAIL_WS=0: C = 192 tails on the round-1 LDS-ring kernel (A/B)
     f16 *stem2_stream = nullptr;      // conv2 fragments in [k-step][n-tile] order for conv_kernel (cunet_kernels.hip)
     int stem2_conv = 0;               // NUNIF_STEM2_CONV=1: conv_kernel<6,4> instead of gemm_kernel<18,2> (measured slower: 1131 vs 914 us)
     bool has_proj2 = false;
@@ -263,6 +265,27 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
             }
             NUNIF_REQUIRE((int)fi == nf, "internal: tail stream has %zu fragments, expected %d", fi, nf);
             if ((rc = upload(h, stream, &bl.tail_stream))) return rc;
+            if (dim == 192) {
+                // weight-stationary tail: output-channel slice w of 4 owns proj / mlp.3 tiles 3w..3w+2 and mlp.0 tiles 6w..6w+5
+                //   Wp [w][nt 3][ks 6] (plain k order) | W0 [w][nt 6][ks 6] | W3 [w][nt 3][ks 12] (both chained)
+                std::vector<f16> ws((size_t)proj_mlp_ws_stream_frags() * 512, (f16)0.0f);
+                size_t wi = 0;
+                auto putw = [&](const std::vector<f16> &src, int frag) {
+                    std::copy(src.begin() + (size_t)frag * 512, src.begin() + (size_t)(frag + 1) * 512, ws.begin() + wi * 512);
+                    ++wi;
+                };
+                for (int w = 0; w < 4; ++w)
+                    for (int nt = 0; nt < 3; ++nt)
+                        for (int ks = 0; ks < KS; ++ks) putw(hp, (3 * w + nt) * KS + ks);
+                for (int w = 0; w < 4; ++w)
+                    for (int nt = 0; nt < 6; ++nt)
+                        for (int ks = 0; ks < KS; ++ks) putw(h0, (6 * w + nt) * KS + ks);
+                for (int w = 0; w < 4; ++w)
+                    for (int nt = 0; nt < 3; ++nt)
+                        for (int ks = 0; ks < SH; ++ks) putw(h3, (3 * w + nt) * SH + ks);
+                NUNIF_REQUIRE((int)wi == proj_mlp_ws_stream_frags(), "internal: ws tail stream has %zu fragments", wi);
+                if ((rc = upload(h, ws, &bl.tail_ws))) return rc;
+            }
         }
         const HostTensor *tab;
         if ((rc = find(m, p + "attn.relative_position_bias_table", &tab))) return rc;
@@ -392,8 +415,12 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         if ((rc = tap(h, tn + ".attn", att, tok * dim * 2, s))) return rc;
         // x = y + mlp(y), y = x + proj(attn): three GEMMs chained through registers, one read + one write of x
         const bool last = i + 1 == blocks.size();
-        if ((rc = launch_proj_mlp(att, x, bl.tail_stream, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, dim, s,
-                                  last ? to_image : nullptr, next_dir(h))))
+        if (dim == 192 && bl.tail_ws && h->tail_ws && !(last && to_image)) {
+            // C = 192: weights stationary in registers / LDS (swin_block_tail_ws.hip); NUNIF_TAIL_WS=0 restores the ring kernel
+            if ((rc = launch_proj_mlp_ws(att, x, bl.tail_ws, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, s, next_dir(h))))
+                return rc;
+        } else if ((rc = launch_proj_mlp(att, x, bl.tail_stream, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, dim, s,
+                                         last ? to_image : nullptr, next_dir(h))))
             return rc;
         if (last && to_image) break;               // x of the last block is not materialised
         if ((rc = tap(h, tn + ".out", x, tok * dim * 2, s))) return rc;
@@ -544,6 +571,7 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
     if (const char *v = getenv("NUNIF_STEM2_CONV")) h->stem2_conv = atoi(v);
     if (const char *v = getenv("NUNIF_FUSE_TOIMAGE")) h->fuse_to_image = atoi(v);
     if (const char *v = getenv("NUNIF_SNAKE")) h->snake = atoi(v);
+    if (const char *v = getenv("NUNIF_TAIL_WS")) h->tail_ws = atoi(v);
     if (const char *v = getenv("NUNIF_STEM_FUSED")) h->stem_fused = atoi(v);
     h->scale_factor = scale_factor;
     const std::string P = "unet.";
