@@ -52,9 +52,29 @@ constexpr int kWsLdsKiB = 2 * kInSlots * 6 + 3 * 6 + 2 * 12 + kWsWpFrags;     //
 
 int proj_mlp_ws_stream_frags() { return kWsWpFrags + kWsW0Frags + kWsW3Frags; }
 
+#ifdef NUNIF_ABLATIONS
+// ABL & 256: per-trip s_memtime stamps of workgroup 0 into g_ws_trace[wave 8][trip 64][point 8] (tools/trace_tail_ws.py)
+__device__ long long *g_ws_trace = nullptr;
+extern "C" int nunif_dbg_ws_trace(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ws_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define WS_STAMP(pt)                                                                                          \
+    do {                                                                                                      \
+        if constexpr ((ABL & 256) != 0) {                                                                     \
+            if (blockIdx.x == 0 && i >= 8 && i < 72 && g_ws_trace) {                                         \
+                const long long t_ = __builtin_readcyclecounter();                                            \
+                if (lane == 0) g_ws_trace[(wave * 64 + (i - 8)) * 8 + (pt)] = t_;                             \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+#else
+#define WS_STAMP(pt) do { } while (0)
+#endif
+
 // ABL != 0: timing-only ablations (wrong results), compiled only with -DNUNIF_ABLATIONS (NUNIF_BUILD_ABL=1 python -m
 // nunif_amd.build) and selected with NUNIF_TAIL_WS_ABL: 1 = no GELU polynomial, 2 = no MFMA, 4 = no HBM traffic inside the
-// loop (no att DMA, no x loads, no x' stores), 8 = no barrier
+// loop (no att DMA, no x loads, no x' stores), 8 = no barrier, 16 = no bias reads from LDS, 32 = no Wp reads from LDS,
+// 64 = stage C reads only 4 of its 12 hidden fragments
 template <int ABL>
 __global__ void __launch_bounds__(512, 2)
 proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wws, const float *__restrict__ bp,
@@ -154,12 +174,14 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
     for (int i = -2; i < n_mine; ++i) {
         if (role_h) {
             // ---- H wave: DMA of tile i + 2 + kDmaAhead, stage B of tile i + 1 ---------------------------------------------
+            WS_STAMP(0);
             const bool pipe = i + 2 + kDmaAhead < n_mine;
             if (!(ABL & 4) && pipe) {
                 int slot = in_a + kDmaAhead;
                 slot = slot >= kInSlots ? slot - kInSlots : slot;
                 dma_in(i + 2 + kDmaAhead, slot);
             }
+            WS_STAMP(1);
             if (i + 1 >= 0 && i + 1 < n_mine) {
                 const f16x8 *ys = y_l + y_b * Y_SLOT + lane;
                 f16x8 *hd = h_l + h_b * H_SLOT + lane;
@@ -168,30 +190,50 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
                 for (int ks = 0; ks < KS; ++ks) bq[ks] = ys[ks * 64];
                 f32x4 acc[HT];
 #pragma unroll
-                for (int nt = 0; nt < HT; ++nt) acc[nt] = *reinterpret_cast<const f32x4 *>(bias_l + C + ch_h + 16 * nt);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-                    for (int nt = 0; nt < HT; ++nt) {
-                        if constexpr (ABL & 2) { acc[nt][0] += (float)wr[nt * KS + ks][0] * (float)bq[ks][nt]; continue; }
-                        acc[nt] = MFMA_16x16x32(wr[nt * KS + ks], bq[ks], acc[nt]);
-                    }
+                for (int nt = 0; nt < HT; ++nt) {
+                    if constexpr (ABL & 16) { acc[nt] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f}; continue; }
+                    acc[nt] = *reinterpret_cast<const f32x4 *>(bias_l + C + ch_h + 16 * nt);
                 }
-                // two adjacent 16-channel tiles = one 8-slot fragment of the next contraction (chained k order)
+                // The GELU of this wave is ~230 VALU operations per tile and a lone wave issues one per ~5.5 cycles, so it
+                // must not queue up behind the MFMAs: the six hidden tiles go in three PAIRS (two adjacent 16-channel tiles
+                // = one 8-slot fragment of the next contraction, chained k order), and the GELU of pair p is issued next to
+                // the 12 MFMAs of pair p + 1.  (Pinning one row of 8 GELU operations behind each MFMA with sched_barrier
+                // measured the same, 164-168 vs 161-163 us, so the placement is left to the compiler.)
+                auto mfma_at = [&](int p, int j) {          // j-th of the 12 MFMAs of pair p: k-step j / 2, tile 2p + (j & 1)
+                    const int ks = j >> 1, nt = 2 * p + (j & 1);
+                    if constexpr (ABL & 2) { acc[nt][0] += (float)wr[nt * KS + ks][0] * (float)bq[ks][nt]; return; }
+                    acc[nt] = MFMA_16x16x32(wr[nt * KS + ks], bq[ks], acc[nt]);
+                };
+                auto raw_pair = [&](int p) {
+                    const f32x4 &u = acc[2 * p], &v = acc[2 * p + 1];
+                    hd[(3 * slice + p) * 64] = (f16x8){(f16)u[0], (f16)u[1], (f16)u[2], (f16)u[3], (f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                };
 #pragma unroll
-                for (int p = 0; p < HT / 2; ++p) {
+                for (int j = 0; j < 2 * KS; ++j) mfma_at(0, j);
+                WS_STAMP(2);
+#pragma unroll
+                for (int p = 1; p < HT / 2; ++p) {
                     if constexpr (ABL & 1) {
-                        const f32x4 &u = acc[2 * p], &v = acc[2 * p + 1];
-                        hd[(3 * slice + p) * 64] = (f16x8){(f16)u[0], (f16)u[1], (f16)u[2], (f16)u[3], (f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+#pragma unroll
+                        for (int j = 0; j < 2 * KS; ++j) mfma_at(p, j);
+                        raw_pair(p - 1);
                     } else {
-                        hd[(3 * slice + p) * 64] = gelu8(acc[2 * p], acc[2 * p + 1]);
+#pragma unroll
+                        for (int j = 0; j < 2 * KS; ++j) mfma_at(p, j);
+                        hd[(3 * slice + p - 1) * 64] = gelu8(acc[2 * p - 2], acc[2 * p - 1]);
                     }
                 }
+                WS_STAMP(3);
+                if constexpr (ABL & 1) raw_pair(HT / 2 - 1);
+                else hd[(3 * slice + HT / 2 - 1) * 64] = gelu8(acc[HT - 2], acc[HT - 1]);
+                WS_STAMP(4);
             }
             // the next trip's stage A reads tile i + 3: requested kDmaAhead trips ago
             dma_wait(pipe);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WS_STAMP(5);
         } else {
+            WS_STAMP(0);
             // ---- P wave: stage C of tile i, stage A of tile i + 2 -------------------------------------------------------------
             const bool do_a = i + 2 < n_mine, do_c = i >= 0;
             const f16x8 *as = att_l + in_a * ATT_SLOT + lane;
@@ -203,7 +245,10 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
             auto req_a = [&](int ks) {
                 aq[ks % 3] = as[ks * 64];
 #pragma unroll
-                for (int nt = 0; nt < PT; ++nt) wq[ks % 3][nt] = ws[(nt * KS + ks) * 64];
+                for (int nt = 0; nt < PT; ++nt) {
+                    if constexpr (ABL & 32) { wq[ks % 3][nt] = wr[nt * KS + ks]; continue; }
+                    wq[ks % 3][nt] = ws[(nt * KS + ks) * 64];
+                }
             };
             // ---- stage C: x' = y + b3 + W3 hidden ------------------------------------------------------------------------
             if (do_c) {
@@ -215,14 +260,14 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
                 f32x4 acc[PT];
 #pragma unroll
                 for (int nt = 0; nt < PT; ++nt) {
-                    const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_l + 3 * C + ch_p + 16 * nt);
+                    const f32x4 b = (ABL & 16) ? (f32x4){0.1f, 0.2f, 0.3f, 0.4f} : *reinterpret_cast<const f32x4 *>(bias_l + 3 * C + ch_p + 16 * nt);
                     const int tile = 3 * slice + nt;
                     const f16x4 yo = *(reinterpret_cast<const f16x4 *>(ys + (tile >> 1) * 64) + (tile & 1));
                     acc[nt] = (f32x4){(float)yo[0] + b[0], (float)yo[1] + b[1], (float)yo[2] + b[2], (float)yo[3] + b[3]};
                 }
 #pragma unroll
                 for (int ks = 0; ks < HS; ++ks) {
-                    if (ks + kHAhead < HS) hq[(ks + kHAhead) % (kHAhead + 1)] = hs[(ks + kHAhead) * 64];
+                    if (!(ABL & 64) && ks + kHAhead < HS) hq[(ks + kHAhead) % (kHAhead + 1)] = hs[(ks + kHAhead) * 64];
                     if (ks == HS - 4) req_a(0);
                     if (ks == HS - 2) req_a(1);
 #pragma unroll
@@ -231,6 +276,7 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
                         acc[nt] = MFMA_16x16x32(wr[nt * HS + ks], hq[ks % (kHAhead + 1)], acc[nt]);
                     }
                 }
+                WS_STAMP(2);
                 const long m = tile_of(i) * TOK + r16;
                 if (m < M && (!(ABL & 4) || acc[0][0] == 12345.f)) {
 #pragma unroll
@@ -239,6 +285,7 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
                         *reinterpret_cast<f16x4 *>(x + m * C + ch_p + 16 * nt) = o;
                     }
                 }
+                WS_STAMP(3);
             } else {
                 req_a(0);
                 req_a(1);
@@ -250,7 +297,7 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
                 f32x4 acc[PT];
 #pragma unroll
                 for (int nt = 0; nt < PT; ++nt) {
-                    const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_l + ch_p + 16 * nt);
+                    const f32x4 b = (ABL & 16) ? (f32x4){0.1f, 0.2f, 0.3f, 0.4f} : *reinterpret_cast<const f32x4 *>(bias_l + ch_p + 16 * nt);
                     // channels c .. c + 3 of token r16 in the plain layout: fragment c / 32, lane r16 + 16 ((c % 32) / 8)
                     const int c = ch_p + 16 * nt;
                     const f16x4 xv = *(reinterpret_cast<const f16x4 *>(xs + (c >> 5) * 64 + r16 + 16 * ((c & 31) >> 3)) + ((c >> 2) & 1));
@@ -272,11 +319,14 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
                     *(reinterpret_cast<f16x4 *>(yd + (tile >> 1) * 64) + (tile & 1)) = yv;
                 }
             }
+            WS_STAMP(4);
             // no vmcnt wait here: the x' stores of stage C are fire-and-forget
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WS_STAMP(5);
         }
         // one rendezvous per trip: LDS writes of stages A / B (and the DMA'd tiles) become visible to the other waves
         if constexpr (!(ABL & 8)) asm volatile("s_barrier" ::: "memory");
+        WS_STAMP(6);
         in_a = in_a + 1 == kInSlots ? 0 : in_a + 1;
         { const int t = y_c; y_c = y_b; y_b = y_a; y_a = t; }
         { const int t = h_c; h_c = h_b; h_b = t; }
@@ -291,7 +341,7 @@ int launch_proj_mlp_ws(const f16 *att, f16 *x, const f16 *wws, const float *bp, 
     const long n_tiles = (M + 15) / 16;
     const unsigned blocks = (unsigned)std::min<long>(n_tiles, 256);
     auto go = [&](auto kern, int slot) -> int {
-        static bool configured[16] = {false};
+        static bool configured[1024] = {false};
         if (!configured[slot]) {
             NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             configured[slot] = true;
@@ -303,13 +353,11 @@ int launch_proj_mlp_ws(const f16 *att, f16 *x, const f16 *wws, const float *bp, 
 #ifdef NUNIF_ABLATIONS
     static const int abl = getenv("NUNIF_TAIL_WS_ABL") ? atoi(getenv("NUNIF_TAIL_WS_ABL")) : 0;
     switch (abl) {
-        case 1: rc = go(proj_mlp_ws_kernel<1>, 1); break;
-        case 2: rc = go(proj_mlp_ws_kernel<2>, 2); break;
-        case 3: rc = go(proj_mlp_ws_kernel<3>, 3); break;
-        case 4: rc = go(proj_mlp_ws_kernel<4>, 4); break;
-        case 7: rc = go(proj_mlp_ws_kernel<7>, 7); break;
-        case 8: rc = go(proj_mlp_ws_kernel<8>, 8); break;
-        case 12: rc = go(proj_mlp_ws_kernel<12>, 12); break;
+#define WS_ABL_CASE(v) case v: rc = go(proj_mlp_ws_kernel<v>, v); break;
+        WS_ABL_CASE(1) WS_ABL_CASE(2) WS_ABL_CASE(3) WS_ABL_CASE(4) WS_ABL_CASE(7) WS_ABL_CASE(8) WS_ABL_CASE(12)
+        WS_ABL_CASE(16) WS_ABL_CASE(32) WS_ABL_CASE(48) WS_ABL_CASE(112) WS_ABL_CASE(23) WS_ABL_CASE(39) WS_ABL_CASE(55)
+        WS_ABL_CASE(119) WS_ABL_CASE(127) WS_ABL_CASE(256) WS_ABL_CASE(257) WS_ABL_CASE(258) WS_ABL_CASE(259)
+#undef WS_ABL_CASE
         default: rc = go(proj_mlp_ws_kernel<0>, 0); break;
     }
 #else

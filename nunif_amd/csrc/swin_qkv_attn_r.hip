@@ -36,6 +36,9 @@ struct QkvAttnRArgs {
     const float *btab32;     // CBIAS: [heads][36][52] fp32: log2e * bias, cols 36..47 = -1000 (padded keys), 48..51 unused
     int B, H, W, shift, n_windows;
     int rev;                 // 1: walk the windows from the last to the first (snake order, see launch_qkv_attn_r)
+#ifdef NUNIF_ABLATIONS
+    int abl;                 // timing-only (NUNIF_ATTN_ABL): 1 = x is loaded for the first window of a wave only, 2 = no att stores
+#endif
 };
 
 __device__ __forceinline__ f16x8 cat8r(f16x4 lo, f16x4 hi) {
@@ -269,7 +272,11 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                         sum += __shfl_xor(sum, 32);
                     }
                     const float inv = __builtin_amdgcn_rcpf(sum);
+#ifdef NUNIF_ABLATIONS
+                    const bool store = (16 * qt + r16) < 36 && !(a.abl & 2);
+#else
                     const bool store = (16 * qt + r16) < 36;
+#endif
                     // 16-byte stores: two adjacent 16-channel tiles -> one 8-channel run per lane (common.h pair_to_run).
                     // head_dim 32: the two tiles of this head.
                     f16x4 ov[NTH];
@@ -299,6 +306,9 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = xn[mt][ks];
                 }
             } else {
+#ifdef NUNIF_ABLATIONS
+                if (a.abl & 1) continue;
+#endif
                 if (wi + wstride < a.n_windows) load_x(wmap(wi + wstride), xf, pix);
             }
         }
@@ -331,6 +341,10 @@ int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv
     a.B = B; a.H = H; a.W = W; a.shift = shift;
     a.n_windows = B * (H / 6) * (W / 6);
     a.rev = rev;            // snake order between consecutive kernels (swin_unet.cpp next_dir)
+#ifdef NUNIF_ABLATIONS
+    static const int attn_abl = getenv("NUNIF_ATTN_ABL") ? atoi(getenv("NUNIF_ATTN_ABL")) : 0;
+    a.abl = attn_abl;
+#endif
     const double tok = (double)B * H * W;
     static const bool cbias = !(getenv("NUNIF_ATTN_CBIAS") && atoi(getenv("NUNIF_ATTN_CBIAS")) == 0);   // A/B switch
     static const int waves96 = getenv("NUNIF_ATTN_WAVES") ? atoi(getenv("NUNIF_ATTN_WAVES")) : 16;

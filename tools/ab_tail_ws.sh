@@ -13,4 +13,4 @@ print("TAIL_WS=$v value", r["value"], "single", r.get("single_stream"))
 for c in r["kernel_classes"][:5]: print("   ", c)
 PY
 done
-tools/abl_tail_ws.sh
+ABLS="${ABLS:-0 1 2 3 8}" tools/abl_tail_ws.sh

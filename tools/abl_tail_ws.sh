@@ -1,7 +1,7 @@
 #!/bin/bash
 # timing-only ablations of the weight-stationary C = 192 tail (needs a NUNIF_BUILD_ABL=1 build; results are wrong)
 mkdir -p gpurun_out
-for v in 0 1 2 3 4 7 8 12; do
+for v in ${ABLS:-0 1 2 3 4 7 8 12}; do
   NUNIF_TAIL_WS_ABL=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-host-frames --streams 1 > gpurun_out/abl_$v.json 2> gpurun_out/abl_$v.err
   python - <<PY
 import json
