@@ -1,32 +1,44 @@
 #!/usr/bin/env python3
-"""Benchmark of the nunif hot path on MI355X: waifu2x swin_unet 2x, tile 256, synthetic 1080p frames.
+"""Benchmark of the nunif hot path on MI355X.  Headline: waifu2x swin_unet 2x, tile 256, synthetic 1080p frames.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
 
-A *step* is one full tiled render (gather -> 45 tiles through the net -> stitch) of one 1080p frame per rank, with
-the input frame already resident in HBM.  Frames are independent, so ranks shard frames with no data-path
-collective (weak scaling: every rank renders K frames).  ``value`` = input megapixels of all ranks / wall time
-(max over ranks), the metric BASELINE.json names ("MPix" = source-frame pixels).
+``--gpus N`` with N > 1 and no rendezvous in the environment RE-LAUNCHES this script as N ranks (one per GPU) through
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``; launched by torchrun (the
+driver's form) it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  Backend: ``nccl`` (= RCCL).
+
+A *step* is one full tiled render (gather -> 45 tiles through the net -> stitch) of ``--streams`` 1080p frames per
+rank, the input frames already resident in HBM.  Frames are independent, so ranks shard frames with no data-path
+collective (weak scaling: every rank renders K steps).  ``value`` = input megapixels of all ranks / wall time (barrier +
+``torch.cuda.synchronize()`` on both sides, max over ranks), the metric BASELINE.json names ("MPix" = source-frame
+pixels).  The default K gives a timed region of >= 3 s.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     — the dominant kernel (largest share of HIP-event time, classes are kernel symbols): algorithmic
-                 FLOPs or bytes per launch / measured average launch duration, against the MI355X peak that bounds
-                 it (arithmetic intensity vs the 2.5 PFLOP/s / 8 TB/s ridge); ``traffic`` = HBM bytes per launch
-                 from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE, KiB units)
-  cpu_baseline — the CPU oracle (oracle/, a torch-fp32 port of the reference path) timed on the host cores on a
-                 bounded sample of the same workload
+  roofline      — the dominant kernel (largest share of HIP-event time; classes are kernel symbols): algorithmic FLOPs or
+                  bytes per launch / measured average launch duration, against the MI355X peak that bounds it
+                  (arithmetic intensity vs the 2.5 PFLOP/s / 8 TB/s ridge); ``traffic`` = HBM bytes per launch from the
+                  newest committed rocprofv3 PMC passes that contain THIS build's kernel (profiles/, FETCH_SIZE x2 +
+                  WRITE_SIZE, KiB units), null otherwise
+  single_stream — the same frames one at a time on one stream (the per-kernel numbers are measured this way)
+  gathered      — N > 1: the same frames through ``nunif_amd.parallel.render_sharded``: every finished frame is quantised
+                  on the device (HIP kernel) and sent to rank 0 with a non-blocking point-to-point transfer (RCCL over
+                  xGMI) that overlaps the next render; rate = frames DELIVERED to rank 0 / wall time
+  iw3           — BASELINE config 4 on one GPU: uint8 1080p frames in HBM -> FrameCallbackPool -> Depth-Anything-V2 ViT-S
+                  geometry -> forward_fill / row_flow_v3 -> SBS uint8, with the forward-warp kernel's own HBM roofline
+                  (40 B / pixel) and the CPU oracle of forward_fill + dilate_edge timed beside it
+  scale4x_4k    — BASELINE config 3 on one GPU: swin_unet 4x on a 4K frame (170 tiles of 256)
+  cpu_baseline  — the CPU oracle (oracle/, a torch-fp32 port of the reference path) on the host cores: warm-up, then the
+                  median of 3 passes over a stated crop, thread count = physical cores
 """
 import argparse
 import json
 import math
 import os
 import re
+import socket
+import statistics
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -37,32 +49,88 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP
 HBM_PEAK_GBS = 8000.0       # spec (≈6.3 TB/s achievable)
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("NUNIF_BENCH_BATCH", "45")),
+                    help="tiles per model launch (the reference's tile minibatch; results do not depend on it)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("NUNIF_BENCH_STREAMS", "2")),
+                    help="frames rendered CONCURRENTLY per step, one HIP stream + one engine handle each (a step then "
+                         "covers this many frames; the tails of one frame's kernels overlap the other frame's work)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-frames", action="store_true",
+                    help="skip the extra (reported, never `value`) PCIe-inclusive measurement through the pinned frame ring")
+    ap.add_argument("--no-iw3", action="store_true", help="skip the iw3 (config 4) sub-record")
+    ap.add_argument("--no-4k", action="store_true", help="skip the 4K 4x (config 3) sub-record")
+    return ap.parse_args()
+
+
+def relaunch_as_ranks(args):
+    """``python bench.py --gpus N`` without a rendezvous: become ``torch.distributed.run`` with N local ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(cmd[0], cmd, env)
+
+
 def synth_frame(seed, h, w):
+    import torch
     g = torch.Generator().manual_seed(seed)
     low = torch.rand(1, 3, h // 16 + 1, w // 16 + 1, generator=g)
     up = torch.nn.functional.interpolate(low, size=(h, w), mode="bilinear", align_corners=False)[0]
     return torch.clamp(up * 0.8 + 0.2 * torch.rand(3, h, w, generator=g), 0, 1)
 
 
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def median_time(fn, repeats=3):
+    """One untimed warm-up call, then the median wall time of ``repeats`` calls."""
+    out = fn()
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), out
+
+
 def cpu_baseline(sd, frame):
-    """Time the oracle's tiled_render on a crop of the same frame (bounded: ~10-30 s of CPU work)."""
+    """The oracle's tiled_render on a crop of the same frame: 4 tiles of 256 in ONE minibatch, all physical cores."""
+    import torch
     from oracle import seam_blending as OS
     from oracle import swin_unet as O
-    crop = frame[:, :480, :480].contiguous()        # 3x3 tiles of 256 (step 236) — same tile size as the GPU run
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    crop = frame[:, :476, :476].contiguous()        # 2x2 tiles of 256 (input step 236 + 2 x 8 offset rows), same tile size
     fn = lambda mb: O.model_forward(sd, mb)         # noqa: E731
-    t0 = time.perf_counter()
-    out = OS.tiled_render(crop, fn, 2, 16, 8, TILE, 4)
-    dt = time.perf_counter() - t0
-    return {"value": round(crop.shape[1] * crop.shape[2] / 1e6 / dt, 5), "unit": "MPix/s",
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle tiled_render of a 480x480 crop (9 tiles of 256, batch 4), {dt:.1f} s"}, crop, out
+    dt, out = median_time(lambda: OS.tiled_render(crop, fn, 2, 16, 8, TILE, 4), repeats=3)
+    return {"value": round(crop.shape[1] * crop.shape[2] / 1e6 / dt, 5), "unit": "MPix/s", "cores": cores, "kind": "port",
+            "sample": f"oracle tiled_render of a 476x476 crop of the bench frame (4 tiles of 256 in one minibatch of 4), "
+                      f"1 warm-up + median of 3 passes, {dt:.2f} s per pass, torch threads = physical cores"}, crop, out
 
 
 def pmc_traffic_bytes(symbol):
-    """HBM bytes per launch of ``symbol`` from the newest committed PMC summaries (profiles/rNN_pmc_*.txt)."""
+    """HBM bytes per launch of ``symbol`` from the newest committed PMC summaries (profiles/rNN_pmc_*.txt) that list it."""
     def per_launch(path):
         key = re.sub(r"[^A-Za-z0-9]", "", symbol.split("<")[0])
         args = re.findall(r"\d+", symbol.split("<", 1)[1]) if "<" in symbol else []
+        if not os.path.exists(path):
+            return None
         for line in open(path):
             name = line.split(" launches=")[0]
             flat = re.sub(r"[^A-Za-z0-9]", "", name)
@@ -83,31 +151,186 @@ def pmc_traffic_bytes(symbol):
     return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("NUNIF_BENCH_BATCH", "45")),
-                    help="tiles per model launch (the reference's tile minibatch; results do not depend on it)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("NUNIF_BENCH_STREAMS", "2")),
-                    help="frames rendered CONCURRENTLY per step, one HIP stream + one engine handle each (a step then "
-                         "covers this many frames; the tails of one frame's kernels overlap the other frame's work)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-frames", action="store_true",
-                    help="skip the extra (reported, never `value`) PCIe-inclusive measurement through the pinned frame ring")
-    args = ap.parse_args()
+def kernel_table(recs, n_frames):
+    classes = []
+    total = sum(r["total_ms"] for r in recs) or 1.0
+    for r in sorted(recs, key=lambda r: -r["total_ms"]):
+        sec = r["total_ms"] * 1e-3
+        classes.append({"kernel": r["name"], "share": round(r["total_ms"] / total, 4),
+                        "avg_us": round(1e3 * r["total_ms"] / max(1, r["launches"]), 2),
+                        "launches_per_frame": r["launches"] // max(1, n_frames),
+                        "tflops": round(r["flops"] / sec / 1e12, 2) if sec else 0.0,
+                        "gbs": round(r["bytes"] / sec / 1e9, 1) if sec else 0.0})
+    return classes
 
+
+def roofline_of(rec, with_pmc=True):
+    n = max(1, rec["launches"])
+    avg_s = rec["total_ms"] * 1e-3 / n
+    flops_l, bytes_l = rec["flops"] / n, rec["bytes"] / n
+    intensity = flops_l / bytes_l if bytes_l else float("inf")
+    ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    traffic, src = pmc_traffic_bytes(rec["name"]) if with_pmc else (None, None)
+    if intensity >= ridge:
+        ach = flops_l / avg_s / 1e12
+        roof = {"kernel": rec["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
+    else:
+        ach = bytes_l / avg_s / 1e9
+        roof = {"kernel": rec["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+    roof.update({"traffic": traffic, "traffic_source": f"profiles/{src}_pmc_*" if src else None,
+                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": n, "algorithmic_flops_per_launch": flops_l,
+                 "algorithmic_bytes_per_launch": bytes_l,
+                 "flop_per_byte": round(intensity, 1) if math.isfinite(intensity) else None})
+    if flops_l:
+        roof.update({"achieved_tflops": round(flops_l / avg_s / 1e12, 2),
+                     "mfma_frac": round(flops_l / avg_s / 1e12 / MFMA_PEAK_TFLOPS, 4)})
+    return roof
+
+
+# ---- iw3 (BASELINE config 4) on one GPU ------------------------------------------------------------------------------------
+class DeviceFrame:
+    """A decoded frame that already sits in HBM as HWC uint8 (PCIe stays out of the timed region)."""
+
+    def __init__(self, data, pts):
+        self.data, self.pts = data, pts
+
+
+def iw3_record(dev, with_cpu):
+    import torch
+    from nunif_amd import _hip
+    from nunif_amd.iw3 import utils as U
+    from nunif_amd.iw3.base_depth_model import CallableDepthModel
+    from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+    from nunif_amd.iw3.frame_pipeline import FrameCallbackPool, PipelineOps, bind_batch_frame_callback
+    from nunif_amd.iw3.models.row_flow_v3 import RowFlowV3
+    from nunif_amd.synthetic import depth_anything_v2_state_dict, row_flow_v3_state_dict, synth_depth
+
+    H, W, batch, n_frames = FRAME_H, FRAME_W, 4, 96
+    depth_model = CallableDepthModel(HipDepthAnythingV2(depth_anything_v2_state_dict(601), str(dev)))
+    depth_model.load(gpu=dev.index or 0)
+    side = RowFlowV3().eval()
+    side.load_state_dict(row_flow_v3_state_dict(301))
+    side = side.to(dev)
+    side.delta_output = True
+    g = torch.Generator().manual_seed(5)
+    frames = [(synth_frame(900 + i, H, W) * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().to(dev) for i in range(4)]
+
+    def run(method, n):
+        a = argparse.Namespace(batch_size=batch, mapper="none", convergence=0.5, divergence=2.0, method=method,
+                               synthetic_view="both", warp_steps=None, stereo_width=None, preserve_screen_border=False,
+                               disable_amp=False, edge_dilation=2, pix_fmt="yuv420p", state={"device": dev})
+        depth_model.reset()
+        depth_model.enable_ema(0.75, buffer_size=4)
+        ops = PipelineOps(to_tensor=lambda frame, device=None: U.to_tensor(frame.data, device=device))
+        cb, pre = bind_batch_frame_callback(depth_model, side, {n // 2}, a, ops=ops)
+        pool = FrameCallbackPool(frame_callback=cb, preprocess_callback=pre, batch_size=batch, device=str(dev), max_workers=2,
+                                 max_batch_queue=3, require_pts=True, require_flush=True, ops=ops)
+        n_out = 0
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n):
+            r = pool(DeviceFrame(frames[i % len(frames)], i))
+            n_out += len(r) if r else 0
+        n_out += len(pool(None))
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        assert n_out == n, (n_out, n)
+        return dt / n
+
+    rec = {"config": "BASELINE configs[3]: uint8 1080p frames in HBM -> FrameCallbackPool -> bind_batch_frame_callback "
+                     f"(batch {batch}, Depth-Anything-V2 ViT-S geometry with random-init weights — parity unpinned, "
+                     "EMA 0.75 x 4-frame look-ahead, one scene cut, edge_dilation 2) -> stereo -> SBS uint8",
+           "frame": [H, W], "frames": n_frames, "batch": batch, "unit": "input MPix/s"}
+    for method in ("forward_fill", "row_flow_v3"):
+        run(method, 2 * batch)
+        dt = min(run(method, n_frames) for _ in range(2))
+        rec[method] = {"ms_per_frame": round(dt * 1e3, 3), "fps": round(1 / dt, 1), "value": round(H * W / dt / 1e6, 1)}
+    # the forward-warp kernel on its own: algorithmic 40 B / pixel (read rgb + depth once, write two eyes)
+    from nunif_amd.iw3.forward_warp import apply_divergence_forward_warp
+    from nunif_amd.iw3.dilation import dilate_edge
+    c = torch.stack([synth_frame(910 + i, H, W) for i in range(2)]).to(dev)
+    d = synth_depth(1, 2, H, W, "smooth_edges").to(dev)
+    dsmall = synth_depth(2, 2, 392, 686, "smooth_edges").to(dev) * 5
+    fw = lambda: apply_divergence_forward_warp(c, d, 2.0, 0.5, method="forward_fill", width_base=False)      # noqa: E731
+    for _ in range(3):
+        fw()
+        dilate_edge(dsmall, 2)
+    torch.cuda.synchronize(dev)
+    _hip.profile_read(reset=True)
+    _hip.profile_enable(True)
+    for _ in range(20):
+        fw()
+    torch.cuda.synchronize(dev)
+    recs = {r["name"]: r for r in _hip.profile_read(reset=True)}
+    _hip.profile_enable(False)
+    if "forward_warp" in recs:
+        roof = roofline_of(recs["forward_warp"], with_pmc=True)
+        roof["kernel"] = "forward_warp_kernel"
+        roof["workload"] = "forward_fill, both eyes, 2 x 1080p per launch, divergence 2.0"
+        rec["roofline"] = roof
+    t0 = time.perf_counter()
+    for _ in range(50):
+        dilate_edge(dsmall, 2)
+    torch.cuda.synchronize(dev)
+    rec["dilate_edge_us_per_call"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+    if with_cpu:
+        from oracle import dilation as OD
+        from oracle import forward_warp as OF
+        cores = physical_cores()
+        torch.set_num_threads(cores)
+        cc, dc, dsc = c[:1].cpu(), d[:1].cpu(), dsmall[:1].cpu()
+        dt, _ = median_time(lambda: (OD.dilate_edge(dsc, 2), OF.forward_warp(cc, dc, 2.0, 0.5, fill=True)), repeats=3)
+        rec["cpu_baseline"] = {"value": round(H * W / 1e6 / dt, 3), "unit": "MPix/s", "cores": cores, "kind": "port",
+                               "sample": "oracle dilate_edge(392x686 depth, 2 iterations) + forward_fill of one whole 1080p "
+                                         f"frame (both eyes), 1 warm-up + median of 3, {dt:.2f} s per pass; the depth "
+                                         "network is external to the reference and not part of this baseline"}
+    return rec
+
+
+def scale4x_record(dev):
+    import torch
+    from nunif_amd.nunif.utils.render import tiled_render
+    from nunif_amd.synthetic import swin_unet_state_dict
+    from nunif_amd.waifu2x.models.swin_unet import SwinUNet4x
+    m = SwinUNet4x().eval()
+    m.load_state_dict(swin_unet_state_dict(104, 4))
+    m = m.to(dev)
+    x = synth_frame(77, 2160, 3840).to(dev)
+    for _ in range(2):
+        tiled_render(x, m, tile_size=TILE, batch_size=34)
+    torch.cuda.synchronize(dev)
+    n = 12
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tiled_render(x, m, tile_size=TILE, batch_size=34)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / n
+    del m
+    return {"config": "BASELINE configs[2] on one GPU: swin_unet 4x (photo geometry, random-init), 4K frame, tile 256 "
+                      "(170 tiles in minibatches of 34) -> 8640 x 15360", "frames": n, "ms_per_frame": round(dt * 1e3, 2),
+            "value": round(2160 * 3840 / dt / 1e6, 1), "unit": "input MPix/s",
+            "output_mpix_per_s": round(16 * 2160 * 3840 / dt / 1e6, 1)}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_as_ranks(args)                      # does not return
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus})")
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
@@ -115,6 +338,7 @@ def main():
     from nunif_amd.nunif.utils.render import tiled_render
     from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x
     from nunif_amd.synthetic import swin_unet_state_dict    # seeded random-init weights (no checkpoints offline)
+    from nunif_amd.parallel import ConcurrentRenderer, render_sharded
 
     torch.set_grad_enabled(False)
     sd = swin_unet_state_dict(102, 2)
@@ -125,7 +349,6 @@ def main():
         mm.load_state_dict(sd)
         return mm
 
-    from nunif_amd.parallel import ConcurrentRenderer
     pool = ConcurrentRenderer(make_model, n_streams, dev)       # n_streams engine replicas, one HIP stream each
     model = pool.models[0]
     # a few distinct frames per rank, resident in HBM before the timed region
@@ -159,56 +382,64 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- N > 1: the same work with every finished frame delivered to rank 0 (quantised on the device, one non-blocking
+    # point-to-point transfer per frame over RCCL / xGMI, overlapped with the next render) --------------------------------
+    gathered = None
+    if world > 1:
+        n_g = max(world, min(args.steps, 32)) * world
+        n_g -= n_g % world
+        shared = [frames[i % len(frames)] for i in range(n_g)]          # content differs per rank; geometry is what matters
+        delivered = [0]
+
+        def count(i, f):
+            delivered[0] += 1
+
+        render_sharded(shared[:2 * world], lambda f: render(model, f), dst=0, on_frame=count)      # warm-up (RCCL init)
+        delivered[0] = 0
+        barrier()
+        t1 = time.perf_counter()
+        render_sharded(shared, lambda f: render(model, f), dst=0, on_frame=count)
+        barrier()
+        dtg = time.perf_counter() - t1
+        tg = torch.tensor([dtg], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        dtg = float(tg.item())
+        if rank == 0:
+            assert delivered[0] == n_g, (delivered[0], n_g)
+            gathered = {"value": round(FRAME_H * FRAME_W / 1e6 * n_g / dtg, 2), "unit": "MPix/s", "frames": n_g,
+                        "ms_per_frame_per_gpu": round(1e3 * dtg / (n_g / world), 3),
+                        "bytes_delivered_per_frame": 2 * FRAME_H * 2 * FRAME_W * 3,
+                        "path": "render (one frame at a time per rank) -> HIP quantise to HWC uint8 -> batch_isend_irecv "
+                                "to rank 0, overlapped with the next render (nunif_amd.parallel.render_sharded)"}
+
     # ---- the same K frames on ONE stream (reported next to `value`; the per-kernel roofline below is measured this way) ----
     single = None
     if n_streams > 1 and rank == 0:
+        n1 = min(args.steps, 100)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(n1):
             render(model, frames[i % len(frames)])
         torch.cuda.synchronize(dev)
         dt1 = time.perf_counter() - t1
-        single = {"value": round(FRAME_H * FRAME_W / 1e6 * args.steps / dt1, 2), "unit": "MPix/s",
-                  "ms_per_frame": round(1e3 * dt1 / args.steps, 3), "frames": args.steps}
+        single = {"value": round(FRAME_H * FRAME_W / 1e6 * n1 / dt1, 2), "unit": "MPix/s",
+                  "ms_per_frame": round(1e3 * dt1 / n1, 3), "frames": n1}
 
     # ---- per-kernel timing with HIP events on the launch stream (library hooks), outside the timed region ----------
     roofline, classes = None, []
     if rank == 0:
+        _hip.profile_read(reset=True)
         _hip.profile_enable(True)
-        n_prof = max(1, min(3, args.steps))
+        n_prof = max(1, min(5, args.steps))
         for i in range(n_prof):             # per-kernel durations are measured on ONE stream (no overlap between frames)
             tiled_render(frames[i % len(frames)], model, tile_size=TILE, batch_size=args.batch_size)
         torch.cuda.synchronize(dev)
         recs = _hip.profile_read(reset=True)
         _hip.profile_enable(False)
-        total = sum(r["total_ms"] for r in recs) or 1.0
-        for r in sorted(recs, key=lambda r: -r["total_ms"]):
-            sec = r["total_ms"] * 1e-3
-            classes.append({"kernel": r["name"], "share": round(r["total_ms"] / total, 4),
-                            "avg_us": round(1e3 * r["total_ms"] / max(1, r["launches"]), 2),
-                            "launches_per_frame": r["launches"] // n_prof,
-                            "tflops": round(r["flops"] / sec / 1e12, 2) if sec else 0.0,
-                            "gbs": round(r["bytes"] / sec / 1e9, 1) if sec else 0.0})
+        classes = kernel_table(recs, n_prof)
         dom = max(recs, key=lambda r: r["total_ms"])
-        n = max(1, dom["launches"])
-        avg_s = dom["total_ms"] * 1e-3 / n
-        flops_l, bytes_l = dom["flops"] / n, dom["bytes"] / n
-        intensity = flops_l / bytes_l if bytes_l else float("inf")
-        ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-        traffic, src = pmc_traffic_bytes(dom["name"])
-        if intensity >= ridge:
-            ach = flops_l / avg_s / 1e12
-            roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
-        else:
-            ach = bytes_l / avg_s / 1e9
-            roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
-        roofline.update({"traffic": traffic, "traffic_source": f"profiles/{src}_pmc_*" if src else None,
-                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_flops_per_launch": flops_l,
-                         "algorithmic_bytes_per_launch": bytes_l, "flop_per_byte": round(intensity, 1),
-                         "achieved_tflops": round(flops_l / avg_s / 1e12, 2),
-                         "mfma_frac": round(flops_l / avg_s / 1e12 / MFMA_PEAK_TFLOPS, 4)})
+        roofline = roofline_of(dom)
+        roofline["measured"] = "single-stream leg, HIP events on the launch stream (kernel durations are not overlapped with another frame)"
 
     if rank == 0:
         mpix_in = FRAME_H * FRAME_W / 1e6
@@ -221,7 +452,7 @@ def main():
             "config": {"workload": "waifu2x swin_unet 2x (art scale2x geometry), tile_size=256, 1080p frame, "
                                    "random-init weights", "frame": [FRAME_H, FRAME_W], "tile_size": TILE,
                        "tile_batch": args.batch_size, "tiles_per_frame": 45, "frames_per_step_per_gpu": n_streams,
-                       "concurrent_streams": n_streams,
+                       "concurrent_streams": n_streams, "timed_region_s": round(elapsed, 3),
                        "parallelism": f"frame-sharded x{world}"},
             "output_mpix_per_s": round(value * 4, 2),
             "model_tflops": round(45 * 98e9 * args.steps * n_streams * world / elapsed / 1e12, 2),
@@ -230,18 +461,18 @@ def main():
         }
         if single is not None:
             result["single_stream"] = single        # one frame at a time on one stream, same build, same run
-            result["roofline"]["measured"] = "single-stream leg (kernel durations are not overlapped with another frame)"
+        if gathered is not None:
+            result["gathered"] = gathered
         if not args.no_host_frames and world == 1:
             # host uint8 frame -> pinned ring -> H2D -> to_tensor -> render -> quantise -> D2H -> host uint8 frame
             from nunif_amd.frame_ring import FrameRing
-            import numpy as np
             host = [(f.clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy() for f in frames]
             ring = FrameRing(lambda x: tiled_render(x, model, tile_size=TILE, batch_size=args.batch_size),
                              (FRAME_H, FRAME_W, 3), (2 * FRAME_H, 2 * FRAME_W, 3), device=dev, depth=3)
             for i in range(3):
                 ring.submit(host[i % len(host)])
             ring.drain()
-            n_host = max(8, args.steps)
+            n_host = max(8, min(args.steps, 48))
             t1 = time.perf_counter()
             for i in range(n_host):
                 ring.submit(host[i % len(host)])
@@ -250,9 +481,14 @@ def main():
             result["host_frames"] = {"mpix_per_s": round(mpix_in * n_host / dt, 2), "ms_per_frame": round(1e3 * dt / n_host, 3),
                                      "frames": n_host, "path": "uint8 HWC host -> pinned ring (depth 3) -> H2D -> render -> "
                                      "quantise -> D2H -> uint8 HWC host", "bytes_per_frame": int(FRAME_H * FRAME_W * 3 * 5)}
+            del ring
+        if not args.no_4k and world == 1:
+            result["scale4x_4k"] = scale4x_record(dev)
+        if not args.no_iw3 and world == 1:
+            result["iw3"] = iw3_record(dev, with_cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
             base, crop, ref = cpu_baseline(sd, frames[0].cpu())
-            got = tiled_render(crop, model, tile_size=TILE, batch_size=args.batch_size).cpu()
+            got = tiled_render(crop.to(dev), model, tile_size=TILE, batch_size=args.batch_size).cpu()
             mse = torch.mean((got.double() - ref.double()) ** 2).item()
             result["cpu_baseline"] = base
             result["psnr_vs_oracle_db"] = round(10 * math.log10(1.0 / (mse + 1e-6)), 2)

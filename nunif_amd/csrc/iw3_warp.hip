@@ -64,12 +64,14 @@ __global__ void __launch_bounds__(1024) forward_warp_kernel(FwdWarpArgs a) {
     float *img = reinterpret_cast<float *>(kc + Wp);                         // [3][W]
     float *idx = img + 3 * W;                                                // [W] warped x index
     float *idx2 = idx + W;                                                   // [W] after shift_fill
+    float *dl = idx2 + W;                                                    // [W] the depth row (read once, both eyes)
     const int row = blockIdx.x;                  // b*H + y
     const int b = row / a.H, y = row - b * a.H;
     const float *drow = a.depth + (long)row * W;
     const float *crow = a.c + ((long)b * 3 * a.H + y) * W;
     const long cplane = (long)a.H * W;
     const int tid = threadIdx.x;
+    for (int x = tid; x < W; x += kWarpThreads) dl[x] = drow[x];
 
     for (int eye = 0; eye < 2; ++eye) {
         if (a.out[eye] == nullptr) continue;
@@ -78,7 +80,7 @@ __global__ void __launch_bounds__(1024) forward_warp_kernel(FwdWarpArgs a) {
         __syncthreads();
         // ---- splat: z-test per destination ---------------------------------------------------------------------------
         for (int xs = tid; xs < Wp; xs += kWarpThreads) {
-            const float d = drow[min(max(xs - pad, 0), W - 1)];
+            const float d = dl[min(max(xs - pad, 0), W - 1)];
             int fl, ce; float fw, cw;
             bilinear_target(d, sgn, a.shift_size, a.shift_conv, xs, Wp, fl, ce, fw, cw);
             const unsigned long long key = ((unsigned long long)order_key(d) << 32) | (unsigned int)(xs + 1);
@@ -95,14 +97,14 @@ __global__ void __launch_bounds__(1024) forward_warp_kernel(FwdWarpArgs a) {
             if (sf >= 0) {
                 const int sx = min(max(sf - pad, 0), W - 1);
                 int fl, ce; float fw, cw;
-                bilinear_target(drow[sx], sgn, a.shift_size, a.shift_conv, sf, Wp, fl, ce, fw, cw);
+                bilinear_target(dl[sx], sgn, a.shift_size, a.shift_conv, sf, Wp, fl, ce, fw, cw);
                 fwt = fw;
                 fv[0] = crow[sx]; fv[1] = crow[cplane + sx]; fv[2] = crow[2 * cplane + sx]; fv[3] = (float)sf;
             }
             if (sc >= 0) {
                 const int sx = min(max(sc - pad, 0), W - 1);
                 int fl, ce; float fw, cw;
-                bilinear_target(drow[sx], sgn, a.shift_size, a.shift_conv, sc, Wp, fl, ce, fw, cw);
+                bilinear_target(dl[sx], sgn, a.shift_size, a.shift_conv, sc, Wp, fl, ce, fw, cw);
                 cwt = cw;
                 cv[0] = crow[sx]; cv[1] = crow[cplane + sx]; cv[2] = crow[2 * cplane + sx]; cv[3] = (float)sc;
             }
@@ -132,17 +134,34 @@ __global__ void __launch_bounds__(1024) forward_warp_kernel(FwdWarpArgs a) {
         }
         __syncthreads();
         // ---- fix_layered_holes: windowed running min (left) / max (right) of the index; changed pixels become -2 ------------
-        for (int j = tid; j < W; j += kWarpThreads) {
-            const float v0 = idx2[j];
-            float m = v0;
-            if (eye == 0) {
-                const int hi = min(j + kMaxTries, W - 1);
-                for (int q = j + 1; q <= hi; ++q) m = fminf(m, idx2[q]);
-            } else {
-                const int lo = max(j - kMaxTries, 0);
-                for (int q = j - 1; q >= lo; --q) m = fmaxf(m, idx2[q]);
+        // The window is [j, j + kMaxTries] (left eye) / [j - kMaxTries, j] (right eye), clipped to the row.  Scanning it
+        // per pixel was 100 LDS reads per pixel per eye and ~85 % of this kernel; min / max are exact in any order, so
+        // the window is covered by two overlapping power-of-two windows built by doubling (a sparse table's top row):
+        // w64[j] = op over 64 elements from j, result = op(w64[j], w64[j +- (kMaxTries + 1 - 64)]) — 6 passes of 2 reads.
+        {
+            static_assert(kMaxTries + 1 > 64 && kMaxTries + 1 <= 128, "window = 64 + remainder");
+            constexpr int kRem = kMaxTries + 1 - 64;
+            float *t0 = reinterpret_cast<float *>(kf), *t1 = t0 + W;      // the z-test keys are dead until the next eye
+            const float *src = idx2;
+            float *dst = t0;
+            for (int st = 1; st <= 32; st <<= 1) {
+                for (int j = tid; j < W; j += kWarpThreads) {
+                    float v = src[j];
+                    if (eye == 0) { if (j + st < W) v = fminf(v, src[j + st]); }
+                    else { if (j - st >= 0) v = fmaxf(v, src[j - st]); }
+                    dst[j] = v;
+                }
+                __syncthreads();
+                src = dst;
+                dst = dst == t0 ? t1 : t0;
             }
-            if (m != v0) { img[j] = -2.f; img[W + j] = -2.f; img[2 * W + j] = -2.f; }
+            for (int j = tid; j < W; j += kWarpThreads) {
+                const float v0 = idx2[j];
+                float m = src[j];
+                if (eye == 0) { if (j + kRem < W) m = fminf(m, src[j + kRem]); }
+                else { if (j - kRem >= 0) m = fmaxf(m, src[j - kRem]); }
+                if (m != v0) { img[j] = -2.f; img[W + j] = -2.f; img[2 * W + j] = -2.f; }
+            }
         }
         __syncthreads();
         // ---- mask, then fill or clamp, straight to HBM -------------------------------------------------------------------------
@@ -273,7 +292,7 @@ extern "C" int nunif_hip_forward_warp(const float *c, const float *depth, float 
     a.shift_size = (float)shift_size;
     a.shift_conv = (float)(shift_size * p->convergence);
     const long Wp = (long)p->W + 2 * pad;
-    const size_t smem = (size_t)Wp * 16 + (size_t)p->W * 5 * sizeof(float);
+    const size_t smem = (size_t)Wp * 16 + (size_t)p->W * 6 * sizeof(float);
     NUNIF_REQUIRE(smem <= 160 * 1024, "forward_warp: row of %d (+2*%d pad) does not fit LDS", p->W, pad);
     hipStream_t s = (hipStream_t)stream;
     static bool attr_set = false;

@@ -53,7 +53,8 @@ __device__ __forceinline__ float gelu_fast(float v) {
 
 constexpr int kChunkFrags = 8;   // 8 KiB per chunk: 256 threads x 2 x 16 B
 
-// ABL != 0 are timing-only ablations used to find what bounds the kernel (NUNIF_TAIL_ABL; results are wrong):
+// ABL != 0 are timing-only ablations used to find what bounds the kernel (NUNIF_TAIL_ABL in a NUNIF_BUILD_ABL=1 build;
+// results are wrong; the shipping library instantiates ABL = 0 only):
 // 1 = no GELU polynomial, 2 = no stores, 4 = no residual read, 8 = no MFMA in the MLP loop, 16 = no ring barrier
 template <int C, int MF, int ABL = 0, int WAVES = 4, int CHF = kChunkFrags>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1)
@@ -488,6 +489,8 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
     } else if (C == 192) {
         constexpr int MF = 2;
         const unsigned blocks = (unsigned)((M + 4 * MF * 16 - 1) / (4 * MF * 16));
+#ifdef NUNIF_ABLATIONS
+        // timing-only ablations (wrong results): only in a NUNIF_BUILD_ABL=1 build, never in the shipping library
         static const int abl = getenv("NUNIF_TAIL_ABL") ? atoi(getenv("NUNIF_TAIL_ABL")) : 0;
         switch (abl) {
             case 1: proj_mlp_kernel<192, MF, 1><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
@@ -497,18 +500,11 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
             case 9: proj_mlp_kernel<192, MF, 9><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
             case 16: proj_mlp_kernel<192, MF, 16><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
             case 6: proj_mlp_kernel<192, MF, 6><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
-            case 64: {   // 8-wave workgroups (half the L2 -> LDS weight traffic): measured SLOWER, 242 vs 221 us
-                const unsigned blocks8 = (unsigned)((M + 8 * MF * 16 - 1) / (8 * MF * 16));
-                proj_mlp_kernel<192, MF, 0, 8><<<blocks8, 512, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev);
-                break;
-            }
-            case 128: {  // 16-KiB ring chunks: twice the prefetch distance
-                const int nc16 = (proj_mlp_stream_frags(C) + 15) / 16;
-                proj_mlp_kernel<192, MF, 0, 4, 16><<<blocks, 256, 0, s>>>(att, x, wstream, nc16, bp, b0, b3, M, rev);
-                break;
-            }
             default: proj_mlp_kernel<192, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev); break;
         }
+#else
+        proj_mlp_kernel<192, MF><<<blocks, 256, 0, s>>>(att, x, wstream, n_chunks, bp, b0, b3, M, rev);
+#endif
     } else {
         set_error("proj_mlp: channel count %d unsupported (96, 192)", C);
         return NUNIF_HIP_EUNSUPPORTED;

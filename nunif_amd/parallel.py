@@ -4,9 +4,9 @@ The reference has no collective backend: it wraps the tile minibatch in ``nn.Dat
 (``nunif/models/data_parallel.py:41-50``) or round-robins frame batches over per-device replicas from a thread pool
 (``nunif/utils/video.py:1622-1757``, ``iw3/utils.py:709-831``).  Frames are independent, so here each
 rank renders frames ``rank, rank+world, ...`` entirely on its own GPU — tiles, stitch and quantisation included —
-and the only communication is the ordered gather of finished, already-quantised frames to the I/O rank
-(uint8/uint16 HWC, exactly what ``VU.to_frame`` hands to the encoder, ``nunif/utils/video.py:236-245``).  There is no
-all-reduce anywhere.
+and the only communication is the delivery of finished, already-quantised frames to the I/O rank (uint8/uint16 HWC,
+exactly what ``VU.to_frame`` hands to the encoder, ``nunif/utils/video.py:236-245``): one non-blocking point-to-point
+send per frame, overlapped with the next render.  There is no all-reduce anywhere.
 """
 import torch
 import torch.distributed as dist
@@ -18,7 +18,14 @@ def shard_indices(n_items, rank, world_size):
 
 
 def to_frame(x, bits=8):
-    """CHW float [0,1] -> HWC uint8/uint16, round-to-nearest like ``VU.to_frame`` (video.py:236-245)."""
+    """CHW float [0,1] -> HWC uint8/uint16, round-to-nearest like ``VU.to_frame`` (video.py:236-245).
+
+    Device tensors go through the HIP quantise kernel (``nunif_hip_stereo_to_frame``, one pass: clamp, scale, round,
+    CHW -> HWC); host tensors (the gloo tests, the oracle side of a comparison) through the same arithmetic in torch."""
+    if x.device.type == "cuda":
+        from .iw3 import _ops
+        q = _ops.to_frame(x.float().contiguous(), bits)
+        return q if bits == 8 else q.to(torch.int32) & 0xFFFF           # uint16 bit pattern -> widened like the host path
     maxv = 255.0 if bits == 8 else 65535.0
     q = torch.clamp(torch.round(x.float() * maxv), 0, maxv)
     if bits == 8:
@@ -26,37 +33,84 @@ def to_frame(x, bits=8):
     return q.to(torch.int32).permute(1, 2, 0).contiguous()        # torch has no uint16 arithmetic; widen
 
 
-def render_sharded(frames, render_fn, group=None, dst=0, bits=8):
+def render_sharded(frames, render_fn, group=None, dst=0, bits=8, on_frame=None):
     """Render ``frames`` (sequence of CHW tensors, identical on every rank) frame-sharded across the group.
 
-    ``render_fn(frame) -> CHW float tensor in [0,1]`` runs on the calling rank's device.  Returns, on ``dst``, the
-    list of quantised HWC frames in the original order; ``None`` on the other ranks.  Works for any backend
-    (``nccl`` == RCCL on ROCm; ``gloo`` in the CPU tests)."""
+    ``render_fn(frame) -> CHW float tensor in [0,1]`` runs on the calling rank's device.  Rank r owns frames
+    r, r + world, ...; every finished frame is quantised on the device and SENT to ``dst`` right away with a
+    non-blocking point-to-point transfer (RCCL over xGMI under the ``nccl`` backend), so the transfer of frame k overlaps
+    the render of frame k + 1 and nothing but the frames in flight is held on the workers — no padded block, no
+    end-of-job collective.  ``dst`` posts the matching receives round by round (one grouped launch per round) into
+    buffers of exactly the frame size.  Returns, on ``dst``, the list of quantised HWC frames in the original order
+    (``on_frame(i, frame)`` is called instead of collecting when given — the streaming form); ``None`` elsewhere.
+    Works for any backend (``gloo`` in the CPU tests)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return [to_frame(render_fn(f), bits) for f in frames]
+        out = []
+        for i, f in enumerate(frames):
+            q = to_frame(render_fn(f), bits)
+            if on_frame is not None:
+                on_frame(i, q)
+            else:
+                out.append(q)
+        return None if on_frame is not None else out
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    mine = shard_indices(len(frames), rank, world)
-    local = [to_frame(render_fn(frames[i]), bits) for i in mine]
-    per_rank = (len(frames) + world - 1) // world
-    # every rank contributes a fixed-size [per_rank, H, W, C] block (padding with zeros) -> one gather
-    if local:
-        shape, dtype, device = local[0].shape, local[0].dtype, local[0].device
-    else:
-        probe = to_frame(render_fn(frames[0]), bits)                # shape discovery for an idle rank
-        shape, dtype, device = probe.shape, probe.dtype, probe.device
-    block = torch.zeros((per_rank, *shape), dtype=dtype, device=device)
-    for k, f in enumerate(local):
-        block[k] = f
-    if rank == dst:
-        parts = [torch.empty_like(block) for _ in range(world)]
-        dist.gather(block, parts, dst=dst, group=group)
-        out = [None] * len(frames)
+    n = len(frames)
+    rounds = (n + world - 1) // world
+    mine = shard_indices(n, rank, world)
+    out = [None] * n
+    pending = []                      # (requests, [(index, buffer)]) of earlier rounds
+
+    def deliver(done):
+        for i, buf in done:
+            if on_frame is not None:
+                on_frame(i, buf)
+            else:
+                out[i] = buf
+
+    shape = dtype = device = None
+    for k in range(rounds):
+        q = None
+        if k < len(mine):
+            q = to_frame(render_fn(frames[mine[k]]), bits)
+            shape, dtype, device = q.shape, q.dtype, q.device
+        if rank != dst:
+            if q is not None:
+                pending.append((dist.batch_isend_irecv([dist.P2POp(dist.isend, q, dst, group)]), q))
+            # at most two sends in flight: the buffer of round k - 2 is released before round k renders
+            while len(pending) > 2:
+                reqs, _ = pending.pop(0)
+                for r in reqs:
+                    r.wait()
+            continue
+        # ---- dst: receives of this round (peers whose k-th frame exists), grouped into one launch --------------------
+        if shape is None:               # dst owns no frame at all (n < dst + 1): learn the frame geometry from a probe
+            probe = to_frame(render_fn(frames[0]), bits)
+            shape, dtype, device = probe.shape, probe.dtype, probe.device
+        ops, bufs = [], []
         for r in range(world):
-            for k, i in enumerate(shard_indices(len(frames), r, world)):
-                out[i] = parts[r][k]
-        return out
-    dist.gather(block, None, dst=dst, group=group)
-    return None
+            i = r + k * world
+            if r == dst or i >= n:
+                continue
+            buf = torch.empty(shape, dtype=dtype, device=device)
+            ops.append(dist.P2POp(dist.irecv, buf, r, group))
+            bufs.append((i, buf))
+        if q is not None:
+            deliver([(mine[k], q)])
+        if ops:
+            pending.append((dist.batch_isend_irecv(ops), bufs))
+        while len(pending) > 1:          # round k - 1 has had a whole render to arrive
+            reqs, done = pending.pop(0)
+            for r in reqs:
+                r.wait()
+            deliver(done)
+    for reqs, done in pending:
+        for r in reqs:
+            r.wait()
+        if rank == dst:
+            deliver(done)
+    if rank != dst:
+        return None
+    return None if on_frame is not None else out
 
 
 class ConcurrentRenderer:

@@ -20,14 +20,21 @@ def _fake_render(frame):
     return up * 0.5 + 0.25
 
 
-def _worker(rank, world, port, n_frames, result_path):
+def _worker(rank, world, port, n_frames, result_path, streaming=False, dst=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = torch.Generator().manual_seed(7)
     frames = [torch.rand(3, 10, 12, generator=g) for _ in range(n_frames)]
-    out = render_sharded(frames, _fake_render, dst=0)
-    if rank == 0:
+    if streaming:
+        got = {}
+        out = render_sharded(frames, _fake_render, dst=dst, on_frame=lambda i, f: got.__setitem__(i, f.clone()))
+        assert out is None
+        if rank == dst:
+            out = [got[i] for i in range(n_frames)]
+    else:
+        out = render_sharded(frames, _fake_render, dst=dst)
+    if rank == dst:
         torch.save(out, result_path)
     else:
         assert out is None
@@ -59,3 +66,16 @@ def test_render_sharded_two_ranks_matches_single_process(tmp_path):
         assert len(got) == n_frames
         for a, b in zip(got, ref):
             assert a.dtype == torch.uint8 and torch.equal(a, b)
+
+
+def test_render_sharded_three_ranks_streaming_and_nonzero_dst(tmp_path):
+    """world 3, 7 frames (uneven shards), the streaming ``on_frame`` form, and an I/O rank other than 0."""
+    for streaming, dst in ((True, 0), (False, 2)):
+        path = str(tmp_path / f"out_{int(streaming)}_{dst}.pt")
+        mp.spawn(_worker, args=(3, _free_port(), 7, path, streaming, dst), nprocs=3, join=True)
+        got = torch.load(path)
+        g = torch.Generator().manual_seed(7)
+        ref = [to_frame(_fake_render(torch.rand(3, 10, 12, generator=g))) for _ in range(7)]
+        assert len(got) == 7
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
