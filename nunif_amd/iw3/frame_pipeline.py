@@ -164,7 +164,7 @@ def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=No
             stages[key] = _StagePipeline(device, os.environ.get("NUNIF_IW3_STAGE_STREAMS", "1") != "0")
         return stages[key]
 
-    def _stereo(depth_list, device, st):
+    def _stereo(depth_list, device, st, flush=False):
         results = FrameList()
         for depths in chunks(depth_list, args.batch_size):
             depths = [d.to(device) for d in depths]
@@ -181,6 +181,12 @@ def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=No
                     continue
                 frames = [ops.postprocess_image(left[i], right[i], args) for i in range(left.shape[0])]
                 results += [ops.to_frame(f, use_16bit=use_16bit) for f in frames]
+        if flush:
+            # end of stream: frames still inside a side model with a temporal queue (the video inpaint FrameQueue) come
+            # out here — the reference only sends inpaint methods through the single-frame route, which flushes the side
+            # model at iw3/utils.py:658-663; this route accepts them too, so it must not drop the queue's tail
+            with st.stereo_stage([]):
+                results += _side_flush(side_model, args, ops, use_16bit)
         results.event = st.stereo_done()
         return results
 
@@ -192,7 +198,7 @@ def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=No
             st = _stage(device)
             with st.depth_stage():
                 depth_list = depth_model.flush_minmax_normalize()
-            return _stereo(depth_list, device, st)
+            return _stereo(depth_list, device, st, flush=True)
         device = x.device
         st = _stage(device)
         reset_ema = [t in segment_pts for t in pts]

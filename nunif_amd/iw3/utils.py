@@ -21,6 +21,12 @@ def apply_divergence(depth, im, args, side_model=None, reset_pts=None):
     batch = depth.ndim == 4
     if not batch:
         depth, im = depth.unsqueeze(0), im.unsqueeze(0)
+    state = getattr(args, "state", None)
+    if isinstance(state, dict) and state.get("convergence_model") is not None:
+        # iw3/utils.py:303-307: --convergence auto feeds a per-frame convergence TENSOR (ConvergenceEstimator on a U2NETP
+        # saliency net) through the mapper into every warp; the warp kernels here take a scalar.  Refuse instead of
+        # silently using args.convergence (same policy as --autocrop).
+        raise NotImplementedError("--convergence auto (args.state['convergence_model']) is not supported by the HIP engine")
     depth = get_mapper(args.mapper)(depth)
     convergence = args.convergence
     if args.method == "NULL":

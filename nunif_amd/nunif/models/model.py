@@ -28,6 +28,15 @@ class Model(nn.Module):
     def to_inference_model(self):
         return copy.deepcopy(self).eval()
 
+    def __deepcopy__(self, memo):
+        """Engine-backed models hold a ctypes handle to device state in ``_engine`` (not copyable, and a shallow copy would
+        free it twice): the copy gets its own weights and NO engine — it is rebuilt lazily on the first forward."""
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k == "_engine" else copy.deepcopy(v, memo)
+        return new
+
 
 _validators = {}
 

@@ -63,9 +63,13 @@ class SeamBlending(torch.nn.Module):
         if self.tile_out is not None:
             self.tile_out.zero_()
 
-    def gather(self, x, tile_begin, n_tiles, out):
-        """out[k] = replicate-padded x[:, i:i+T, j:j+T] for the row-major tile range (reference :82,:90)."""
-        _hip.check(_hip.lib().nunif_hip_gather_tiles(_ptr(x), _ptr(out), ctypes.byref(self.grid), self.channels,
+    def gather(self, x, tile_begin, n_tiles, out, channels=None):
+        """out[k] = replicate-padded x[:, i:i+T, j:j+T] for the row-major tile range (reference :82,:90).  ``channels`` is
+        the INPUT channel count (x.shape[0]); ``self.channels`` is the stitch store's OUTPUT count, which differs when a
+        config_callback changes the channel count (reference :64-72 slices x with its own C there)."""
+        channels = x.shape[0] if channels is None else channels
+        assert out.shape[1] == channels, (out.shape, channels)
+        _hip.check(_hip.lib().nunif_hip_gather_tiles(_ptr(x), _ptr(out), ctypes.byref(self.grid), channels,
                                                      tile_begin, n_tiles, _hip.current_stream_ptr(x.device)))
         return out
 
@@ -114,7 +118,7 @@ class SeamBlending(torch.nn.Module):
                     else:
                         minibatch[k] = x[:, i:i + tile_size, j:j + tile_size]
             else:
-                sb.gather(x, t0, nb, minibatch)
+                sb.gather(x, t0, nb, minibatch, channels=C)
             with _device.autocast(device, enabled=enable_amp):
                 z = model(minibatch[:nb])
             sb._store(device)[t0:t0 + nb].copy_(z)

@@ -115,8 +115,6 @@ class Waifu2xImageModel():
             return self.infer_pil(x, tta=tta, output_type=output_type, **kwargs)
         raise ValueError("Unsupported input format")
 
-    __call__ = infer
-
     @staticmethod
     def normalize_method(method, noise_level):
         if method is None:
@@ -136,6 +134,14 @@ def _from_pil(im, keep_alpha):
     x = arr.float() / 255.0
     if has_alpha and keep_alpha:
         return x[:3].contiguous(), x[3:4].contiguous()
+    if has_alpha:
+        # nunif/utils/pil_io.py remove_alpha (:26-30) via _load_image(keep_alpha=False): transparent pixels are composited
+        # onto a WHITE background (bg_color = 255) with PIL's own integer blend — they do not just lose their alpha channel
+        from PIL import Image
+        rgba = im.convert("RGBA")
+        nobg = Image.new("RGB", rgba.size, (255, 255, 255))
+        nobg.paste(rgba, rgba.getchannel("A"))
+        x = torch.from_numpy(np.asarray(nobg).copy()).permute(2, 0, 1).float() / 255.0
     return x[:3].contiguous(), None
 
 

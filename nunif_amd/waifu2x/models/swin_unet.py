@@ -10,6 +10,8 @@ import ctypes
 import math
 from collections import OrderedDict
 
+import copy
+
 import torch
 
 from ...nunif.models import I2IBaseModel, register_model, register_model_factory
@@ -264,12 +266,15 @@ class SwinUNet4x(_HipSwinUNetModel):
         return super().forward(x)
 
     def to_2x(self, shared=True):
+        # reference :283-289: shared=False gives the downscaled model its own copy of the 4x net
+        unet = self if shared else copy.deepcopy(self)
         return SwinUNetDownscaled(in_channels=self.i2i_in_channels, out_channels=self.out_channels,
-                                  downscale_factor=2, unet=self)
+                                  downscale_factor=2, unet=unet)
 
     def to_1x(self, shared=True):
+        unet = self if shared else copy.deepcopy(self)
         return SwinUNetDownscaled(in_channels=self.i2i_in_channels, out_channels=self.out_channels,
-                                  downscale_factor=4, unet=self)
+                                  downscale_factor=4, unet=unet)
 
 
 def swin_unet_4xl(**kwargs):

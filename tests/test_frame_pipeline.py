@@ -218,3 +218,72 @@ def test_sharded_refuses_temporal_models():
     dm.has_temporal_state = True
     with pytest.raises(ValueError):
         stereo_frames_sharded(frame_pool_frames(2), [0, 1], set(), dm, lambda *a: [], 2)
+
+
+class _QueueSide:
+    """A side model with a temporal queue (the shape of ForwardInpaintVideo / MLBWInpaintVideo): it swallows frames until
+    ``depth`` of them are waiting, answers with all of them at once, and hands out the rest on ``flush``."""
+
+    def __init__(self, depth=5):
+        self.depth, self.q = depth, []
+
+    def push(self, le, re):
+        self.q += list(zip(le, re))
+        if len(self.q) < self.depth:
+            return None, None
+        out, self.q = self.q, []
+        return torch.stack([a for a, _ in out]), torch.stack([b for _, b in out])
+
+    def flush(self, enable_amp=True):
+        if not self.q:
+            return None, None
+        out, self.q = self.q, []
+        return torch.stack([a for a, _ in out]), torch.stack([b for _, b in out])
+
+
+def test_batch_route_flushes_a_queueing_side_model():
+    """frames in == frames out when the side model keeps a temporal queue: the end-of-stream flush of the batch route has
+    to drain it (the reference only sends such models through the single-frame route, iw3/utils.py:658-663)."""
+    side = _QueueSide(depth=5)
+    ops = _cpu_ops()
+    base = ops.apply_divergence
+
+    def apply_divergence(depths, x, args, side_model=None, reset_pts=None):
+        le, re = base(depths, x, args, None, reset_pts)
+        return side_model.push(le, re)
+
+    ops.apply_divergence = apply_divergence
+    n, bs = 13, 3
+    cb, pre = bind_batch_frame_callback(_model(None), side, set(), _args(bs), ops=ops)
+    pool = FrameCallbackPool(frame_callback=cb, preprocess_callback=pre, batch_size=bs, device=[torch.device("cpu")],
+                             max_workers=0, max_batch_queue=1, require_pts=True, require_flush=True, ops=ops)
+    frames = []
+    xs = frame_pool_frames(n)
+    for i, x in enumerate(xs):
+        frames += pool(Frame(x, i)) or []
+    frames += pool(None)
+    pool.shutdown()
+    assert len(frames) == n and not side.q
+    # order and content: the same frames as the queue-less route
+    _, ref = _run_pool(n, bs, (), None, 0)
+    assert torch.equal(torch.stack(frames), torch.stack(ref))
+
+
+def test_engine_models_deepcopy_without_their_handle():
+    """Model.to_inference_model() deep-copies; an engine-backed model holds a ctypes handle once it has run."""
+    import copy
+    import ctypes
+    from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x, SwinUNet4x
+    m = SwinUNet2x()
+    m._engine = ctypes.c_void_p(1234)                    # what a built engine looks like to copy.deepcopy
+    c = m.to_inference_model()
+    assert c._engine is None and c is not m and not c.training
+    a, b = m.state_dict(), c.state_dict()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    k0 = next(iter(a))
+    c._weights[k0] += 1.0
+    assert not torch.equal(m._weights[k0], c._weights[k0])          # own storage
+    m._engine = None
+    m4 = SwinUNet4x()
+    assert m4.to_2x(shared=True).net4x is m4 and m4.to_2x(shared=False).net4x is not m4
+    assert copy.deepcopy(m4.to_1x(shared=False)).net4x is not m4

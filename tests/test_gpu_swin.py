@@ -47,20 +47,17 @@ def read_taps(engine):
     return taps
 
 
-def test_stagewise_taps_2x(hiplib, capsys):
-    """Every intermediate of the 2x net against the oracle (relative RMS error per stage) — localises a wrong
-    kernel to its stage.  Tile 64: level maps 48 / 24 / 12 (the 12x12 map has 2x2 windows: shift + mask active)."""
+def _stagewise(hiplib, capsys, m, sd, sf, min_taps):
     from nunif_amd import _hip
-    m, sd = make_model(2, 102)
     x = torch.stack([synth_image(21, 3, 64, 64), synth_image(22, 3, 64, 64)])
     ref_taps = {}
-    y_ref = torch.clamp(O.unet_forward(sd, x, 2, taps=ref_taps), 0, 1)
+    y_ref = torch.clamp(O.unet_forward(sd, x, sf, taps=ref_taps), 0, 1)
     eng = m.engine()
     _hip.check(hiplib.nunif_hip_swin_unet_debug_taps(eng.handle, 1))
     y = m(x.to("cuda:0")).cpu()
     taps = read_taps(eng)
     _hip.check(hiplib.nunif_hip_swin_unet_debug_taps(eng.handle, 0))
-    assert set(taps) <= set(ref_taps) and len(taps) > 30    # fused kernels expose fewer intermediates
+    assert set(taps) <= set(ref_taps) and len(taps) >= min_taps    # fused kernels expose fewer intermediates
     report, worst = [], 0.0
     for name, ref in ref_taps.items():
         if name not in taps:
@@ -74,6 +71,29 @@ def test_stagewise_taps_2x(hiplib, capsys):
         print(f"final PSNR {psnr(y, y_ref):.2f} dB")
     assert worst < 2e-2, "a stage deviates by more than fp16 noise:\n" + "\n".join(report)
     assert psnr(y, y_ref) >= PSNR_MIN
+
+
+def test_stagewise_taps_2x(hiplib, capsys):
+    """Every intermediate of the 2x net against the oracle (relative RMS error per stage) — localises a wrong
+    kernel to its stage.  Tile 64: level maps 48 / 24 / 12 (the 12x12 map has 2x2 windows: shift + mask active)."""
+    m, sd = make_model(2, 102)
+    _stagewise(hiplib, capsys, m, sd, 2, 31)
+
+
+def test_stagewise_taps_4x(hiplib, capsys):
+    """The 4x net: proj2 on the skip, a C = 192 TOP level (swin5 on the C = 192 kernels, ToImage as its own GEMM)."""
+    m, sd = make_model(4, 104)
+    _stagewise(hiplib, capsys, m, sd, 4, 31)
+
+
+def test_stagewise_taps_4xl(hiplib, capsys):
+    """swin_unet_4xl (base_dim 192, 12 heads, LayerNormNoBias): every block on the generic path (layernorm + GEMMs + the
+    fused-qkv-map attention), K = 1536 PatchDown as two passes, unfused stem."""
+    from nunif_amd.nunif.models import create_model
+    m = create_model("waifu2x.swin_unet_4xl").eval()
+    sd = O.random_state_dict(204, 4, base_dim=192, layer_norm=True)
+    m.load_state_dict(sd, strict=True)
+    _stagewise(hiplib, capsys, m.to("cuda:0"), sd, 4, 31)
 
 
 @pytest.mark.parametrize("sf,tag", [(1, "1x"), (2, "2x"), (4, "4x")])

@@ -238,3 +238,62 @@ def test_i2i_contract_attributes_match_for_every_registered_model():
                 return "ValueError"              # below the smallest valid tile both raise
         for t in list(range(8, 1025, 4)) + [None]:
             assert valid(a, t) == valid(b, t), (name, t, valid(a, t), valid(b, t))
+
+
+def test_hub_keep_alpha_false_composites_on_white_like_pil_io():
+    """Waifu2xImageModel.infer_file(keep_alpha=False): the reference loads through pil_io._load_image(keep_alpha=False),
+    which pastes the image onto a white background (nunif/utils/pil_io.py:26-30,:60-70) — pixels must match exactly."""
+    refstub.install()
+    import numpy as np
+    from PIL import Image
+    from nunif.utils import pil_io
+    from nunif_amd.waifu2x.hub import _from_pil
+    arr = np.random.RandomState(0).randint(0, 256, (8, 9, 4), dtype=np.uint8)
+    im = Image.fromarray(arr, "RGBA")
+    rgb, alpha = _from_pil(im, False)
+    ref, _ = pil_io._load_image(im.copy(), "x.png", keep_alpha=False)
+    assert alpha is None and ref.mode == "RGB"
+    assert torch.equal((rgb * 255).round().to(torch.uint8), torch.from_numpy(np.asarray(ref).copy()).permute(2, 0, 1))
+    rgb2, alpha2 = _from_pil(im, True)
+    assert alpha2 is not None and torch.equal((rgb2 * 255).round().to(torch.uint8), torch.from_numpy(arr[..., :3].copy()).permute(2, 0, 1))
+
+
+class _FakeI2I(torch.nn.Module):
+    """A deterministic stand-in for an I2I net (fp32 CPU): nearest x``scale`` up-sampling of a per-pixel polynomial of the
+    input with a position-dependent term, cropped by ``offset`` — every tile gets different values in its overlap region,
+    so any deviation in the blend recurrence shows."""
+
+    def __init__(self, scale, offset, blend_size):
+        super().__init__()
+        self.i2i_scale, self.i2i_offset, self.i2i_blend_size = scale, offset, blend_size
+        self.i2i_default_batch_size, self.i2i_default_tile_size = 4, 64
+        self.w = torch.nn.Parameter(torch.zeros(1))
+
+    def find_valid_tile_size(self, t):
+        return t
+
+    def forward(self, x):
+        s, o = self.i2i_scale, self.i2i_offset
+        z = torch.nn.functional.interpolate(x, scale_factor=s, mode="nearest") if s > 1 else x
+        ramp = torch.linspace(0, 0.3, z.shape[-1]).view(1, 1, 1, -1) + torch.linspace(0, 0.2, z.shape[-2]).view(1, 1, -1, 1)
+        z = z * 0.7 + ramp * (0.5 + x.mean(dim=(1, 2, 3), keepdim=True))
+        return z[:, :, o:z.shape[-2] - o, o:z.shape[-1] - o].contiguous()
+
+
+@pytest.mark.parametrize("scale,offset,blend,tile,h,w,bs", [
+    (2, 16, 8, 64, 100, 130, 4), (1, 8, 4, 64, 97, 64, 3), (4, 32, 16, 64, 70, 150, 5), (2, 16, 0, 64, 90, 90, 4),
+    (2, 16, 8, 48, 48, 49, 2)])
+def test_oracle_stitcher_is_bit_identical_to_reference_tiled_render(scale, offset, blend, tile, h, w, bs):
+    """``oracle.seam_blending.tiled_render`` == the live ``SeamBlending.tiled_render`` (nunif/utils/seam_blending.py:48-106,
+    update :156-174) with the SAME fake model: torch.equal — the seams are pinned bit for bit, not to a PSNR."""
+    refstub.install()
+    from nunif.utils.seam_blending import SeamBlending as RefSB
+    from oracle import seam_blending as OS
+    torch.manual_seed(scale * 1000 + h)
+    x = torch.rand(3, h, w)
+    model = _FakeI2I(scale, offset, blend).eval()
+    with torch.inference_mode():
+        ref = RefSB.tiled_render(x, model, tile_size=tile, batch_size=bs, enable_amp=False)
+        got = OS.tiled_render(x, lambda mb: model(mb), scale, offset, blend, tile, bs)
+    assert ref.shape == got.shape == (3, h * scale, w * scale)
+    assert torch.equal(ref, got)
