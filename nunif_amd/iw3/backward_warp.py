@@ -83,8 +83,7 @@ def apply_divergence_nn_delta(model, c, depth, divergence, convergence, steps, s
     """One eye.  The reference flips ``c`` and ``depth`` for the right eye, runs the same net and flips the result back;
     here the mirror is folded into the first and the last kernel (no flipped copies)."""
     assert model.delta_output
-    if steps != 1:
-        raise NotImplementedError("warp_steps > 1 is not on the HIP engine yet")
+    steps = 1 if steps is None else int(steps)
     flip = shift > 0
     B, _, H, W = depth.shape
     base_size = max(H, W)
@@ -94,12 +93,27 @@ def apply_divergence_nn_delta(model, c, depth, divergence, convergence, steps, s
         convergence = [convergence] * B
     # (the screen-border taper is mirror-symmetric — linspace(0,1,n) on the left, linspace(1,0,n) on the right — so the
     #  planes can be built un-mirrored and mirrored together with the depth inside the first kernel)
-    x = torch.stack([make_input_tensor(None, depth[i], divergence=divergence, convergence=convergence[i],
-                                       image_width=base_size, preserve_screen_border=preserve_screen_border)
-                     for i in range(B)])
-    delta = model.infer_delta(x, flip=flip)
     delta_scale = 1.0 / (W // 2 - 1)
-    return _ops.delta_warp(c, delta, delta_scale, flip=flip).to(c.dtype)
+    divergence_step = divergence / steps
+    # warp_steps > 1 (reference :190-231; calc_auto_warp_steps turns it on for row_flow_v3 at divergence > 5): every step
+    # runs the net on the depth warped by the previous steps' flows at divergence / steps, then the image is warped by
+    # the flows one after the other (each warp clamps to [0, 1], :81).  The mirror of the right eye stays folded into the
+    # kernels: both the net and the warp read mirrored and write un-mirrored, so every intermediate — the warped depth of
+    # step j included — lives in un-mirrored coordinates and the same ``flip`` goes to every call.
+    depth_warp = depth
+    deltas = []
+    for j in range(steps):
+        x = torch.stack([make_input_tensor(None, depth_warp[i], divergence=divergence_step, convergence=convergence[i],
+                                           image_width=base_size, preserve_screen_border=preserve_screen_border)
+                         for i in range(B)])
+        delta = model.infer_delta(x, flip=flip)
+        deltas.append(delta)
+        if j + 1 < steps:
+            depth_warp = _ops.delta_warp(depth_warp, delta, delta_scale, flip=flip)
+    z = c
+    for delta in deltas:
+        z = _ops.delta_warp(z, delta, delta_scale, flip=flip)
+    return z.to(c.dtype)
 
 
 def apply_divergence_nn_delta_weight(model, c, depth, divergence, convergence, steps, shift, preserve_screen_border=False,

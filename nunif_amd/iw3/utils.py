@@ -17,6 +17,25 @@ from .forward_warp import apply_divergence_forward_warp
 from .mapper import get_mapper
 
 
+# iw3/utils.py:48-51
+ROW_FLOW_V2_MAX_DIVERGENCE = 2.5
+ROW_FLOW_V3_MAX_DIVERGENCE = 5.0
+ROW_FLOW_V2_AUTO_STEP_DIVERGENCE = 2.0
+ROW_FLOW_V3_AUTO_STEP_DIVERGENCE = 4.0
+
+
+def calc_auto_warp_steps(method, divergence, synthetic_view):
+    """``iw3/utils.py:2179-2186``: the warp_steps the reference's CLI fills in when ``--warp-steps`` is not given
+    (``set_state_args`` :2314-2316): beyond the divergence a flow net was trained for, the warp is split into steps."""
+    import math
+    divergence = divergence if synthetic_view == "both" else divergence * 2
+    if method == "row_flow_v2" and divergence > ROW_FLOW_V2_MAX_DIVERGENCE:
+        return math.ceil(divergence / ROW_FLOW_V2_AUTO_STEP_DIVERGENCE)
+    if method in {"row_flow", "row_flow_v3"} and divergence > ROW_FLOW_V3_MAX_DIVERGENCE:
+        return math.ceil(divergence / ROW_FLOW_V3_AUTO_STEP_DIVERGENCE)
+    return None
+
+
 def apply_divergence(depth, im, args, side_model=None, reset_pts=None):
     batch = depth.ndim == 4
     if not batch:

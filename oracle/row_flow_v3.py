@@ -116,24 +116,34 @@ def backward_warp(c, grid, delta, delta_scale):
     return torch.clamp(z, 0, 1)
 
 
-def apply_divergence_nn_delta(sd, c, depth, divergence, convergence, shift):
-    """One eye, steps = 1 (apply_divergence_nn_delta :191-236): the right eye runs on horizontally flipped inputs."""
+def apply_divergence_nn_delta(sd, c, depth, divergence, convergence, shift, steps=1):
+    """One eye (apply_divergence_nn_delta :191-236): the right eye runs on horizontally flipped inputs.  ``steps`` > 1: the
+    net runs ``steps`` times at divergence / steps on the depth warped by the previous flows (:209-222), then the image
+    is warped by the flows one after the other (:224-227)."""
     if shift > 0:
         c, depth = torch.flip(c, (3,)), torch.flip(depth, (3,))
     B, _, H, W = depth.shape
-    delta = delta_forward(sd, make_input(depth, divergence, convergence, max(H, W)))
-    delta = torch.cat([delta, torch.zeros_like(delta)], dim=1)
-    z = backward_warp(c, make_grid(B, W, H), delta, torch.tensor(1.0 / (W // 2 - 1)))
+    grid, scale = make_grid(B, W, H), torch.tensor(1.0 / (W // 2 - 1))
+    depth_warp, deltas = depth, []
+    for j in range(steps):
+        delta = delta_forward(sd, make_input(depth_warp, divergence / steps, convergence, max(H, W)))
+        delta = torch.cat([delta, torch.zeros_like(delta)], dim=1)
+        deltas.append(delta)
+        if j + 1 < steps:
+            depth_warp = backward_warp(depth_warp, grid, delta, scale)
+    z = c
+    for delta in deltas:
+        z = backward_warp(z, grid, delta, scale)
     return torch.flip(z, (3,)) if shift > 0 else z
 
 
-def apply_divergence_nn_LR(sd, c, depth, divergence, convergence, synthetic_view="both"):
+def apply_divergence_nn_LR(sd, c, depth, divergence, convergence, synthetic_view="both", steps=1):
     if synthetic_view == "both":
-        return (apply_divergence_nn_delta(sd, c, depth, divergence, convergence, -1),
-                apply_divergence_nn_delta(sd, c, depth, divergence, convergence, 1))
+        return (apply_divergence_nn_delta(sd, c, depth, divergence, convergence, -1, steps),
+                apply_divergence_nn_delta(sd, c, depth, divergence, convergence, 1, steps))
     if synthetic_view == "right":
-        return c, apply_divergence_nn_delta(sd, c, depth, divergence * 2, convergence, 1)
-    return apply_divergence_nn_delta(sd, c, depth, divergence * 2, convergence, -1), c
+        return c, apply_divergence_nn_delta(sd, c, depth, divergence * 2, convergence, 1, steps)
+    return apply_divergence_nn_delta(sd, c, depth, divergence * 2, convergence, -1, steps), c
 
 
 def apply_divergence_nn_symmetric(sd, c, depth, divergence, convergence, synthetic_view="both"):

@@ -537,6 +537,38 @@ def gen_row_flow():
     save("row_flow", **out)
 
 
+def gen_row_flow_steps():
+    """apply_divergence_nn_LR with warp_steps 2 and 3 (iw3/backward_warp.py:190-231): the net runs on the depth warped by
+    the previous steps' flows, the image is warped by the flows one after the other.  divergence 6 / 9 are what
+    calc_auto_warp_steps (iw3/utils.py:2179-2186) maps to 2 / 3 steps for row_flow_v3."""
+    from iw3.models.row_flow_v3 import RowFlowV3
+    from iw3 import backward_warp as RB
+    import av
+    av.__version__ = "14.2.0"                      # the inert stub's version string does not parse (nunif/utils/video.py)
+    from iw3.utils import calc_auto_warp_steps
+    from oracle import row_flow_v3 as ORF
+    from oracle.forward_warp import synth_depth
+    out = {}
+    sd = ORF.random_state_dict(301)
+    m = RowFlowV3().eval()
+    m.load_state_dict(sd, strict=True)
+    m.delta_output = True
+    depth = synth_depth(3, 2, 58, 104, "smooth_edges")
+    c = torch.stack([synth_image(71, 3, 116, 208), synth_image(72, 3, 116, 208)])
+    out["depth"], out["c"] = depth, c
+    out["sdsum"] = sd_checksum({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    for steps, div in ((2, 6.0), (3, 9.0)):
+        assert calc_auto_warp_steps("row_flow_v3", div, "both") == steps
+        le, ri = RB.apply_divergence_nn_LR(m, c, depth, div, 0.5, steps=steps, synthetic_view="both", enable_amp=False)
+        out[f"left_s{steps}"], out[f"right_s{steps}"] = le, ri
+    _, out["right_only_s2"] = RB.apply_divergence_nn_LR(m, c[:1], depth[:1], 3.0, 0.4, steps=2, synthetic_view="right",
+                                                        preserve_screen_border=True, enable_amp=False)
+    out["auto_steps"] = torch.tensor([[d, calc_auto_warp_steps("row_flow_v3", d, v) or 0]
+                                      for d in (1.0, 2.5, 5.0, 5.1, 6.0, 8.0, 8.1, 12.0) for v in ("both",)] +
+                                     [[d, calc_auto_warp_steps("row_flow_v3", d, "right") or 0] for d in (2.5, 2.6, 4.0, 4.1)])
+    save("row_flow_steps", **out)
+
+
 def gen_row_flow_sym():
     """The symmetric use of sbs.row_flow_v3 (``row_flow_v3_sym``: model.symmetric = True, apply_divergence_nn_symmetric)."""
     from iw3.models.row_flow_v3 import RowFlowV3
@@ -820,7 +852,7 @@ def gen_depth_aa():
 
 
 GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
-          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "vda_online": gen_vda_online, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint, "light_video_inpaint_ml": gen_light_video_inpaint_ml,
+          "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "row_flow_steps": gen_row_flow_steps, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "vda_online": gen_vda_online, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint, "light_video_inpaint_ml": gen_light_video_inpaint_ml,
           "frame_pool": gen_frame_pool, "forward_inpaint": gen_forward_inpaint, "swin_v2": gen_swin_v2}
 
 if __name__ == "__main__":

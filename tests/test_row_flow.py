@@ -126,3 +126,52 @@ def test_hip_row_flow_symmetric(hiplib, gs):
     assert le is c and psnr(r.cpu(), gs["right_only"]) >= 50.0
     l, ri = apply_divergence_nn_LR(m, c, depth, 2.0, 0.5, steps=1, synthetic_view="left")
     assert ri is c and psnr(l.cpu(), gs["left_only"]) >= 50.0
+
+
+# ---- warp_steps > 1 (iw3/backward_warp.py:190-231) --------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gst():
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "row_flow_steps.npz")).items()}
+
+
+def test_oracle_warp_steps_match_reference_fixture(gst):
+    sd = ORF.random_state_dict(301)
+    assert sd_checksum(sd) == pytest.approx(float(gst["sdsum"]), rel=1e-12)
+    depth, c = gst["depth"], gst["c"]
+    for steps, div in ((2, 6.0), (3, 9.0)):
+        left, right = ORF.apply_divergence_nn_LR(sd, c, depth, div, 0.5, steps=steps)
+        assert (left - gst[f"left_s{steps}"]).abs().max().item() < 5e-4
+        assert (right - gst[f"right_s{steps}"]).abs().max().item() < 5e-4
+        one, _ = ORF.apply_divergence_nn_LR(sd, c, depth, div, 0.5, steps=1)
+        assert (one - left).abs().mean().item() > 1e-3            # the stepped warp really differs from the single one
+
+
+def test_calc_auto_warp_steps_matches_reference_table(gst):
+    from nunif_amd.iw3.utils import calc_auto_warp_steps
+    tab = gst["auto_steps"].tolist()
+    for d, want in tab[:8]:
+        assert (calc_auto_warp_steps("row_flow_v3", d, "both") or 0) == int(want), d
+    for d, want in tab[8:]:
+        assert (calc_auto_warp_steps("row_flow_v3", d, "right") or 0) == int(want), d
+    assert calc_auto_warp_steps("row_flow", 6.0, "both") == 2 and calc_auto_warp_steps("mlbw_l2", 20.0, "both") is None
+    assert calc_auto_warp_steps("row_flow_v2", 2.6, "both") == 2
+
+
+@pytest.mark.gpu
+def test_hip_warp_steps(hiplib, gst):
+    """steps 2 and 3 on the engine against the reference's own outputs (>= 50 dB), the mirror of the right eye folded into
+    the kernels for every step; the single-eye + screen-border case against the oracle."""
+    from nunif_amd.iw3.models.row_flow_v3 import RowFlowV3
+    from nunif_amd.iw3.backward_warp import apply_divergence_nn_LR
+    sd = ORF.random_state_dict(301)
+    m = RowFlowV3().eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda:0")
+    m.delta_output = True
+    depth, c = gst["depth"].to("cuda:0"), gst["c"].to("cuda:0")
+    for steps, div in ((2, 6.0), (3, 9.0)):
+        left, right = apply_divergence_nn_LR(m, c, depth, div, 0.5, steps=steps, synthetic_view="both")
+        pl, pr = psnr(left.cpu(), gst[f"left_s{steps}"]), psnr(right.cpu(), gst[f"right_s{steps}"])
+        assert pl >= 50.0 and pr >= 50.0, (steps, pl, pr)
+    le, ro = apply_divergence_nn_LR(m, c[:1], depth[:1], 3.0, 0.4, steps=2, synthetic_view="right", preserve_screen_border=True)
+    assert torch.equal(le, c[:1]) and psnr(ro.cpu(), gst["right_only_s2"]) >= 50.0
