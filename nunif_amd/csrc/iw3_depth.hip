@@ -239,6 +239,98 @@ __global__ void __launch_bounds__(256) minmax_apply_kernel(const float *__restri
     y[(long)b * n_per + i] = fminf(fmaxf(o, 0.f), 1.f);
 }
 
+// ---- EMAMinMaxScaler on the device (iw3/depth_scaler.py:33-142) ---------------------------------------------------------------
+// The reference keeps the look-ahead ring, the running extrema and the frame's own min / max as 0-dim device tensors and
+// runs ~14 tiny ATen kernels + one host sync (`if scale > 0`) per frame.  Here the SAME arithmetic (fp32, separately
+// rounded: this file is built with -ffp-contract=off) is one single-thread kernel on a small state block, and the
+// normalisation reads lo / hi from that block — no host round trip.
+//   state: [0 .. 2N)  MinMaxBuffer.data      [2N] min_value   [2N + 1] max_value
+// The bookkeeping that is data-independent (count, whether the ring is filled, whether an EMA value exists) stays on the
+// host, exactly as the reference's Python does it.
+__global__ void ema_scaler_push_kernel(float *state, const float *mm_keys, int size, long count, int filled, int first,
+                                       float decay, float one_minus_decay) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto unkey = [](unsigned int k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); };
+    const unsigned int *u = reinterpret_cast<const unsigned int *>(mm_keys);
+    const float mn = unkey(u[0]), mx = unkey(u[1]);
+    if (count == 0) {                                           // MinMaxBuffer.add :41-45: the first sample fills the ring
+        for (int i = 0; i < size; i += 2) { state[i] = mn; state[i + 1] = mx; }
+    } else {
+        state[count % size] = mn;
+        state[(count + 1) % size] = mx;
+    }
+    if (!filled) return;
+    float lo = state[0], hi = state[0];                         // get_minmax :60-61: amin / amax over the whole ring
+    for (int i = 1; i < size; ++i) { lo = fminf(lo, state[i]); hi = fmaxf(hi, state[i]); }
+    if (first) {
+        state[size] = lo; state[size + 1] = hi;
+    } else {                                                    // :110-111
+        state[size] = decay * state[size] + one_minus_decay * lo;
+        state[size + 1] = decay * state[size + 1] + one_minus_decay * hi;
+    }
+}
+
+// flush() before any EMA value exists (:124-125): lo / hi = the ring's extrema
+__global__ void ema_scaler_ring_minmax_kernel(float *state, int size) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float lo = state[0], hi = state[0];
+    for (int i = 1; i < size; ++i) { lo = fminf(lo, state[i]); hi = fmaxf(hi, state[i]); }
+    state[size] = lo; state[size + 1] = hi;
+}
+
+// minmax_normalize / max_normalize with given extrema (depth_scaler.py:4-30); lohi on the device
+__global__ void __launch_bounds__(256) range_normalize_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                              const float *lohi, long n, int max_mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float lo = lohi[0], hi = lohi[1];
+    const float v = x[i];
+    float o;
+    if (max_mode) o = hi > 0.f ? v / hi : v;
+    else { const float scale = hi - lo; o = scale > 0.f ? (v - lo) / scale : v; }
+    y[i] = o != o ? o : fminf(fmaxf(o, 0.f), 1.f);             // torch.clamp keeps NaN
+}
+
+// make_input_tensor (iw3/backward_warp.py:33-64, c = None): [depth | divergence plane | convergence plane] with the
+// optional screen-border taper (linspace(0, 1, n) on the left, linspace(1, 0, n) on the right, multiplied in fp32)
+__device__ __forceinline__ float linspace01(int i, int n) {    // torch.linspace(0, 1, n)[i] in fp32 (ATen's two-sided form)
+    if (n == 1) return 0.0f;
+    const float step = 1.0f / (float)(n - 1);
+    return i < n / 2 ? step * (float)i : 1.0f - step * (float)(n - 1 - i);
+}
+__global__ void __launch_bounds__(256) make_input_planes_kernel(const float *__restrict__ depth, float *__restrict__ out,
+                                                                int B, int H, int W, float dv, float cv, int border) {
+    const long hw = (long)H * W;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * hw) return;
+    const long b = i / hw, p = i - b * hw;
+    const int x = (int)(p % W);
+    float d = dv, c = cv;
+    if (border > 0) {
+        // left strip first, then the right strip on the result (a narrow map's strips may overlap), like the reference's
+        // two in-place slice multiplications
+        if (x < border) { const float w = linspace01(x, border); d = w * d; c = w * c; }
+        if (x >= W - border) { const float w = linspace01(border - 1 - (x - (W - border)), border); d = w * d; c = w * c; }
+    }
+    float *o = out + b * 3 * hw;
+    o[p] = depth[i];
+    o[hw + p] = d;
+    o[2 * hw + p] = c;
+}
+
+// torch.stack of up to 16 equally sized device buffers (the per-frame tensors of a batch) in ONE launch
+struct StackArgs { const void *src[16]; };
+__global__ void __launch_bounds__(256) stack_kernel(StackArgs a, uint4 *__restrict__ dst, long vec_each, int n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= vec_each) return;
+    for (int k = 0; k < n; ++k) dst[(long)k * vec_each + i] = reinterpret_cast<const uint4 *>(a.src[k])[i];
+}
+__global__ void __launch_bounds__(256) stack_bytes_kernel(StackArgs a, unsigned char *__restrict__ dst, long bytes_each, int n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= bytes_each) return;
+    for (int k = 0; k < n; ++k) dst[(long)k * bytes_each + i] = reinterpret_cast<const unsigned char *>(a.src[k])[i];
+}
+
 }  // namespace nunif
 
 using namespace nunif;
@@ -381,6 +473,72 @@ extern "C" int nunif_hip_depth_postprocess(const float *x, float *y, int64_t n, 
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("depth_post_kernel", s, 0.0, (double)n * 8.0);
     depth_post_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x, y, (long)n, max_dist, to_disparity, eps, negate);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+// ---- EMAMinMaxScaler on the device --------------------------------------------------------------------------------------------
+extern "C" int nunif_hip_minmax(const float *x, float *minmax_keys, int32_t B, int64_t n_per, void *stream) {
+    NUNIF_REQUIRE(x && minmax_keys && B > 0 && n_per > 0, "minmax: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    minmax_init_kernel<<<(B + 63) / 64, 64, 0, s>>>(reinterpret_cast<unsigned int *>(minmax_keys), B);
+    dim3 g1((unsigned)std::min<long>((n_per + 255) / 256, kStatBlocks), B);
+    minmax_stats_kernel<<<g1, 256, 0, s>>>(x, minmax_keys, n_per);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_ema_scaler_push(float *state, const float *minmax_keys, int32_t ring_size, int64_t count,
+                                         int32_t filled, int32_t first, double decay, void *stream) {
+    NUNIF_REQUIRE(state && minmax_keys && ring_size >= 2 && ring_size % 2 == 0 && count >= 0, "ema_scaler_push: bad argument");
+    // the reference multiplies fp32 0-dim tensors by Python floats: `decay` and `1. - decay` are rounded to fp32 separately
+    ema_scaler_push_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, minmax_keys, ring_size, (long)count, filled, first,
+                                                              (float)decay, (float)(1.0 - decay));
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_ema_scaler_ring_minmax(float *state, int32_t ring_size, void *stream) {
+    NUNIF_REQUIRE(state && ring_size >= 2, "ema_scaler_ring_minmax: bad argument");
+    ema_scaler_ring_minmax_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, ring_size);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_range_normalize(const float *x, float *y, const float *lohi, int64_t n, int32_t max_mode,
+                                         void *stream) {
+    NUNIF_REQUIRE(x && y && lohi && n > 0, "range_normalize: bad argument");
+    range_normalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, lohi, (long)n, max_mode);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_make_input_planes(const float *depth, float *out, int32_t B, int32_t H, int32_t W,
+                                           double divergence_value, double convergence_value, int32_t border_pix,
+                                           void *stream) {
+    NUNIF_REQUIRE(depth && out && B > 0 && H > 0 && W > 0 && border_pix >= 0, "make_input_planes: bad argument");
+    const long n = (long)B * H * W;
+    make_input_planes_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        depth, out, B, H, W, (float)divergence_value, (float)convergence_value, border_pix);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_stack(const void *const *srcs, int32_t n, int64_t bytes_each, void *dst, void *stream) {
+    NUNIF_REQUIRE(srcs && dst && n > 0 && n <= 16 && bytes_each > 0, "stack: 1..16 buffers of equal size");
+    StackArgs a;
+    bool aligned = (bytes_each % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+    for (int k = 0; k < 16; ++k) {
+        a.src[k] = k < n ? srcs[k] : nullptr;
+        if (k < n) { NUNIF_REQUIRE(srcs[k], "stack: NULL source"); aligned = aligned && ((uintptr_t)srcs[k] % 16 == 0); }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (aligned) {
+        const long v = bytes_each / 16;
+        stack_kernel<<<(unsigned)((v + 255) / 256), 256, 0, s>>>(a, reinterpret_cast<uint4 *>(dst), v, n);
+    } else {
+        stack_bytes_kernel<<<(unsigned)((bytes_each + 255) / 256), 256, 0, s>>>(a, reinterpret_cast<unsigned char *>(dst), bytes_each, n);
+    }
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }

@@ -50,8 +50,6 @@ class BaseDepthModel(metaclass=ABCMeta):
         pass
 
     def load(self, gpu=0, resolution=None, limit_resolution=False, **kwargs):
-        if isinstance(gpu, (list, tuple)) and len(gpu) > 1:
-            raise ValueError(f"{self.model_type} does not support Multi-GPU (shard frames with nunif_amd.parallel)")
         self.device = create_device(gpu)
         self.limit_resolution = limit_resolution
         self.model = self.load_model(self.model_type, resolution=resolution, device=self.device, **kwargs)
@@ -59,6 +57,13 @@ class BaseDepthModel(metaclass=ABCMeta):
             self.model = self.model.to(self.device)
         if hasattr(self.model, "eval"):
             self.model = self.model.eval()
+        if isinstance(gpu, (list, tuple)) and len(gpu) > 1:
+            # iw3/base_depth_model.py:129-133: one replica per listed device, the call goes to the replica of x.device
+            if self.multi_gpu_supported(self.model_type):
+                from ..nunif.models.data_parallel import DeviceSwitchInference
+                self.model = DeviceSwitchInference(self.model, device_ids=list(gpu))
+            else:
+                raise ValueError(f"{self.model_type} does not support Multi-GPU")
         return self
 
     def get_model(self):

@@ -41,6 +41,7 @@ class HipDepthAnythingV2:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the Depth-Anything HIP engine needs a ROCm device; there is no CPU fallback")
+        self._state_dict = state_dict             # host tensors; kept so that replica() can build the same engine elsewhere
         self._pos_embed = state_dict["pretrained.pos_embed"].detach().float().cpu()
         self._pos_cache = {}
         keep, descs = [], []
@@ -73,6 +74,11 @@ class HipDepthAnythingV2:
 
     def to(self, *args, **kwargs):
         return self
+
+    def replica(self, device):
+        """The same network on another device (its own engine handle and workspace): what
+        ``nunif.models.data_parallel.DeviceSwitchInference`` keeps one of per listed GPU."""
+        return self if torch.device(device) == self.device else type(self)(self._state_dict, device)
 
     def _pos(self, gh, gw):
         key = (gh, gw)

@@ -13,6 +13,10 @@ def minmax_normalize(frame, min_value=None, max_value=None):
         single = frame.dim() == 3
         y = _ops.minmax_normalize(frame.unsqueeze(0) if single else frame)
         return y[0] if single else y
+    if torch.is_tensor(min_value) and min_value.device != frame.device:
+        # in-process multi-device (FrameCallbackPool over several GPUs): the scaler's running extrema live on the device of
+        # the first frame it saw; a frame from another device gets its own copy of the two scalars
+        min_value, max_value = min_value.to(frame.device), max_value.to(frame.device)
     scale = max_value - min_value
     if scale > 0:
         return ((frame - min_value) / scale).clamp(0.0, 1.0)
@@ -20,6 +24,8 @@ def minmax_normalize(frame, min_value=None, max_value=None):
 
 
 def max_normalize(frame, min_value, max_value):
+    if torch.is_tensor(max_value) and max_value.device != frame.device:
+        max_value = max_value.to(frame.device)
     if max_value > 0:
         return (frame / max_value).clamp(0.0, 1.0)
     return frame.clamp(0.0, 1.0)
@@ -77,7 +83,10 @@ class EMAMinMaxScaler():
         if self.minmax_buffer is None:
             self.minmax_buffer = MinMaxBuffer(self.buffer_size, dtype=frame.dtype, device=frame.device)
         self.frame_queue.append(frame)
-        self.minmax_buffer.add(frame.amin(), frame.amax())
+        lo_f, hi_f = frame.amin(), frame.amax()
+        if lo_f.device != self.minmax_buffer.data.device:
+            lo_f, hi_f = lo_f.to(self.minmax_buffer.data.device), hi_f.to(self.minmax_buffer.data.device)
+        self.minmax_buffer.add(lo_f, hi_f)
         if not self.minmax_buffer.is_filled():
             return (None, None, None) if return_minmax else None
         lo, hi = self.get_minmax()

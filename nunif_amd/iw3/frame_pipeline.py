@@ -355,17 +355,22 @@ class FrameCallbackPool:
 
     ``max_workers`` is the number of *batches in flight on the GPU* (their kernels are queued asynchronously; a batch is
     handed back when its HIP event has fired, or when more than ``max_workers`` are pending); ``max_workers <= 0`` hands a
-    batch back in the call that completed it, exactly like the reference's ``_DummyThreadPool`` path.  ``device`` is ONE
-    device (one process per GPU; ``stereo_frames_sharded`` spans GPUs) — a list with several devices raises."""
+    batch back in the call that completed it, exactly like the reference's ``_DummyThreadPool`` path.  ``device`` may be a
+    list: batches then go to the devices round-robin (one process per GPU with ``stereo_frames_sharded`` is the other,
+    faster layout)."""
 
     def __init__(self, frame_callback, batch_size, device, max_workers=1, max_batch_queue=2, require_pts=False,
                  skip_pts=-1, require_flush=False, preprocess_callback=None, postprocess_callback=None, use_16bit=False,
                  ops=None, to_host=False):
         devices = list(device) if isinstance(device, (tuple, list)) else [device]
-        if len(devices) != 1:
-            raise ValueError("FrameCallbackPool drives ONE device per process; shard frames across ranks with "
-                             "nunif_amd.iw3.frame_pipeline.stereo_frames_sharded")
-        self.device = torch.device(devices[0])
+        if len(devices) == 0:
+            raise ValueError("FrameCallbackPool needs at least one device")
+        # several devices (the reference's ``--gpu 0 1 ...``: one worker thread per device replica, video.py:1650-1700):
+        # whole BATCHES go to the devices round-robin; their kernels are queued asynchronously on each device's own
+        # streams, so the devices run concurrently from this one thread, and ``pending`` keeps the frame order
+        self.devices = [torch.device(d) for d in devices]
+        self.device = self.devices[0]
+        self._next_device = 0
         self.ops = ops or PipelineOps()
         self.frame_callback, self.preprocess_callback = frame_callback, preprocess_callback
         self.postprocess_callback = postprocess_callback
@@ -383,12 +388,12 @@ class FrameCallbackPool:
             return (batch, flush)
         return (batch,)
 
-    def submit(self, *call_args):
+    def submit(self, *call_args, device=None):
         if self.preprocess_callback is not None:
             frames = self.frame_callback(self.preprocess_callback(*call_args))
         else:
             frames = self.frame_callback(*call_args)
-        return _Pending(frames, self.device)
+        return _Pending(frames, device or self.device)
 
     def get_results(self, pending):
         frames = pending.result()
@@ -408,7 +413,9 @@ class FrameCallbackPool:
         pts = list(self.pts_queue)
         self.frame_queue.clear()
         self.pts_queue.clear()
-        self.pending.append(self.submit(*self.make_args(batch, pts, False)))
+        dev = self.devices[self._next_device]
+        self._next_device = (self._next_device + 1) % len(self.devices)
+        self.pending.append(self.submit(*self.make_args(batch, pts, False), device=dev))
 
     def __call__(self, frame):
         if frame is None:
@@ -416,7 +423,7 @@ class FrameCallbackPool:
         if frame.pts <= self.skip_pts:
             return None
         self.pts_queue.append(frame.pts)
-        self.frame_queue.append(self.ops.to_tensor(frame, device=self.device))
+        self.frame_queue.append(self.ops.to_tensor(frame, device=self.devices[self._next_device]))
         if len(self.frame_queue) == self.batch_size:
             self._close_batch()
         if self.pending and (self.max_workers <= 0 or len(self.pending) > self.max_workers or self.pending[0].done()):

@@ -83,7 +83,9 @@ class DepthAnythingModel(BaseDepthModel):
             raise ValueError("infer expects a CHW or BCHW float tensor in [0,1]")
         if depth_aa and self.depth_aa is None:
             raise ValueError(f"depth_aa=True needs {DEPTH_AA_FILE} next to the depth checkpoint (or load(depth_aa=model))")
-        return batch_infer(self.model, x.to(self.device), flip_aug=tta, enable_amp=enable_amp, edge_dilation=edge_dilation,
+        if x.device.type != "cuda":
+            x = x.to(self.device)          # (reference :241-253: a tensor stays on ITS device — that is what picks the replica)
+        return batch_infer(self.model, x, flip_aug=tta, enable_amp=enable_amp, edge_dilation=edge_dilation,
                            lower_bound=self.lower_bound, limit_resolution=self.limit_resolution,
                            metric_depth=self.is_metric(), depth_aa=self.depth_aa if depth_aa else None)
 
@@ -108,7 +110,7 @@ class DepthAnythingModel(BaseDepthModel):
 
     @classmethod
     def multi_gpu_supported(cls, model_type):
-        return True                                      # frame-sharded: one process per GPU (nunif_amd.iw3.frame_pipeline)
+        return True        # load(gpu=[...]): one engine per listed device (DeviceSwitchInference); or one process per GPU
 
     @classmethod
     def force_update(cls):

@@ -1,8 +1,9 @@
 """Name -> model factory registry.  Mirrors ``nunif/models/register.py`` :9-68.
 
-Multi-GPU: the reference wraps the model in ``nn.DataParallel`` over the tile minibatch (:44-49).  This engine
-shards whole frames across one-process-per-GPU ranks instead (``nunif_amd.parallel``), so ``device_ids`` with
-more than one entry binds the model to the first id.
+Multi-GPU: the reference wraps the model in ``nn.DataParallel`` over the tile minibatch (:44-49); ``device_ids`` with more
+than one entry does the same here through ``data_parallel.DataParallelWrapper`` (one engine replica + stream per listed
+device, driven from one process).  One process per GPU with whole-frame sharding (``nunif_amd.parallel``) is the faster
+layout and what bench.py measures.
 """
 import inspect
 
@@ -25,6 +26,10 @@ def register_model_factory(name, func):
 
 
 def data_parallel_model(model, device_ids):
+    """register.py:44-49: wrap once when more than one device is listed."""
+    from .data_parallel import DataParallelWrapper
+    if len(device_ids) > 1 and not isinstance(model, DataParallelWrapper):
+        model = DataParallelWrapper(model, device_ids=device_ids)
     return model
 
 
@@ -33,7 +38,10 @@ def create_model(name, device_ids=None, **kwargs):
         raise ValueError(f"Unknown model name: {name}")
     model = _models[name](**kwargs)
     if device_ids is not None:
-        model = model.to(create_device(device_ids))
+        if len(device_ids) > 1:                      # register.py:56-61
+            model = data_parallel_model(model, device_ids)
+        else:
+            model = model.to(create_device(device_ids))
     return model
 
 

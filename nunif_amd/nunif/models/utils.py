@@ -39,7 +39,13 @@ def load_model(model_path, model=None, device_ids=None, strict=True, map_locatio
         model.updated_at = data["updated_at"]
     data.pop("state_dict")
     if not predefined and device_ids is not None:
-        model = model.to(create_device(device_ids))
+        if len(device_ids) > 1:
+            # the reference creates the DataParallel wrapper first and loads the weights into wrapper.module (:57-66); an
+            # engine replica is a copy of the LOADED weights, so the order is: load, then replicate over the devices
+            from .register import data_parallel_model
+            model = data_parallel_model(model, device_ids)
+        else:
+            model = model.to(create_device(device_ids))
     return model, data
 
 
@@ -49,6 +55,9 @@ def get_model_kwargs(model, key=None):
 
 
 def get_model_device(model):
+    from .data_parallel import DataParallelInference
+    if isinstance(model, DataParallelInference):
+        return model.output_device
     if hasattr(model, "get_device"):
         return model.get_device()
     return next(model.parameters()).device

@@ -3,8 +3,9 @@
 Mirrors ``waifu2x/utils.py`` (reference) :42-297 — constructor, model slots per method / noise level, ``load_model``,
 ``load_model_all``, ``render``, ``convert`` (alpha handling + TTA), ``to/half/float/compile/warmup`` — with the same
 assertions and exceptions (AssertionError for bad arguments, FileNotFoundError for missing model files, ValueError for
-an unknown method).  Differences: no ``nn.DataParallel`` (multi-GPU = frame sharding, nunif_amd/parallel.py) and
-``compile``/``half`` are no-ops because the engine is native fp16-storage / fp32-accumulate already.
+an unknown method).  ``gpus`` with several ids drives one engine replica per listed device from this process (the tile minibatch is split like the
+reference's ``nn.DataParallel``, ``nunif/models/data_parallel.py``); ``compile``/``half`` are no-ops because the engine is
+native fp16-storage / fp32-accumulate already.
 """
 from os import path
 
@@ -13,6 +14,7 @@ import torch.nn.functional as F
 
 from ..nunif.device import create_device
 from ..nunif.models import load_model
+from ..nunif.models.register import data_parallel_model
 from ..nunif.transforms.tta import tta_merge, tta_split
 from ..nunif.utils.alpha import AlphaBorderPadding
 from ..nunif.utils.render import tiled_render
@@ -88,6 +90,11 @@ class Waifu2x():
         return load_model(path.join(self.model_dir, filename), map_location="cpu", device_ids=self.gpus,
                           weights_only=True)[0]
 
+    def _dp(self, model):
+        """waifu2x/utils.py:144,163,174: a model derived from the 4x net is wrapped for the listed devices like a loaded one."""
+        gpus = self.gpus if isinstance(self.gpus, (list, tuple)) else [self.gpus]
+        return data_parallel_model(model, device_ids=list(gpus)) if len(gpus) > 1 else model
+
     def _require(self, filename):
         if not self.has_model_file(filename):
             raise FileNotFoundError(f"{filename} not found in {self.model_dir}")
@@ -103,7 +110,7 @@ class Waifu2x():
                     self.scale_model = self.load_model_by_name("scale2x.pth")
                 else:
                     self._load_model("scale4x", noise_level)
-                    self.scale_model = self.scale4x_model.to_2x()
+                    self.scale_model = self._dp(self.scale4x_model.to_2x())
         elif method == "noise_scale4x":
             if self.noise_scale4x_models[noise_level] is None:
                 self.noise_scale4x_models[noise_level] = self._require(f"noise{noise_level}_scale4x.pth")
@@ -113,14 +120,14 @@ class Waifu2x():
                     self.noise_scale_models[noise_level] = self.load_model_by_name(f"noise{noise_level}_scale2x.pth")
                 else:
                     self._load_model("noise_scale4x", noise_level)
-                    self.noise_scale_models[noise_level] = self.noise_scale4x_models[noise_level].to_2x()
+                    self.noise_scale_models[noise_level] = self._dp(self.noise_scale4x_models[noise_level].to_2x())
         elif method == "noise":
             if self.noise_models[noise_level] is None:
                 if self.has_model_file(f"noise{noise_level}.pth"):
                     self.noise_models[noise_level] = self.load_model_by_name(f"noise{noise_level}.pth")
                 else:
                     self._load_model("noise_scale4x", noise_level)
-                    self.noise_models[noise_level] = self.noise_scale4x_models[noise_level].to_1x()
+                    self.noise_models[noise_level] = self._dp(self.noise_scale4x_models[noise_level].to_1x())
         else:
             raise ValueError(method)
 

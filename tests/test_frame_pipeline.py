@@ -106,10 +106,24 @@ def test_pool_matches_reference_scheduler(name):
         assert sum(counts) == n
 
 
-def test_pool_refuses_several_devices_and_skips_pts():
+def test_pool_round_robins_batches_over_several_devices_and_skips_pts():
     ops = _cpu_ops()
     with pytest.raises(ValueError):
-        FrameCallbackPool(lambda *a: [], 2, device=["cuda:0", "cuda:1"], ops=ops)
+        FrameCallbackPool(lambda *a: [], 2, device=[], ops=ops)
+    # the reference's ``--gpu 0 1``: whole batches go to the listed devices in turn, frames come back in order
+    # (a fake device table: to_tensor records which device each frame was sent to)
+    sent = []
+    ops2 = _cpu_ops()
+    ops2.to_tensor = lambda frame, device=None: (sent.append(str(device)) or frame.x)
+    pool2 = FrameCallbackPool(lambda batch, pts: [b for b in batch], 2, device=["cpu", "meta"], max_workers=0,
+                              require_pts=True, ops=ops2)
+    got = []
+    xs = frame_pool_frames(7)
+    for i, x in enumerate(xs):
+        got += pool2(Frame(x, i)) or []
+    got += pool2(None)
+    assert sent == ["cpu", "cpu", "meta", "meta", "cpu", "cpu", "meta"]
+    assert len(got) == 7 and all(torch.equal(a, b) for a, b in zip(got, xs))
     seen = []
     pool = FrameCallbackPool(lambda batch, pts: (seen.append(list(pts)) or [b for b in batch]), 2, device="cpu",
                              max_workers=0, require_pts=True, skip_pts=1, ops=ops)
