@@ -262,6 +262,28 @@ int nunif_hip_dilate_edge(const float *x, float *y, float *work, int32_t B, int3
  * min/max, i.e. EMA off).  minmax: [B,2] device scratch that receives the order-keyed min/max. */
 int nunif_hip_minmax_normalize(const float *x, float *y, float *minmax, int32_t B, int64_t n_per, void *stream);
 
+/* EMAMinMaxScaler on the device (iw3/depth_scaler.py MinMaxBuffer :33-61, EMAMinMaxScaler.update :95-114, flush :116-133):
+ * the reference's 0-dim-tensor arithmetic (amin / amax of the frame, ring insert, ring amin / amax, the EMA recurrence, the
+ * `if scale > 0` host sync, (x - lo) / scale, clamp) as four kernels on a small device state block, no host round trip.
+ *   nunif_hip_minmax: minmax_keys[B][2] <- order-keyed min / max of every item of x [B, n_per]
+ *   nunif_hip_ema_scaler_push: one frame's keys into state = [ring 2N | min_value | max_value]; `count` is
+ *     MinMaxBuffer.count before the add, `filled` whether the ring is full after it, `first` whether no EMA value exists yet
+ *   nunif_hip_ema_scaler_ring_minmax: state[2N], state[2N+1] <- extrema of the ring (flush before the first EMA value)
+ *   nunif_hip_range_normalize: y = clamp((x - lo) / (hi - lo)) (max_mode: clamp(x / hi)) with lohi[2] on the device */
+int nunif_hip_minmax(const float *x, float *minmax_keys, int32_t B, int64_t n_per, void *stream);
+int nunif_hip_ema_scaler_push(float *state, const float *minmax_keys, int32_t ring_size, int64_t count, int32_t filled,
+                              int32_t first, double decay, void *stream);
+int nunif_hip_ema_scaler_ring_minmax(float *state, int32_t ring_size, void *stream);
+int nunif_hip_range_normalize(const float *x, float *y, const float *lohi, int64_t n, int32_t max_mode, void *stream);
+
+/* iw3/backward_warp.py make_input_tensor :33-64 with c = None for a whole batch: out [B,3,H,W] = depth | divergence plane |
+ * convergence plane, with the screen-border taper of `border_pix` columns (0: none). */
+int nunif_hip_make_input_planes(const float *depth, float *out, int32_t B, int32_t H, int32_t W, double divergence_value,
+                                double convergence_value, int32_t border_pix, void *stream);
+
+/* torch.stack of n <= 16 equally sized device buffers into dst (one launch; the per-frame tensors of a batch). */
+int nunif_hip_stack(const void *const *srcs, int32_t n, int64_t bytes_each, void *dst, void *stream);
+
 /* Stand-alone mask morphology on fp32 0/1 masks [B,H,W] (iw3/dilation.py dilate :41-46, erode :49-54, closing :57-64,
  * mask_closing :145-153, dilate_outer :67-81, dilate_inner :84-98).  op: 0 dilate x n_a (3x3 max, window clipped at the border),
  * 1 erode x n_a, 2 closing(n_iter = n_a), 3 mask_closing(n_iter = n_a) = clamp(closing + mask), 4 horizontal OR-dilation with

@@ -112,6 +112,12 @@ SIGNATURES = {
     "nunif_hip_swin_unet_debug_taps": (c_int32, [c_void_p, c_int32]),
     "nunif_hip_swin_unet_get_tap": (c_int32, [c_void_p, c_int32, c_char_p, c_int32, c_void_p, c_int64,
                                               ctypes.POINTER(c_int64)]),
+    "nunif_hip_minmax": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "nunif_hip_ema_scaler_push": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_double, c_void_p]),
+    "nunif_hip_ema_scaler_ring_minmax": (c_int32, [c_void_p, c_int32, c_void_p]),
+    "nunif_hip_range_normalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "nunif_hip_make_input_planes": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_double, c_double, c_int32, c_void_p]),
+    "nunif_hip_stack": (c_int32, [ctypes.POINTER(c_void_p), c_int32, c_int64, c_void_p, c_void_p]),
     "nunif_hip_profile_enable": (c_int32, [c_int32]),
     "nunif_hip_profile_read": (c_int32, [ctypes.POINTER(ProfRecord), c_int32, c_int32]),
 }

@@ -293,10 +293,12 @@ __global__ void __launch_bounds__(256) range_normalize_kernel(const float *__res
 
 // make_input_tensor (iw3/backward_warp.py:33-64, c = None): [depth | divergence plane | convergence plane] with the
 // optional screen-border taper (linspace(0, 1, n) on the left, linspace(1, 0, n) on the right, multiplied in fp32)
-__device__ __forceinline__ float linspace01(int i, int n) {    // torch.linspace(0, 1, n)[i] in fp32 (ATen's two-sided form)
-    if (n == 1) return 0.0f;
-    const float step = 1.0f / (float)(n - 1);
-    return i < n / 2 ? step * (float)i : 1.0f - step * (float)(n - 1 - i);
+__device__ __forceinline__ float linspace_at(float start, float end, int i, int n) {
+    // torch.linspace(start, end, n)[i] in fp32, ATen's two-sided form: the first half counts up from `start`, the second
+    // half down from `end` (RangeFactories: step = (end - start) / (n - 1))
+    if (n == 1) return start;
+    const float step = (end - start) / (float)(n - 1);
+    return i < n / 2 ? start + step * (float)i : end - step * (float)(n - 1 - i);
 }
 __global__ void __launch_bounds__(256) make_input_planes_kernel(const float *__restrict__ depth, float *__restrict__ out,
                                                                 int B, int H, int W, float dv, float cv, int border) {
@@ -309,8 +311,8 @@ __global__ void __launch_bounds__(256) make_input_planes_kernel(const float *__r
     if (border > 0) {
         // left strip first, then the right strip on the result (a narrow map's strips may overlap), like the reference's
         // two in-place slice multiplications
-        if (x < border) { const float w = linspace01(x, border); d = w * d; c = w * c; }
-        if (x >= W - border) { const float w = linspace01(border - 1 - (x - (W - border)), border); d = w * d; c = w * c; }
+        if (x < border) { const float w = linspace_at(0.0f, 1.0f, x, border); d = w * d; c = w * c; }
+        if (x >= W - border) { const float w = linspace_at(1.0f, 0.0f, x - (W - border), border); d = w * d; c = w * c; }
     }
     float *o = out + b * 3 * hw;
     o[p] = depth[i];

@@ -59,6 +59,70 @@ def minmax_normalize(x):
     return y
 
 
+def minmax_keys(x):
+    """Order-keyed (min, max) of every item of x [B, ...] -> [B, 2] fp32 device scratch (feeds ema_scaler_push)."""
+    x = _cuda_f32(x, "minmax_keys")
+    mm = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_minmax(_p(x), _p(mm), x.shape[0], x[0].numel(), _hip.current_stream_ptr(x.device)))
+    return mm
+
+
+def ema_scaler_push(state, keys, ring_size, count, filled, first, decay):
+    with torch.cuda.device(state.device):
+        _hip.check(_hip.lib().nunif_hip_ema_scaler_push(_p(state), _p(keys), ring_size, count, 1 if filled else 0,
+                                                        1 if first else 0, float(decay), _hip.current_stream_ptr(state.device)))
+
+
+def ema_scaler_ring_minmax(state, ring_size):
+    with torch.cuda.device(state.device):
+        _hip.check(_hip.lib().nunif_hip_ema_scaler_ring_minmax(_p(state), ring_size, _hip.current_stream_ptr(state.device)))
+
+
+def range_normalize(x, lohi, max_mode=False):
+    """clamp((x - lo) / (hi - lo), 0, 1) (or clamp(x / hi)) with the two extrema in a device tensor ``lohi`` [2]."""
+    x = _cuda_f32(x, "range_normalize")
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _hip.check(_hip.lib().nunif_hip_range_normalize(_p(x), _p(y), _p(lohi), x.numel(), 1 if max_mode else 0,
+                                                        _hip.current_stream_ptr(x.device)))
+    return y
+
+
+def make_input_planes(depth, divergence_value, convergence_value, border_pix=0):
+    """[B,1,H,W] depth -> [B,3,H,W] = depth | divergence plane | convergence plane (+ screen-border taper)."""
+    depth = _cuda_f32(depth, "make_input_planes")
+    b, _, h, w = depth.shape
+    out = torch.empty((b, 3, h, w), dtype=torch.float32, device=depth.device)
+    with torch.cuda.device(depth.device):
+        _hip.check(_hip.lib().nunif_hip_make_input_planes(_p(depth), _p(out), b, h, w, float(divergence_value),
+                                                          float(convergence_value), int(border_pix),
+                                                          _hip.current_stream_ptr(depth.device)))
+    return out
+
+
+def stack(tensors):
+    """torch.stack(tensors) for equally shaped contiguous device tensors, as ONE copy launch of the engine's own (a view
+    when the tensors already are consecutive slices of one buffer)."""
+    t0 = tensors[0]
+    n = len(tensors)
+    if not (t0.is_cuda and all(t.is_cuda and t.shape == t0.shape and t.dtype == t0.dtype and t.is_contiguous()
+                               and t.device == t0.device for t in tensors)):
+        return torch.stack(list(tensors))
+    nbytes = t0.numel() * t0.element_size()
+    if all(tensors[k].data_ptr() == t0.data_ptr() + k * nbytes and tensors[k].untyped_storage().data_ptr() ==
+           t0.untyped_storage().data_ptr() for k in range(n)):
+        return t0.as_strided((n, *t0.shape), (t0.numel(), *t0.stride()))          # consecutive slices: no copy at all
+    out = torch.empty((n, *t0.shape), dtype=t0.dtype, device=t0.device)
+    with torch.cuda.device(t0.device):
+        for k0 in range(0, n, 16):
+            grp = tensors[k0:k0 + 16]
+            arr = (ctypes.c_void_p * len(grp))(*[t.data_ptr() for t in grp])
+            _hip.check(_hip.lib().nunif_hip_stack(arr, len(grp), nbytes, out[k0].data_ptr(),
+                                                  _hip.current_stream_ptr(t0.device)))
+    return out
+
+
 VIEW = {"both": 0, "left": 1, "right": 2}
 
 

@@ -78,6 +78,26 @@ def make_input_tensor(c, depth, divergence, convergence, image_width, mapper=Non
     return torch.stack([depth, divergence_feat, convergence_feat], dim=0)
 
 
+def make_input_batch(depth, divergence, convergence, image_width, preserve_screen_border=False):
+    """``torch.stack([make_input_tensor(None, depth[i], ...) for i in range(B)])`` (reference :206-211 / :280-285).  With a
+    scalar convergence on a device batch this is ONE launch of ``nunif_hip_make_input_planes`` (the reference's per-item
+    full_like / linspace / slice-multiply / stack chain is ~10 ATen kernels per frame and eye); per-item convergence tensors
+    take the per-item form."""
+    B = depth.shape[0]
+    if depth.is_cuda and not torch.is_tensor(convergence) and not (isinstance(convergence, (list, tuple))
+                                                                   and len(set(map(float, convergence))) > 1):
+        conv = float(convergence[0]) if isinstance(convergence, (list, tuple)) else float(convergence)
+        dv, cv = make_divergence_feature_value(divergence, conv, image_width)
+        border_pix = 0
+        if preserve_screen_border:
+            border_pix = max(round(divergence * 0.75 * 0.01 * image_width * (depth.shape[-1] / image_width)), 0)
+        return _ops.make_input_planes(depth, dv, cv, border_pix)
+    conv = convergence.flatten() if torch.is_tensor(convergence) else (
+        list(convergence) if isinstance(convergence, (list, tuple)) else [convergence] * B)
+    return torch.stack([make_input_tensor(None, depth[i], divergence=divergence, convergence=conv[i], image_width=image_width,
+                                          preserve_screen_border=preserve_screen_border) for i in range(B)])
+
+
 def apply_divergence_nn_delta(model, c, depth, divergence, convergence, steps, shift, preserve_screen_border=False,
                               enable_amp=True):
     """One eye.  The reference flips ``c`` and ``depth`` for the right eye, runs the same net and flips the result back;
@@ -103,9 +123,7 @@ def apply_divergence_nn_delta(model, c, depth, divergence, convergence, steps, s
     depth_warp = depth
     deltas = []
     for j in range(steps):
-        x = torch.stack([make_input_tensor(None, depth_warp[i], divergence=divergence_step, convergence=convergence[i],
-                                           image_width=base_size, preserve_screen_border=preserve_screen_border)
-                         for i in range(B)])
+        x = make_input_batch(depth_warp, divergence_step, convergence, base_size, preserve_screen_border)
         delta = model.infer_delta(x, flip=flip)
         deltas.append(delta)
         if j + 1 < steps:
@@ -128,9 +146,7 @@ def apply_divergence_nn_delta_weight(model, c, depth, divergence, convergence, s
         convergence = convergence.flatten()
     else:
         convergence = [convergence] * B
-    x = torch.stack([make_input_tensor(None, depth[i], divergence=divergence, convergence=convergence[i],
-                                       image_width=base_size, preserve_screen_border=preserve_screen_border)
-                     for i in range(B)])
+    x = make_input_batch(depth, divergence, convergence, base_size, preserve_screen_border)
     if hole_mask:
         delta, layer_weight, hole_mask_logits = model.infer_delta(x, flip=flip)   # logits already in image coordinates
     else:

@@ -45,7 +45,9 @@ def batch_infer(model, im, flip_aug=True, enable_amp=False, edge_dilation=2, low
     x = batch_preprocess(im.unsqueeze(0) if single else im, lower_bound, limit_resolution=limit_resolution)
     if flip_aug:
         x = torch.cat([x, torch.flip(x, dims=[3])], dim=0)
-    out = torch.nan_to_num(model(x).unsqueeze(1).float())
+    out = model(x).unsqueeze(1).float()
+    # torch.nan_to_num (reference :150): the engine's depth_post_kernel with every other step switched off
+    out = _ops.depth_postprocess(out) if out.is_cuda else torch.nan_to_num(out)
     if depth_aa is not None:
         out = depth_aa.infer(out)                      # depth_anything_model.py:153-154 (nunif_amd.iw3.models.DepthAA)
     if edge_dilation_is_enabled(edge_dilation):

@@ -56,8 +56,15 @@ class MinMaxBuffer():
 
 
 class EMAMinMaxScaler():
+    """Reference :64-142.  Host tensors run the reference's torch arithmetic line by line (that is what the CPU tests compare
+    with the live reference class); DEVICE tensors run the same arithmetic as four HIP kernels on a small device state block
+    (``nunif_hip_minmax`` / ``ema_scaler_push`` / ``ema_scaler_ring_minmax`` / ``range_normalize``): no ATen reduce / fill /
+    elementwise kernels and no ``if scale > 0`` host synchronisation per frame.  The data-independent bookkeeping (ring
+    count, "filled", "an EMA value exists") is host state in both paths."""
+
     def __init__(self, decay=0, buffer_size=1, mode="minmax"):
         assert mode in {"minmax", "max"}
+        self.mode = mode
         self.normalize = {"minmax": minmax_normalize, "max": max_normalize}[mode]
         assert buffer_size > 0
         self.frame_queue = []
@@ -71,6 +78,10 @@ class EMAMinMaxScaler():
         self.min_value = self.max_value = None
         self.frame_queue = []
         self.minmax_buffer = None
+        # device path: [ring 2N | min_value | max_value] + the host-side mirror of MinMaxBuffer.count
+        self._dev_state = None
+        self._dev_count = 0
+        self._dev_has_value = False
 
     def get_minmax(self):
         assert self.minmax_buffer is not None and self.minmax_buffer.is_filled()
@@ -79,7 +90,55 @@ class EMAMinMaxScaler():
     def __call__(self, frame, return_minmax=False):
         return self.update(frame, return_minmax=return_minmax)
 
+    # -- device path ----------------------------------------------------------------------------------------------------
+    def _on_device(self, frame):
+        return frame.is_cuda and frame.dtype == torch.float32 and self.minmax_buffer is None
+
+    def _dev_lohi(self, device=None):
+        """(min_value, max_value) as a 2-element device tensor; a frame that lives on ANOTHER device than the state (the
+        in-process multi-device pool deals batches round-robin) gets its own copy of the two scalars."""
+        n2 = 2 * self.buffer_size
+        lohi = self._dev_state[n2:n2 + 2]
+        return lohi if device is None or device == lohi.device else lohi.to(device)
+
+    def _dev_update(self, frame, return_minmax):
+        n2 = 2 * self.buffer_size
+        if self._dev_state is None:
+            self._dev_state = torch.empty(n2 + 2, dtype=torch.float32, device=frame.device)
+        self.frame_queue.append(frame)
+        keys = _ops.minmax_keys(frame.reshape(1, -1))
+        if keys.device != self._dev_state.device:
+            keys = keys.to(self._dev_state.device)
+        filled = (2 if self._dev_count == 0 else self._dev_count + 2) >= n2
+        _ops.ema_scaler_push(self._dev_state, keys, n2, self._dev_count, filled, not self._dev_has_value, self.decay)
+        self._dev_count = 2 if self._dev_count == 0 else self._dev_count + 2
+        if not filled:
+            return (None, None, None) if return_minmax else None
+        self._dev_has_value = True
+        first = self.frame_queue.pop(0)
+        out = _ops.range_normalize(first, self._dev_lohi(first.device), max_mode=self.mode == "max")
+        if return_minmax:
+            lohi = self._dev_lohi().clone()
+            return out, lohi[0], lohi[1]
+        return out
+
+    def _dev_flush(self, return_minmax):
+        if not self._dev_has_value:
+            _ops.ema_scaler_ring_minmax(self._dev_state, 2 * self.buffer_size)
+        lohi = self._dev_lohi()
+        frames = [_ops.range_normalize(f, self._dev_lohi(f.device), max_mode=self.mode == "max") for f in self.frame_queue]
+        if return_minmax:
+            c = lohi.clone()
+            frames = [(f, c[0], c[1]) for f in frames]
+        self.reset()
+        return frames
+
+    # -- reference path (host tensors; device tensors of another device than the state's) --------------------------------
     def update(self, frame, return_minmax=False):
+        if self._on_device(frame):
+            return self._dev_update(frame, return_minmax)
+        if self._dev_state is not None:
+            raise RuntimeError("EMAMinMaxScaler: a stream started with device frames cannot continue with host frames; reset()")
         if self.minmax_buffer is None:
             self.minmax_buffer = MinMaxBuffer(self.buffer_size, dtype=frame.dtype, device=frame.device)
         self.frame_queue.append(frame)
@@ -102,6 +161,8 @@ class EMAMinMaxScaler():
         if not self.frame_queue:
             self.reset()
             return []
+        if self._dev_state is not None:
+            return self._dev_flush(return_minmax)
         if self.min_value is None:
             lo, hi = self.minmax_buffer.get_minmax()
         else:

@@ -140,6 +140,16 @@ class _NullContext:
         return False
 
 
+def _stack(tensors):
+    """``torch.stack`` of the per-frame tensors of a batch: device tensors go through the engine's own copy kernel (one launch,
+    or no copy at all when they are consecutive slices of one buffer) instead of ATen's CatArrayBatchedCopy."""
+    tensors = list(tensors)
+    if tensors and torch.is_tensor(tensors[0]) and tensors[0].is_cuda:
+        from . import _ops
+        return _ops.stack(tensors)
+    return torch.stack(tensors)
+
+
 def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=None):
     """``iw3/utils.py:709-831``.  Returns ``(frame_callback, preprocess_callback)``:
     ``preprocess_callback(x, pts, flush) -> call_args`` and ``frame_callback(call_args) -> [quantised frames]``.
@@ -171,8 +181,8 @@ def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=No
             pairs = [src_queue.pop(0) for _ in range(len(depths))]
             reset_pts = [t in segment_pts for _, t in pairs]
             with st.stereo_stage(depths + [x for x, _ in pairs]):
-                depths = torch.stack(depths)
-                x_srcs = torch.stack([x for x, _ in pairs])
+                depths = _stack(depths)
+                x_srcs = _stack([x for x, _ in pairs])
                 if getattr(args, "rgbd", False) or getattr(args, "half_rgbd", False):
                     left, right = ops.apply_rgbd(x_srcs, depths, mapper=args.mapper)
                 else:
@@ -289,9 +299,9 @@ def bind_vda_frame_callback(depth_model, side_model, segment_pts, args, ops=None
     def _postprocess(depth_list, flush=False):
         results = []
         for depths in chunks(depth_list, args.batch_size):
-            depths = torch.stack(depths)
+            depths = _stack(depths)
             pairs = [src_queue.pop(0) for _ in range(depths.shape[0])]
-            x_srcs = torch.stack([x for x, _ in pairs])
+            x_srcs = _stack([x for x, _ in pairs])
             if getattr(args, "rgbd", False) or getattr(args, "half_rgbd", False):
                 left, right = ops.apply_rgbd(x_srcs, depths, mapper=args.mapper)
             else:
@@ -305,7 +315,7 @@ def bind_vda_frame_callback(depth_model, side_model, segment_pts, args, ops=None
         return results
 
     def _batch_infer():
-        x = ops.preprocess_image(torch.stack(batch_queue), args)
+        x = ops.preprocess_image(_stack(batch_queue), args)
         for x_, t in zip(x, pts_queue):
             src_queue.append((x_, t))
         depth_list = depth_model.infer_with_normalize(x, list(pts_queue), segment_pts, **kw())
@@ -409,7 +419,7 @@ class FrameCallbackPool:
         return out
 
     def _close_batch(self):
-        batch = torch.stack(self.frame_queue)
+        batch = _stack(self.frame_queue)
         pts = list(self.pts_queue)
         self.frame_queue.clear()
         self.pts_queue.clear()

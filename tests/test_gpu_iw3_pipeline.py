@@ -207,3 +207,51 @@ def test_process_image_entry(hiplib):
     assert dbg.shape[0] == 3 and dbg.shape[2] == 2 * depth.shape[2]
     with pytest.raises(NotImplementedError):
         process_image(x, SimpleNamespace(**{**vars(args), "autocrop": "black"}), model)
+
+
+@pytest.mark.parametrize("decay,buffer_size,mode", [(0.0, 1, "minmax"), (0.75, 4, "minmax"), (0.9, 2, "max"), (0.5, 7, "minmax")])
+def test_device_ema_scaler_is_bit_identical_to_the_host_path(hiplib, decay, buffer_size, mode):
+    """EMAMinMaxScaler on device frames (four HIP kernels on a device state block, no ATen, no host sync) against the SAME
+    class on host frames — which tests/test_oracle_vs_reference.py pins to the reference class: every output bit-identical,
+    same None / flush schedule, including a scene cut and a flush before the ring ever filled."""
+    from nunif_amd.iw3.depth_scaler import EMAMinMaxScaler
+    g = torch.Generator().manual_seed(31 + buffer_size)
+    frames = [torch.rand(1, 40, 56, generator=g) * (0.5 + i % 5) + (i % 3) * 0.25 - 0.3 for i in range(23)]
+    a, b = EMAMinMaxScaler(decay, buffer_size, mode), EMAMinMaxScaler(decay, buffer_size, mode)
+    outs_a, outs_b = [], []
+    for i, f in enumerate(frames):
+        if i in (2, 15):                                  # scene cuts: the first one before a ring of 4 / 7 has filled
+            outs_a += a.flush()
+            outs_b += [t.cpu() for t in b.flush()]
+        ra, rb = a.update(f), b.update(f.to("cuda:0"))
+        assert (ra is None) == (rb is None)
+        if ra is not None:
+            outs_a.append(ra)
+            outs_b.append(rb.cpu())
+    ra = a.flush(return_minmax=True)
+    rb = b.flush(return_minmax=True)
+    assert len(ra) == len(rb)
+    for (fa, lo_a, hi_a), (fb, lo_b, hi_b) in zip(ra, rb):
+        assert torch.equal(fa, fb.cpu()) and float(lo_a) == float(lo_b) and float(hi_a) == float(hi_b)
+    assert len(outs_a) == len(outs_b) and len(outs_a) + len(ra) == len(frames)
+    for x, y in zip(outs_a, outs_b):
+        assert torch.equal(x, y)
+
+
+def test_make_input_planes_and_stack_are_bit_identical_to_torch(hiplib):
+    from nunif_amd.iw3 import _ops
+    from nunif_amd.iw3.backward_warp import make_input_batch, make_input_tensor
+    g = torch.Generator().manual_seed(5)
+    for (h, w, div, conv, border) in ((58, 104, 2.5, 0.4, True), (60, 33, 6.0, 0.5, True), (20, 64, 2.0, 0.5, False),
+                                      (16, 9, 9.0, 0.3, True)):
+        d = torch.rand(3, 1, h, w, generator=g)
+        ref = torch.stack([make_input_tensor(None, d[i], div, conv, max(h, w), preserve_screen_border=border) for i in range(3)])
+        got = make_input_batch(d.to("cuda:0"), div, conv, max(h, w), preserve_screen_border=border)
+        assert torch.equal(got.cpu(), ref), (h, w)
+    xs = [torch.rand(3, 17, 29, generator=g).to("cuda:0") for _ in range(5)]
+    assert torch.equal(_ops.stack(xs), torch.stack(xs))
+    base = torch.rand(4, 3, 8, 8, generator=g).to("cuda:0")
+    v = _ops.stack([base[1], base[2], base[3]])
+    assert v.data_ptr() == base[1].data_ptr() and torch.equal(v, base[1:4])          # consecutive slices: a view, no copy
+    u8 = [torch.randint(0, 256, (5, 7, 3), generator=g, dtype=torch.uint8).to("cuda:0") for _ in range(3)]
+    assert torch.equal(_ops.stack(u8), torch.stack(u8))
