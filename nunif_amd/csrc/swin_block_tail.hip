@@ -257,6 +257,20 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
     __syncthreads();
     const f16x8 *wlane = wl + lane;
     auto wfrag = [&](int fi) -> f16x8 { return wlane[fi * 64]; };
+    // Both residual adds ride the matrix pipe: this kernel is VALU-issue bound (GELU alone is 9.5 operations per hidden
+    // element, tools/ubench_mix.hip) while the MFMA pipe is a quarter busy, so `y = x + ...` and `x' = y + ...` are one
+    // extra MFMA per 16-channel tile against a constant IDENTITY fragment instead of 48 + 48 v_cvt_f32_f16 / v_add_f32
+    // (+ 24 v_permlane) per 32 tokens.  fp16 x 1.0 is exact and the accumulation stays fp32, so only the summation order
+    // changes.  ie / io: identity rows of the even / odd tile of a pair for a PLAIN-k-order B fragment (k = 8 grp + j);
+    // je / jo: the same for a CHAINED-k-order fragment (slots 0-3 = tile 2s channels 4 grp + j, slots 4-7 = tile 2s + 1).
+    f16x8 ie, io, je, jo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ie[j] = (f16)((r16 == 8 * grp + j) ? 1.f : 0.f);
+        io[j] = (f16)((r16 + 16 == 8 * grp + j) ? 1.f : 0.f);
+        je[j] = (f16)((j < 4 && r16 == 4 * grp + j) ? 1.f : 0.f);
+        jo[j] = (f16)((j >= 4 && r16 == 4 * grp + j - 4) ? 1.f : 0.f);
+    }
 
     const long n_groups = (M + MF * 16 - 1) / (MF * 16);
     const long gstride = (long)gridDim.x * WAVES;
@@ -270,11 +284,11 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
             const long m = gmap(g) * (MF * 16) + f * 16 + r16;
             const long r = m < M ? m : M - 1;
             const f16 *p = att + r * C + grp * 8;
-            const f16 *px = x + r * C + pair_run_channel(grp);
+            const f16 *px = x + r * C + grp * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 of[f][ks] = *reinterpret_cast<const f16x8 *>(p + ks * 32);
-                xr[f][ks] = *reinterpret_cast<const f16x8 *>(px + ks * 32);      // 8-channel run, see pair_to_run()
+                xr[f][ks] = *reinterpret_cast<const f16x8 *>(px + ks * 32);      // B-operand layout: the residual rides an MFMA
             }
         }
     };
@@ -331,13 +345,13 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
                 }
 #pragma unroll
                 for (int f = 0; f < MF; ++f) {
-                    f16x4 va, vb;
-                    run_to_pair(xr[f][s], va, vb);
-                    yf[f][s] = (f16x8){(f16)(a0[f][0] + (float)va[0]), (f16)(a0[f][1] + (float)va[1]),
-                                       (f16)(a0[f][2] + (float)va[2]), (f16)(a0[f][3] + (float)va[3]),
-                                       (f16)(a1[f][0] + (float)vb[0]), (f16)(a1[f][1] + (float)vb[1]),
-                                       (f16)(a1[f][2] + (float)vb[2]), (f16)(a1[f][3] + (float)vb[3])};
+                    a0[f] = MFMA_16x16x32(ie, xr[f][s], a0[f]);          // + x (channels 32 s .. 32 s + 15)
+                    a1[f] = MFMA_16x16x32(io, xr[f][s], a1[f]);          // + x (channels 32 s + 16 .. 32 s + 31)
                 }
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+                    yf[f][s] = (f16x8){(f16)a0[f][0], (f16)a0[f][1], (f16)a0[f][2], (f16)a0[f][3],
+                                       (f16)a1[f][0], (f16)a1[f][1], (f16)a1[f][2], (f16)a1[f][3]};
             }
         }
         f32x4 acc[NT][MF];
@@ -348,10 +362,8 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
             const f32x4 cb = *reinterpret_cast<const f32x4 *>(lb3 + n0 + 16);
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
-                acc[2 * s][f] = (f32x4){(float)yf[f][s][0] + ca[0], (float)yf[f][s][1] + ca[1],
-                                        (float)yf[f][s][2] + ca[2], (float)yf[f][s][3] + ca[3]};
-                acc[2 * s + 1][f] = (f32x4){(float)yf[f][s][4] + cb[0], (float)yf[f][s][5] + cb[1],
-                                            (float)yf[f][s][6] + cb[2], (float)yf[f][s][7] + cb[3]};
+                acc[2 * s][f] = MFMA_16x16x32(je, yf[f][s], ca);             // b3 + y
+                acc[2 * s + 1][f] = MFMA_16x16x32(jo, yf[f][s], cb);
             }
         }
         constexpr int F_MLP = 2 * KS * KS;
