@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0       # spec (≈6.3 TB/s achievable)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=220)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-size", type=int, default=int(os.environ.get("NUNIF_BENCH_BATCH", "45")),
                     help="tiles per model launch (the reference's tile minibatch; results do not depend on it)")

@@ -7,7 +7,7 @@ OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pt
-rocprofv3 --kernel-trace --output-format csv -d /tmp/pt -o kt -- python $REPO/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-host-frames > "$OUT/timeline.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/pt -o kt -- python $REPO/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-host-frames --no-iw3 --no-4k > "$OUT/timeline.log" 2>&1
 f=$(find /tmp/pt -name '*kernel_trace.csv' | head -1)
 python - "$f" > "$OUT/timeline.txt" <<'PY'
 import csv, sys
