@@ -100,6 +100,22 @@ int nunif_hip_swin_unet_forward(nunif_swin_unet *handle, const float *x, float *
 int nunif_hip_swin_unet_render(nunif_swin_unet *handle, const float *x, float *y, int32_t x_h, int32_t x_w,
                                int32_t tile_size, int32_t batch_size, void *stream);
 
+/* Tile-ROW sharding of one huge image (the multi-GPU fallback of SURVEY.md §8e; the reference has no counterpart — its
+ * SeamBlending.tiled_render, seam_blending.py:48-106, runs every tile on one model): the same render cut into
+ *   render_tile_rows  the tiles of tile rows [row_begin, row_end) of the grid into the handle's tile store,
+ *   tile_row_band     export (import_band = 0) / import (1) of output rows [row0, row0 + n_rows) of every tile of one tile row,
+ *                     band = [w_blocks][3][n_rows][out_tile_size] f32 device — what neighbouring ranks exchange,
+ *   stitch_rows       the single-pass stitch of output rows [y_row_begin, y_row_end) into a compact [3][rows][y_w] band.
+ * Same tile grid, same tile store layout and the same stitch kernel as nunif_hip_swin_unet_render: bit-identical results. */
+int nunif_hip_swin_unet_render_tile_rows(nunif_swin_unet *handle, const float *x, int32_t x_h, int32_t x_w,
+                                         int32_t tile_size, int32_t batch_size, int32_t row_begin, int32_t row_end,
+                                         void *stream);
+int nunif_hip_swin_unet_tile_row_band(nunif_swin_unet *handle, int32_t x_h, int32_t x_w, int32_t tile_size,
+                                      int32_t tile_row, int32_t row0, int32_t n_rows, float *band, int32_t import_band,
+                                      void *stream);
+int nunif_hip_swin_unet_stitch_rows(nunif_swin_unet *handle, float *y_band, int32_t x_h, int32_t x_w, int32_t tile_size,
+                                    int32_t y_row_begin, int32_t y_row_end, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * waifu2x CUNet.  Replaces waifu2x/models/cunet.py CUNet.forward :183-196 (UNet1 :52-67, UNet2 :99-121, SEBlock
  * nunif/modules/attention.py:29-44).  Geometry: scale 1, offset 28, no blending (cunet.py:177).

@@ -12,7 +12,8 @@
 #include "swin_kernels.h"
 
 namespace nunif {
-int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int C, hipStream_t s);
+int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int C, hipStream_t s, int y0 = 0, int rows = -1,
+                  int compact = 0);
 }
 
 using namespace nunif;

@@ -34,6 +34,8 @@ gather_tiles_kernel(const float *__restrict__ x, float *__restrict__ tiles, int 
 
 struct StitchParams {
     int C, y_h, y_w, hb, wb, ostep, To, blend;
+    int y0;          // first output row of this launch (tile-row sharding: a band of the image), 0 for the whole image
+    int dst_rows;    // rows per channel plane of the destination: y_h for the whole image, the band height for a compact band
     float ramp[64];
 };
 
@@ -49,7 +51,7 @@ stitch_kernel(const float *__restrict__ tiles, float *__restrict__ y, StitchPara
     // and the result is 1 ulp off the reference's separately rounded mul/mul/add (seen on gfx950).
 #pragma clang fp contract(off)
     const int xg = blockIdx.x * blockDim.x + threadIdx.x;   // group of VEC pixels along x
-    const int Y = blockIdx.y;
+    const int Y = blockIdx.y + p.y0;                        // (y0 > 0: a row band of the image, tile-row sharding)
     const int X0 = xg * VEC;
     if (X0 >= p.y_w) return;
     const int i_hi = min(Y / p.ostep, p.hb - 1);
@@ -103,7 +105,7 @@ stitch_kernel(const float *__restrict__ tiles, float *__restrict__ y, StitchPara
                 P[0] = src[0];
             }
         }
-        float *dst = y + ((long)c * p.y_h + Y) * p.y_w + X0;
+        float *dst = y + ((long)c * p.dst_rows + (Y - (p.dst_rows == p.y_h ? 0 : p.y0))) * p.y_w + X0;
         if (VEC == 4) {
             float4 o;
             o.x = fminf(fmaxf(P[0], 0.f), 1.f); o.y = fminf(fmaxf(P[1 % VEC], 0.f), 1.f);
@@ -115,8 +117,14 @@ stitch_kernel(const float *__restrict__ tiles, float *__restrict__ y, StitchPara
     }
 }
 
-int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int C, hipStream_t s) {
+int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int C, hipStream_t s, int y0, int rows,
+                  int compact) {
     StitchParams p;
+    if (rows < 0) rows = g->y_h - y0;
+    p.dst_rows = compact ? rows : g->y_h;
+    NUNIF_REQUIRE(y0 >= 0 && rows >= 0 && y0 + rows <= g->y_h, "stitch: row band [%d, %d) outside the image", y0, y0 + rows);
+    if (rows == 0) return NUNIF_HIP_OK;
+    p.y0 = y0;
     p.C = C; p.y_h = g->y_h; p.y_w = g->y_w; p.hb = g->h_blocks; p.wb = g->w_blocks;
     p.ostep = g->output_tile_step; p.To = g->out_tile_size; p.blend = g->blend_size;
     NUNIF_REQUIRE(g->blend_size <= 64, "blend_size %d > 64 unsupported", g->blend_size);
@@ -126,13 +134,13 @@ int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int
     // if a tile boundary is not VEC-aligned; the alignment test below covers that too.
     const bool vec = (p.To % 4 == 0) && (p.ostep % 4 == 0) && (p.y_w % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(tile_out) | reinterpret_cast<uintptr_t>(y)) % 16 == 0);
-    const double bytes = (double)C * p.y_h * p.y_w * 4.0 * 2.0;
+    const double bytes = (double)C * rows * p.y_w * 4.0 * 2.0;
     ProfScope ps(vec ? "stitch_kernel<4>" : "stitch_kernel<1>", s, 0.0, bytes);
     if (vec) {
-        dim3 grid(cdiv(p.y_w / 4, 256), p.y_h);
+        dim3 grid(cdiv(p.y_w / 4, 256), rows);
         stitch_kernel<4><<<grid, 256, 0, s>>>(tile_out, y, p);
     } else {
-        dim3 grid(cdiv(p.y_w, 256), p.y_h);
+        dim3 grid(cdiv(p.y_w, 256), rows);
         stitch_kernel<1><<<grid, 256, 0, s>>>(tile_out, y, p);
     }
     NUNIF_LAUNCH_CHECK();
@@ -197,5 +205,5 @@ extern "C" int nunif_hip_gather_tiles(const float *x, float *tiles, const nunif_
 extern "C" int nunif_hip_stitch_tiles(const float *tile_out, float *y, const nunif_tile_grid *g, int32_t C,
                                       void *stream) {
     NUNIF_REQUIRE(tile_out && y && g, "stitch_tiles: NULL pointer");
-    return launch_stitch(tile_out, y, g, C, (hipStream_t)stream);
+    return launch_stitch(tile_out, y, g, C, (hipStream_t)stream, 0, -1, 0);
 }

@@ -14,7 +14,8 @@
 
 namespace nunif {
 
-int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int C, hipStream_t s);
+int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int C, hipStream_t s, int y0 = 0, int rows = -1,
+                  int compact = 0);
 
 namespace {
 
@@ -762,4 +763,68 @@ extern "C" int nunif_hip_swin_unet_render(nunif_swin_unet *h, const float *x, fl
             return rc;
     }
     return launch_stitch(tile_out, y, &g, 3, st);
+}
+
+// ---- tile-ROW sharding of ONE huge image (SURVEY.md §8e fallback): a rank renders the tiles of its tile rows, neighbours
+// exchange the (out_tile_size - output_tile_step)-row overlap band of their boundary tile rows, every rank stitches its own
+// band of output rows.  The tile store of the handle is addressed like the whole-frame render's ([tile][3][To][To]), so the
+// stitch kernel — and therefore the blend recurrence — is the same one: a sharded render is bit-identical to a whole one.
+static int rows_grid(nunif_swin_unet *h, int32_t x_h, int32_t x_w, int32_t tile_size, nunif_tile_grid *g) {
+    NUNIF_REQUIRE(h->scale_factor != 8, "swin_unet: the 8x net has no consistent tile geometry");
+    const int s = h->scale_factor;
+    int rc = nunif_hip_tile_grid_init(x_h, x_w, s, 8 * s, tile_size, 4 * s, g);
+    if (rc) return rc;
+    const size_t To = g->out_tile_size;
+    return h->tile_out.ensure((size_t)g->h_blocks * g->w_blocks * 3 * To * To * sizeof(float));
+}
+
+extern "C" int nunif_hip_swin_unet_render_tile_rows(nunif_swin_unet *h, const float *x, int32_t x_h, int32_t x_w,
+                                                    int32_t tile_size, int32_t batch_size, int32_t row_begin,
+                                                    int32_t row_end, void *stream) {
+    NUNIF_REQUIRE(h && x && batch_size > 0, "swin_unet_render_tile_rows: bad argument");
+    nunif_tile_grid g;
+    int rc = rows_grid(h, x_h, x_w, tile_size, &g);
+    if (rc) return rc;
+    NUNIF_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= g.h_blocks, "tile rows [%d, %d) outside the grid of %d rows",
+                  row_begin, row_end, g.h_blocks);
+    const size_t To = g.out_tile_size;
+    float *tile_out = (float *)h->tile_out.p;
+    const int t_end = row_end * g.w_blocks;
+    for (int t0 = row_begin * g.w_blocks; t0 < t_end; t0 += batch_size) {
+        const int nb = std::min(batch_size, t_end - t0);
+        if ((rc = forward_impl(h, nullptr, x, &g, t0, tile_out + (size_t)t0 * 3 * To * To, nb, tile_size, (hipStream_t)stream)))
+            return rc;
+    }
+    return NUNIF_HIP_OK;
+}
+
+// band: [w_blocks][3][n_rows][To] fp32 = output rows [row0, row0 + n_rows) of every tile of tile row `tile_row`
+extern "C" int nunif_hip_swin_unet_tile_row_band(nunif_swin_unet *h, int32_t x_h, int32_t x_w, int32_t tile_size,
+                                                 int32_t tile_row, int32_t row0, int32_t n_rows, float *band,
+                                                 int32_t import_band, void *stream) {
+    NUNIF_REQUIRE(h && band, "swin_unet_tile_row_band: bad argument");
+    nunif_tile_grid g;
+    int rc = rows_grid(h, x_h, x_w, tile_size, &g);
+    if (rc) return rc;
+    const int To = g.out_tile_size;
+    NUNIF_REQUIRE(0 <= tile_row && tile_row < g.h_blocks && row0 >= 0 && n_rows > 0 && row0 + n_rows <= To, "tile_row_band: bad window");
+    float *store = (float *)h->tile_out.p + (size_t)tile_row * g.w_blocks * 3 * To * To + (size_t)row0 * To;
+    // (tile, channel) planes: To * To apart in the store, n_rows * To apart in the band
+    const size_t planes = (size_t)g.w_blocks * 3;
+    if (import_band)
+        NUNIF_HIP_CHECK(hipMemcpy2DAsync(store, (size_t)To * To * 4, band, (size_t)n_rows * To * 4, (size_t)n_rows * To * 4, planes,
+                                         hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    else
+        NUNIF_HIP_CHECK(hipMemcpy2DAsync(band, (size_t)n_rows * To * 4, store, (size_t)To * To * 4, (size_t)n_rows * To * 4, planes,
+                                         hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return NUNIF_HIP_OK;
+}
+
+extern "C" int nunif_hip_swin_unet_stitch_rows(nunif_swin_unet *h, float *y_band, int32_t x_h, int32_t x_w, int32_t tile_size,
+                                               int32_t y_row_begin, int32_t y_row_end, void *stream) {
+    NUNIF_REQUIRE(h && y_band, "swin_unet_stitch_rows: bad argument");
+    nunif_tile_grid g;
+    int rc = rows_grid(h, x_h, x_w, tile_size, &g);
+    if (rc) return rc;
+    return launch_stitch((const float *)h->tile_out.p, y_band, &g, 3, (hipStream_t)stream, y_row_begin, y_row_end - y_row_begin, 1);
 }

@@ -113,6 +113,83 @@ def render_sharded(frames, render_fn, group=None, dst=0, bits=8, on_frame=None):
     return None if on_frame is not None else out
 
 
+def tile_row_plan(h_blocks, output_tile_step, out_tile_size, y_h, world):
+    """Contiguous tile rows per rank for ``render_rows_sharded``: a list of ``(r0, r1, y0, y1)`` — rank k renders tile rows
+    [r0, r1) and owns output rows [y0, y1).  Ranks beyond the number of tile rows get an empty share at the end."""
+    overlap = out_tile_size - output_tile_step
+    if overlap > output_tile_step:
+        raise ValueError("tile-row sharding needs at most two tile rows over any output row")
+    active = max(1, min(world, h_blocks))
+    base, extra = divmod(h_blocks, active)
+    plan, r = [], 0
+    for k in range(world):
+        n = (base + (1 if k < extra else 0)) if k < active else 0
+        r0, r1 = r, r + n
+        y0 = min(r0 * output_tile_step, y_h)
+        y1 = y_h if (r1 >= h_blocks) else min(r1 * output_tile_step, y_h)
+        if n == 0:
+            y0 = y1 = y_h
+        plan.append((r0, r1, y0, y1))
+        r = r1
+    return plan
+
+
+def render_rows_sharded(x, eng, group=None, dst=0):
+    """ONE image over the ranks of ``group`` by TILE ROWS (the fallback of SURVEY.md §8e for a single huge image; frames
+    should be sharded whole with ``render_sharded``).  ``eng`` is a tile-row engine for this image on this rank's device
+    (``model.row_engine(x)`` → ``SwinRowEngine``: ``render_tile_rows``, ``export_band`` / ``import_band``, ``stitch_rows`` and
+    the grid numbers).  Every rank renders the tiles of its own tile rows; the ONLY exchange is the overlap band — the bottom
+    ``out_tile_size - output_tile_step`` output rows of a rank's last tile row go to the next rank (one point-to-point
+    message per boundary, RCCL over xGMI under ``nccl``), which imports them into its tile store and stitches its own band of
+    output rows with the unchanged stitch kernel.  The bands are then delivered to ``dst``.  Tiles, recurrence order and
+    arithmetic are those of the whole-frame render, so the result is bit-identical to it.  Returns CHW float on ``dst``,
+    ``None`` elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        eng.render_tile_rows(x, 0, eng.h_blocks)
+        return eng.stitch_rows(0, eng.y_h)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    plan = tile_row_plan(eng.h_blocks, eng.output_tile_step, eng.out_tile_size, eng.y_h, world)
+    r0, r1, y0, y1 = plan[rank]
+    overlap = eng.out_tile_size - eng.output_tile_step
+    reqs = []
+    recv_band = None
+    if r1 > r0 and r0 > 0 and overlap > 0:               # the previous rank's last tile row covers my first `overlap` rows
+        recv_band = torch.empty((eng.w_blocks, 3, overlap, eng.out_tile_size), dtype=torch.float32, device=eng.device)
+        reqs += dist.batch_isend_irecv([dist.P2POp(dist.irecv, recv_band, rank - 1, group)])
+    if r1 > r0:
+        eng.render_tile_rows(x, r0, r1)
+        nxt = rank + 1
+        if nxt < world and plan[nxt][1] > plan[nxt][0] and overlap > 0:
+            send_band = eng.export_band(r1 - 1, eng.output_tile_step, overlap)
+            reqs += dist.batch_isend_irecv([dist.P2POp(dist.isend, send_band, nxt, group)])
+    for r in reqs:
+        r.wait()
+    if recv_band is not None:
+        eng.import_band(r0 - 1, eng.output_tile_step, recv_band)
+    band = eng.stitch_rows(y0, y1)
+    # ---- deliver the bands to dst (they are disjoint row ranges of the output) ------------------------------------------
+    if rank != dst:
+        if y1 > y0:
+            for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, band.contiguous(), dst, group)]):
+                r.wait()
+        return None
+    out = torch.empty((band.shape[0], eng.y_h, band.shape[2]), dtype=band.dtype, device=band.device)
+    out[:, y0:y1] = band
+    ops, bufs = [], []
+    for k, (_, _, a, b) in enumerate(plan):
+        if k == dst or b <= a:
+            continue
+        buf = torch.empty((band.shape[0], b - a, band.shape[2]), dtype=band.dtype, device=band.device)
+        ops.append(dist.P2POp(dist.irecv, buf, k, group))
+        bufs.append((a, b, buf))
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+    for a, b, buf in bufs:
+        out[:, a:b] = buf
+    return out
+
+
 class ConcurrentRenderer:
     """Frame-level concurrency INSIDE one GPU: ``n_streams`` replicas of a model (each with its own engine handle and
     workspace) on ``n_streams`` HIP streams; frames are dealt round-robin and come back in submission order.

@@ -145,6 +145,46 @@ class HipSwinUNetEngine:
         return y
 
 
+class SwinRowEngine:
+    """The tile-row interface ``nunif_amd.parallel.render_rows_sharded`` drives (one huge image over several GPUs): the
+    whole-frame render of ``engine`` cut into partial renders of tile rows, band export / import and a row-band stitch."""
+
+    def __init__(self, engine, H, W, tile_size, batch_size):
+        self.e, self.H, self.W, self.tile_size, self.batch_size = engine, H, W, tile_size, batch_size
+        s = engine.scale_factor
+        self.grid = _hip.tile_grid(H, W, s, 8 * s, tile_size, 4 * s)
+        self.h_blocks, self.w_blocks = self.grid.h_blocks, self.grid.w_blocks
+        self.out_tile_size, self.output_tile_step = self.grid.out_tile_size, self.grid.output_tile_step
+        self.y_h, self.y_w = self.grid.y_h, self.grid.y_w
+        self.device = engine.device
+
+    def _call(self, fn, *args):
+        with torch.cuda.device(self.device):
+            _hip.check(fn(*args, _hip.current_stream_ptr(self.device)))
+
+    def render_tile_rows(self, x, r0, r1):
+        self._call(_hip.lib().nunif_hip_swin_unet_render_tile_rows, self.e.handle, ctypes.c_void_p(x.data_ptr()), self.H, self.W,
+                   self.tile_size, self.batch_size, r0, r1)
+
+    def export_band(self, tile_row, row0, n_rows):
+        band = torch.empty((self.w_blocks, 3, n_rows, self.out_tile_size), dtype=torch.float32, device=self.device)
+        self._call(_hip.lib().nunif_hip_swin_unet_tile_row_band, self.e.handle, self.H, self.W, self.tile_size, tile_row, row0,
+                   n_rows, ctypes.c_void_p(band.data_ptr()), 0)
+        return band
+
+    def import_band(self, tile_row, row0, band):
+        band = band.to(device=self.device, dtype=torch.float32).contiguous()
+        self._call(_hip.lib().nunif_hip_swin_unet_tile_row_band, self.e.handle, self.H, self.W, self.tile_size, tile_row, row0,
+                   band.shape[2], ctypes.c_void_p(band.data_ptr()), 1)
+
+    def stitch_rows(self, y0, y1):
+        out = torch.empty((3, y1 - y0, self.y_w), dtype=torch.float32, device=self.device)
+        if y1 > y0:
+            self._call(_hip.lib().nunif_hip_swin_unet_stitch_rows, self.e.handle, ctypes.c_void_p(out.data_ptr()), self.H, self.W,
+                       self.tile_size, y0, y1)
+        return out
+
+
 class _HipSwinUNetModel(I2IBaseModel):
     """Common machinery: flat fp32 master weights under the reference's keys + a lazily built HIP engine."""
     unet_scale_factor = 1
@@ -209,6 +249,12 @@ class _HipSwinUNetModel(I2IBaseModel):
     def render_frame(self, x, tile_size, batch_size):
         """Whole-frame tiled render in one C call (used by SeamBlending.tiled_render)."""
         return self.engine().render(self._prepare(x), tile_size, batch_size)
+
+    def row_engine(self, x, tile_size=None, batch_size=None):
+        """-> (prepared frame, SwinRowEngine): the tile-row form of ``render_frame`` for ``parallel.render_rows_sharded``."""
+        x = self._prepare(x)
+        return x, SwinRowEngine(self.engine(), x.shape[1], x.shape[2], self.find_valid_tile_size(tile_size),
+                                batch_size or self.i2i_default_batch_size)
 
 
 @register_model

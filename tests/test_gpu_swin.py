@@ -323,3 +323,26 @@ def test_swin_unet_4xl(hiplib):
     img = x[0, :, :50, :60].contiguous()
     out = tiled_render(img.to("cuda:0"), m, tile_size=64, batch_size=4).cpu()
     assert out.shape == (3, 200, 240) and torch.isfinite(out).all()
+
+
+def test_tile_row_sharding_matches_whole_render_bit_exact(hiplib):
+    """nunif_hip_swin_unet_render_tile_rows / tile_row_band / stitch_rows: two engine handles play two ranks of
+    ``parallel.render_rows_sharded`` on one GPU — each renders its tile rows, the upper one hands the overlap band of its last
+    tile row to the lower one, each stitches its band of output rows.  Same tiles, same stitch kernel: torch.equal."""
+    from nunif_amd.parallel import render_rows_sharded, tile_row_plan
+    m, sd = make_model(2, 102)
+    m2, _ = make_model(2, 102)
+    x = synth_image(31, 3, 300, 200).to("cuda:0")
+    ref = m.render_frame(x, tile_size=64, batch_size=5)
+    xa, ea = m.row_engine(x, tile_size=64, batch_size=5)
+    xb, eb = m2.row_engine(x, tile_size=64, batch_size=3)
+    assert torch.equal(render_rows_sharded(xa, ea), ref)                      # world 1 through the tile-row calls
+    plan = tile_row_plan(ea.h_blocks, ea.output_tile_step, ea.out_tile_size, ea.y_h, 2)
+    (a0, a1, ya0, ya1), (b0, b1, yb0, yb1) = plan
+    assert a0 == 0 and a1 == b0 and b1 == ea.h_blocks and a1 > 0 and b1 > b0
+    overlap = ea.out_tile_size - ea.output_tile_step
+    ea.render_tile_rows(xa, a0, a1)
+    eb.render_tile_rows(xb, b0, b1)
+    eb.import_band(b0 - 1, eb.output_tile_step, ea.export_band(a1 - 1, ea.output_tile_step, overlap))
+    got = torch.cat([ea.stitch_rows(ya0, ya1), eb.stitch_rows(yb0, yb1)], dim=1)
+    assert got.shape == ref.shape and torch.equal(got, ref)

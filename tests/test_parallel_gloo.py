@@ -79,3 +79,97 @@ def test_render_sharded_three_ranks_streaming_and_nonzero_dst(tmp_path):
         assert len(got) == 7
         for a, b in zip(got, ref):
             assert torch.equal(a, b)
+
+
+# ---- tile-row sharding of ONE image (render_rows_sharded) --------------------------------------------------------------------
+class _FakeRowEngine:
+    """A torch-CPU stand-in with the SwinRowEngine interface: tile outputs are a deterministic function of the tile's pixels,
+    the stitch is the reference's running-mean recurrence (oracle.seam_blending) over whatever the tile store holds."""
+
+    def __init__(self, H, W, scale=2, offset=16, blend=8, tile=64):
+        from oracle import seam_blending as OS
+        self.OS, self.scale, self.offset, self.blend, self.tile = OS, scale, offset, blend, tile
+        cfg = OS.create_config(H, W, scale, offset, tile, blend)
+        self.cfg = cfg
+        self.h_blocks, self.w_blocks = cfg["h_blocks"], cfg["w_blocks"]
+        self.out_tile_size, self.output_tile_step = tile * scale - 2 * offset, cfg["output_tile_step"]
+        self.y_h, self.y_w = cfg["y_h"], cfg["y_w"]
+        self.device = torch.device("cpu")
+        self.store = torch.full((self.h_blocks * self.w_blocks, 3, self.out_tile_size, self.out_tile_size), float("nan"))
+
+    def _net(self, mb):
+        z = torch.nn.functional.interpolate(mb, scale_factor=self.scale, mode="nearest")
+        z = z * 0.6 + 0.3 * mb.mean(dim=(1, 2, 3), keepdim=True)
+        o = self.offset
+        return z[:, :, o:-o, o:-o]
+
+    def render_tile_rows(self, x, r0, r1):
+        xp = torch.nn.functional.pad(x[None], self.cfg["pad"], mode="replicate")[0]
+        st, T = self.cfg["input_tile_step"], self.tile
+        for i in range(r0, r1):
+            for j in range(self.w_blocks):
+                self.store[i * self.w_blocks + j] = self._net(xp[None, :, i * st:i * st + T, j * st:j * st + T])[0]
+
+    def export_band(self, tile_row, row0, n):
+        return self.store[tile_row * self.w_blocks:(tile_row + 1) * self.w_blocks, :, row0:row0 + n].clone()
+
+    def import_band(self, tile_row, row0, band):
+        self.store[tile_row * self.w_blocks:(tile_row + 1) * self.w_blocks, :, row0:row0 + band.shape[2]] = band
+
+    def stitch_rows(self, y0, y1):
+        OS, To, ostep = self.OS, self.out_tile_size, self.output_tile_step
+        px = torch.zeros(3, self.cfg["y_buffer_h"], self.cfg["y_buffer_w"])
+        wt = torch.zeros_like(px)
+        filt = OS.blend_filter(self.scale, self.offset, self.tile, self.blend, 3)
+        for i in range(self.h_blocks):
+            if i * ostep >= y1 or i * ostep + To <= y0:
+                continue                                       # this tile row does not touch the band
+            for j in range(self.w_blocks):
+                t = self.store[i * self.w_blocks + j]
+                ys, xs = slice(ostep * i, ostep * i + To), slice(ostep * j, ostep * j + To)
+                w_old = wt[:, ys, xs]
+                w_new = w_old + filt
+                a = w_old / w_new
+                px[:, ys, xs] = px[:, ys, xs] * a + t * (1 - a)
+                wt[:, ys, xs] = w_new
+        return torch.clamp(px[:, y0:y1, :self.y_w], 0, 1).contiguous()
+
+
+def _rows_worker(rank, world, port, H, W, path, dst):
+    from nunif_amd.parallel import render_rows_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = torch.rand(3, H, W, generator=torch.Generator().manual_seed(11))
+    out = render_rows_sharded(x, _FakeRowEngine(H, W), dst=dst)
+    if rank == dst:
+        torch.save(out, path)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_row_plan_covers_rows_and_tiles_once():
+    from nunif_amd.parallel import tile_row_plan
+    for hb, ostep, To, y_h in ((5, 472, 480, 2160), (10, 944, 960, 8640), (1, 96, 100, 90), (3, 96, 96, 250)):
+        for world in (1, 2, 3, 8):
+            plan = tile_row_plan(hb, ostep, To, y_h, world)
+            assert len(plan) == world and plan[0][0] == 0 and plan[-1][1] == hb
+            assert all(a[1] == b[0] and a[3] == b[2] for a, b in zip(plan, plan[1:]))
+            assert plan[0][2] == 0 and plan[-1][3] == y_h
+            assert all(r0 <= r1 and y0 <= y1 for r0, r1, y0, y1 in plan)
+
+
+def test_render_rows_sharded_is_bit_identical_to_the_whole_render(tmp_path):
+    """2 and 3 ranks (and more ranks than tile rows): the band exchange + per-rank stitch reproduces the whole-frame render bit
+    for bit, because tiles, recurrence order and arithmetic are the same."""
+    from nunif_amd.parallel import render_rows_sharded
+    for H, W, world, dst in ((150, 100, 2, 0), (230, 70, 3, 1), (60, 90, 3, 0)):
+        x = torch.rand(3, H, W, generator=torch.Generator().manual_seed(11))
+        ref = render_rows_sharded(x, _FakeRowEngine(H, W))                 # world 1: render everything, stitch everything
+        path = str(tmp_path / f"rows_{H}_{world}.pt")
+        mp.spawn(_rows_worker, args=(world, _free_port(), H, W, path, dst), nprocs=world, join=True)
+        got = torch.load(path)
+        assert got.shape == ref.shape == (3, 2 * H, 2 * W)
+        assert torch.equal(got, ref), (H, W, world)
