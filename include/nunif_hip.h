@@ -120,6 +120,19 @@ int nunif_hip_swin_unet_stitch_rows(nunif_swin_unet *handle, float *y_band, int3
  * waifu2x CUNet.  Replaces waifu2x/models/cunet.py CUNet.forward :183-196 (UNet1 :52-67, UNet2 :99-121, SEBlock
  * nunif/modules/attention.py:29-44).  Geometry: scale 1, offset 28, no blending (cunet.py:177).
  * ---------------------------------------------------------------------------------------------------------- */
+/* waifu2x "waifu2x.swin_unet_v2_1x / _2x / _4x" (aliases winc_unet_*; waifu2x/models/swin_unet_v2.py SwinUNetV2Base :272-352,
+ * the model classes :361-466): IR stem, window-MHA + conv-MLP blocks (zero-padded half-window shift, learned score bias),
+ * shortcut PatchDown / PatchUp, ToImage + SourceResidual.  State dict in the reference's key layout ("unet." prefix); base_dim
+ * (64 / 96 / 128), lv2_ratio and the block counts are read from the tensor shapes.
+ * forward: x [B,3,T,T] f32 device -> z [B,3,T*s - 18*s, ...] f32 device (offset 9 s), clamp01 != 0 = eval-mode clamp; T must
+ * satisfy the reference's tile_size_validator :355-358 ((T - 16) % 48 == 0). */
+typedef struct nunif_swin_unet_v2 nunif_swin_unet_v2;
+int nunif_hip_swin_unet_v2_create(const nunif_tensor_desc *tensors, int32_t n_tensors, int32_t scale_factor,
+                                  nunif_swin_unet_v2 **handle);
+void nunif_hip_swin_unet_v2_destroy(nunif_swin_unet_v2 *handle);
+int nunif_hip_swin_unet_v2_forward(nunif_swin_unet_v2 *handle, const float *x, float *z, int32_t batch, int32_t tile_size,
+                                   int32_t clamp01, void *stream);
+
 typedef struct nunif_cunet nunif_cunet;
 int nunif_hip_cunet_create(const nunif_tensor_desc *tensors, int32_t n_tensors, int32_t no_clip, nunif_cunet **handle);
 void nunif_hip_cunet_destroy(nunif_cunet *handle);

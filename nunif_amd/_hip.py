@@ -63,6 +63,9 @@ SIGNATURES = {
     "nunif_hip_swin_unet_render_tile_rows": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "nunif_hip_swin_unet_tile_row_band": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "nunif_hip_swin_unet_stitch_rows": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_swin_unet_v2_create": (c_int32, [ctypes.POINTER(TensorDesc), c_int32, c_int32, ctypes.POINTER(c_void_p)]),
+    "nunif_hip_swin_unet_v2_destroy": (None, [c_void_p]),
+    "nunif_hip_swin_unet_v2_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "nunif_hip_cunet_create": (c_int32, [ctypes.POINTER(TensorDesc), c_int32, c_int32, ctypes.POINTER(c_void_p)]),
     "nunif_hip_cunet_destroy": (None, [c_void_p]),
     "nunif_hip_cunet_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),

@@ -599,8 +599,11 @@ int launch_layernorm_nobias(const f16 *x, f16 *y, const float *gamma, long M, in
     if (C == 96) layernorm_nobias_kernel<96><<<blocks, 256, 0, s>>>(x, y, gamma, M, 1e-5f);
     else if (C == 192) layernorm_nobias_kernel<192><<<blocks, 256, 0, s>>>(x, y, gamma, M, 1e-5f);
     else if (C == 384) layernorm_nobias_kernel<384><<<blocks, 256, 0, s>>>(x, y, gamma, M, 1e-5f);
+    else if (C == 64) layernorm_nobias_kernel<64><<<blocks, 256, 0, s>>>(x, y, gamma, M, 1e-5f);
+    else if (C == 128) layernorm_nobias_kernel<128><<<blocks, 256, 0, s>>>(x, y, gamma, M, 1e-5f);
+    else if (C == 256) layernorm_nobias_kernel<256><<<blocks, 256, 0, s>>>(x, y, gamma, M, 1e-5f);
     else {
-        set_error("layernorm: channel count %d unsupported (96, 192, 384)", C);
+        set_error("layernorm: channel count %d unsupported (64, 96, 128, 192, 256, 384)", C);
         return NUNIF_HIP_EUNSUPPORTED;
     }
     NUNIF_LAUNCH_CHECK();

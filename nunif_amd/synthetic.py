@@ -111,6 +111,72 @@ def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_c
     return sd
 
 
+def swin_unet_v2_state_dict(seed, scale_factor=2, base_dim=None, lv1_mlp_ratio=2, lv2_mlp_ratio=2, lv2_ratio=2,
+                            first_layers=2, last_layers=3):
+    """Seeded random weights of ``waifu2x.swin_unet_v2_{1,2,4}x`` in the reference's key layout and shapes
+    (waifu2x/models/swin_unet_v2.py SwinUNetV2Base :272-312; ``base_dim`` defaults to the registered model's: 64 / 96 / 128).
+
+    Same conditioning as ``swin_unet_state_dict``: xavier / kaiming magnitudes, the residual-branch outputs (head_proj,
+    conv_mlp.w2 — this net has no norm in front of its MLP, so the stream grows multiplicatively — and the PatchDown / PatchUp
+    convs beside their shortcuts) damped so that the stream rms stays O(1) over the 13 blocks, every bias N(0, 0.02), norm weights 1 + N(0, 0.1), the score-bias MLP
+    drawn wide enough that the bias table matters (+-0.5), the resampling conv = nearest neighbour + N(0, 0.02) so that all 27
+    taps are exercised, and ``scale_bias`` sized so that source + scale_bias * residual stays a picture inside [0, 1]."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    C = base_dim or {1: 64, 2: 96, 4: 128}[scale_factor]
+    C2 = int(C * lv2_ratio)
+
+    def normal(shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    def lin(key, cin, cout, gain=1.0):
+        bound = gain * math.sqrt(6.0 / (cin + cout))
+        sd[key + ".weight"] = (torch.rand((cout, cin), generator=g) * 2 - 1) * bound
+        sd[key + ".bias"] = normal((cout,), 0.02)
+
+    def conv(key, cin, cout, k, gain=1.0):
+        sd[key + ".weight"] = normal((cout, cin, k, k), gain * math.sqrt(2.0 / (cin * k * k)))
+        sd[key + ".bias"] = normal((cout,), 0.02)
+
+    def wac(p, dim, ws, mlp_ratio, conv_mlp=True):
+        lin(p + "mha.mha.qkv_proj", dim, dim * 3)
+        lin(p + "mha.mha.head_proj", dim, dim, 0.5)
+        sd[p + "relative_bias.index"], sd[p + "relative_bias.delta"] = window_score_bias_input((ws, ws))
+        sd[p + "relative_bias.to_bias.0.weight"] = normal((2 * ws, 2), 1.0)
+        sd[p + "relative_bias.to_bias.0.bias"] = normal((2 * ws,), 0.3)
+        sd[p + "relative_bias.to_bias.2.weight"] = normal((1, 2 * ws), 0.4)
+        sd[p + "relative_bias.to_bias.2.bias"] = normal((1,), 0.1)
+        sd[p + "norm.weight"] = 1.0 + normal((dim,), 0.1)
+        mid = int(dim * mlp_ratio)
+        conv(p + "conv_mlp.w1", dim, mid, 1)
+        if conv_mlp:
+            conv(p + "conv_mlp.w2", mid // 2, dim, 3, 0.35)
+        else:
+            conv(p + "conv_mlp.w2", mid, dim, 1, 0.2)
+
+    P = "unet."
+    conv(P + "ir.path1.0", 3, 16, 3)
+    conv(P + "ir.path2.1", 12, 64, 1)
+    wac(P + "ir.path2.2.", 64, 8, 1)
+    wac(P + "ir.path2.3.", 64, 8, 1)
+    conv(P + "patch", 32, C, 3)
+    for i in range(first_layers):
+        wac(f"{P}wac1.blocks.{i}.", C, [8, 6][i], lv1_mlp_ratio)
+    conv(P + "down1.conv", C, C2, 2, 0.5)
+    for i in range(4):
+        wac(f"{P}wac2.blocks.{i}.", C2, 8, lv2_mlp_ratio)
+    conv(P + "up1.proj", C2, C * 4, 1, 0.5)
+    for i in range(last_layers):
+        wac(f"{P}wac3.blocks.{i}.", C, 8, lv1_mlp_ratio, conv_mlp=i < last_layers - 1)
+    conv(P + "to_residual_image.proj", C, 3 * scale_factor ** 2, 1, 0.5)
+    sd[P + "to_image.scale_bias"] = torch.full((1,), 0.05)
+    w = normal((3 * scale_factor ** 2, 3, 3, 3), 0.02)
+    for c in range(3):
+        w[c * scale_factor ** 2:(c + 1) * scale_factor ** 2, c, 1, 1] += 1.0
+    sd[P + "to_image.resampling.weight"] = w
+    return sd
+
+
 def cunet_state_dict(seed, up=False, in_channels=3, out_channels=3):
     """Seeded weights in the reference's key layout; biases non-zero; the two image heads are scaled so that z1 and
     the final image sit inside [0,1] like a trained net's (same reasoning as oracle.swin_unet.random_state_dict)."""

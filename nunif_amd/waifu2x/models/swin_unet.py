@@ -185,19 +185,19 @@ class SwinRowEngine:
         return out
 
 
-class _HipSwinUNetModel(I2IBaseModel):
-    """Common machinery: flat fp32 master weights under the reference's keys + a lazily built HIP engine."""
+class _FlatWeightsModel(I2IBaseModel):
+    """Common machinery: flat fp32 master weights under the reference's keys + a lazily built HIP engine
+    (``_make_engine(device)``, one handle per device)."""
     unet_scale_factor = 1
 
-    def _setup(self, in_channels, out_channels, base_dim=96, layer_norm=False):
-        if in_channels != 3 or out_channels != 3:
-            raise ValueError("the HIP swin_unet engine supports in_channels = out_channels = 3")
-        if base_dim not in (96, 192):
-            raise ValueError("the HIP swin_unet engine supports base_dim 96 and 192 (swin_unet_4xl)")
+    def _setup_weights(self, weights):
         self.register_tile_size_validator(tile_size_validator)
         self.register_buffer("_device_probe", torch.empty(0), persistent=False)
-        self._weights = _init_weights(self.unet_scale_factor, base_dim, in_channels, out_channels, layer_norm)
+        self._weights = weights
         self._engine = None
+
+    def _make_engine(self, device):
+        raise NotImplementedError
 
     # -- nn.Module surface ------------------------------------------------------------------------------------
     def get_device(self):
@@ -234,7 +234,7 @@ class _HipSwinUNetModel(I2IBaseModel):
     def engine(self):
         dev = self.get_device()
         if self._engine is None or self._engine.device != dev:
-            self._engine = HipSwinUNetEngine(self._weights, self.unet_scale_factor, dev)
+            self._engine = self._make_engine(dev)
         return self._engine
 
     def _prepare(self, x):
@@ -245,6 +245,18 @@ class _HipSwinUNetModel(I2IBaseModel):
             raise RuntimeError("the HIP engine is inference-only; call .eval()")
         dtype = x.dtype
         return self.engine().forward(self._prepare(x)).to(dtype)
+
+
+class _HipSwinUNetModel(_FlatWeightsModel):
+    def _setup(self, in_channels, out_channels, base_dim=96, layer_norm=False):
+        if in_channels != 3 or out_channels != 3:
+            raise ValueError("the HIP swin_unet engine supports in_channels = out_channels = 3")
+        if base_dim not in (96, 192):
+            raise ValueError("the HIP swin_unet engine supports base_dim 96 and 192 (swin_unet_4xl)")
+        self._setup_weights(_init_weights(self.unet_scale_factor, base_dim, in_channels, out_channels, layer_norm))
+
+    def _make_engine(self, device):
+        return HipSwinUNetEngine(self._weights, self.unet_scale_factor, device)
 
     def render_frame(self, x, tile_size, batch_size):
         """Whole-frame tiled render in one C call (used by SeamBlending.tiled_render)."""

@@ -18,7 +18,7 @@ from ..nunif.models.register import data_parallel_model
 from ..nunif.transforms.tta import tta_merge, tta_split
 from ..nunif.utils.alpha import AlphaBorderPadding
 from ..nunif.utils.render import tiled_render
-from .models import cunet, swin_unet, vgg_7  # noqa: F401  (registers waifu2x.swin_unet_*, cunet, upcunet, vgg_7, upconv_7)
+from .models import cunet, swin_unet, swin_unet_v2, vgg_7  # noqa: F401  (registers waifu2x.swin_unet_*, swin_unet_v2_*, cunet, upcunet, vgg_7, upconv_7)
 
 METHODS = ("scale", "scale4x", "noise_scale", "noise_scale4x", "noise")
 
