@@ -283,7 +283,10 @@ int nunif_hip_resize_aa(const float *x, float *y, float *tmp, int64_t planes, in
                         int32_t h_out, int32_t w_out, int32_t bicubic, int32_t align_corners, int32_t clamp01,
                         const float *mean3, const float *std3, void *stream);
 
-/* Replaces iw3/dilation.py dilate_edge :116-142.  x,y: [B,1,H,W]; work: B*H*W + 16*B + 8 floats of scratch. */
+/* Replaces iw3/dilation.py dilate_edge :116-142.  x,y: [B,1,H,W]; work: nunif_hip_dilate_edge_work_floats(B,H,W) floats of
+ * scratch (a ping-pong image + the per-workgroup range statistics that carry edge_weight's mean / std / min / max from one
+ * iteration's kernel to the next: n iterations are n + 1 launches). */
+int64_t nunif_hip_dilate_edge_work_floats(int32_t B, int32_t H, int32_t W);
 int nunif_hip_dilate_edge(const float *x, float *y, float *work, int32_t B, int32_t H, int32_t W, int32_t n_x,
                           int32_t n_y, void *stream);
 

@@ -106,6 +106,7 @@ SIGNATURES = {
     "nunif_hip_resize_aa": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64] + [c_int32] * 7 +
                             [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
     "nunif_hip_dilate_edge": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
+    "nunif_hip_dilate_edge_work_floats": (ctypes.c_int64, [c_int32, c_int32, c_int32]),
     "nunif_hip_minmax_normalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
     "nunif_hip_mask_morphology": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p]),
     "nunif_hip_reflection_pad2d": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

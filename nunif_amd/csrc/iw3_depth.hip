@@ -66,7 +66,10 @@ resize_aa_axis_kernel(const float *__restrict__ in, float *__restrict__ out, lon
 }
 
 // ---- dilate_edge ------------------------------------------------------------------------------------------------------
-struct RangeStats { double sum, sumsq; unsigned int rmin, rmax; };   // range >= 0: float bits order as unsigned
+// Statistics of the 3x3 range map (edge_weight :101-113 needs its mean, std, min and max over the whole image) travel as
+// one PARTIAL per workgroup, reduced in a fixed order by every consumer workgroup: no atomics (round 1: 4 same-line atomics
+// per workgroup serialised in L2 and WERE the kernel), no init launch, deterministic sums.
+struct RangePartial { double sum, sumsq; float rmin, rmax; };
 
 __device__ __forceinline__ float range3x3(const float *__restrict__ img, int H, int W, int y, int x) {
     float mx = -3.0e38f, mn = 3.0e38f;
@@ -84,9 +87,23 @@ __device__ __forceinline__ float range3x3(const float *__restrict__ img, int H, 
     return mx - mn;
 }
 
-__global__ void range_stats_init_kernel(RangeStats *stats, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) { stats[b].sum = 0.0; stats[b].sumsq = 0.0; stats[b].rmin = 0xFFFFFFFFu; stats[b].rmax = 0u; }
+// 256 threads -> one RangePartial in sh[0..3] order (wave shuffles, then the four waves in order); all threads get the result
+__device__ __forceinline__ RangePartial block_range_reduce(double s, double s2, float mn, float mx) {
+    __shared__ RangePartial sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o);
+        mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    __syncthreads();                                           // sh may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = RangePartial{s, s2, mn, mx};
+    __syncthreads();
+    RangePartial r = sh[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        r.sum += sh[w].sum; r.sumsq += sh[w].sumsq; r.rmin = fminf(r.rmin, sh[w].rmin); r.rmax = fmaxf(r.rmax, sh[w].rmax);
+    }
+    return r;
 }
 
 __global__ void minmax_init_kernel(unsigned int *mm, int B) {
@@ -94,8 +111,9 @@ __global__ void minmax_init_kernel(unsigned int *mm, int B) {
     if (b < B) { mm[2 * b] = 0xFFFFFFFFu; mm[2 * b + 1] = 0u; }
 }
 
+// statistics of the INPUT of the first iteration: grid (blocks, B), one partial per workgroup
 __global__ void __launch_bounds__(256)
-range_stats_kernel(const float *__restrict__ x, RangeStats *stats, int H, int W) {
+range_partials_kernel(const float *__restrict__ x, RangePartial *__restrict__ part, int H, int W) {
     const int b = blockIdx.y;
     const float *img = x + (long)b * H * W;
     double s = 0.0, s2 = 0.0;
@@ -105,48 +123,55 @@ range_stats_kernel(const float *__restrict__ x, RangeStats *stats, int H, int W)
         s += r; s2 += (double)r * r;
         mn = fminf(mn, r); mx = fmaxf(mx, r);
     }
-    __shared__ double sh_s[256], sh_s2[256];
-    __shared__ float sh_mn[256], sh_mx[256];
-    sh_s[threadIdx.x] = s; sh_s2[threadIdx.x] = s2; sh_mn[threadIdx.x] = mn; sh_mx[threadIdx.x] = mx;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) {
-            sh_s[threadIdx.x] += sh_s[threadIdx.x + st];
-            sh_s2[threadIdx.x] += sh_s2[threadIdx.x + st];
-            sh_mn[threadIdx.x] = fminf(sh_mn[threadIdx.x], sh_mn[threadIdx.x + st]);
-            sh_mx[threadIdx.x] = fmaxf(sh_mx[threadIdx.x], sh_mx[threadIdx.x + st]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        atomicAdd(&stats[b].sum, sh_s[0]);
-        atomicAdd(&stats[b].sumsq, sh_s2[0]);
-        atomicMin(&stats[b].rmin, __float_as_uint(sh_mn[0]));
-        atomicMax(&stats[b].rmax, __float_as_uint(sh_mx[0]));
-    }
+    const RangePartial r = block_range_reduce(s, s2, mn, mx);
+    if (threadIdx.x == 0) part[(long)b * gridDim.x + blockIdx.x] = r;
 }
 
-// One workgroup = a 64x4 output patch.  The patch's (64+4)x(4+4) input halo is staged in LDS once (replicate-clamped
-// coordinates, which is exactly the blur's padding), the 3x3 blur is evaluated once per (64+2)x(4+2) position into a
-// second LDS tile, and the ky x kx max-pool + edge weight read only LDS: ~1.3 global loads per pixel instead of 90.
-constexpr int kDilTW = 64, kDilTH = 4;
+// One iteration of dilate_edge for a 64 x 8 output patch per workgroup — AND the range statistics of its own output, which
+// are the next iteration's edge-weight normalisation: n iterations are n + 1 launches (round 1: 3 n, 12 us each on a
+// 392 x 686 map, launch-bound).  The patch's input halo (3 px: blur 1 + pool 1 + one more ring) is staged in LDS once
+// (replicate-clamped coordinates, which is exactly the blur's padding); the blur is evaluated once per position of the
+// patch + 2 ring, the output on the patch + 1 ring (the ring is recomputed by the neighbours bit-identically: same code, same
+// inputs), and the 3x3 range of the OUTPUT is taken on the patch itself.  ~1.5 global loads per pixel instead of 90.
+constexpr int kDilTW = 64, kDilTH = 8;
 __global__ void __launch_bounds__(256)
-dilate_apply_kernel(const float *__restrict__ x, float *__restrict__ y, const RangeStats *stats, int H, int W,
-                    int ky, int kx) {
-    __shared__ float tin[kDilTH + 4][kDilTW + 4];
-    __shared__ float tbl[kDilTH + 2][kDilTW + 2];
+dilate_fused_kernel(const float *__restrict__ x, float *__restrict__ y, const RangePartial *__restrict__ pin, int n_in,
+                    RangePartial *__restrict__ pout, int H, int W, int ky, int kx) {
+    __shared__ float tin[kDilTH + 6][kDilTW + 6];
+    __shared__ float tbl[kDilTH + 4][kDilTW + 4];
+    __shared__ float tyv[kDilTH + 2][kDilTW + 2];
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * kDilTW, y0 = blockIdx.y * kDilTH;
     const float *img = x + (long)b * H * W;
-    for (int t = threadIdx.x; t < (kDilTH + 4) * (kDilTW + 4); t += 256) {
-        const int ty = t / (kDilTW + 4), tx = t % (kDilTW + 4);
-        const int yy = min(max(y0 + ty - 2, 0), H - 1), xx = min(max(x0 + tx - 2, 0), W - 1);
+    for (int t = threadIdx.x; t < (kDilTH + 6) * (kDilTW + 6); t += 256) {
+        const int ty = t / (kDilTW + 6), tx = t % (kDilTW + 6);
+        const int yy = min(max(y0 + ty - 3, 0), H - 1), xx = min(max(x0 + tx - 3, 0), W - 1);
         tin[ty][tx] = img[(long)yy * W + xx];
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < (kDilTH + 2) * (kDilTW + 2); t += 256) {
-        const int ty = t / (kDilTW + 2), tx = t % (kDilTW + 2);
-        const int cy = y0 + ty - 1, cx = x0 + tx - 1;
+    // the whole image's range statistics from the producer's partials (fixed order: thread-strided, then block_range_reduce)
+    float mean, denom, w_min, w_scale;
+    {
+        double s = 0.0, s2 = 0.0;
+        float mn = 3.0e38f, mx = 0.f;
+        const RangePartial *pp = pin + (long)b * n_in;
+        for (int i = threadIdx.x; i < n_in; i += 256) {
+            const RangePartial q = pp[i];
+            s += q.sum; s2 += q.sumsq; mn = fminf(mn, q.rmin); mx = fmaxf(mx, q.rmax);
+        }
+        const RangePartial st = block_range_reduce(s, s2, mn, mx);          // (its barriers also publish tin)
+        const double n = (double)H * W;
+        const double meand = st.sum / n;
+        mean = (float)meand;
+        double var = st.sumsq / n - meand * meand;
+        if (var < 0.0) var = 0.0;
+        denom = (float)sqrt(var) + 1e-6f;                                                  // dilation.py:107-108
+        const float wa = fminf(fmaxf((st.rmin - mean) / denom, -3.f), 3.f), wb = fminf(fmaxf((st.rmax - mean) / denom, -3.f), 3.f);
+        w_min = wa;
+        w_scale = (wb - wa) + 1e-6f;                                                       // :109-110
+    }
+    for (int t = threadIdx.x; t < (kDilTH + 4) * (kDilTW + 4); t += 256) {
+        const int ty = t / (kDilTW + 4), tx = t % (kDilTW + 4);
+        const int cy = y0 + ty - 2, cx = x0 + tx - 2;
         float g = -3.0e38f;                                   // outside the image: the pool's -inf padding
         if (cy >= 0 && cy < H && cx >= 0 && cx < W) {
             g = 0.f;
@@ -164,37 +189,59 @@ dilate_apply_kernel(const float *__restrict__ x, float *__restrict__ y, const Ra
         tbl[ty][tx] = g;
     }
     __syncthreads();
-    const int lx = threadIdx.x % kDilTW, ly = threadIdx.x / kDilTW;
-    const int px = x0 + lx, py = y0 + ly;
-    if (px >= W || py >= H) return;
-    const double n = (double)H * W;
-    const double meand = stats[b].sum / n;
-    const float mean = (float)meand;
-    double var = stats[b].sumsq / n - meand * meand;
-    if (var < 0.0) var = 0.0;
-    const float denom = (float)sqrt(var) + 1e-6f;                                     // dilation.py:107-108
-    float rmx = -3.0e38f, rmn = 3.0e38f;
+    for (int t = threadIdx.x; t < (kDilTH + 2) * (kDilTW + 2); t += 256) {
+        const int ty = t / (kDilTW + 2), tx = t % (kDilTW + 2);
+        const int py = y0 + ty - 1, px = x0 + tx - 1;
+        if (py < 0 || py >= H || px < 0 || px >= W) continue;          // never read: range3x3 skips out-of-image taps
+        float rmx = -3.0e38f, rmn = 3.0e38f;
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+        for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int yy = py + dy, xx = px + dx;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                const float v = tin[ly + 2 + dy][lx + 2 + dx];
-                rmx = fmaxf(rmx, v);
-                rmn = fminf(rmn, v);
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = py + dy, xx = px + dx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const float v = tin[ty + 2 + dy][tx + 2 + dx];
+                    rmx = fmaxf(rmx, v);
+                    rmn = fminf(rmn, v);
+                }
             }
-        }
-    const float r = rmx - rmn;
-    auto weight = [&](float rv) { return fminf(fmaxf((rv - mean) / denom, -3.f), 3.f); };
-    const float w_min = weight(__uint_as_float(stats[b].rmin)), w_max = weight(__uint_as_float(stats[b].rmax));
-    const float w = (weight(r) - w_min) / ((w_max - w_min) + 1e-6f);                   // :109-110
-    // x2 = max_pool(gaussian_blur(x)) over a ky x kx window (blur: replicate pad; pool: -inf pad)
-    float x2 = -3.0e38f;
-    for (int dy = -(ky / 2); dy <= ky / 2; ++dy)
-        for (int dx = -(kx / 2); dx <= kx / 2; ++dx) x2 = fmaxf(x2, tbl[ly + 1 + dy][lx + 1 + dx]);
-    const float v = tin[ly + 2][lx + 2];
-    y[(long)b * H * W + (long)py * W + px] = (v * (1.f - w)) + (x2 * w);                 // :121
+        const float wr = fminf(fmaxf(((rmx - rmn) - mean) / denom, -3.f), 3.f);
+        const float w = (wr - w_min) / w_scale;
+        // x2 = max_pool(gaussian_blur(x)) over a ky x kx window (blur: replicate pad; pool: -inf pad)
+        float x2 = -3.0e38f;
+        for (int dy = -(ky / 2); dy <= ky / 2; ++dy)
+            for (int dx = -(kx / 2); dx <= kx / 2; ++dx) x2 = fmaxf(x2, tbl[ty + 1 + dy][tx + 1 + dx]);
+        const float v = tin[ty + 2][tx + 2];
+        const float o = (v * (1.f - w)) + (x2 * w);                                       // :121
+        tyv[ty][tx] = o;
+        if (ty >= 1 && ty <= kDilTH && tx >= 1 && tx <= kDilTW) y[(long)b * H * W + (long)py * W + px] = o;
+    }
+    if (!pout) return;
+    __syncthreads();
+    double s = 0.0, s2 = 0.0;
+    float mn = 3.0e38f, mx = 0.f;
+    for (int t = threadIdx.x; t < kDilTH * kDilTW; t += 256) {
+        const int ly = t / kDilTW, lx = t % kDilTW;
+        const int py = y0 + ly, px = x0 + lx;
+        if (py >= H || px >= W) continue;
+        float rmx = -3.0e38f, rmn = 3.0e38f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = py + dy, xx = px + dx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const float v = tyv[ly + 1 + dy][lx + 1 + dx];
+                    rmx = fmaxf(rmx, v);
+                    rmn = fminf(rmn, v);
+                }
+            }
+        const float r = rmx - rmn;
+        s += r; s2 += (double)r * r;
+        mn = fminf(mn, r); mx = fmaxf(mx, r);
+    }
+    const RangePartial r = block_range_reduce(s, s2, mn, mx);
+    if (threadIdx.x == 0) pout[(long)b * gridDim.x * gridDim.y + (long)blockIdx.y * gridDim.x + blockIdx.x] = r;
 }
 
 // ---- per-image min-max normalise (depth_scaler.py:4-17, reset path: ema disabled) ----------------------------------------
@@ -368,14 +415,29 @@ extern "C" int nunif_hip_resize_aa(const float *x, float *y, float *tmp, int64_t
 
 static const long kStatBlocks = []() { const char *e = getenv("NUNIF_STAT_BLOCKS"); return e ? atol(e) : 96L; }();
 
+namespace {
+constexpr long kFirstStatBlocks = 512;
+long dilate_blocks(int H, int W) { return (long)((W + kDilTW - 1) / kDilTW) * ((H + kDilTH - 1) / kDilTH); }
+long dilate_partials(int H, int W) { return std::max(dilate_blocks(H, W), std::min<long>(((long)H * W + 255) / 256, kFirstStatBlocks)); }
+}  // namespace
+
+// floats of scratch nunif_hip_dilate_edge needs: one ping-pong image + two sets of per-workgroup statistics partials
+extern "C" int64_t nunif_hip_dilate_edge_work_floats(int32_t B, int32_t H, int32_t W) {
+    const long n = (long)B * H * W;
+    return ((n + 3) / 4) * 4 + 4 + 2 * (long)B * dilate_partials(H, W) * (long)(sizeof(RangePartial) / sizeof(float));
+}
+
 extern "C" int nunif_hip_dilate_edge(const float *x, float *y, float *work, int32_t B, int32_t H, int32_t W,
                                      int32_t n_x, int32_t n_y, void *stream) {
     NUNIF_REQUIRE(x && y && work && B > 0 && H > 0 && W > 0 && n_x >= 0 && n_y >= 0, "dilate_edge: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const long n = (long)B * H * W;
-    // work: [n floats ping-pong][B RangeStats]
+    // work: [n floats ping-pong][2 x B x partials RangePartial]
     float *bufs[2] = {y, work};
-    RangeStats *stats = reinterpret_cast<RangeStats *>(work + ((n + 3) / 4) * 4 + 4);
+    const long np = dilate_partials(H, W);
+    RangePartial *parts[2];
+    parts[0] = reinterpret_cast<RangePartial *>(work + ((n + 3) / 4) * 4 + 4);
+    parts[1] = parts[0] + (long)B * np;
     const int xy = n_x < n_y ? n_x : n_y;                       // dilation.py:118-120
     const int total_iters = xy + (n_y - xy) + (n_x - xy);
     if (total_iters == 0) {
@@ -387,15 +449,14 @@ extern "C" int nunif_hip_dilate_edge(const float *x, float *y, float *work, int3
     int it = 0;
     // the last iteration must land in y: choose the starting buffer by parity
     int dst_i = (total_iters % 2 == 1) ? 0 : 1;
+    int n_in = (int)std::min<long>(((long)H * W + 255) / 256, kFirstStatBlocks), pi = 0;
+    range_partials_kernel<<<dim3((unsigned)n_in, B), 256, 0, s>>>(src, parts[pi], H, W);
+    const dim3 g2((unsigned)((W + kDilTW - 1) / kDilTW), (unsigned)((H + kDilTH - 1) / kDilTH), B);
     auto run = [&](int ky, int kx) -> int {
-        range_stats_init_kernel<<<(B + 63) / 64, 64, 0, s>>>(stats, B);   // rmin starts at the largest uint key
-        // every workgroup ends in 4 atomics on ONE cache line (stats[b]); they serialise in L2 at ~25 ns each, so the
-        // grid is kept small: with 512 workgroups the 2048 atomics WERE the kernel (56 us for a 392 x 686 map,
-        // profiles/r01d_kernel_stats_iw3_sched.csv); 96 workgroups leave ~3 px x 9 taps x 10 rounds per thread
-        dim3 g1((unsigned)std::min<long>(((long)H * W + 255) / 256, kStatBlocks), B);
-        range_stats_kernel<<<g1, 256, 0, s>>>(src, stats, H, W);
-        dim3 g2((unsigned)((W + kDilTW - 1) / kDilTW), (unsigned)((H + kDilTH - 1) / kDilTH), B);
-        dilate_apply_kernel<<<g2, 256, 0, s>>>(src, bufs[dst_i], stats, H, W, ky, kx);
+        const bool last = it + 1 == total_iters;
+        dilate_fused_kernel<<<g2, 256, 0, s>>>(src, bufs[dst_i], parts[pi], n_in, last ? nullptr : parts[pi ^ 1], H, W, ky, kx);
+        n_in = (int)dilate_blocks(H, W);
+        pi ^= 1;
         src = bufs[dst_i];
         dst_i ^= 1;
         ++it;

@@ -40,7 +40,7 @@ def dilate_edge(x, n_x, n_y):
     b, c, h, w = x.shape
     assert c == 1
     y = torch.empty_like(x)
-    work = torch.empty(b * h * w + 16 * b + 8, dtype=torch.float32, device=x.device)
+    work = torch.empty(_hip.lib().nunif_hip_dilate_edge_work_floats(b, h, w), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _hip.check(_hip.lib().nunif_hip_dilate_edge(_p(x), _p(y), _p(work), b, h, w, n_x, n_y,
                                                     _hip.current_stream_ptr(x.device)))
