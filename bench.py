@@ -275,6 +275,23 @@ def iw3_record(dev, with_cpu):
         dilate_edge(dsmall, 2)
     torch.cuda.synchronize(dev)
     rec["dilate_edge_us_per_call"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+    # the reference's own depth harness (iw3/depth_anything_model.py _bench :289-308: model.infer on a 4 x 1080p batch, 20
+    # calls, FPS) for the three published geometries, random-init weights (parity unpinned)
+    x4 = torch.stack([synth_frame(920 + i, H, W) for i in range(4)]).to(dev)
+    rec["depth_infer_fps"] = {"protocol": "BaseDepthModel.infer(x[4,3,1080,1920]) -> [4,1,392,686], 20 calls after 2 warm-ups "
+                                          "(reference _bench: Any_L, B = 4, N = 20)"}
+    for enc in ("vits", "vitb", "vitl"):
+        dm = CallableDepthModel(HipDepthAnythingV2(depth_anything_v2_state_dict(601, grid=37, encoder=enc), str(dev)))
+        dm.load(gpu=dev.index or 0)
+        for _ in range(2):
+            dm.infer(x4)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dm.infer(x4)
+        torch.cuda.synchronize(dev)
+        rec["depth_infer_fps"][enc] = round(20 * 4 / (time.perf_counter() - t0), 1)
+        del dm
     if with_cpu:
         from oracle import dilation as OD
         from oracle import forward_warp as OF

@@ -181,6 +181,12 @@ int nunif_hip_forward_warp(const float *c, const float *depth, float *left, floa
  * once per resolution); depth: [B,h,w] f32 device (relu'd inverse depth, larger = nearer). */
 typedef struct nunif_depth_anything nunif_depth_anything;
 int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors, int32_t n_tensors, nunif_depth_anything **handle);
+/* The same with the two things a checkpoint does not say: taps = the four encoder blocks that feed the DPT head (NULL: the V2
+ * layout of the checkpoint's depth — 2, 5, 8, 11 of 12 blocks, 4, 11, 17, 23 of 24; Depth-Anything V1 takes the last four),
+ * and max_depth > 0 for the V2 metric heads (Sigmoid x max_depth: 20 hypersim, 80 vkitti) instead of ReLU.  The geometry —
+ * ViT-S / B / L (embed 384 / 768 / 1024, 12 / 24 blocks), DPT out_channels and fusion width — is read from the tensors. */
+int nunif_hip_depth_anything_create_ex(const nunif_tensor_desc *tensors, int32_t n_tensors, const int32_t *taps, float max_depth,
+                                       nunif_depth_anything **handle);
 void nunif_hip_depth_anything_destroy(nunif_depth_anything *handle);
 int nunif_hip_depth_anything_forward(nunif_depth_anything *handle, const float *x, const float *pos, float *depth,
                                      int32_t B, int32_t h, int32_t w, void *stream);

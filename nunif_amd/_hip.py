@@ -98,6 +98,8 @@ SIGNATURES = {
     "nunif_hip_depth_aa_destroy": (None, [c_void_p]),
     "nunif_hip_depth_aa_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "nunif_hip_depth_anything_create": (c_int32, [ctypes.POINTER(TensorDesc), c_int32, ctypes.POINTER(c_void_p)]),
+    "nunif_hip_depth_anything_create_ex": (c_int32, [ctypes.POINTER(TensorDesc), c_int32, ctypes.POINTER(c_int32), ctypes.c_float,
+                                                     ctypes.POINTER(c_void_p)]),
     "nunif_hip_depth_anything_destroy": (None, [c_void_p]),
     "nunif_hip_depth_anything_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "nunif_hip_tta_view": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
                     g.out32[(((long)pb[f] * g.n_real + n) * g.Ho + py[f]) * g.Wo + px[f]] = o;
                 }
             } else if (n0 < g.n_real) {
-                const long off = (((long)pb[f] * g.Ho + py[f]) * g.Wo + px[f]) * g.n_real + n0;
+                const long off = (((long)pb[f] * g.Ho + py[f]) * g.Wo + px[f]) * (g.ldo > 0 ? g.ldo : g.n_real) + n0;
                 if (g.res) {
                     const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
 #pragma unroll

@@ -1,9 +1,11 @@
-// Depth-Anything-V2 ViT-S (DINOv2 ViT-S/14 encoder + DPT head) on gfx950 — the depth backbone behind
+// Depth-Anything (V1 / V2 / V2-metric; DINOv2 ViT-S / B / L /14 encoder + DPT head) on gfx950 — the depth backbone behind
 // BaseDepthModel.infer (iw3/depth_anything_model.py:113-119,200-230 loads it through torch.hub; the network itself is
 // NOT in the reference tree, see oracle/depth_anything_v2.py: parity is against that restatement of the published
 // architecture only — "parity unpinned").
 //
-// Layout: tokens [B][1 + gh*gw][384] fp16 (class token first), DPT maps NHWC fp16.  GEMM-shaped work reuses the engine's
+// Geometry is read from the checkpoint (embed 384 / 768 / 1024 = 6 / 12 / 16 heads of 64, 12 / 24 blocks, DPT out_channels and
+// fusion width from the head's own tensors); which four blocks feed the head and the metric head's max_depth are arguments.
+// Layout: tokens [B][1 + gh*gw][D] fp16 (class token first), DPT maps NHWC fp16.  GEMM-shaped work reuses the engine's
 // kernels: gemm_kernel (Linear with K <= 608: patch embed, qkv, proj, fc1, 1x1 convs, the k = stride ConvTranspose2d
 // resize layers as pixel-shuffle GEMMs), conv_kernel (K-looped: fc2 with K = 1536, every 3x3 of the head with zero
 // padding, pre-activation ReLU and up to two residuals fused).  LayerScale is folded into proj / fc2 on the host, the
@@ -29,7 +31,7 @@ namespace nunif {
 
 #define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
-constexpr int kD = 384, kHeads = 6, kHd = 64, kPatch = 14, kKp = 608;   // 3*14*14 = 588 padded to 19 k-steps
+constexpr int kHd = 64, kPatch = 14, kKp = 608;   // 3*14*14 = 588 padded to 19 k-steps
 
 __global__ void __launch_bounds__(256) da_im2col_kernel(const float *__restrict__ x, f16 *__restrict__ a, int B, int h,
                                                         int w, int gh, int gw) {
@@ -51,7 +53,8 @@ __global__ void __launch_bounds__(256) da_im2col_kernel(const float *__restrict_
 
 // t[b][0] = cls + pos[0];  t[b][1+m] = patch[b][m] + pos[1+m]
 __global__ void __launch_bounds__(256) da_assemble_kernel(const f16 *__restrict__ pe, const float *__restrict__ cls,
-                                                          const float *__restrict__ pos, f16 *__restrict__ t, int B, int Np) {
+                                                          const float *__restrict__ pos, f16 *__restrict__ t, int B, int Np,
+                                                          int kD) {
     const long total = (long)B * Np * kD;
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= total) return;
@@ -62,33 +65,36 @@ __global__ void __launch_bounds__(256) da_assemble_kernel(const f16 *__restrict_
     t[id] = (f16)(v + pos[(long)n * kD + c]);
 }
 
+template <int NP>                                   // D = 64 * NP channels, one wave per token
 __global__ void __launch_bounds__(256) da_layernorm_kernel(const f16 *__restrict__ x, const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, f16 *__restrict__ y, long T) {
+    constexpr int kD = 64 * NP;
     const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= T) return;
     const int lane = threadIdx.x & 63;
-    float v[6];
+    float v[NP];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { v[i] = (float)x[tok * kD + lane + 64 * i]; s += v[i]; }
+    for (int i = 0; i < NP; ++i) { v[i] = (float)x[tok * kD + lane + 64 * i]; s += v[i]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s * (1.0f / kD);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { const float d = v[i] - mean; q += d * d; }
+    for (int i = 0; i < NP; ++i) { const float d = v[i] - mean; q += d * d; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = rsqrtf(q * (1.0f / kD) + 1e-6f);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NP; ++i) {
         const int c = lane + 64 * i;
         y[tok * kD + c] = (f16)((v[i] - mean) * rstd * gamma[c] + beta[c]);
     }
 }
 
 // vt[b][h][ch][t] = V[b][t][h*64 + ch]; zero for t >= Np (t < Tp)
-__global__ void __launch_bounds__(256) da_vt_kernel(const f16 *__restrict__ qkv, f16 *__restrict__ vt, int B, int Np, int Tp) {
+__global__ void __launch_bounds__(256) da_vt_kernel(const f16 *__restrict__ qkv, f16 *__restrict__ vt, int B, int Np, int Tp,
+                                                    int kD, int kHeads) {
     const long total = (long)B * kHeads * kHd * Tp;
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= total) return;
@@ -106,7 +112,7 @@ __device__ __forceinline__ f16x8 cat8a(f16x4 lo, f16x4 hi) {
 
 // grid (ceil(Np/16)/4 rounded up, heads, B), 4 waves per workgroup = 4 query tiles
 __global__ void __launch_bounds__(256) da_attn_kernel(const f16 *__restrict__ qkv, const f16 *__restrict__ vt,
-                                                      f16 *__restrict__ att, int Np, int Tp) {
+                                                      f16 *__restrict__ att, int Np, int Tp, int kD, int kHeads) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, grp = lane >> 4;
     const int qt = blockIdx.x * 4 + wave;
     if (qt * 16 >= Np) return;
@@ -181,7 +187,7 @@ __global__ void __launch_bounds__(256) da_attn_kernel(const f16 *__restrict__ qk
 // global-load latencies (measured 59.7 us per launch = 97 TFLOP/s, profiles/r01d_kernel_stats_iw3_sched.csv); here the same
 // launch is 4128 waves (4 per SIMD) of 11 key steps.  grid (ceil(Np/16), heads, B).
 __global__ void __launch_bounds__(256) da_attn_split_kernel(const f16 *__restrict__ qkv, const f16 *__restrict__ vt,
-                                                            f16 *__restrict__ att, int Np, int Tp) {
+                                                            f16 *__restrict__ att, int Np, int Tp, int kD, int kHeads) {
     __shared__ float sh_o[4][64][17];          // [wave][channel][query] (+1: no bank conflicts on the column reads)
     __shared__ float sh_m[4][16], sh_l[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, grp = lane >> 4;
@@ -294,16 +300,17 @@ __global__ void __launch_bounds__(256) da_upsample_kernel(const f16 *__restrict_
     *reinterpret_cast<f16x8 *>(y + (((long)b * Ho + Y) * Wo + X) * C + c8 * 8) = o;
 }
 
-// relu(conv1x1 32 -> 1) (+ the model's final relu, idempotent) -> fp32 [B,h,w]
+// relu(conv1x1 32 -> 1) (+ the model's final relu, idempotent) -> fp32 [B,h,w]; metric heads (max_depth > 0) end in a
+// Sigmoid instead and the model scales by max_depth (Depth-Anything-V2 metric_depth dpt.py)
 __global__ void __launch_bounds__(256) da_final_kernel(const f16 *__restrict__ x, const float *__restrict__ w, float *__restrict__ y,
-                                                       long n) {
+                                                       long n, float max_depth) {
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= n) return;
     float acc = w[32];
     const f16 *p = x + id * 32;
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc = fmaf((float)p[k], w[k], acc);
-    y[id] = fmaxf(acc, 0.f);
+    y[id] = max_depth > 0.f ? max_depth / (1.0f + __expf(-acc)) : fmaxf(acc, 0.f);
 }
 
 }  // namespace nunif
@@ -334,17 +341,20 @@ struct Buf {
 };
 struct Lin { f16 *w = nullptr; float *b = nullptr; int N = 0, K = 0; };              // gemm_kernel packing [nt][ks]
 struct Cnv { f16 *w = nullptr; float *b = nullptr; int N = 0, Cin = 0, k = 3; };     // conv_kernel stream [ks][nt]
-struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2a, fc2b; };   // fc2 (K = 1536) = two K = 768 GEMMs
+struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2[4]; int n_fc2; };   // fc2 (K = 4 D) = 2 or 4 GEMMs of K = 768 / 1024
 struct Rcu { Cnv c1, c2; };
 struct Fus { Rcu r1, r2; Lin out; };
 }  // namespace
 
 struct nunif_depth_anything {
     std::vector<void *> owned;
+    int D = 384, heads = 6, depth = 12, taps[4] = {2, 5, 8, 11};
+    int OC[4] = {48, 96, 192, 384}, OCP[4] = {64, 96, 192, 384}, feat_ch = 64;
+    float max_depth = 0.f;                 // > 0: metric head (Sigmoid * max_depth)
     Lin patch; float *cls = nullptr, *norm_g = nullptr, *norm_b = nullptr;
-    Blk blk[12];
-    Lin proj[4], rs0, rs1; Cnv rs3, rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
-    Buf a_col, pe, t, y, qkv, vt, att, hid, feat[4], m1, m2, m3, m4, m5;
+    std::vector<Blk> blk;
+    Lin proj[4], rs0, rs1; std::vector<Cnv> rs3; Cnv rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
+    Buf a_col, pe, t, y, qkv, vt, att, hid, feat[4], rnb[4], m1, m2, m3, m4, m5;
 };
 
 namespace {
@@ -415,19 +425,34 @@ int run_lin(const Lin &L, const f16 *a, int B, int Wi, int Wo, int ox, int act, 
     return launch_gemm(g, s, tag);
 }
 int run_cnv(const Cnv &C, const f16 *a, int B, int Hi, int Wi, int stride, int zpad, int relu_in, int act, const f16 *res,
-            const f16 *res2, f16 *out, hipStream_t s) {
+            const f16 *res2, f16 *out, hipStream_t s, int ldo = 0) {
     ConvArgs c;
     memset(&c, 0, sizeof(c));
     c.a = a; c.B = B; c.Hi = Hi; c.Wi = Wi; c.Cin = C.Cin; c.stride = stride; c.kh = C.k; c.kw = C.k;
     c.Ho = (Hi + 2 * zpad - C.k) / stride + 1; c.Wo = (Wi + 2 * zpad - C.k) / stride + 1;
     c.wstream = C.w; c.bias = C.b; c.N = C.N; c.n_real = C.N; c.act = act; c.out = out; c.zpad = zpad; c.relu_in = relu_in;
-    c.res = res; c.res2 = res2;
+    c.res = res; c.res2 = res2; c.ldo = ldo;
     return launch_conv(c, s);
 }
 }  // namespace
 
-extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors, int32_t n_tensors,
-                                               nunif_depth_anything **handle) {
+namespace {
+int launch_da_layernorm(const f16 *x, const float *g, const float *b, f16 *y, long T, int D, hipStream_t s) {
+    const unsigned grid = (unsigned)((T + 3) / 4);
+    if (D == 384) da_layernorm_kernel<6><<<grid, 256, 0, s>>>(x, g, b, y, T);
+    else if (D == 768) da_layernorm_kernel<12><<<grid, 256, 0, s>>>(x, g, b, y, T);
+    else if (D == 1024) da_layernorm_kernel<16><<<grid, 256, 0, s>>>(x, g, b, y, T);
+    else { set_error("depth_anything: embed dim %d unsupported (384, 768, 1024)", D); return NUNIF_HIP_EUNSUPPORTED; }
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+}  // namespace
+
+// taps: the four encoder blocks whose (final-norm'ed) tokens feed the DPT head, or NULL for the V2 defaults of the checkpoint's
+// depth (12 blocks: 2, 5, 8, 11; 24 blocks: 4, 11, 17, 23; V1 checkpoints pass the LAST four blocks).  max_depth > 0 selects the
+// metric head (Sigmoid, x max_depth); 0 the relative head (ReLU).
+extern "C" int nunif_hip_depth_anything_create_ex(const nunif_tensor_desc *tensors, int32_t n_tensors, const int32_t *taps,
+                                                  float max_depth, nunif_depth_anything **handle) {
     NUNIF_REQUIRE(tensors && handle && n_tensors > 0, "depth_anything_create: NULL argument");
     TMap m;
     for (int i = 0; i < n_tensors; ++i) {
@@ -438,12 +463,30 @@ extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors,
         m[tensors[i].name] = t;
     }
     nunif_depth_anything *h = new nunif_depth_anything();
+    h->max_depth = max_depth > 0.f ? max_depth : 0.f;
     int rc = NUNIF_HIP_OK;
     do {
         const std::string P = "pretrained.", H = "depth_head.";
         const HostT *w, *b, *t1, *t2;
         if ((rc = find(m, P + "patch_embed.proj.weight", &w)) || (rc = find(m, P + "patch_embed.proj.bias", &b))) break;
-        if (w->numel != (int64_t)kD * 588) { set_error("depth_anything: only ViT-S/14 (embed 384) is supported"); rc = NUNIF_HIP_EUNSUPPORTED; break; }
+        const int kD = (int)b->numel;
+        if ((kD != 384 && kD != 768 && kD != 1024) || w->numel != (int64_t)kD * 588) {
+            set_error("depth_anything: ViT-S / B / L with 14 x 14 patches expected (embed 384 / 768 / 1024), got embed %d", kD);
+            rc = NUNIF_HIP_EUNSUPPORTED; break;
+        }
+        h->D = kD; h->heads = kD / kHd;
+        int depth = 0;
+        while (m.find(P + "blocks." + std::to_string(depth) + ".attn.qkv.weight") != m.end()) ++depth;
+        if (depth != 12 && depth != 24) { set_error("depth_anything: %d encoder blocks (12 or 24 expected)", depth); rc = NUNIF_HIP_EUNSUPPORTED; break; }
+        h->depth = depth;
+        for (int i = 0; i < 4; ++i) {
+            static const int t12[4] = {2, 5, 8, 11}, t24[4] = {4, 11, 17, 23};
+            h->taps[i] = taps ? taps[i] : (depth == 12 ? t12[i] : t24[i]);
+            if (h->taps[i] < 0 || h->taps[i] >= depth || (i > 0 && h->taps[i] <= h->taps[i - 1])) {
+                set_error("depth_anything: taps must be 4 increasing block indices < %d", depth); rc = NUNIF_HIP_EINVAL; break;
+            }
+        }
+        if (rc) break;
         {
             const float *wd = w->data, *bd = b->data;
             if ((rc = make_lin(h, kD, kKp, [=](int n, int k) { return k < 588 ? wd[(size_t)n * 588 + k] : 0.f; },
@@ -454,7 +497,11 @@ extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors,
             (rc = up_f32(h, t2, &h->norm_b)))
             break;
         const float qs = (1.0f / sqrtf((float)kHd)) * 1.4426950408889634f;
-        for (int i = 0; i < 12 && !rc; ++i) {
+        h->blk.resize(depth);
+        // fc2 contracts over 4 D = 1536 / 3072 / 4096 hidden channels: gemm_kernel takes K <= 1024, so it runs as 2 or 4 K-slices
+        // that accumulate into the residual stream
+        const int kpiece = kD == 384 ? 768 : kD, npiece = 4 * kD / kpiece;
+        for (int i = 0; i < depth && !rc; ++i) {
             const std::string bp = P + "blocks." + std::to_string(i) + ".";
             Blk &bk = h->blk[i];
             const HostT *g1, *b1, *g2, *b2, *wq, *bq, *wp, *bpj, *w1, *bb1, *w2, *bb2, *ls1, *ls2;
@@ -466,6 +513,9 @@ extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors,
                 (rc = find(m, bp + "mlp.fc2.weight", &w2)) || (rc = find(m, bp + "mlp.fc2.bias", &bb2)) ||
                 (rc = find(m, bp + "ls1.gamma", &ls1)) || (rc = find(m, bp + "ls2.gamma", &ls2)))
                 break;
+            if (wq->numel != (int64_t)3 * kD * kD || w1->numel != (int64_t)4 * kD * kD || w2->numel != (int64_t)4 * kD * kD) {
+                set_error("%s: unexpected shapes for embed %d", bp.c_str(), kD); rc = NUNIF_HIP_EINVAL; break;
+            }
             if ((rc = up_f32(h, g1, &bk.g1)) || (rc = up_f32(h, b1, &bk.b1)) || (rc = up_f32(h, g2, &bk.g2)) || (rc = up_f32(h, b2, &bk.b2))) break;
             const float *d;
             const float *e;
@@ -479,61 +529,82 @@ extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors,
             }
             d = w1->data; e = bb1->data;
             if ((rc = make_lin(h, 4 * kD, kD, [=](int n, int k) { return d[(size_t)n * kD + k]; }, [=](int n) { return e[n]; }, &bk.fc1))) break;
-            {   // fc2 with LayerScale folded, split along K into two halves that accumulate into the residual stream
+            {   // fc2 with LayerScale folded, split along K; the bias rides on the first slice
                 const float *wd = w2->data, *bd = bb2->data, *ls = ls2->data;
-                if ((rc = make_lin(h, kD, 2 * kD, [=](int n, int k) { return wd[(size_t)n * 4 * kD + k] * ls[n]; },
-                                   [=](int n) { return bd[n] * ls[n]; }, &bk.fc2a)) ||
-                    (rc = make_lin(h, kD, 2 * kD, [=](int n, int k) { return wd[(size_t)n * 4 * kD + 2 * kD + k] * ls[n]; },
-                                   [=](int) { return 0.f; }, &bk.fc2b)))
-                    break;
+                bk.n_fc2 = npiece;
+                for (int q = 0; q < npiece && !rc; ++q)
+                    rc = make_lin(h, kD, kpiece, [=](int n, int k) { return wd[(size_t)n * 4 * kD + (size_t)q * kpiece + k] * ls[n]; },
+                                  [=](int n) { return q == 0 ? bd[n] * ls[n] : 0.f; }, &bk.fc2[q]);
+                if (rc) break;
             }
         }
         if (rc) break;
-        // ---- DPT head.  Channel counts: 48 (stored padded to 64), 96, 192, 384; fusion features 64
-        static const int OC[4] = {48, 96, 192, 384}, OCP[4] = {64, 96, 192, 384};
+        // ---- DPT head.  out_channels from projects.{i}, fusion width from layer1_rn; channel counts are stored padded to 32
+        const HostT *rnw;
+        if ((rc = find(m, H + "scratch.layer1_rn.weight", &rnw))) break;
+        const int F = (int)rnw->shape[0];
+        if (F != 64 && F != 128 && F != 256) { set_error("depth_anything: DPT features %d unsupported (64, 128, 256)", F); rc = NUNIF_HIP_EUNSUPPORTED; break; }
+        h->feat_ch = F;
         for (int i = 0; i < 4 && !rc; ++i) {
             const HostT *pw, *pb;
             if ((rc = find(m, H + "projects." + std::to_string(i) + ".weight", &pw)) ||
                 (rc = find(m, H + "projects." + std::to_string(i) + ".bias", &pb)))
                 break;
             const float *wd = pw->data, *bd = pb->data;
-            const int oc = OC[i];
-            if ((rc = make_lin(h, OCP[i], kD, [=](int n, int k) { return n < oc ? wd[(size_t)n * kD + k] : 0.f; },
+            const int oc = (int)pb->numel, ocp = (oc + 31) / 32 * 32;
+            if (pw->numel != (int64_t)oc * kD) { set_error("depth_head.projects.%d: unexpected shape", i); rc = NUNIF_HIP_EINVAL; break; }
+            h->OC[i] = oc; h->OCP[i] = ocp;
+            if ((rc = make_lin(h, ocp, kD, [=](int n, int k) { return n < oc ? wd[(size_t)n * kD + k] : 0.f; },
                                [=](int n) { return n < oc ? bd[n] : 0.f; }, &h->proj[i])))
                 break;
-            rc = conv_from(h, m, H + "scratch.layer" + std::to_string(i + 1) + "_rn", 64, oc, OCP[i], 3, false, &h->rn[i]);
+            rc = conv_from(h, m, H + "scratch.layer" + std::to_string(i + 1) + "_rn", F, oc, ocp, 3, false, &h->rn[i]);
         }
         if (rc) break;
-        {   // resize_layers.0: ConvTranspose2d(48, 48, 4, 4): N = (i*4+j)*64 + co, K = ci (padded to 64); weight [ci][co][4][4]
+        {   // resize_layers.0: ConvTranspose2d(oc0, oc0, 4, 4): N = (i*4+j)*ocp0 + co, K = ci (padded); weight [ci][co][4][4]
             if ((rc = find(m, H + "resize_layers.0.weight", &w)) || (rc = find(m, H + "resize_layers.0.bias", &b))) break;
             const float *wd = w->data, *bd = b->data;
-            if ((rc = make_lin(h, 16 * 64, 64, [=](int n, int k) {
-                    const int q = n / 64, co = n % 64;
-                    return (co < 48 && k < 48) ? wd[((size_t)k * 48 + co) * 16 + q] : 0.f; },
-                    [=](int n) { return n % 64 < 48 ? bd[n % 64] : 0.f; }, &h->rs0))) break;
-            // resize_layers.1: ConvTranspose2d(96, 96, 2, 2)
+            const int o0 = h->OC[0], p0 = h->OCP[0];
+            if (w->numel != (int64_t)o0 * o0 * 16) { set_error("depth_head.resize_layers.0: unexpected shape"); rc = NUNIF_HIP_EINVAL; break; }
+            if ((rc = make_lin(h, 16 * p0, p0, [=](int n, int k) {
+                    const int q = n / p0, co = n % p0;
+                    return (co < o0 && k < o0) ? wd[((size_t)k * o0 + co) * 16 + q] : 0.f; },
+                    [=](int n) { return n % p0 < o0 ? bd[n % p0] : 0.f; }, &h->rs0))) break;
+            // resize_layers.1: ConvTranspose2d(oc1, oc1, 2, 2)
             if ((rc = find(m, H + "resize_layers.1.weight", &w)) || (rc = find(m, H + "resize_layers.1.bias", &b))) break;
             const float *w1d = w->data, *b1d = b->data;
-            if ((rc = make_lin(h, 4 * 96, 96, [=](int n, int k) { return w1d[((size_t)k * 96 + n % 96) * 4 + n / 96]; },
-                               [=](int n) { return b1d[n % 96]; }, &h->rs1))) break;
-            if ((rc = conv_from(h, m, H + "resize_layers.3", 384, 384, 384, 3, true, &h->rs3))) break;
+            const int o1 = h->OC[1];
+            if (o1 % 32 || w->numel != (int64_t)o1 * o1 * 4) { set_error("depth_head.resize_layers.1: unexpected shape"); rc = NUNIF_HIP_EINVAL; break; }
+            if ((rc = make_lin(h, 4 * o1, o1, [=](int n, int k) { return w1d[((size_t)k * o1 + n % o1) * 4 + n / o1]; },
+                               [=](int n) { return b1d[n % o1]; }, &h->rs1))) break;
+            // resize_layers.3: Conv2d(oc3, oc3, 3, stride 2, pad 1); conv_kernel holds <= 384 output channels per launch: chunks
+            if ((rc = find(m, H + "resize_layers.3.weight", &w)) || (rc = find(m, H + "resize_layers.3.bias", &b))) break;
+            const int o3 = h->OC[3];
+            if (o3 % 32 || h->OC[2] % 32 || w->numel != (int64_t)o3 * o3 * 9) { set_error("depth_head.resize_layers.3: unexpected shape"); rc = NUNIF_HIP_EINVAL; break; }
+            const int chunk = o3 <= 384 ? o3 : 256;
+            if (o3 % chunk) { set_error("depth_head.resize_layers.3: %d channels unsupported", o3); rc = NUNIF_HIP_EUNSUPPORTED; break; }
+            h->rs3.resize(o3 / chunk);
+            const float *w3 = w->data, *b3 = b->data;
+            for (int c = 0; c < o3 / chunk && !rc; ++c)
+                rc = make_cnv(h, chunk, o3, 3, [=](int n, int tap, int ci) { return w3[((size_t)(c * chunk + n) * o3 + ci) * 9 + tap]; },
+                              [=](int n) { return b3[c * chunk + n]; }, &h->rs3[c]);
+            if (rc) break;
         }
         for (int k = 0; k < 4 && !rc; ++k) {
             const std::string r = H + "scratch.refinenet" + std::to_string(k + 1) + ".";
             Fus &f = h->fus[k];
-            if ((rc = conv_from(h, m, r + "resConfUnit1.conv1", 64, 64, 64, 3, true, &f.r1.c1)) ||
-                (rc = conv_from(h, m, r + "resConfUnit1.conv2", 64, 64, 64, 3, true, &f.r1.c2)) ||
-                (rc = conv_from(h, m, r + "resConfUnit2.conv1", 64, 64, 64, 3, true, &f.r2.c1)) ||
-                (rc = conv_from(h, m, r + "resConfUnit2.conv2", 64, 64, 64, 3, true, &f.r2.c2)))
+            if ((rc = conv_from(h, m, r + "resConfUnit1.conv1", F, F, F, 3, true, &f.r1.c1)) ||
+                (rc = conv_from(h, m, r + "resConfUnit1.conv2", F, F, F, 3, true, &f.r1.c2)) ||
+                (rc = conv_from(h, m, r + "resConfUnit2.conv1", F, F, F, 3, true, &f.r2.c1)) ||
+                (rc = conv_from(h, m, r + "resConfUnit2.conv2", F, F, F, 3, true, &f.r2.c2)))
                 break;
             const HostT *ow, *ob;
             if ((rc = find(m, r + "out_conv.weight", &ow)) || (rc = find(m, r + "out_conv.bias", &ob))) break;
             const float *wd = ow->data, *bd = ob->data;
-            rc = make_lin(h, 64, 64, [=](int n, int kk) { return wd[(size_t)n * 64 + kk]; }, [=](int n) { return bd[n]; }, &f.out);
+            rc = make_lin(h, F, F, [=](int n, int kk) { return wd[(size_t)n * F + kk]; }, [=](int n) { return bd[n]; }, &f.out);
         }
         if (rc) break;
-        if ((rc = conv_from(h, m, H + "scratch.output_conv1", 32, 64, 64, 3, true, &h->oc1)) ||
-            (rc = conv_from(h, m, H + "scratch.output_conv2.0", 32, 32, 32, 3, true, &h->oc2)))
+        if ((rc = conv_from(h, m, H + "scratch.output_conv1", F / 2, F, F, 3, true, &h->oc1)) ||
+            (rc = conv_from(h, m, H + "scratch.output_conv2.0", 32, F / 2, F / 2, 3, true, &h->oc2)))
             break;
         if ((rc = find(m, H + "scratch.output_conv2.2.weight", &w)) || (rc = find(m, H + "scratch.output_conv2.2.bias", &b))) break;
         std::vector<float> wf(33);
@@ -546,29 +617,40 @@ extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors,
     return NUNIF_HIP_OK;
 }
 
+extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors, int32_t n_tensors,
+                                               nunif_depth_anything **handle) {
+    return nunif_hip_depth_anything_create_ex(tensors, n_tensors, nullptr, 0.f, handle);
+}
+
 extern "C" void nunif_hip_depth_anything_destroy(nunif_depth_anything *h) {
     if (!h) return;
     for (void *p : h->owned) (void)hipFree(p);
     Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->vt, &h->att, &h->hid, &h->feat[0], &h->feat[1], &h->feat[2],
-                   &h->feat[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5};
+                   &h->feat[3], &h->rnb[0], &h->rnb[1], &h->rnb[2], &h->rnb[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5};
     for (Buf *b : bufs) b->release();
     delete h;
 }
 
-// x: [B,3,h,w] f32 (ImageNet-normalised), pos: [1 + gh*gw][384] f32 (interpolated position embedding, device),
+// x: [B,3,h,w] f32 (ImageNet-normalised), pos: [1 + gh*gw][D] f32 (interpolated position embedding, device),
 // depth: [B,h,w] f32
 extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const float *x, const float *pos, float *depth,
                                                 int32_t B, int32_t hh, int32_t ww, void *stream) {
     NUNIF_REQUIRE(h && x && pos && depth && B > 0 && hh >= 28 && ww >= 28 && hh % kPatch == 0 && ww % kPatch == 0,
                   "depth_anything_forward: h, w must be multiples of 14 (>= 28)");
     hipStream_t s = (hipStream_t)stream;
+    const int kD = h->D, kHeads = h->heads, F = h->feat_ch;
     const int gh = hh / kPatch, gw = ww / kPatch, N = gh * gw, Np = N + 1, Tp = (Np + 31) / 32 * 32;
     const long T = (long)B * Np;
     const size_t e2 = sizeof(f16);
     // DPT map sizes
     const int H1 = gh * 4, W1 = gw * 4, H2 = gh * 2, W2 = gw * 2, H3 = gh, W3 = gw, H4 = (gh + 2 - 3) / 2 + 1, W4 = (gw + 2 - 3) / 2 + 1;
     const int HF = 2 * H1, WF = 2 * W1;
-    const size_t big = std::max<size_t>((size_t)B * HF * WF * 64, (size_t)B * hh * ww * 32);
+    const int Hs[4] = {H1, H2, H3, H4}, Ws[4] = {W1, W2, W3, W4};
+    const int ocp_max = std::max(std::max(h->OCP[0], h->OCP[1]), std::max(h->OCP[2], h->OCP[3]));
+    size_t big = std::max<size_t>((size_t)B * HF * WF * F, (size_t)B * hh * ww * std::max(32, F / 2));
+    big = std::max<size_t>(big, (size_t)B * N * ocp_max);
+    big = std::max<size_t>(big, (size_t)B * H1 * W1 * h->OCP[0]);
+    big = std::max<size_t>(big, (size_t)B * H2 * W2 * h->OCP[1]);
     int rc;
     if ((rc = h->a_col.ensure((size_t)B * N * kKp * e2)) || (rc = h->pe.ensure((size_t)B * N * kD * e2)) ||
         (rc = h->t.ensure(T * kD * e2)) || (rc = h->y.ensure(T * kD * e2)) || (rc = h->qkv.ensure(T * 3 * kD * e2)) ||
@@ -576,7 +658,8 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         (rc = h->hid.ensure(T * 4 * kD * e2)) || (rc = h->m1.ensure(big * e2)) || (rc = h->m2.ensure(big * e2)) ||
         (rc = h->m3.ensure(big * e2)) || (rc = h->m4.ensure(big * e2)) || (rc = h->m5.ensure(big * e2)))
         return rc;
-    for (int i = 0; i < 4; ++i) if ((rc = h->feat[i].ensure(T * kD * e2))) return rc;
+    for (int i = 0; i < 4; ++i)
+        if ((rc = h->feat[i].ensure(T * kD * e2)) || (rc = h->rnb[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2))) return rc;
     f16 *a_col = (f16 *)h->a_col.p, *pe = (f16 *)h->pe.p, *t = (f16 *)h->t.p, *y = (f16 *)h->y.p, *qkv = (f16 *)h->qkv.p;
     f16 *vt = (f16 *)h->vt.p, *att = (f16 *)h->att.p, *hid = (f16 *)h->hid.p;
     auto blocks = [](long n) { return (unsigned)((n + 255) / 256); };
@@ -587,61 +670,61 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         NUNIF_LAUNCH_CHECK();
     }
     if ((rc = run_lin(h->patch, a_col, 1, B * N, B * N, 0, 0, nullptr, pe, s, "da_patch"))) return rc;
-    da_assemble_kernel<<<blocks(T * kD), 256, 0, s>>>(pe, h->cls, pos, t, B, Np);
+    da_assemble_kernel<<<blocks(T * kD), 256, 0, s>>>(pe, h->cls, pos, t, B, Np, kD);
     NUNIF_LAUNCH_CHECK();
 
     int tap = 0;
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < h->depth; ++i) {
         const Blk &bk = h->blk[i];
         {
             ProfScope ps("da_layernorm_kernel", s, 0.0, (double)T * kD * 4.0);
-            da_layernorm_kernel<<<(unsigned)((T + 3) / 4), 256, 0, s>>>(t, bk.g1, bk.b1, y, T);
-            NUNIF_LAUNCH_CHECK();
+            if ((rc = launch_da_layernorm(t, bk.g1, bk.b1, y, T, kD, s))) return rc;
         }
         if ((rc = run_lin(bk.qkv, y, 1, (int)T, (int)T, 0, 0, nullptr, qkv, s, "da_qkv"))) return rc;
-        da_vt_kernel<<<blocks((long)B * kHeads * kHd * Tp), 256, 0, s>>>(qkv, vt, B, Np, Tp);
+        da_vt_kernel<<<blocks((long)B * kHeads * kHd * Tp), 256, 0, s>>>(qkv, vt, B, Np, Tp, kD, kHeads);
         NUNIF_LAUNCH_CHECK();
         {
             ProfScope ps("da_attn_kernel", s, 4.0 * B * (double)Np * Np * kD, (double)T * kD * 8.0);
             static const bool split = []() { const char *e = getenv("NUNIF_DA_ATTN_SPLIT"); return e ? atoi(e) != 0 : true; }();
             if (split) {
                 dim3 grid((unsigned)((Np + 15) / 16), kHeads, B);
-                da_attn_split_kernel<<<grid, 256, 0, s>>>(qkv, vt, att, Np, Tp);
+                da_attn_split_kernel<<<grid, 256, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
             } else {
                 dim3 grid((unsigned)(((Np + 15) / 16 + 3) / 4), kHeads, B);
-                da_attn_kernel<<<grid, 256, 0, s>>>(qkv, vt, att, Np, Tp);
+                da_attn_kernel<<<grid, 256, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
             }
             NUNIF_LAUNCH_CHECK();
         }
         if ((rc = run_lin(bk.proj, att, 1, (int)T, (int)T, 0, 0, t, t, s, "da_proj"))) return rc;        // t += ls1 * proj(att)
-        da_layernorm_kernel<<<(unsigned)((T + 3) / 4), 256, 0, s>>>(t, bk.g2, bk.b2, y, T);
-        NUNIF_LAUNCH_CHECK();
+        if ((rc = launch_da_layernorm(t, bk.g2, bk.b2, y, T, kD, s))) return rc;
         if ((rc = run_lin(bk.fc1, y, 1, (int)T, (int)T, 0, 1, nullptr, hid, s, "da_fc1"))) return rc;      // GELU(erf)
-        // t += ls2 * fc2(.): two K = 768 halves of the 1536-wide hidden rows (lda = 1536)
-        if ((rc = run_lin(bk.fc2a, hid, 1, (int)T, (int)T, 0, 0, t, t, s, "da_fc2", 0, 0, 1, 1, 4 * kD))) return rc;
-        if ((rc = run_lin(bk.fc2b, hid + 2 * kD, 1, (int)T, (int)T, 0, 0, t, t, s, "da_fc2", 0, 0, 1, 1, 4 * kD))) return rc;
-        if (i == 2 || i == 5 || i == 8 || i == 11) {
-            da_layernorm_kernel<<<(unsigned)((T + 3) / 4), 256, 0, s>>>(t, h->norm_g, h->norm_b, (f16 *)h->feat[tap].p, T);
-            NUNIF_LAUNCH_CHECK();
+        // t += ls2 * fc2(.): K-slices of the 4 D-wide hidden rows (lda = 4 D)
+        for (int q = 0; q < bk.n_fc2; ++q)
+            if ((rc = run_lin(bk.fc2[q], hid + (size_t)q * bk.fc2[q].K, 1, (int)T, (int)T, 0, 0, t, t, s, "da_fc2", 0, 0, 1, 1, 4 * kD)))
+                return rc;
+        if (tap < 4 && i == h->taps[tap]) {
+            if ((rc = launch_da_layernorm(t, h->norm_g, h->norm_b, (f16 *)h->feat[tap].p, T, kD, s))) return rc;
             ++tap;
         }
     }
 
     // ---- DPT head ----------------------------------------------------------------------------------------------------
     f16 *m1 = (f16 *)h->m1.p, *m2 = (f16 *)h->m2.p, *m3 = (f16 *)h->m3.p, *m4 = (f16 *)h->m4.p, *m5 = (f16 *)h->m5.p;
-    f16 *rn[4];                                       // layer{1..4}_rn outputs live in the (now free) encoder buffers
-    rn[0] = hid; rn[1] = qkv; rn[2] = att; rn[3] = y;
-    NUNIF_REQUIRE((size_t)B * H1 * W1 * 64 <= (size_t)T * 4 * kD && (size_t)B * H2 * W2 * 64 <= (size_t)T * 3 * kD,
-                  "internal: DPT buffer reuse");
-    const int Hs[4] = {H1, H2, H3, H4}, Ws[4] = {W1, W2, W3, W4};
+    f16 *rn[4];
+    for (int i = 0; i < 4; ++i) rn[i] = (f16 *)h->rnb[i].p;
     for (int i = 0; i < 4; ++i) {
         const f16 *feat = (const f16 *)h->feat[i].p;
         // projects[i]: 1x1 on the patch tokens (row 0 of every image = class token is skipped: Wi = Np, ox = 1)
         if ((rc = run_lin(h->proj[i], feat, B, Np, N, 1, 0, nullptr, m1, s, "da_project"))) return rc;
         const f16 *src = m1;
-        if (i == 0) { if ((rc = run_lin(h->rs0, m1, B, gw, gw, 0, 0, nullptr, m2, s, "da_resize0", 1, 64, 4, gh))) return rc; src = m2; }
-        else if (i == 1) { if ((rc = run_lin(h->rs1, m1, B, gw, gw, 0, 0, nullptr, m2, s, "da_resize1", 1, 96, 2, gh))) return rc; src = m2; }
-        else if (i == 3) { if ((rc = run_cnv(h->rs3, m1, B, gh, gw, 2, 1, 0, 0, nullptr, nullptr, m2, s))) return rc; src = m2; }
+        if (i == 0) { if ((rc = run_lin(h->rs0, m1, B, gw, gw, 0, 0, nullptr, m2, s, "da_resize0", 1, h->OCP[0], 4, gh))) return rc; src = m2; }
+        else if (i == 1) { if ((rc = run_lin(h->rs1, m1, B, gw, gw, 0, 0, nullptr, m2, s, "da_resize1", 1, h->OCP[1], 2, gh))) return rc; src = m2; }
+        else if (i == 3) {
+            const int chunk = h->rs3[0].N;
+            for (size_t c = 0; c < h->rs3.size(); ++c)
+                if ((rc = run_cnv(h->rs3[c], m1, B, gh, gw, 2, 1, 0, 0, nullptr, nullptr, m2 + c * chunk, s, h->OCP[3]))) return rc;
+            src = m2;
+        }
         if ((rc = run_cnv(h->rn[i], src, B, Hs[i], Ws[i], 1, 1, 0, 0, nullptr, nullptr, rn[i], s))) return rc;
     }
     // refinenet k: x = path (+ RCU1(skip)); x = RCU2(x); upsample; out_conv
@@ -658,7 +741,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     };
     // path4
     if ((rc = rcu(h->fus[3].r2, rn[3], H4, W4, nullptr, m1, m2))) return rc;
-    if ((rc = upsample(m2, H4, W4, H3, W3, 64, m3))) return rc;
+    if ((rc = upsample(m2, H4, W4, H3, W3, F, m3))) return rc;
     if ((rc = run_lin(h->fus[3].out, m3, B, W3, W3, 0, 0, nullptr, m4, s, "da_out_conv", 0, 0, 1, H3))) return rc;      // path4 in m4
     // path3 .. path1
     const f16 *path = m4;
@@ -668,19 +751,19 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         const int Hn = k > 0 ? Hs[k - 1] : HF, Wn = k > 0 ? Ws[k - 1] : WF;
         if ((rc = rcu(h->fus[k].r1, rn[k], Hc, Wc, path, m1, m2))) return rc;        // m2 = path + RCU1(skip)
         if ((rc = rcu(h->fus[k].r2, m2, Hc, Wc, nullptr, m1, m3))) return rc;        // m3 = RCU2(m2)
-        if ((rc = upsample(m3, Hc, Wc, Hn, Wn, 64, m2))) return rc;
+        if ((rc = upsample(m3, Hc, Wc, Hn, Wn, F, m2))) return rc;
         if ((rc = run_lin(h->fus[k].out, m2, B, Wn, Wn, 0, 0, nullptr, pout, s, "da_out_conv", 0, 0, 1, Hn))) return rc;
         path = pout;
         pout = (pout == m5) ? m4 : m5;
     }
-    // output_conv1 (64 -> 32) at 8x the patch grid, resize to the input size, output_conv2
+    // output_conv1 (F -> F / 2) at 8x the patch grid, resize to the input size, output_conv2
     if ((rc = run_cnv(h->oc1, path, B, HF, WF, 1, 1, 0, 0, nullptr, nullptr, m1, s))) return rc;
-    if ((rc = upsample(m1, HF, WF, hh, ww, 32, m2))) return rc;
+    if ((rc = upsample(m1, HF, WF, hh, ww, F / 2, m2))) return rc;
     if ((rc = run_cnv(h->oc2, m2, B, hh, ww, 1, 1, 0, 3, nullptr, nullptr, m3, s))) return rc;
     {
         const long n = (long)B * hh * ww;
         ProfScope ps("da_final_kernel", s, 64.0 * n, (double)n * 68.0);
-        da_final_kernel<<<blocks(n), 256, 0, s>>>(m3, h->w_final, depth, n);
+        da_final_kernel<<<blocks(n), 256, 0, s>>>(m3, h->w_final, depth, n, h->max_depth);
         NUNIF_LAUNCH_CHECK();
     }
     return NUNIF_HIP_OK;

@@ -122,6 +122,8 @@ struct ConvArgs {
                               //      the caller passes Ho = (Hi + 2*zpad - k) / stride + 1
     int relu_in;              // 1: ReLU applied to the input as it is loaded (pre-activation residual units)
     const f16 *res2;          // optional second residual (same indexing as res)
+    int ldo;                  // > 0: channel stride of the NHWC output / residual pixels (default n_real): lets a conv write a
+                              //      channel slice of a wider map (out pre-offset by the slice's first channel)
 };
 int launch_conv(const ConvArgs &g, hipStream_t s);
 

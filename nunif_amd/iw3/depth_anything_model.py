@@ -51,8 +51,10 @@ def batch_infer(model, im, flip_aug=True, enable_amp=False, edge_dilation=2, low
     if depth_aa is not None:
         out = depth_aa.infer(out)                      # depth_anything_model.py:153-154 (nunif_amd.iw3.models.DepthAA)
     if edge_dilation_is_enabled(edge_dilation):
-        out = dilate_edge(-out if metric_depth else out, edge_dilation)
+        out = dilate_edge(-out if metric_depth else out, edge_dilation)          # :156-160: metric = -dilate_edge(-out)
         out = -out if metric_depth else out
+    if metric_depth:
+        out = -out                                                             # :162-164 "invert for zoedepth compatibility"
     if flip_aug:
         a, b = out.chunk(2, dim=0)
         out = (a + torch.flip(b, dims=[3])) * 0.5

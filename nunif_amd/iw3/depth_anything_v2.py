@@ -1,10 +1,14 @@
-"""Depth-Anything-V2 ViT-S backbone on the HIP engine (``nunif_hip_depth_anything_*``, nunif_amd/csrc/depth_anything.hip).
+"""Depth-Anything (V1 / V2 / V2-metric, ViT-S / B / L) backbone on the HIP engine (``nunif_hip_depth_anything_*``, nunif_amd/csrc/depth_anything.hip).
 
 The reference obtains this network with ``torch.hub.load("nagadomi/Depth-Anything_iw3", "DepthAnything", encoder=...)``
 (``iw3/depth_anything_model.py:200-230``) and calls it as ``model(x)`` on the ImageNet-normalised, /14-aligned batch from
 ``batch_preprocess`` (``_forward`` :113-119).  Neither that repository nor its weights are reachable offline, so this
 class follows the PUBLISHED architecture and checkpoint key layout (``pretrained.*`` DINOv2 ViT-S/14, ``depth_head.*``
 DPT) — see ``oracle/depth_anything_v2.py``; parity against the real hub model is unpinned.
+
+The geometry (embed 384 / 768 / 1024, 12 / 24 blocks, DPT widths) is read from the checkpoint; ``taps`` (the four encoder blocks
+that feed the head: V2 default, V1 = the last four) and ``max_depth`` (> 0: the V2 metric head, Sigmoid x max_depth) are what
+the hub entry points ``DepthAnything`` / ``DepthAnythingMetricDepthV2`` decide from the model name.
 
 ``HipDepthAnythingV2(state_dict)(x[B,3,h,w]) -> [B,h,w]`` is a drop-in ``backbone`` for
 ``nunif_amd.iw3.base_depth_model.CallableDepthModel`` (pre/post-processing, TTA flip, edge dilation, DepthAA, EMA
@@ -18,11 +22,12 @@ import torch.nn.functional as F
 
 from .. import _hip
 
-EMBED, PATCH = 384, 14
+PATCH = 14
 
 
 def interpolate_pos_embed(pos_embed, gh, gw):
     """DINOv2 ``interpolate_pos_encoding`` (bicubic, +0.1 offset, no antialias) — weight preparation, once per grid."""
+    EMBED = pos_embed.shape[-1]
     n = pos_embed.shape[1] - 1
     s = int(math.sqrt(n))
     if gh == s and gw == s:
@@ -37,8 +42,11 @@ def interpolate_pos_embed(pos_embed, gh, gw):
 class HipDepthAnythingV2:
     metric_depth = False
 
-    def __init__(self, state_dict, device="cuda:0"):
+    def __init__(self, state_dict, device="cuda:0", taps=None, max_depth=0.0):
         self.device = torch.device(device)
+        self.taps = None if taps is None else tuple(int(t) for t in taps)
+        self.max_depth = float(max_depth or 0.0)
+        self.metric_depth = self.max_depth > 0
         if self.device.type != "cuda":
             raise RuntimeError("the Depth-Anything HIP engine needs a ROCm device; there is no CPU fallback")
         self._state_dict = state_dict             # host tensors; kept so that replica() can build the same engine elsewhere
@@ -58,7 +66,9 @@ class HipDepthAnythingV2:
         arr = (_hip.TensorDesc * len(descs))(*descs)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _hip.check(_hip.lib().nunif_hip_depth_anything_create(arr, len(descs), ctypes.byref(handle)))
+            taps_arr = None if self.taps is None else (ctypes.c_int32 * 4)(*self.taps)
+            _hip.check(_hip.lib().nunif_hip_depth_anything_create_ex(arr, len(descs), taps_arr, ctypes.c_float(self.max_depth),
+                                                                    ctypes.byref(handle)))
         self.handle = handle
 
     def __del__(self):
@@ -78,7 +88,7 @@ class HipDepthAnythingV2:
     def replica(self, device):
         """The same network on another device (its own engine handle and workspace): what
         ``nunif.models.data_parallel.DeviceSwitchInference`` keeps one of per listed GPU."""
-        return self if torch.device(device) == self.device else type(self)(self._state_dict, device)
+        return self if torch.device(device) == self.device else type(self)(self._state_dict, device, self.taps, self.max_depth)
 
     def _pos(self, gh, gw):
         key = (gh, gw)

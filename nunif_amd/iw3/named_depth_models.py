@@ -3,9 +3,11 @@
 
 ``DepthAnythingModel("Any_V2_S")`` reads the PUBLISHED checkpoint (``depth_anything_v2_vits.pth``, key layout ``pretrained.*`` /
 ``depth_head.*``) from ``<model_dir>/checkpoints`` — the reference lets ``torch.hub`` fetch repository and weights — and runs it
-on the engine's ViT-S/14 + DPT kernels (``HipDepthAnythingV2``; parity unpinned).  The engine instantiates
-the ViT-S geometry only: the B / L / metric / V1 names are *known* (``supported`` is the reference's table) but ``load``
-raises ``NotImplementedError`` for them instead of silently running something else."""
+on the engine's ViT + DPT kernels (``HipDepthAnythingV2``; parity unpinned).  Every name of the reference's table
+maps onto that engine: the geometry (ViT-S / B / L) comes from the checkpoint itself; what the hub entry points decide from the
+name is set here — Depth-Anything V1 (``Any_S/B/L``) feeds the DPT head from the last four encoder blocks, the V2 metric
+models (``Any_V2_N*`` hypersim, ``Any_V2_K*`` vkitti) end in Sigmoid x max_depth (20 / 80), ``Distill_Any_*`` are V2
+geometries with their own weights."""
 import os
 
 import torch
@@ -34,7 +36,17 @@ MODEL_FILE_NAMES = {
     "Distill_Any_L": "distill_any_depth_vitl.safetensors",
 }
 AA_SUPPORTED_MODELS = {"Any_V2_S", "Any_V2_B", "Any_V2_L"}
-ENGINE_MODELS = {"Any_V2_S", "Distill_Any_S"}           # relative-depth ViT-S/14 + DPT(64; 48/96/192/384), the engine's geometry
+ENGINE_MODELS = set(MODEL_FILE_NAMES)
+V1_MODELS = {"Any_S", "Any_B", "Any_L"}                  # DPT_DINOv2: get_intermediate_layers(x, 4) = the last four blocks
+
+
+def head_options(model_type, n_blocks):
+    """-> (taps, max_depth) of a Depth-Anything name: what ``hubconf.DepthAnything`` / ``DepthAnythingMetricDepthV2`` configure."""
+    taps = tuple(range(n_blocks - 4, n_blocks)) if model_type in V1_MODELS else None
+    enc = NAME_MAP[model_type]
+    max_depth = 20.0 if enc.startswith("hypersim") else (80.0 if enc.startswith("vkitti") else 0.0)
+    return taps, max_depth
+
 DEPTH_AA_FILE = "iw3_depth_aa_20250530.pth"
 
 
@@ -53,8 +65,7 @@ class DepthAnythingModel(BaseDepthModel):
         """``state_dict`` / ``depth_aa`` let a caller hand over weights it already holds (tests, the benches)."""
         from .depth_anything_v2 import HipDepthAnythingV2
         if model_type not in ENGINE_MODELS:
-            raise NotImplementedError(f"{model_type} ({NAME_MAP[model_type]}): the HIP engine instantiates the ViT-S/14 relative-"
-                                      f"depth geometry only ({sorted(ENGINE_MODELS)})")
+            raise NotImplementedError(f"{model_type}: not a Depth-Anything name ({sorted(ENGINE_MODELS)})")
         if state_dict is None:
             p = self._path(model_type, self.model_dir)
             if not os.path.exists(p):
@@ -73,7 +84,9 @@ class DepthAnythingModel(BaseDepthModel):
         self.lower_bound = resolution or 392
         if self.lower_bound % 14 != 0:
             self.lower_bound += 14 - self.lower_bound % 14          # from the GUI: 512 -> 518 (:228-230)
-        model = HipDepthAnythingV2(state_dict, device)
+        n_blocks = sum(1 for k in state_dict if k.startswith("pretrained.blocks.") and k.endswith(".attn.qkv.weight"))
+        taps, max_depth = head_options(model_type, n_blocks)
+        model = HipDepthAnythingV2(state_dict, device, taps=taps, max_depth=max_depth)
         model.prep_lower_bound = self.lower_bound
         return model
 

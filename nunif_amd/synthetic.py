@@ -415,11 +415,23 @@ def depth_aa_state_dict(seed):
     return sd
 
 
-def depth_anything_v2_state_dict(seed, grid=37):
-    """Seeded weights in the public checkpoint's key layout.  LayerScale gammas are O(1) * 0.3 and the residual branches
-    are damped so that 12 blocks keep the token rms O(1) (a trained ViT's regime), every bias is non-zero."""
+DEPTH_ANYTHING_ENCODERS = {      # published geometries (Depth-Anything-V2 dpt.py model_configs)
+    "vits": dict(embed=384, depth=12, out_channels=(48, 96, 192, 384), features=64),
+    "vitb": dict(embed=768, depth=12, out_channels=(96, 192, 384, 768), features=128),
+    "vitl": dict(embed=1024, depth=24, out_channels=(256, 512, 1024, 1024), features=256),
+}
+
+
+def depth_anything_v2_state_dict(seed, grid=37, encoder="vits"):
+    """Seeded weights in the public checkpoint's key layout (``encoder``: vits / vitb / vitl).  LayerScale gammas are
+    O(1) * 0.3 (0.2 for the 24 blocks of vitl) and the residual branches are damped so that the blocks keep the token rms O(1)
+    (a trained ViT's regime), every bias is non-zero."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
+    cfg = DEPTH_ANYTHING_ENCODERS[encoder]
+    EMBED, DEPTH, OUT_CH, FEAT = cfg["embed"], cfg["depth"], cfg["out_channels"], cfg["features"]
+    MLP = 4 * EMBED
+    ls = 0.3 if DEPTH == 12 else 0.2
 
     def rnd(*shape, std):
         return torch.randn(shape, generator=g) * std
@@ -445,8 +457,8 @@ def depth_anything_v2_state_dict(seed, grid=37):
         lin(b + "attn.proj", EMBED, EMBED)
         lin(b + "mlp.fc1", MLP, EMBED)
         lin(b + "mlp.fc2", EMBED, MLP)
-        sd[b + "ls1.gamma"] = 0.3 + rnd(EMBED, std=0.05)
-        sd[b + "ls2.gamma"] = 0.3 + rnd(EMBED, std=0.05)
+        sd[b + "ls1.gamma"] = ls + rnd(EMBED, std=0.05)
+        sd[b + "ls2.gamma"] = ls + rnd(EMBED, std=0.05)
     sd[p + "norm.weight"] = 1.0 + rnd(EMBED, std=0.1)
     sd[p + "norm.bias"] = rnd(EMBED, std=0.05)
     h = "depth_head."

@@ -1,4 +1,4 @@
-"""Oracle: Depth-Anything-V2 (DINOv2 ViT-S/14 encoder + DPT head), torch CPU fp32 — **parity unpinned**.
+"""Oracle: Depth-Anything V1 / V2 / V2-metric (DINOv2 ViT-S / B / L /14 encoder + DPT head), torch CPU fp32 — **parity unpinned**.
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
@@ -11,6 +11,12 @@ the call-site contract in SURVEY.md §8c: input B x 3 x h x w ImageNet-normalise
 B x h x w (ReLU'd inverse depth).  State-dict key names follow the public checkpoint (``pretrained.*``, ``depth_head.*``)
 so that a real ``depth_anything_v2_vits.pth`` can be tried as soon as one is available; until then nothing here is
 pinned against the real network, and tests compare the HIP engine with THIS restatement only.
+
+The geometry is read from the state dict (``config_of``): embed 384 / 768 / 1024 with heads of 64, 12 / 24 blocks, DPT
+out_channels (48-96-192-384 / 96-192-384-768 / 256-512-1024-1024) and fusion width (64 / 128 / 256) as published for vits /
+vitb / vitl.  ``taps`` are the V2 ``intermediate_layer_idx`` (2-5-8-11 / 4-11-17-23); Depth-Anything V1 takes the last four
+blocks (``get_intermediate_layers(x, 4)``).  ``max_depth`` > 0 is the V2 metric head: Sigmoid instead of the last ReLU and the
+model output scaled by max_depth (hypersim 20, vkitti 80).
 """
 import math
 
@@ -23,8 +29,17 @@ OUT_CH = (48, 96, 192, 384)
 FEAT = 64
 
 
+def config_of(sd, taps=None):
+    embed = sd["pretrained.patch_embed.proj.bias"].shape[0]
+    depth = sum(1 for k in sd if k.startswith("pretrained.blocks.") and k.endswith(".attn.qkv.weight"))
+    if taps is None:
+        taps = {12: (2, 5, 8, 11), 24: (4, 11, 17, 23)}[depth]
+    return {"embed": embed, "heads": embed // 64, "depth": depth, "taps": tuple(taps)}
+
+
 def interpolate_pos_embed(pos_embed, gh, gw):
     """DINOv2 interpolate_pos_encoding for a gh x gw patch grid (bicubic, +0.1 offset, no antialias)."""
+    EMBED = pos_embed.shape[-1]
     n = pos_embed.shape[1] - 1
     s = int(math.sqrt(n))
     if gh == s and gw == s:
@@ -36,8 +51,10 @@ def interpolate_pos_embed(pos_embed, gh, gw):
     return torch.cat([cls, patch.permute(0, 2, 3, 1).reshape(1, gh * gw, EMBED)], dim=1)
 
 
-def encoder_features(sd, x):
-    """-> 4 tensors [B, gh*gw, 384]: blocks 2, 5, 8, 11 through the final LayerNorm, class token dropped."""
+def encoder_features(sd, x, taps=None):
+    """-> 4 tensors [B, gh*gw, embed]: the tapped blocks through the final LayerNorm, class token dropped."""
+    cfg = config_of(sd, taps)
+    EMBED, HEADS, DEPTH, TAPS = cfg["embed"], cfg["heads"], cfg["depth"], cfg["taps"]
     B, _, h, w = x.shape
     gh, gw = h // PATCH, w // PATCH
     p = "pretrained."
@@ -78,11 +95,11 @@ def _fusion(sd, p, x, skip=None, size=None):
     return F.conv2d(x, sd[p + "out_conv.weight"], sd[p + "out_conv.bias"])
 
 
-def head(sd, feats, gh, gw):
+def head(sd, feats, gh, gw, max_depth=0.0):
     p = "depth_head."
     layers = []
     for i, f in enumerate(feats):
-        x = f.permute(0, 2, 1).reshape(f.shape[0], EMBED, gh, gw)
+        x = f.permute(0, 2, 1).reshape(f.shape[0], f.shape[2], gh, gw)
         x = F.conv2d(x, sd[f"{p}projects.{i}.weight"], sd[f"{p}projects.{i}.bias"])
         if i == 0:
             x = F.conv_transpose2d(x, sd[p + "resize_layers.0.weight"], sd[p + "resize_layers.0.bias"], stride=4)
@@ -100,14 +117,16 @@ def head(sd, feats, gh, gw):
     out = F.conv2d(path1, sd[s + "output_conv1.weight"], sd[s + "output_conv1.bias"], padding=1)
     out = F.interpolate(out, (gh * PATCH, gw * PATCH), mode="bilinear", align_corners=True)
     out = F.relu(F.conv2d(out, sd[s + "output_conv2.0.weight"], sd[s + "output_conv2.0.bias"], padding=1))
-    out = F.relu(F.conv2d(out, sd[s + "output_conv2.2.weight"], sd[s + "output_conv2.2.bias"]))
-    return out
+    out = F.conv2d(out, sd[s + "output_conv2.2.weight"], sd[s + "output_conv2.2.bias"])
+    return torch.sigmoid(out) if max_depth > 0 else F.relu(out)
 
 
-def model_forward(sd, x):
-    """x: [B,3,h,w] ImageNet-normalised, h and w multiples of 14 -> [B,h,w] (relu(depth), larger = nearer)."""
-    feats, gh, gw = encoder_features(sd, x)
-    return F.relu(head(sd, feats, gh, gw)).squeeze(1)
+def model_forward(sd, x, taps=None, max_depth=0.0):
+    """x: [B,3,h,w] ImageNet-normalised, h and w multiples of 14 -> [B,h,w]: relu(inverse depth), larger = nearer — or, for the
+    metric heads (max_depth > 0), sigmoid * max_depth = distance."""
+    feats, gh, gw = encoder_features(sd, x, taps)
+    out = head(sd, feats, gh, gw, max_depth)
+    return (out * max_depth if max_depth > 0 else F.relu(out)).squeeze(1)
 
 
 def random_state_dict(*args, **kwargs):

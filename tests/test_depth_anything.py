@@ -19,6 +19,23 @@ def test_oracle_shapes_and_parameter_count():
     assert pe.shape == (1, 25, 384) and torch.equal(pe[:, 0], sd["pretrained.pos_embed"][:, 0])
 
 
+@pytest.mark.parametrize("encoder,mparams", [("vitb", 97.5), ("vitl", 335.3)])
+def test_oracle_larger_encoders(encoder, mparams):
+    """Published sizes: Depth-Anything-V2-Base 97.5 M, -Large 335.3 M parameters; V1 taps and the metric head run."""
+    sd = ODA.random_state_dict(611, grid=4, encoder=encoder)
+    n = sum(v.numel() for k, v in sd.items() if k != "pretrained.pos_embed") + 1370 * sd["pretrained.pos_embed"].shape[-1]
+    assert abs(n / 1e6 - mparams) < 0.15, n / 1e6
+    cfg = ODA.config_of(sd)
+    assert cfg["taps"] == ((2, 5, 8, 11) if encoder == "vitb" else (4, 11, 17, 23)) and cfg["heads"] * 64 == cfg["embed"]
+    x = torch.randn(1, 3, 28, 42)
+    y = ODA.model_forward(sd, x)
+    last4 = tuple(range(cfg["depth"] - 4, cfg["depth"]))
+    y1 = ODA.model_forward(sd, x, taps=last4)
+    ym = ODA.model_forward(sd, x, max_depth=20.0)
+    assert y.shape == y1.shape == ym.shape == (1, 28, 42)
+    assert float((y - y1).abs().max()) > 1e-3 and 0.0 < float(ym.min()) and float(ym.max()) < 20.0
+
+
 def _norm(img):
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
@@ -42,6 +59,26 @@ def test_hip_backbone_vs_restatement(hiplib):
     assert torch.equal(net(x.to("cuda:0")).cpu(), y)                        # deterministic
     with pytest.raises(ValueError):
         net(torch.zeros(1, 3, 50, 56))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("encoder,taps,max_depth", [("vitb", None, 0.0), ("vitl", None, 0.0), ("vitl", (20, 21, 22, 23), 0.0),
+                                                    ("vitb", None, 20.0), ("vits", None, 80.0), ("vits", (8, 9, 10, 11), 0.0)])
+def test_hip_backbone_variants_vs_restatement(hiplib, encoder, taps, max_depth):
+    """ViT-B / ViT-L geometries (embed 768 / 1024, 24 blocks, DPT 128 / 256 wide, the chunked 768 / 1024-channel stride-2 conv),
+    Depth-Anything V1's taps (the last four blocks) and the V2 metric head, all from the checkpoint's own shapes."""
+    from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+    sd = ODA.random_state_dict(620, grid=8, encoder=encoder)
+    net = HipDepthAnythingV2(sd, "cuda:0", taps=taps, max_depth=max_depth)
+    assert net.metric_depth == (max_depth > 0)
+    x = _norm(torch.stack([synth_image(190 + i, 3, 70, 98) for i in range(2)]))
+    ref = ODA.model_forward(sd, x, taps=taps, max_depth=max_depth)
+    y = net(x.to("cuda:0")).cpu()
+    assert y.shape == ref.shape == (2, 70, 98)
+    span = float(ref.max() - ref.min())
+    p = psnr(y / span, ref / span)
+    rel = ((y - ref).pow(2).mean().sqrt() / ref.std()).item()
+    assert float(ref.std()) > 1e-3 and p >= 50.0 and rel < 1.5e-2, (encoder, taps, max_depth, p, rel)
 
 
 @pytest.mark.gpu

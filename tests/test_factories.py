@@ -76,8 +76,19 @@ def test_create_depth_model_names():
     assert create_depth_model("Any_V2_K_L").is_metric() and not create_depth_model("Any_V2_S").is_metric()
     with pytest.raises(ValueError):
         create_depth_model("ZoeD_N")                                   # external hub nets that are not restated
-    with pytest.raises(NotImplementedError):
-        create_depth_model("Any_V2_L").load(gpu=-1)                    # known name, geometry not instantiated: loud
+    # every Depth-Anything name maps onto the engine: what the hub entry points decide from the NAME (V1 feeds the DPT head from the
+    # last four blocks; the V2 metric heads end in Sigmoid x 20 (hypersim) / x 80 (vkitti)) is set by head_options
+    from nunif_amd.iw3.named_depth_models import head_options, ENGINE_MODELS
+    assert ENGINE_MODELS == set(MODEL_FILE_NAMES)
+    assert head_options("Any_L", 24) == ((20, 21, 22, 23), 0.0) and head_options("Any_S", 12) == ((8, 9, 10, 11), 0.0)
+    assert head_options("Any_V2_L", 24) == (None, 0.0) and head_options("Distill_Any_B", 12) == (None, 0.0)
+    assert head_options("Any_V2_N_B", 12) == (None, 20.0) and head_options("Any_V2_K", 24) == (None, 80.0)
+    for n in MODEL_FILE_NAMES:
+        assert create_depth_model(n).is_metric() == (head_options(n, 12)[1] > 0)
+    with pytest.raises(FileNotFoundError):
+        m = create_depth_model("Any_V2_L")                             # a known name without its checkpoint file: loud
+        m.model_dir = "/nonexistent"
+        m.load(gpu=-1)
     with pytest.raises(FileNotFoundError):
         m = create_depth_model("Any_V2_S")
         m.model_dir = "/nonexistent"
@@ -108,3 +119,13 @@ def test_named_depth_model_on_the_engine(hiplib, tmp_path):
     assert m.infer(x[0]).shape[0] == 1
     with pytest.raises(ValueError):
         m.infer(x, depth_aa=True)                                     # no DepthAA checkpoint next to it
+    # a metric ViT-B checkpoint by name: Sigmoid x 20 head, output inverted by the wrapper (reference :156-164)
+    sdb = depth_anything_v2_state_dict(603, grid=8, encoder="vitb")
+    torch.save(sdb, tmp_path / "checkpoints" / "depth_anything_v2_metric_hypersim_vitb.pth")
+    mb = create_depth_model("Any_V2_N_B")
+    mb.model_dir = str(tmp_path)
+    mb.load(gpu=0, resolution=56)
+    assert mb.is_metric() and mb.model.metric_depth and mb.model.max_depth == 20.0
+    d = mb.infer(x)
+    raw = HipDepthAnythingV2(sdb, "cuda:0", max_depth=20.0)
+    assert d.shape[0] == 2 and float(d.max()) < 0 and float(d.min()) > -20.0 and raw.metric_depth

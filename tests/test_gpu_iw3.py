@@ -127,6 +127,12 @@ def test_preprocess_dilate_normalize_vs_reference_fixture(hiplib, g):
     net = lambda t: t.mean(1)                                        # noqa: E731
     dep = batch_infer(net, g["pre_in"].to(DEV), flip_aug=True, edge_dilation=[2, 1], lower_bound=56)
     assert dep.shape == (2, 1, 56, 98) and torch.isfinite(dep).all()
+    # metric models (reference :156-164): out = -dilate_edge(-out), then inverted once more "for zoedepth compatibility"
+    pre = batch_preprocess(g["pre_in"].to(DEV), lower_bound=56)
+    met = batch_infer(net, g["pre_in"].to(DEV), flip_aug=False, edge_dilation=2, lower_bound=56, metric_depth=True)
+    assert torch.equal(met, dilate_edge(-net(pre).unsqueeze(1), 2))
+    met0 = batch_infer(net, g["pre_in"].to(DEV), flip_aug=False, edge_dilation=0, lower_bound=56, metric_depth=True)
+    assert torch.equal(met0, -net(pre).unsqueeze(1))
 
 
 def test_backward_warp_vs_reference_fixture(hiplib, g):
