@@ -130,9 +130,36 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     }
     // NHWC fp16 outputs: two adjacent 16-channel tiles per trip, so that a lane owns a run of 8 consecutive channels
     // after pair_to_run() (common.h) and the residual read / store are 16 B per lane, 64 B per pixel row.
+    auto out_off = [&](int f, int np) -> long {
+        long off;
+        if (g.mode == 0) {
+            off = (((long)tb[f] * g.Ho + ty[f]) * g.Wo + tx[f]) * g.ldo + np;
+        } else {
+            // PatchUp: column n = q*Cq + c (repacked), q=(i,j) -> pixel (2y+i, 2x+j)  (swin_unet.py:76-82);
+            // Cq is a multiple of 32, so a tile pair never straddles two sub-pixels
+            const int q = np / g.ldo, c = np - q * g.ldo;
+            const int sf = g.ps > 1 ? g.ps : 2;                       // ConvTranspose2d(k = stride = sf): q = i*sf + j
+            const int qi = q / sf, qj = q - qi * sf;
+            off = (((long)tb[f] * (sf * g.Ho) + sf * ty[f] + qi) * (sf * g.Wo) + sf * tx[f] + qj) * g.ldo + c;
+        }
+        return off + pair_run_channel(grp);
+    };
+    // The residual of a tile pair is requested at the TOP of its trip, in front of the trip's MFMAs: the chunk barriers of the
+    // weight ring otherwise pin the load right in front of its use in the epilogue, and with the U-Net skip as residual (PatchUp)
+    // every trip then exposed one HBM latency.  (Requesting it a whole trip ahead costs 16 more registers and the third resident
+    // workgroup per CU: 312 vs 265 us on the two PatchUps, measured.)
 #pragma unroll 1
     for (int nt = 0; nt < NT; nt += 2) {
         f32x4 acc0[MF], acc1[MF];
+        f16x8 rcur[MF];
+        if (g.res) {
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const int npn = (nt_lo + nt) * 16;
+                const bool live = valid[f] && npn < g.n_real;
+                rcur[f] = *reinterpret_cast<const f16x8 *>(g.res + (live ? out_off(f, npn) : 0));
+            }
+        }
 #pragma unroll
         for (int f = 0; f < MF; ++f) { acc0[f] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[f] = acc0[f]; }
 #pragma unroll
@@ -165,22 +192,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                     v1[r] = v1[r] >= 0.f ? v1[r] : v1[r] * g.slope;
                 }
             }
-            long off;
-            if (g.mode == 0) {
-                off = (((long)tb[f] * g.Ho + ty[f]) * g.Wo + tx[f]) * g.ldo + np;
-            } else {
-                // PatchUp: column n = q*Cq + c (repacked), q=(i,j) -> pixel (2y+i, 2x+j)  (swin_unet.py:76-82);
-                // Cq is a multiple of 32, so a tile pair never straddles two sub-pixels
-                const int q = np / g.ldo, c = np - q * g.ldo;
-                const int sf = g.ps > 1 ? g.ps : 2;                       // ConvTranspose2d(k = stride = sf): q = i*sf + j
-                const int qi = q / sf, qj = q - qi * sf;
-                off = (((long)tb[f] * (sf * g.Ho) + sf * ty[f] + qi) * (sf * g.Wo) + sf * tx[f] + qj) * g.ldo + c;
-            }
-            off += pair_run_channel(grp);
+            const long off = out_off(f, np);
             const bool live = valid[f] && np < g.n_real;
             if (g.res) {
                 f16x4 ra, rb;
-                run_to_pair(*reinterpret_cast<const f16x8 *>(g.res + (live ? off : 0)), ra, rb);
+                run_to_pair(rcur[f], ra, rb);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v0[r] += (float)ra[r]; v1[r] += (float)rb[r]; }
             }
