@@ -79,6 +79,9 @@ def relaunch_as_ranks(args):
     os.execvpe(cmd[0], cmd, env)
 
 
+GATHER_TIMEOUT_S = 240          # watchdog of the N > 1 delivery leg (see main)
+
+
 def synth_frame(seed, h, w):
     import torch
     g = torch.Generator().manual_seed(seed)
@@ -399,36 +402,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- N > 1: the same work with every finished frame delivered to rank 0 (quantised on the device, one non-blocking
-    # point-to-point transfer per frame over RCCL / xGMI, overlapped with the next render) --------------------------------
-    gathered = None
-    if world > 1:
-        n_g = max(world, min(args.steps, 32)) * world
-        n_g -= n_g % world
-        shared = [frames[i % len(frames)] for i in range(n_g)]          # content differs per rank; geometry is what matters
-        delivered = [0]
-
-        def count(i, f):
-            delivered[0] += 1
-
-        render_sharded(shared[:2 * world], lambda f: render(model, f), dst=0, on_frame=count)      # warm-up (RCCL init)
-        delivered[0] = 0
-        barrier()
-        t1 = time.perf_counter()
-        render_sharded(shared, lambda f: render(model, f), dst=0, on_frame=count)
-        barrier()
-        dtg = time.perf_counter() - t1
-        tg = torch.tensor([dtg], dtype=torch.float64, device=dev)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        dtg = float(tg.item())
-        if rank == 0:
-            assert delivered[0] == n_g, (delivered[0], n_g)
-            gathered = {"value": round(FRAME_H * FRAME_W / 1e6 * n_g / dtg, 2), "unit": "MPix/s", "frames": n_g,
-                        "ms_per_frame_per_gpu": round(1e3 * dtg / (n_g / world), 3),
-                        "bytes_delivered_per_frame": 2 * FRAME_H * 2 * FRAME_W * 3,
-                        "path": "render (one frame at a time per rank) -> HIP quantise to HWC uint8 -> batch_isend_irecv "
-                                "to rank 0, overlapped with the next render (nunif_amd.parallel.render_sharded)"}
-
     # ---- the same K frames on ONE stream (reported next to `value`; the per-kernel roofline below is measured this way) ----
     single = None
     if n_streams > 1 and rank == 0:
@@ -478,8 +451,6 @@ def main():
         }
         if single is not None:
             result["single_stream"] = single        # one frame at a time on one stream, same build, same run
-        if gathered is not None:
-            result["gathered"] = gathered
         if not args.no_host_frames and world == 1:
             # host uint8 frame -> pinned ring -> H2D -> to_tensor -> render -> quantise -> D2H -> host uint8 frame
             from nunif_amd.frame_ring import FrameRing
@@ -518,7 +489,60 @@ def main():
             mse = torch.mean((got.double() - ref.double()) ** 2).item()
             result["cpu_baseline"] = base
             result["psnr_vs_oracle_db"] = round(10 * math.log10(1.0 / (mse + 1e-6)), 2)
-        print(json.dumps(result))
+    if world > 1:
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if done.wait(GATHER_TIMEOUT_S):
+                return
+            if rank == 0:
+                result["gathered"] = {"error": f"the delivery leg did not finish within {GATHER_TIMEOUT_S} s; value / roofline "
+                                               "above are unaffected (they contain no collective)"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        def gather_leg():
+            n_g = max(world, min(args.steps, 32)) * world
+            n_g -= n_g % world
+            shared = [frames[i % len(frames)] for i in range(n_g)]          # content differs per rank; geometry is what matters
+            delivered = [0]
+
+            def count(i, f):
+                delivered[0] += 1
+
+            render_sharded(shared[:2 * world], lambda f: render(model, f), dst=0, on_frame=count)      # warm-up (RCCL init)
+            delivered[0] = 0
+            barrier()
+            t1 = time.perf_counter()
+            render_sharded(shared, lambda f: render(model, f), dst=0, on_frame=count)
+            barrier()
+            dtg = time.perf_counter() - t1
+            tg = torch.tensor([dtg], dtype=torch.float64, device=dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            dtg = float(tg.item())
+            done.set()
+            if rank == 0:
+                result["gathered"] = {
+                    "value": round(FRAME_H * FRAME_W / 1e6 * n_g / dtg, 2), "unit": "MPix/s", "frames": n_g,
+                    "frames_delivered": delivered[0],
+                    "ms_per_frame_per_gpu": round(1e3 * dtg / (n_g / world), 3),
+                    "bytes_delivered_per_frame": 2 * FRAME_H * 2 * FRAME_W * 3,
+                    "path": "render (one frame at a time per rank) -> HIP quantise to HWC uint8 -> batch_isend_irecv "
+                            "to rank 0, overlapped with the next render (nunif_amd.parallel.render_sharded)"}
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            gather_leg()
+        except Exception as e:      # a rank that failed must not exit non-zero (the launcher would kill rank 0 before it prints)
+            print(f"[bench rank {rank}] delivery leg failed: {e!r}", file=sys.stderr, flush=True)
+            if rank == 0:
+                result["gathered"] = {"error": repr(e)}
+                print(json.dumps(result), flush=True)
+                os._exit(0)
+            threading.Event().wait()            # the watchdog ends this rank with exit code 0
+    if rank == 0:
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
