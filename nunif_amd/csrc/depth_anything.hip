@@ -341,7 +341,7 @@ struct Buf {
 };
 struct Lin { f16 *w = nullptr; float *b = nullptr; int N = 0, K = 0; };              // gemm_kernel packing [nt][ks]
 struct Cnv { f16 *w = nullptr; float *b = nullptr; int N = 0, Cin = 0, k = 3; };     // conv_kernel stream [ks][nt]
-struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2[4]; int n_fc2; };   // fc2 (K = 4 D) = 2 or 4 GEMMs of K = 768 / 1024
+struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2[4], fc2_full; int n_fc2; };   // fc2 (K = 4 D) = 2 or 4 GEMMs of K = 768 / 1024
 struct Rcu { Cnv c1, c2; };
 struct Fus { Rcu r1, r2; Lin out; };
 }  // namespace
@@ -423,6 +423,17 @@ int run_lin(const Lin &L, const f16 *a, int B, int Wi, int Wo, int ox, int act, 
     g.K = L.K; g.w = L.w; g.bias = L.b; g.N = L.N; g.mode = mode; g.act = act; g.res = res; g.out = out;
     g.ldo = ldo ? ldo : L.N; g.n_real = L.N; g.ps = ps; g.lda = lda;
     return launch_gemm(g, s, tag);
+}
+// token-matrix Linear [T][K] -> [T][N]: the output-stationary kernel when the shape allows, else gemm_kernel
+int run_tok(const Lin &L, const f16 *a, long T, int act, const f16 *res, f16 *out, hipStream_t s, const char *tag) {
+    if (gemm_os_supported(T, L.N, L.K)) {
+        GemmOsArgs g;
+        memset(&g, 0, sizeof(g));
+        g.a = a; g.M = T; g.lda = L.K; g.K = L.K; g.w = L.w; g.bias = L.b; g.N = L.N; g.act = act; g.res = res; g.out = out;
+        g.ldo = L.N;
+        return launch_gemm_os(g, s, tag);
+    }
+    return run_lin(L, a, 1, (int)T, (int)T, 0, act, res, out, s, tag);
 }
 int run_cnv(const Cnv &C, const f16 *a, int B, int Hi, int Wi, int stride, int zpad, int relu_in, int act, const f16 *res,
             const f16 *res2, f16 *out, hipStream_t s, int ldo = 0) {
@@ -532,7 +543,12 @@ extern "C" int nunif_hip_depth_anything_create_ex(const nunif_tensor_desc *tenso
             {   // fc2 with LayerScale folded, split along K; the bias rides on the first slice
                 const float *wd = w2->data, *bd = bb2->data, *ls = ls2->data;
                 bk.n_fc2 = npiece;
-                for (int q = 0; q < npiece && !rc; ++q)
+                if (gemm_os_supported(1, kD, 4 * kD)) {     // output-stationary GEMM: the whole K = 4 D contraction in one launch
+                    bk.n_fc2 = 0;
+                    rc = make_lin(h, kD, 4 * kD, [=](int n, int k) { return wd[(size_t)n * 4 * kD + k] * ls[n]; },
+                                  [=](int n) { return bd[n] * ls[n]; }, &bk.fc2_full);
+                }
+                for (int q = 0; q < bk.n_fc2 && !rc; ++q)
                     rc = make_lin(h, kD, kpiece, [=](int n, int k) { return wd[(size_t)n * 4 * kD + (size_t)q * kpiece + k] * ls[n]; },
                                   [=](int n) { return q == 0 ? bd[n] * ls[n] : 0.f; }, &bk.fc2[q]);
                 if (rc) break;
@@ -680,7 +696,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             ProfScope ps("da_layernorm_kernel", s, 0.0, (double)T * kD * 4.0);
             if ((rc = launch_da_layernorm(t, bk.g1, bk.b1, y, T, kD, s))) return rc;
         }
-        if ((rc = run_lin(bk.qkv, y, 1, (int)T, (int)T, 0, 0, nullptr, qkv, s, "da_qkv"))) return rc;
+        if ((rc = run_tok(bk.qkv, y, T, 0, nullptr, qkv, s, "da_qkv"))) return rc;
         da_vt_kernel<<<blocks((long)B * kHeads * kHd * Tp), 256, 0, s>>>(qkv, vt, B, Np, Tp, kD, kHeads);
         NUNIF_LAUNCH_CHECK();
         {
@@ -695,10 +711,11 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             }
             NUNIF_LAUNCH_CHECK();
         }
-        if ((rc = run_lin(bk.proj, att, 1, (int)T, (int)T, 0, 0, t, t, s, "da_proj"))) return rc;        // t += ls1 * proj(att)
+        if ((rc = run_tok(bk.proj, att, T, 0, t, t, s, "da_proj"))) return rc;        // t += ls1 * proj(att)
         if ((rc = launch_da_layernorm(t, bk.g2, bk.b2, y, T, kD, s))) return rc;
-        if ((rc = run_lin(bk.fc1, y, 1, (int)T, (int)T, 0, 1, nullptr, hid, s, "da_fc1"))) return rc;      // GELU(erf)
+        if ((rc = run_tok(bk.fc1, y, T, 1, nullptr, hid, s, "da_fc1"))) return rc;      // GELU(erf)
         // t += ls2 * fc2(.): K-slices of the 4 D-wide hidden rows (lda = 4 D)
+        if (bk.n_fc2 == 0 && (rc = run_tok(bk.fc2_full, hid, T, 0, t, t, s, "da_fc2"))) return rc;
         for (int q = 0; q < bk.n_fc2; ++q)
             if ((rc = run_lin(bk.fc2[q], hid + (size_t)q * bk.fc2[q].K, 1, (int)T, (int)T, 0, 0, t, t, s, "da_fc2", 0, 0, 1, 1, 4 * kD)))
                 return rc;

@@ -31,6 +31,22 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag);
 
+// ---- output-stationary Linear for TOKEN matrices of a few thousand rows (the ViT encoders of the depth nets) -----------------
+// out[m][n] = act(sum_k a[m][k] W[n][k] + bias[n]) (+ res[m][n]); a: [M][lda] fp16, W in gemm_kernel's packing [nt][ks].
+// gemm_kernel is token-stationary (a wave keeps 16-32 tokens' whole K extent and sweeps all of N through the LDS ring): with
+// K >= 384 that is ONE MFMA per fragment read.  Here a wave owns 4 token tiles x 2 channel tiles, loops over K with both
+// operands read straight from L2 three k-steps ahead (no LDS, no barrier), 8 MFMAs per 6 fragment loads; a workgroup's four
+// waves share their tokens.  Needs N % 128 == 0 and (K / 32) % 4 == 0.
+struct GemmOsArgs {
+    const f16 *a; long M; int lda, K;
+    const f16 *w; const float *bias; int N;
+    int act;                  // 0 none, 1 GELU(erf)
+    const f16 *res;           // optional residual [M][ldo] (may alias out)
+    f16 *out; int ldo;
+};
+bool gemm_os_supported(long M, int N, int K);
+int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag);
+
 // ---- first conv of the stem (3 -> C1 real channels, stored padded to C1P), VALU ----------------------------------
 struct Stem1Args {
     const float *x;           // tile mode: [B,3,T,T]; frame mode: [3,H,W]

@@ -476,6 +476,120 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
 }
 
 // =================================================================================================================
+// Output-stationary Linear (swin_kernels.h GemmOsArgs).  Workgroup = 4 waves = 64 tokens x 128 channels; wave w owns channel
+// tiles 2w, 2w + 1 of the workgroup's 8 and all 4 token tiles: acc[4][2].  K loop in groups of 4 k-steps over 4 register
+// buffers: the loads of step k + 3 are issued in front of the MFMAs of step k (static buffer indices, nothing dynamic).
+// =================================================================================================================
+__global__ void __launch_bounds__(256) gemm_os_kernel(GemmOsArgs g) {
+    constexpr int MT = 4, NTW = 2, PF = 4;
+    // the activation tile of a k-group (64 tokens x 128 k = 16 KiB) is shared by the four waves: it goes through LDS once
+    // (fragment-major, double-buffered, one barrier per 4 k-steps) instead of four times through the vector memory pipe, which
+    // at 64 B / clk / CU was the bound of the all-global form (24 KiB of loads per 32 MFMAs); the weights stay direct loads
+    __shared__ __attribute__((aligned(16))) f16x8 act[2][PF][MT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, grp = lane >> 4;
+    const int KS = g.K >> 5;
+    const int n_blocks = g.N >> 7;
+    const int nb = blockIdx.x % n_blocks;
+    const long mb = blockIdx.x / n_blocks;
+    const long m0 = mb * (MT * 16);
+    const int nt0 = nb * 8 + wave * NTW;                          // first 16-channel tile of this wave
+    const f16 *arow[MT];                                          // wave w stages k-step w of every group
+#pragma unroll
+    for (int f = 0; f < MT; ++f) {
+        long m = m0 + f * 16 + r16;
+        m = m < g.M ? m : g.M - 1;
+        arow[f] = g.a + m * g.lda + grp * 8 + wave * 32;
+    }
+    const f16x8 *wbase = reinterpret_cast<const f16x8 *>(g.w) + (long)nt0 * KS * 64 + lane;
+    f16x8 st[MT], aq[PF][NTW];
+    auto load_act = [&](int k0) {
+#pragma unroll
+        for (int f = 0; f < MT; ++f) st[f] = *reinterpret_cast<const f16x8 *>(arow[f] + k0 * 32);
+    };
+    auto load_w = [&](int ks, int buf) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) aq[buf][n] = wbase[((long)n * KS + ks) * 64];
+    };
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const float4 bv = *reinterpret_cast<const float4 *>(g.bias + (nt0 + n) * 16 + grp * 4);
+#pragma unroll
+        for (int f = 0; f < MT; ++f) acc[f][n] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+    }
+    load_act(0);
+#pragma unroll
+    for (int j = 0; j < PF - 1; ++j) load_w(j, j);
+#pragma unroll
+    for (int f = 0; f < MT; ++f) act[0][wave][f][lane] = st[f];
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (int k0 = 0; k0 < KS; k0 += PF) {
+        const bool more = k0 + PF < KS;
+        if (more) load_act(k0 + PF);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int kn = k0 + j + PF - 1;
+            if (kn < KS) load_w(kn, (j + PF - 1) % PF);
+            f16x8 bq[MT];
+#pragma unroll
+            for (int f = 0; f < MT; ++f) bq[f] = act[buf][j][f][lane];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                for (int f = 0; f < MT; ++f) acc[f][n] = MFMA_16x16x32(aq[j][n], bq[f], acc[f][n]);
+        }
+        if (more) {
+#pragma unroll
+            for (int f = 0; f < MT; ++f) act[buf ^ 1][wave][f][lane] = st[f];
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int np = nt0 * 16;                                      // the wave's two tiles = one 32-channel pair
+#pragma unroll
+    for (int f = 0; f < MT; ++f) {
+        const long m = m0 + f * 16 + r16;
+        float v0[4] = {acc[f][0][0], acc[f][0][1], acc[f][0][2], acc[f][0][3]};
+        float v1[4] = {acc[f][1][0], acc[f][1][1], acc[f][1][2], acc[f][1][3]};
+        if (g.act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf(v0[r]); v1[r] = gelu_erf(v1[r]); }
+        }
+        const bool live = m < g.M;
+        const long off = (live ? m : 0) * g.ldo + np + pair_run_channel(grp);
+        if (g.res) {
+            f16x4 ra, rb;
+            run_to_pair(*reinterpret_cast<const f16x8 *>(g.res + off), ra, rb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v0[r] += (float)ra[r]; v1[r] += (float)rb[r]; }
+        }
+        const f16x8 ov = pair_to_run((f16x4){(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3]},
+                                     (f16x4){(f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]});
+        if (live) *reinterpret_cast<f16x8 *>(g.out + off) = ov;
+    }
+}
+
+bool gemm_os_supported(long M, int N, int K) {
+    static const bool off = getenv("NUNIF_GEMM_OS") && atoi(getenv("NUNIF_GEMM_OS")) == 0;       // A/B switch
+    return !off && M > 0 && N % 128 == 0 && K % 128 == 0 && K >= 128;
+}
+
+int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag) {
+    NUNIF_REQUIRE(gemm_os_supported(g.M, g.N, g.K) && g.lda % 8 == 0 && g.ldo % 8 == 0, "gemm_os %s: M=%ld N=%d K=%d unsupported",
+                  tag, g.M, g.N, g.K);
+    static const bool prof_tags = getenv("NUNIF_PROF_TAGS") != nullptr;
+    ProfScope ps(prof_tags ? tag : "gemm_os_kernel", s, 2.0 * (double)g.M * g.K * g.N,
+                 (double)g.M * (g.K * 2.0 + g.N * 2.0 * (g.res ? 2.0 : 1.0)));
+    const long blocks = ((g.M + 63) / 64) * (g.N / 128);
+    gemm_os_kernel<<<(unsigned)blocks, 256, 0, s>>>(g);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+// =================================================================================================================
 // Stem conv1: 3 -> C1 3x3 VALID + LeakyReLU on the VALU (K = 27 is too thin for MFMA; 0.15 % of the FLOPs).
 // Fuses the reference's replicate-pad + tile slicing (seam_blending.py:82,90) when reading from the frame.
 // One thread = one output pixel, all channels; weights broadcast from LDS.
