@@ -23,7 +23,7 @@ namespace nunif {
 // over pixel groups — no barrier and no weight latency inside the k loop.  With NT x MF <= 16 MFMAs per k-step the ring's
 // one-chunk prefetch distance (2 k-steps, ~500 cycles) is shorter than an L2 round trip and every chunk boundary stalled
 // all four waves (DPT-head 64 -> 64 3x3 convs: 81 TFLOP/s, profiles/r01d_kernel_stats_iw3_sched.csv).
-template <int NT, int MF, bool RES>
+template <int NT, int MF, bool RES, bool A2 = false>      // A2: a second input is added element-wise (cunet skip)
 __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
     constexpr int CH = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_conv[];
@@ -45,8 +45,18 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
     do {                                                                 // loop condition folds to false at compile time)
     const long m_base = ((long)gi * 4 + wave) * (MF * 16);
 
-    f16x8 st0, st1;
-    if (!RES) { st0 = gsrc[tid]; st1 = gsrc[tid + 256]; }
+    // ring form: the weight chunks (8 KiB) are requested THREE chunks ahead into a register queue (st / sq / sr) and written to
+    // the LDS ring at their own chunk boundary.  One chunk ahead (round 1) is ~500 cycles; the weights of a launch are read once
+    // and come from HBM, so on the small maps of the DPT head (6-22 workgroups, nothing else to switch to) every chunk boundary
+    // waited a full memory round trip: 1.3 us per k-step on the 14 x 25 map (profiles/r02 kernel trace).
+    f16x8 st0, st1, sq0, sq1, sr0, sr1;
+    const int n_chunks = (g.kh * g.kw * (g.Cin >> 5) * NT + CH - 1) / CH;
+    if (!RES) {                                             // (chunk n_chunks is the last one that lies inside the 16-KiB zero padding)
+        const int c1 = min(1, n_chunks), c2 = min(2, n_chunks);
+        st0 = gsrc[tid]; st1 = gsrc[tid + 256];
+        sq0 = gsrc[c1 * CH * 64 + tid]; sq1 = gsrc[c1 * CH * 64 + tid + 256];
+        sr0 = gsrc[c2 * CH * 64 + tid]; sr1 = gsrc[c2 * CH * 64 + tid + 256];
+    }
     auto wfrag = [&](int fi) -> f16x8 {
         if (RES) return ring[fi * 64 + lane];
         const int c = fi / CH;
@@ -54,8 +64,10 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
             ring[(c & 1) * (CH * 64) + tid] = st0;
             ring[(c & 1) * (CH * 64) + tid + 256] = st1;
             __syncthreads();
-            st0 = gsrc[(c + 1) * (CH * 64) + tid];
-            st1 = gsrc[(c + 1) * (CH * 64) + tid + 256];
+            st0 = sq0; st1 = sq1; sq0 = sr0; sq1 = sr1;
+            const int cn = min(c + 3, n_chunks);            // the stream is zero-padded by two chunks (16 KiB) on the host
+            sr0 = gsrc[cn * (CH * 64) + tid];
+            sr1 = gsrc[cn * (CH * 64) + tid + 256];
         }
         return ring[(c & 1) * (CH * 64) + (fi % CH) * 64 + lane];
     };
@@ -79,31 +91,46 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
     }
     const int cpt = g.Cin >> 5;                     // 32-channel chunks per tap
     const int ksteps = g.kh * g.kw * cpt;
-    auto load_x = [&](int ks, f16x8 (&dst)[MF]) {
+    // load_x only ISSUES the gathers (clamped coordinates, so that every lane loads); what has to happen to the loaded values —
+    // zeroing the taps that fell into the zero padding, the pre-activation ReLU — is done by finish_x right in front of the
+    // MFMAs that consume them.  Doing it at load time (round 1) put an s_waitcnt vmcnt(0) behind every load: the prefetch
+    // buffers never had more than one load in flight.
+    // ONE branch-free address path for the three padding modes (a uniform branch per mode inside the unrolled loops made hipcc
+    // reuse load-destination registers across the arms and guard every arm with vmcnt(0)): tap coordinate = pixel * stride +
+    // tap - pad, clamped into the map; replicate padding keeps the clamped value, zero padding remembers which lanes were outside.
+    const int pad = g.rpad ? g.rpad : g.zpad;
+    auto load_x = [&](int ks, f16x8 (&dst)[MF], unsigned &inb_mask) {
         const int tap = ks / cpt, c0 = (ks - tap * cpt) << 5;
         const int dy = tap / g.kw, dx = tap - dy * g.kw;
+        inb_mask = 0u;
+        if constexpr (A2) {         // second input added element-wise (cropped U-Net skip; VALID, stride as given): eager
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                f16x8 v = *reinterpret_cast<const f16x8 *>(g.a + base[f] + ((long)dy * g.Wi + dx) * g.Cin + c0);
+                v += *reinterpret_cast<const f16x8 *>(g.a2 + base2[f] + ((long)dy * g.W2 + dx) * g.Cin + c0);
+                dst[f] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            if (g.rpad) {           // replicate padding = clamp of the tap coordinate
-                const int yy = min(max(py[f] + dy - g.rpad, 0), g.Hi - 1), xx = min(max(px[f] + dx - g.rpad, 0), g.Wi - 1);
-                dst[f] = *reinterpret_cast<const f16x8 *>(g.a + (((long)pb[f] * g.Hi + yy) * g.Wi + xx) * g.Cin + 8 * grp + c0);
-                continue;
-            }
-            if (g.zpad || g.relu_in) {      // zero padding (any stride) and / or pre-activation ReLU
-                const int yy = py[f] * g.stride + dy - g.zpad, xx = px[f] * g.stride + dx - g.zpad;
-                f16x8 v = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-                if (yy >= 0 && yy < g.Hi && xx >= 0 && xx < g.Wi)
-                    v = *reinterpret_cast<const f16x8 *>(g.a + (((long)pb[f] * g.Hi + yy) * g.Wi + xx) * g.Cin + 8 * grp + c0);
-                if (g.relu_in) {
+            const int yy = py[f] * g.stride + dy - pad, xx = px[f] * g.stride + dx - pad;
+            const int yc = min(max(yy, 0), g.Hi - 1), xc = min(max(xx, 0), g.Wi - 1);
+            dst[f] = *reinterpret_cast<const f16x8 *>(g.a + (((long)pb[f] * g.Hi + yc) * g.Wi + xc) * g.Cin + 8 * grp + c0);
+            inb_mask |= ((yy == yc && xx == xc) ? 1u : 0u) << f;
+        }
+    };
+    auto finish_x = [&](f16x8 (&x)[MF], unsigned inb_mask) {
+        if (A2 || !(g.zpad || g.relu_in) || g.rpad) return;
+        const f16x8 z8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = v[j] > (f16)0.f ? v[j] : (f16)0.f;
-                }
-                dst[f] = v;
-                continue;
+        for (int f = 0; f < MF; ++f) {
+            f16x8 v = ((inb_mask >> f) & 1u) ? x[f] : z8;
+            if (g.relu_in) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] > (f16)0.f ? v[j] : (f16)0.f;
             }
-            f16x8 v = *reinterpret_cast<const f16x8 *>(g.a + base[f] + ((long)dy * g.Wi + dx) * g.Cin + c0);
-            if (g.a2) v += *reinterpret_cast<const f16x8 *>(g.a2 + base2[f] + ((long)dy * g.W2 + dx) * g.Cin + c0);
-            dst[f] = v;
+            x[f] = v;
         }
     };
 
@@ -113,24 +140,28 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) acc[nt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f16x8 xa[MF], xb[MF];
-    load_x(0, xa);
+    // NB register buffers of activation fragments: the gathers of k-step ks + NB - 1 are issued in front of the MFMAs of step ks.
+    // With NT x MF <= 16 MFMAs per k-step a one-step distance is ~256 cycles — far less than an L2 / HBM round trip, and the
+    // small maps these shapes run on (DPT head, side nets) leave 1-2 waves per SIMD to hide it: three steps ahead there.
+    constexpr int NB = (NT * MF <= 16) ? 4 : 2;
+    f16x8 xq[NB][MF];
+    unsigned xm[NB];
+#pragma unroll
+    for (int j = 0; j < NB - 1; ++j)
+        if (j < ksteps) load_x(j, xq[j], xm[j]);
 #pragma unroll 1
-    for (int ks = 0; ks < ksteps; ks += 2) {         // two k-steps per trip: statically named register buffers
-        if (ks + 1 < ksteps) load_x(ks + 1, xb);
+    for (int ks = 0; ks < ksteps; ks += NB) {        // NB k-steps per trip: statically named register buffers
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const f16x8 w = wfrag(ks * NT + nt);
+        for (int j = 0; j < NB; ++j) {
+            if (ks + j < ksteps) {
+                if (ks + j + NB - 1 < ksteps) load_x(ks + j + NB - 1, xq[(j + NB - 1) % NB], xm[(j + NB - 1) % NB]);
+                finish_x(xq[j], xm[j]);
 #pragma unroll
-            for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(w, xa[f], acc[nt][f]);
-        }
-        if (ks + 1 < ksteps) {
-            if (ks + 2 < ksteps) load_x(ks + 2, xa);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f16x8 w = wfrag((ks + j) * NT + nt);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f16x8 w = wfrag((ks + 1) * NT + nt);
-#pragma unroll
-                for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(w, xb[f], acc[nt][f]);
+                    for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(w, xq[j][f], acc[nt][f]);
+                }
             }
         }
     }
@@ -197,7 +228,7 @@ static int launch_conv_t(const ConvArgs &g, hipStream_t s) {
     // to amortise its 36-72 KiB copy over.  Measured (profiles/r01d_ab_conv_res.txt, whole iw3 frame, same box): >= 512 groups
     // only: -0.8 %; all launch sizes (NUNIF_CONV_RES_MIN_GROUPS=1): +3.8 % — for the small DPT-head maps one trip per workgroup
     // does not pay for the copy, although both forms are bit-identical on every size (the conv tests pass either way).
-    if (conv_res_enabled() && NT * MF <= 16 && res_bytes <= 80 * 1024 && n_groups >= conv_res_min_groups()) {
+    if (conv_res_enabled() && !g.a2 && NT * MF <= 16 && res_bytes <= 80 * 1024 && n_groups >= conv_res_min_groups()) {
         static bool configured = false;
         if (!configured) {
             NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv_kernel<NT, MF, true>,
@@ -205,6 +236,8 @@ static int launch_conv_t(const ConvArgs &g, hipStream_t s) {
             configured = true;
         }
         conv_kernel<NT, MF, true><<<(unsigned)std::min<long>(n_groups, 512), 256, res_bytes, s>>>(g);
+    } else if (g.a2) {
+        conv_kernel<NT, MF, false, true><<<(unsigned)n_groups, 256, 16 * 1024, s>>>(g);
     } else {
         conv_kernel<NT, MF, false><<<(unsigned)n_groups, 256, 16 * 1024, s>>>(g);
     }

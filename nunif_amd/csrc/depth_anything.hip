@@ -275,6 +275,99 @@ __global__ void __launch_bounds__(256) da_attn_split_kernel(const f16 *__restric
     }
 }
 
+// K / V shared through LDS: a workgroup of 8 waves = 8 query tiles (128 queries) walks the keys together; the 8 operand
+// fragments of a 32-key step (K rows in MFMA row order for both key tiles x 2 k-steps, V^T for the 4 channel tiles) are loaded
+// ONCE per workgroup — one 16-byte load per thread — into a double-buffered 8-KiB LDS slot, and every wave reads them from there.
+// Why: in the two kernels above every wave pulls its own 8 KiB of K / V per step through the vector memory pipe for 8 MFMAs; at
+// 64 B / clk / CU that pipe, not the matrix pipe, was the bound (measured 155 TFLOP/s).  grid (ceil(Np / 128), heads, B).
+__global__ void __launch_bounds__(512) da_attn_lds_kernel(const f16 *__restrict__ qkv, const f16 *__restrict__ vt,
+                                                          f16 *__restrict__ att, int Np, int Tp, int kD, int kHeads) {
+    __shared__ __attribute__((aligned(16))) f16x8 kv[2][8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, grp = lane >> 4;
+    const int qt = blockIdx.x * 8 + wave;
+    const bool has_q = qt * 16 < Np;
+    const int hh = blockIdx.y, b = blockIdx.z;
+    const f16 *base = qkv + (long)b * Np * (3 * kD);
+    const int q = min(qt * 16 + r16, Np - 1);
+    f16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        qf[ks] = *reinterpret_cast<const f16x8 *>(base + (long)q * (3 * kD) + hh * kHd + 32 * ks + 8 * grp);
+    const f16 *vbase = vt + ((long)(b * kHeads + hh) * kHd) * Tp;
+    // MFMA row i of key tile 0 / 1 <-> key k0 + 8*(i>>2) + (i&3) [+ 4]: lane's 8 P^T slots are then keys k0 + 8g + 0..7
+    const int krow = 8 * (r16 >> 2) + (r16 & 3);
+    // this thread's share of the staging: fragment `wave` of the step (0, 1: key tile 0, k-step 0 / 1; 2, 3: key tile 1; 4..7: V^T)
+    auto stage = [&](int k0) -> f16x8 {
+        if (wave < 4) {
+            const int key = min(k0 + krow + (wave >= 2 ? 4 : 0), Np - 1);
+            return *reinterpret_cast<const f16x8 *>(base + (long)key * (3 * kD) + kD + hh * kHd + 32 * (wave & 1) + 8 * grp);
+        }
+        return *reinterpret_cast<const f16x8 *>(vbase + (long)((wave - 4) * 16 + r16) * Tp + k0 + 8 * grp);
+    };
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -1.0e30f, l_run = 0.f;
+    kv[0][wave][lane] = stage(0);
+    __syncthreads();
+    int buf = 0;
+    // (64 keys per barrier — two staged steps — measured slower: 0.69 vs 0.64 ms per 12 launches)
+#pragma unroll 1
+    for (int k0 = 0; k0 < Tp; k0 += 32) {
+        const bool more = k0 + 32 < Tp;
+        f16x8 st;
+        if (more) st = stage(k0 + 32);
+        if (has_q) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s0 = MFMA_16x16x32(kv[buf][ks][lane], qf[ks], s0);
+                s1 = MFMA_16x16x32(kv[buf][2 + ks][lane], qf[ks], s1);
+            }
+            // accumulator row 4g+r of tile 0 is key k0 + 8g + r, of tile 1 key k0 + 8g + 4 + r
+            float mx = -1.0e30f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k0 + 8 * grp + r >= Np) s0[r] = -1.0e30f;
+                if (k0 + 8 * grp + 4 + r >= Np) s1[r] = -1.0e30f;
+                mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float p[8], sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+                p[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+                sum += p[r] + p[4 + r];
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            l_run = l_run * alpha + sum;
+            m_run = m_new;
+            const f16x8 pf = {(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3], (f16)p[4], (f16)p[5], (f16)p[6], (f16)p[7]};
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[dt] = (f32x4){o[dt][0] * alpha, o[dt][1] * alpha, o[dt][2] * alpha, o[dt][3] * alpha};
+                o[dt] = MFMA_16x16x32(kv[buf][4 + dt][lane], pf, o[dt]);
+            }
+        }
+        if (more) kv[buf ^ 1][wave][lane] = st;
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (has_q && qt * 16 + r16 < Np) {
+        const float inv = 1.0f / l_run;
+        f16 *dst = att + ((long)b * Np + qt * 16 + r16) * kD + hh * kHd + 4 * grp;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<f16x4 *>(dst + dt * 16) =
+                (f16x4){(f16)(o[dt][0] * inv), (f16)(o[dt][1] * inv), (f16)(o[dt][2] * inv), (f16)(o[dt][3] * inv)};
+    }
+}
+
 // F.interpolate(bilinear, align_corners=True) on NHWC fp16; one thread = 8 channels of one output pixel
 __global__ void __launch_bounds__(256) da_upsample_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int B, int Hi,
                                                           int Wi, int Ho, int Wo, int C) {
@@ -702,7 +795,11 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         {
             ProfScope ps("da_attn_kernel", s, 4.0 * B * (double)Np * Np * kD, (double)T * kD * 8.0);
             static const bool split = []() { const char *e = getenv("NUNIF_DA_ATTN_SPLIT"); return e ? atoi(e) != 0 : true; }();
-            if (split) {
+            static const bool shared = []() { const char *e = getenv("NUNIF_DA_ATTN_LDS"); return e ? atoi(e) != 0 : true; }();
+            if (shared) {
+                dim3 grid((unsigned)(((Np + 15) / 16 + 7) / 8), kHeads, B);
+                da_attn_lds_kernel<<<grid, 512, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
+            } else if (split) {
                 dim3 grid((unsigned)((Np + 15) / 16), kHeads, B);
                 da_attn_split_kernel<<<grid, 256, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
             } else {
