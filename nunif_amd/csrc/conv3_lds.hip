@@ -1,0 +1,193 @@
+// 3x3 stride-1 "same" conv (zero or replicate padding 1) with the INPUT TILE STAGED IN LDS, for gfx950.
+//
+// conv_kernel (cunet_kernels.hip) gathers the B operand of every tap straight from global memory: each input pixel is
+// fetched nine times and a k-step's MFMAs wait for gathers that were issued at most three k-steps earlier.  On the maps the
+// DPT head of the depth nets runs on (14 x 25 ... 224 x 392, iw3/depth_anything_model.py's external network; 64 / 128
+// channels) that is a chain of memory round trips: 27-47 us per launch regardless of the map size (kernel trace, DESIGN.md
+// 4.10).  Here a workgroup owns an 8 x 32 output patch: its (8+2) x (32+2) input halo with ALL Cin channels is loaded once,
+// every load in flight at the same time (one round trip), padded / ReLU'd while it is written to LDS, and the 9 x Cin/32
+// k-steps read their B fragments from LDS only (pixel stride Cin*2 + 16 bytes: the 16 pixels of a fragment hit 16 distinct
+// bank quads).  Weights come through the same 2 x 8-KiB ring as conv_kernel, requested three chunks ahead.
+// Same contract as conv_kernel for its case (ConvArgs: kh = kw = 3, stride 1, zpad = 1 or rpad = 1, one input, NHWC fp16
+// output with bias, LeakyReLU / ReLU, up to two residuals, ldo), same accumulation order over k — results are identical.
+#include <algorithm>
+#include <cstdlib>
+
+#include "swin_kernels.h"
+
+namespace nunif {
+
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int kC3TH = 8, kC3TW = 32;                     // output patch of a workgroup (4 waves x 2 rows x 32 columns)
+constexpr int kC3HH = kC3TH + 2, kC3HW = kC3TW + 2;      // halo
+
+template <int NT>
+__global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
+    constexpr int CH = 8, MF = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c3[];
+    f16x8 *ring = reinterpret_cast<f16x8 *>(smem_c3);                    // [2][CH * 64]
+    unsigned char *halo = smem_c3 + 2 * CH * 1024;                       // [kC3HH * kC3HW pixels][Cin * 2 + 16 bytes]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, grp = lane >> 4;
+    const int pstride = g.Cin * 2 + 16;
+    const int tiles_x = (g.Wo + kC3TW - 1) / kC3TW, tiles_y = (g.Ho + kC3TH - 1) / kC3TH;
+    const int tx0 = (blockIdx.x % tiles_x) * kC3TW;
+    const int ty0 = ((blockIdx.x / tiles_x) % tiles_y) * kC3TH;
+    const int b = blockIdx.x / (tiles_x * tiles_y);
+    const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.wstream);      // zero-padded by 16 KiB on the host
+    const int cpt = g.Cin >> 5;
+    const int ksteps = 9 * cpt;
+    const int n_chunks = (ksteps * NT + CH - 1) / CH;
+    f16x8 st0, st1, sq0, sq1, sr0, sr1;
+    {
+        const int c1 = min(1, n_chunks), c2 = min(2, n_chunks);
+        st0 = gsrc[tid]; st1 = gsrc[tid + 256];
+        sq0 = gsrc[c1 * CH * 64 + tid]; sq1 = gsrc[c1 * CH * 64 + tid + 256];
+        sr0 = gsrc[c2 * CH * 64 + tid]; sr1 = gsrc[c2 * CH * 64 + tid + 256];
+    }
+    // ---- stage the halo: 16-byte segments, (pixel, segment) = work item; zero / replicate padding and the pre-activation ReLU
+    // are applied here, once per element
+    {
+        const int segs = g.Cin >> 3;                                     // 16-byte segments per pixel
+        const int items = kC3HH * kC3HW * segs;
+        const f16x8 z8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        for (int i0 = 0; i0 < items; i0 += 256 * 4) {                    // four loads in flight per thread and trip
+            f16x8 v[4];
+            bool inb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * 256 + tid, items - 1);
+                const int p = i / segs, sg = i - p * segs;
+                const int hy = p / kC3HW, hx = p - hy * kC3HW;
+                const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
+                const int yc = min(max(yy, 0), g.Hi - 1), xc = min(max(xx, 0), g.Wi - 1);
+                inb[u] = g.rpad || (yy == yc && xx == xc);
+                v[u] = *reinterpret_cast<const f16x8 *>(g.a + (((long)b * g.Hi + yc) * g.Wi + xc) * g.Cin + sg * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + tid;
+                if (i >= items) continue;
+                const int p = i / segs, sg = i - p * segs;
+                f16x8 w = inb[u] ? v[u] : z8;
+                if (g.relu_in) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = w[j] > (f16)0.f ? w[j] : (f16)0.f;
+                }
+                *reinterpret_cast<f16x8 *>(halo + (long)p * pstride + sg * 16) = w;
+            }
+        }
+    }
+    auto wfrag = [&](int fi) -> f16x8 {
+        const int c = fi / CH;
+        if (fi % CH == 0) {
+            ring[(c & 1) * (CH * 64) + tid] = st0;
+            ring[(c & 1) * (CH * 64) + tid + 256] = st1;
+            __syncthreads();                                             // (the first one also publishes the halo)
+            st0 = sq0; st1 = sq1; sq0 = sr0; sq1 = sr1;
+            const int cn = min(c + 3, n_chunks);
+            sr0 = gsrc[cn * (CH * 64) + tid];
+            sr1 = gsrc[cn * (CH * 64) + tid + 256];
+        }
+        return ring[(c & 1) * (CH * 64) + (fi % CH) * 64 + lane];
+    };
+    // token tile f of wave w: output row ty0 + 2w + (f >> 1), columns tx0 + 16 (f & 1) + r16
+    int hoff[MF];                                                        // byte offsets into the halo (tap (0, 0), channel 8 grp)
+#pragma unroll
+    for (int f = 0; f < MF; ++f) hoff[f] = ((2 * wave + (f >> 1)) * kC3HW + 16 * (f & 1) + r16) * pstride + grp * 16;
+
+    f32x4 acc[NT][MF];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int f = 0; f < MF; ++f) acc[nt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        const int toff = (dy * kC3HW + dx) * pstride;
+#pragma unroll 1
+        for (int c = 0; c < cpt; ++c) {
+            const int ks = tap * cpt + c;
+            f16x8 xq[MF];
+            f16x8 w0 = wfrag(ks * NT);                                   // (its barrier, if any, comes before the halo reads)
+#pragma unroll
+            for (int f = 0; f < MF; ++f) xq[f] = *reinterpret_cast<const f16x8 *>(halo + hoff[f] + toff + c * 64);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f16x8 w = nt == 0 ? w0 : wfrag(ks * NT + nt);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(w, xq[f], acc[nt][f]);
+            }
+        }
+    }
+
+    const int ldo = g.ldo > 0 ? g.ldo : g.n_real;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = nt * 16 + grp * 4;
+        const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int oy = ty0 + 2 * wave + (f >> 1), ox = tx0 + 16 * (f & 1) + r16;
+            if (oy >= g.Ho || ox >= g.Wo || n0 >= g.n_real) continue;
+            float v[4] = {acc[nt][f][0] + bv.x, acc[nt][f][1] + bv.y, acc[nt][f][2] + bv.z, acc[nt][f][3] + bv.w};
+            if (g.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * g.slope;
+            } else if (g.act == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            const long off = (((long)b * g.Ho + oy) * g.Wo + ox) * ldo + n0;
+            if (g.res) {
+                const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+            }
+            if (g.res2) {
+                const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res2 + off);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+            }
+            *reinterpret_cast<f16x4 *>(g.out + off) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        }
+    }
+}
+
+static inline int conv3_lds_enabled() { const char *e = getenv("NUNIF_CONV3_LDS"); return e ? atoi(e) : 1; }
+
+bool conv3_lds_applies(const ConvArgs &g) {
+    const int nt = g.N / 16;
+    return conv3_lds_enabled() && g.kh == 3 && g.kw == 3 && g.stride == 1 && !g.a2 && !g.out32 && g.Ho == g.Hi && g.Wo == g.Wi &&
+           (g.zpad == 1 || g.rpad == 1) && !(g.zpad && g.rpad) && g.Cin % 32 == 0 && g.Cin <= 128 && g.N % 16 == 0 &&
+           (nt == 2 || nt == 4 || nt == 8);
+}
+
+template <int NT>
+static int launch_c3(const ConvArgs &g, hipStream_t s, const char *name) {
+    const size_t smem = 2 * 8 * 1024 + (size_t)kC3HH * kC3HW * (g.Cin * 2 + 16);
+    static bool configured = false;
+    if (!configured) {
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_lds_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            2 * 8 * 1024 + kC3HH * kC3HW * (128 * 2 + 16)));
+        configured = true;
+    }
+    const long M = (long)g.B * g.Ho * g.Wo;
+    ProfScope ps(name, s, 2.0 * (double)M * 9.0 * g.Cin * g.n_real, (double)M * (g.Cin + g.n_real) * 2.0);
+    const long blocks = (long)g.B * ((g.Ho + kC3TH - 1) / kC3TH) * ((g.Wo + kC3TW - 1) / kC3TW);
+    conv3_lds_kernel<NT><<<(unsigned)blocks, 256, smem, s>>>(g);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+int launch_conv3_lds(const ConvArgs &g, hipStream_t s) {
+    switch (g.N / 16) {
+        case 2: return launch_c3<2>(g, s, "conv3_lds_kernel<2>");
+        case 4: return launch_c3<4>(g, s, "conv3_lds_kernel<4>");
+        case 8: return launch_c3<8>(g, s, "conv3_lds_kernel<8>");
+        default: set_error("conv3_lds: Cout=%d unsupported", g.N); return NUNIF_HIP_EUNSUPPORTED;
+    }
+}
+
+}  // namespace nunif

@@ -251,6 +251,7 @@ int launch_conv(const ConvArgs &g, hipStream_t s) {
     NUNIF_REQUIRE(!(g.zpad || g.relu_in) || (!g.a2 && !g.rpad), "conv: zero padding / relu_in need a single input");
     const long M = (long)g.B * g.Ho * g.Wo;
     if (M == 0) return NUNIF_HIP_OK;
+    if (conv3_lds_applies(g)) return launch_conv3_lds(g, s);
     const double K = (double)g.kh * g.kw * g.Cin;
     const double flops = 2.0 * (double)M * K * g.n_real;
     const double bytes = (double)g.B * g.Hi * g.Wi * g.Cin * 2.0 * (g.a2 ? 2.0 : 1.0) +

@@ -142,6 +142,9 @@ struct ConvArgs {
                               //      channel slice of a wider map (out pre-offset by the slice's first channel)
 };
 int launch_conv(const ConvArgs &g, hipStream_t s);
+// 3x3 stride-1 same conv with the input tile staged in LDS (conv3_lds.hip); launch_conv takes it when it applies
+bool conv3_lds_applies(const ConvArgs &g);
+int launch_conv3_lds(const ConvArgs &g, hipStream_t s);
 
 struct C3ConvArgs {
     const float *x; int frame_mode, H, W, wb, istep, pad_t, pad_l, tile_begin;

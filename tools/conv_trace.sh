@@ -11,7 +11,7 @@ sel = [r for r in rows if "conv_kernel" in r["Kernel_Name"] or "gemm_os" in r["K
 agg = collections.OrderedDict()
 for r in rows[-260:]:
     k = r["Kernel_Name"][:60]
-    if "conv_kernel" not in k: continue
+    if "conv" not in k: continue
     key = (k, r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size"), r.get("Workgroup_Size_X", ""))
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     agg.setdefault(key, []).append(d)
