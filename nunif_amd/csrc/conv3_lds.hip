@@ -22,64 +22,101 @@ namespace nunif {
 constexpr int kC3TH = 8, kC3TW = 32;                     // output patch of a workgroup (4 waves x 2 rows x 32 columns)
 constexpr int kC3HH = kC3TH + 2, kC3HW = kC3TW + 2;      // halo
 
-template <int NT>
+// RESW: the whole weight stream (9 x Cin/32 x NT KiB) fits next to the halo and is copied into LDS up front, all loads in flight
+// together with the halo's: the weights of a launch are read once, so they come from HBM, and through the ring every 8-KiB
+// chunk boundary waited for a request only three chunks (~0.7 us of MFMAs) old — 23-26 us per launch whatever the map size.
+template <int NT, bool RESW>
 __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
     constexpr int CH = 8, MF = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c3[];
-    f16x8 *ring = reinterpret_cast<f16x8 *>(smem_c3);                    // [2][CH * 64]
-    unsigned char *halo = smem_c3 + 2 * CH * 1024;                       // [kC3HH * kC3HW pixels][Cin * 2 + 16 bytes]
+    f16x8 *ring = reinterpret_cast<f16x8 *>(smem_c3);                    // ring: [2][CH * 64]; RESW: [9 * Cin/32 * NT][64]
+    unsigned char *halo = smem_c3 + (RESW ? 9 * (g.Cin >> 5) * NT : 2 * CH) * 1024;   // [kC3HH * kC3HW pixels][Cin * 2 + 16 bytes]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, grp = lane >> 4;
     const int pstride = g.Cin * 2 + 16;
     const int tiles_x = (g.Wo + kC3TW - 1) / kC3TW, tiles_y = (g.Ho + kC3TH - 1) / kC3TH;
-    const int tx0 = (blockIdx.x % tiles_x) * kC3TW;
-    const int ty0 = ((blockIdx.x / tiles_x) % tiles_y) * kC3TH;
-    const int b = blockIdx.x / (tiles_x * tiles_y);
+    const int n_tiles = g.B * tiles_x * tiles_y;
     const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.wstream);      // zero-padded by 16 KiB on the host
     const int cpt = g.Cin >> 5;
     const int ksteps = 9 * cpt;
     const int n_chunks = (ksteps * NT + CH - 1) / CH;
+    constexpr int UW = 6, UH = 6;                                        // loads in flight per thread and batch: weights, halo
+    const int w_total = ksteps * NT * 64;                                // 16-byte items of the weight stream
+    const int segs = g.Cin >> 3;                                         // 16-byte segments per pixel
+    const int h_items = kC3HH * kC3HW * segs;
+    auto w_load = [&](int i0, f16x8 (&wv)[UW]) {
+#pragma unroll
+        for (int u = 0; u < UW; ++u) wv[u] = gsrc[min(i0 + u * 256 + tid, w_total - 1)];
+    };
+    auto w_store = [&](int i0, const f16x8 (&wv)[UW]) {
+#pragma unroll
+        for (int u = 0; u < UW; ++u)
+            if (i0 + u * 256 + tid < w_total) ring[i0 + u * 256 + tid] = wv[u];
+    };
+    // halo: (pixel, 16-byte segment) = work item; zero / replicate padding and the pre-activation ReLU are applied while it is
+    // written to LDS, once per element
+    auto h_load = [&](int i0, int b, int ty0, int tx0, f16x8 (&v)[UH], unsigned &inb) {
+        inb = 0u;
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+            const int i = min(i0 + u * 256 + tid, h_items - 1);
+            const int p = i / segs, sg = i - p * segs;
+            const int hy = p / kC3HW, hx = p - hy * kC3HW;
+            const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
+            const int yc = min(max(yy, 0), g.Hi - 1), xc = min(max(xx, 0), g.Wi - 1);
+            inb |= ((g.rpad || (yy == yc && xx == xc)) ? 1u : 0u) << u;
+            v[u] = *reinterpret_cast<const f16x8 *>(g.a + (((long)b * g.Hi + yc) * g.Wi + xc) * g.Cin + sg * 8);
+        }
+    };
+    auto h_store = [&](int i0, const f16x8 (&v)[UH], unsigned inb) {
+        const f16x8 z8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+            const int i = i0 + u * 256 + tid;
+            if (i >= h_items) continue;
+            const int p = i / segs, sg = i - p * segs;
+            f16x8 w = ((inb >> u) & 1u) ? v[u] : z8;
+            if (g.relu_in) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = w[j] > (f16)0.f ? w[j] : (f16)0.f;
+            }
+            *reinterpret_cast<f16x8 *>(halo + (long)p * pstride + sg * 16) = w;
+        }
+    };
+    // (the patch loop runs once per workgroup with the grids launch_c3 uses; a persistent RESW grid is supported but not faster)
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tx0 = (tile % tiles_x) * kC3TW;
+    const int ty0 = ((tile / tiles_x) % tiles_y) * kC3TH;
+    const int b = tile / (tiles_x * tiles_y);
     f16x8 st0, st1, sq0, sq1, sr0, sr1;
     {
+        f16x8 hv[UH];
+        unsigned hin;
+        if (RESW && tile == (int)blockIdx.x) {
+            // first patch: the first batches of BOTH streams are requested before anything is waited for: one round trip
+            f16x8 wv[UW];
+            w_load(0, wv);
+            h_load(0, b, ty0, tx0, hv, hin);
+            w_store(0, wv);
+            h_store(0, hv, hin);
+            for (int i0 = 256 * UW; i0 < w_total; i0 += 256 * UW) { w_load(i0, wv); w_store(i0, wv); }
+        } else {
+            if (RESW) __syncthreads();                                   // every wave is done with the previous patch's halo
+            h_load(0, b, ty0, tx0, hv, hin);
+            h_store(0, hv, hin);
+        }
+        for (int i0 = 256 * UH; i0 < h_items; i0 += 256 * UH) { h_load(i0, b, ty0, tx0, hv, hin); h_store(i0, hv, hin); }
+    }
+    if constexpr (!RESW) {
         const int c1 = min(1, n_chunks), c2 = min(2, n_chunks);
         st0 = gsrc[tid]; st1 = gsrc[tid + 256];
         sq0 = gsrc[c1 * CH * 64 + tid]; sq1 = gsrc[c1 * CH * 64 + tid + 256];
         sr0 = gsrc[c2 * CH * 64 + tid]; sr1 = gsrc[c2 * CH * 64 + tid + 256];
     }
-    // ---- stage the halo: 16-byte segments, (pixel, segment) = work item; zero / replicate padding and the pre-activation ReLU
-    // are applied here, once per element
-    {
-        const int segs = g.Cin >> 3;                                     // 16-byte segments per pixel
-        const int items = kC3HH * kC3HW * segs;
-        const f16x8 z8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-        for (int i0 = 0; i0 < items; i0 += 256 * 4) {                    // four loads in flight per thread and trip
-            f16x8 v[4];
-            bool inb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = min(i0 + u * 256 + tid, items - 1);
-                const int p = i / segs, sg = i - p * segs;
-                const int hy = p / kC3HW, hx = p - hy * kC3HW;
-                const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
-                const int yc = min(max(yy, 0), g.Hi - 1), xc = min(max(xx, 0), g.Wi - 1);
-                inb[u] = g.rpad || (yy == yc && xx == xc);
-                v[u] = *reinterpret_cast<const f16x8 *>(g.a + (((long)b * g.Hi + yc) * g.Wi + xc) * g.Cin + sg * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256 + tid;
-                if (i >= items) continue;
-                const int p = i / segs, sg = i - p * segs;
-                f16x8 w = inb[u] ? v[u] : z8;
-                if (g.relu_in) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) w[j] = w[j] > (f16)0.f ? w[j] : (f16)0.f;
-                }
-                *reinterpret_cast<f16x8 *>(halo + (long)p * pstride + sg * 16) = w;
-            }
-        }
-    }
+    if constexpr (RESW) __syncthreads();
     auto wfrag = [&](int fi) -> f16x8 {
+        if constexpr (RESW) return ring[fi * 64 + lane];
         const int c = fi / CH;
         if (fi % CH == 0) {
             ring[(c & 1) * (CH * 64) + tid] = st0;
@@ -153,6 +190,7 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
             *reinterpret_cast<f16x4 *>(g.out + off) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
         }
     }
+    }   // patches
 }
 
 static inline int conv3_lds_enabled() { const char *e = getenv("NUNIF_CONV3_LDS"); return e ? atoi(e) : 1; }
@@ -164,21 +202,33 @@ bool conv3_lds_applies(const ConvArgs &g) {
            (nt == 2 || nt == 4 || nt == 8);
 }
 
-template <int NT>
-static int launch_c3(const ConvArgs &g, hipStream_t s, const char *name) {
-    const size_t smem = 2 * 8 * 1024 + (size_t)kC3HH * kC3HW * (g.Cin * 2 + 16);
+template <int NT, bool RESW>
+static int launch_c3r(const ConvArgs &g, hipStream_t s, size_t smem) {
     static bool configured = false;
     if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_lds_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            2 * 8 * 1024 + kC3HH * kC3HW * (128 * 2 + 16)));
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_lds_kernel<NT, RESW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            150 * 1024));
         configured = true;
     }
-    const long M = (long)g.B * g.Ho * g.Wo;
-    ProfScope ps(name, s, 2.0 * (double)M * 9.0 * g.Cin * g.n_real, (double)M * (g.Cin + g.n_real) * 2.0);
-    const long blocks = (long)g.B * ((g.Ho + kC3TH - 1) / kC3TH) * ((g.Wo + kC3TW - 1) / kC3TW);
-    conv3_lds_kernel<NT><<<(unsigned)blocks, 256, smem, s>>>(g);
+    long blocks = (long)g.B * ((g.Ho + kC3TH - 1) / kC3TH) * ((g.Wo + kC3TW - 1) / kC3TW);
+    conv3_lds_kernel<NT, RESW><<<(unsigned)blocks, 256, smem, s>>>(g);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
+}
+
+template <int NT>
+static int launch_c3(const ConvArgs &g, hipStream_t s, const char *name) {
+    const size_t halo = (size_t)kC3HH * kC3HW * (g.Cin * 2 + 16);
+    const size_t wres = (size_t)9 * (g.Cin >> 5) * NT * 1024;
+    const long M = (long)g.B * g.Ho * g.Wo;
+    ProfScope ps(name, s, 2.0 * (double)M * 9.0 * g.Cin * g.n_real, (double)M * (g.Cin + g.n_real) * 2.0);
+    static const bool no_res = getenv("NUNIF_CONV3_RESW") && atoi(getenv("NUNIF_CONV3_RESW")) == 0;       // A/B switch
+    // resident weights for launches of at most one workgroup per CU (the small maps, where the ring's chunk boundaries are a chain
+    // of memory round trips: 23 -> 17 us); on larger grids the 72-KiB copy per workgroup and one resident workgroup per CU cost
+    // more than they save (392 patches: 34 vs 26 us), and a persistent form with 18 + 12 loads in flight was no better either
+    const long n_tiles = (long)g.B * ((g.Ho + kC3TH - 1) / kC3TH) * ((g.Wo + kC3TW - 1) / kC3TW);
+    if (!no_res && n_tiles <= 256 && halo + wres <= 150 * 1024) return launch_c3r<NT, true>(g, s, halo + wres);
+    return launch_c3r<NT, false>(g, s, halo + 2 * 8 * 1024);
 }
 
 int launch_conv3_lds(const ConvArgs &g, hipStream_t s) {
