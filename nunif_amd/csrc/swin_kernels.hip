@@ -480,8 +480,9 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
 // tiles 2w, 2w + 1 of the workgroup's 8 and all 4 token tiles: acc[4][2].  K loop in groups of 4 k-steps over 4 register
 // buffers: the loads of step k + 3 are issued in front of the MFMAs of step k (static buffer indices, nothing dynamic).
 // =================================================================================================================
+template <int MT>                                   // token tiles per workgroup: 4 (64 tokens) or 2 (32 tokens, narrow N)
 __global__ void __launch_bounds__(256) gemm_os_kernel(GemmOsArgs g) {
-    constexpr int MT = 4, NTW = 2, PF = 4;
+    constexpr int NTW = 2, PF = 4;
     // the activation tile of a k-group (64 tokens x 128 k = 16 KiB) is shared by the four waves: it goes through LDS once
     // (fragment-major, double-buffered, one barrier per 4 k-steps) instead of four times through the vector memory pipe, which
     // at 64 B / clk / CU was the bound of the all-global form (24 KiB of loads per 32 MFMAs); the weights stay direct loads
@@ -583,8 +584,15 @@ int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag) {
     static const bool prof_tags = getenv("NUNIF_PROF_TAGS") != nullptr;
     ProfScope ps(prof_tags ? tag : "gemm_os_kernel", s, 2.0 * (double)g.M * g.K * g.N,
                  (double)g.M * (g.K * 2.0 + g.N * 2.0 * (g.res ? 2.0 : 1.0)));
+    // 32-token workgroups when 64-token ones would leave the chip with fewer than two workgroups per CU (the N = 384 Linears of
+    // ViT-S: 258 workgroups, one wave per SIMD)
+    static const int force_mt = getenv("NUNIF_GEMM_OS_MT") ? atoi(getenv("NUNIF_GEMM_OS_MT")) : 0;
     const long blocks = ((g.M + 63) / 64) * (g.N / 128);
-    gemm_os_kernel<<<(unsigned)blocks, 256, 0, s>>>(g);
+    if (force_mt == 2 || (force_mt == 0 && blocks < 512)) {
+        gemm_os_kernel<2><<<(unsigned)(((g.M + 31) / 32) * (g.N / 128)), 256, 0, s>>>(g);
+    } else {
+        gemm_os_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(g);
+    }
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
