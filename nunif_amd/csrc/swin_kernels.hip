@@ -584,11 +584,11 @@ int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag) {
     static const bool prof_tags = getenv("NUNIF_PROF_TAGS") != nullptr;
     ProfScope ps(prof_tags ? tag : "gemm_os_kernel", s, 2.0 * (double)g.M * g.K * g.N,
                  (double)g.M * (g.K * 2.0 + g.N * 2.0 * (g.res ? 2.0 : 1.0)));
-    // 32-token workgroups when 64-token ones would leave the chip with fewer than two workgroups per CU (the N = 384 Linears of
-    // ViT-S: 258 workgroups, one wave per SIMD)
+    // 32-token workgroups (fewer registers, more resident waves to hide the short K loop's prologue) unless 64-token ones already
+    // give the chip four workgroups per CU; measured on ViT-S (5 492 tokens): fc1 0.339 -> 0.315 ms, fc2 0.345 -> 0.313 ms per 12 launches
     static const int force_mt = getenv("NUNIF_GEMM_OS_MT") ? atoi(getenv("NUNIF_GEMM_OS_MT")) : 0;
     const long blocks = ((g.M + 63) / 64) * (g.N / 128);
-    if (force_mt == 2 || (force_mt == 0 && blocks < 512)) {
+    if (force_mt == 2 || (force_mt == 0 && blocks < 1100)) {
         gemm_os_kernel<2><<<(unsigned)(((g.M + 31) / 32) * (g.N / 128)), 256, 0, s>>>(g);
     } else {
         gemm_os_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(g);
