@@ -30,19 +30,24 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
     constexpr int CH = 8, MF = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c3[];
     f16x8 *ring = reinterpret_cast<f16x8 *>(smem_c3);                    // ring: [2][CH * 64]; RESW: [9 * Cin/32 * NT][64]
-    unsigned char *halo = smem_c3 + (RESW ? 9 * (g.Cin >> 5) * NT : 2 * CH) * 1024;   // [kC3HH * kC3HW pixels][Cin * 2 + 16 bytes]
+    unsigned char *halo = smem_c3 + (RESW ? 9 * ((g.cmaj ? g.cmaj : g.Cin) >> 5) * NT : 2 * CH) * 1024;   // [kC3HH * kC3HW pixels][cin * 2 + 16 B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, grp = lane >> 4;
-    const int pstride = g.Cin * 2 + 16;
+    // split contraction (g.cmaj, grid.y = chunks): this workgroup convolves channels [cmaj * blockIdx.y, + cmaj) of rows that are
+    // lda channels wide and writes an fp32 partial; otherwise cin = lda = g.Cin
+    const int cin = g.cmaj ? g.cmaj : g.Cin, lda = g.Cin;
+    const int pstride = cin * 2 + 16;
     const int tiles_x = (g.Wo + kC3TW - 1) / kC3TW, tiles_y = (g.Ho + kC3TH - 1) / kC3TH;
     const int n_tiles = g.B * tiles_x * tiles_y;
-    const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.wstream);      // zero-padded by 16 KiB on the host
-    const int cpt = g.Cin >> 5;
+    const int cpt = cin >> 5;
+    const f16 *a_in = g.a + (g.cmaj ? (int)blockIdx.y * cin : 0);
+    const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.wstream) +    // zero-padded by 16 KiB on the host
+                        (g.cmaj ? (long)blockIdx.y * 9 * cpt * NT * 64 : 0);
     const int ksteps = 9 * cpt;
     const int n_chunks = (ksteps * NT + CH - 1) / CH;
     constexpr int UW = 6, UH = 6;                                        // loads in flight per thread and batch: weights, halo
     const int w_total = ksteps * NT * 64;                                // 16-byte items of the weight stream
-    const int segs = g.Cin >> 3;                                         // 16-byte segments per pixel
+    const int segs = cin >> 3;                                           // 16-byte segments per pixel
     const int h_items = kC3HH * kC3HW * segs;
     auto w_load = [&](int i0, f16x8 (&wv)[UW]) {
 #pragma unroll
@@ -65,7 +70,7 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
             const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
             const int yc = min(max(yy, 0), g.Hi - 1), xc = min(max(xx, 0), g.Wi - 1);
             inb |= ((g.rpad || (yy == yc && xx == xc)) ? 1u : 0u) << u;
-            v[u] = *reinterpret_cast<const f16x8 *>(g.a + (((long)b * g.Hi + yc) * g.Wi + xc) * g.Cin + sg * 8);
+            v[u] = *reinterpret_cast<const f16x8 *>(a_in + (((long)b * g.Hi + yc) * g.Wi + xc) * lda + sg * 8);
         }
     };
     auto h_store = [&](int i0, const f16x8 (&v)[UH], unsigned inb) {
@@ -159,6 +164,18 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
         }
     }
 
+    if (g.cmaj) {                                                        // fp32 partial [chunk][pixel][N], no epilogue
+        float *part = g.part32 + (long)blockIdx.y * ((long)g.B * g.Ho * g.Wo) * g.N;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const int oy = ty0 + 2 * wave + (f >> 1), ox = tx0 + 16 * (f & 1) + r16;
+                if (oy >= g.Ho || ox >= g.Wo) continue;
+                *reinterpret_cast<f32x4 *>(part + (((long)b * g.Ho + oy) * g.Wo + ox) * g.N + nt * 16 + grp * 4) = acc[nt][f];
+            }
+        continue;
+    }
     const int ldo = g.ldo > 0 ? g.ldo : g.n_real;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -193,13 +210,59 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
     }   // patches
 }
 
+// Wide inputs (Cin > 128: the layer{3,4}_rn convs of the DPT head read 192 ... 1024 channels on 14 x 25 / 28 x 49 maps, 6-22
+// patches).  One workgroup per patch walks 54-108 k-steps with at most 24 KiB of weight requests in flight — ~10 GB/s against a
+// 2.5-us round trip, 51-113 us per launch — and staging the input in LDS does not change that (measured: 90 us).  The
+// contraction is therefore SPLIT ACROSS WORKGROUPS: the owner packs the stream chunk-major (ConvArgs.cmaj = 64:
+// [64-channel chunk][tap][32-channel half][n-tile], i.e. chunk q is a complete tap-major stream of a 64-channel conv), grid.y =
+// chunks, every workgroup runs conv3_lds_kernel<NT, true> on its channel slice (72 KiB of weights + the halo, everything
+// requested at once) and writes an fp32 partial; conv_partial_sum_kernel adds the partials in chunk order (deterministic),
+// then bias, activation, residuals as usual.
+__global__ void __launch_bounds__(256) conv_partial_sum_kernel(ConvArgs g, const float *__restrict__ part, int n_q) {
+    const long M = (long)g.B * g.Ho * g.Wo;
+    const int nq4 = g.N / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * nq4) return;
+    const long p = i / nq4;
+    const int n0 = (int)(i - p * nq4) * 4;
+    if (n0 >= g.n_real) return;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(part + p * g.N + n0);
+    for (int q = 1; q < n_q; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(part + ((long)q * M + p) * g.N + n0);
+        v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+    }
+    const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    if (g.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * g.slope;
+    } else if (g.act == 3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    const long off = p * (g.ldo > 0 ? g.ldo : g.n_real) + n0;
+    if (g.res) {
+        const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+    }
+    if (g.res2) {
+        const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res2 + off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+    }
+    *reinterpret_cast<f16x4 *>(g.out + off) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+}
+
 static inline int conv3_lds_enabled() { const char *e = getenv("NUNIF_CONV3_LDS"); return e ? atoi(e) : 1; }
 
 bool conv3_lds_applies(const ConvArgs &g) {
     const int nt = g.N / 16;
-    return conv3_lds_enabled() && g.kh == 3 && g.kw == 3 && g.stride == 1 && !g.a2 && !g.out32 && g.Ho == g.Hi && g.Wo == g.Wi &&
-           (g.zpad == 1 || g.rpad == 1) && !(g.zpad && g.rpad) && g.Cin % 32 == 0 && g.Cin <= 128 && g.N % 16 == 0 &&
-           (nt == 2 || nt == 4 || nt == 8);
+    const bool shape = g.kh == 3 && g.kw == 3 && g.stride == 1 && !g.a2 && !g.out32 && g.Ho == g.Hi && g.Wo == g.Wi &&
+                       (g.zpad == 1 || g.rpad == 1) && !(g.zpad && g.rpad) && g.N % 16 == 0 && (nt == 2 || nt == 4 || nt == 8);
+    if (!conv3_lds_enabled() || !shape) return false;
+    if (g.cmaj) return (g.cmaj == 64 || g.cmaj == 32) && g.Cin % g.cmaj == 0;     // a chunk-major stream: the split form only
+    return g.Cin % 32 == 0 && g.Cin <= 128;
 }
 
 template <int NT, bool RESW>
@@ -231,7 +294,35 @@ static int launch_c3(const ConvArgs &g, hipStream_t s, const char *name) {
     return launch_c3r<NT, false>(g, s, halo + 2 * 8 * 1024);
 }
 
+template <int NT>
+static int launch_c3cm(const ConvArgs &g, hipStream_t s) {
+    const int n_q = g.Cin / g.cmaj;
+    const size_t smem = (size_t)9 * (g.cmaj >> 5) * NT * 1024 + (size_t)kC3HH * kC3HW * (g.cmaj * 2 + 16);
+    NUNIF_REQUIRE(g.part32 && smem <= 150 * 1024, "conv3_lds: split contraction needs ConvArgs.part32 (B*Ho*Wo*N*Cin/cmaj floats)");
+    static bool configured = false;
+    if (!configured) {
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_lds_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            150 * 1024));
+        configured = true;
+    }
+    const long M = (long)g.B * g.Ho * g.Wo;
+    ProfScope ps("conv3_lds_kernel<split-K>", s, 2.0 * (double)M * 9.0 * g.Cin * g.n_real, (double)M * (g.Cin + g.n_real) * 2.0);
+    const long tiles = (long)g.B * ((g.Ho + kC3TH - 1) / kC3TH) * ((g.Wo + kC3TW - 1) / kC3TW);
+    conv3_lds_kernel<NT, true><<<dim3((unsigned)tiles, (unsigned)n_q), 256, smem, s>>>(g);
+    conv_partial_sum_kernel<<<(unsigned)((M * (g.N / 4) + 255) / 256), 256, 0, s>>>(g, g.part32, n_q);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
 int launch_conv3_lds(const ConvArgs &g, hipStream_t s) {
+    if (g.cmaj) {
+        switch (g.N / 16) {
+            case 2: return launch_c3cm<2>(g, s);
+            case 4: return launch_c3cm<4>(g, s);
+            case 8: return launch_c3cm<8>(g, s);
+            default: set_error("conv3_lds: Cout=%d unsupported", g.N); return NUNIF_HIP_EUNSUPPORTED;
+        }
+    }
     switch (g.N / 16) {
         case 2: return launch_c3<2>(g, s, "conv3_lds_kernel<2>");
         case 4: return launch_c3<4>(g, s, "conv3_lds_kernel<4>");

@@ -252,6 +252,7 @@ int launch_conv(const ConvArgs &g, hipStream_t s) {
     const long M = (long)g.B * g.Ho * g.Wo;
     if (M == 0) return NUNIF_HIP_OK;
     if (conv3_lds_applies(g)) return launch_conv3_lds(g, s);
+    NUNIF_REQUIRE(!g.cmaj, "conv: a chunk-major weight stream needs the 3x3 stride-1 LDS kernel (NUNIF_CONV3_LDS=0 set?)");
     const double K = (double)g.kh * g.kw * g.Cin;
     const double flops = 2.0 * (double)M * K * g.n_real;
     const double bytes = (double)g.B * g.Hi * g.Wi * g.Cin * 2.0 * (g.a2 ? 2.0 : 1.0) +

@@ -433,7 +433,7 @@ struct Buf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 struct Lin { f16 *w = nullptr; float *b = nullptr; int N = 0, K = 0; };              // gemm_kernel packing [nt][ks]
-struct Cnv { f16 *w = nullptr; float *b = nullptr; int N = 0, Cin = 0, k = 3; };     // conv_kernel stream [ks][nt]
+struct Cnv { f16 *w = nullptr; float *b = nullptr; int N = 0, Cin = 0, k = 3, cmaj = 0; };     // conv_kernel stream [ks][nt]
 struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2[4], fc2_full; int n_fc2; };   // fc2 (K = 4 D) = 2 or 4 GEMMs of K = 768 / 1024
 struct Rcu { Cnv c1, c2; };
 struct Fus { Rcu r1, r2; Lin out; };
@@ -447,7 +447,7 @@ struct nunif_depth_anything {
     Lin patch; float *cls = nullptr, *norm_g = nullptr, *norm_b = nullptr;
     std::vector<Blk> blk;
     Lin proj[4], rs0, rs1; std::vector<Cnv> rs3; Cnv rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
-    Buf a_col, pe, t, y, qkv, vt, att, hid, feat[4], rnb[4], m1, m2, m3, m4, m5;
+    Buf a_col, pe, t, y, qkv, vt, att, hid, feat[4], rnb[4], m1, m2, m3, m4, m5, part;
 };
 
 namespace {
@@ -485,27 +485,39 @@ int make_lin(nunif_depth_anything *h, int N, int K, F wt, G bias, Lin *L) {
 }
 // k x k conv, stream [ks][nt], reduction index = tap*Cin + ci (Cin padded), wt(n, tap, ci)
 template <typename F, typename G>
-int make_cnv(nunif_depth_anything *h, int N, int Cin, int k, F wt, G bias, Cnv *C) {
+int make_cnv(nunif_depth_anything *h, int N, int Cin, int k, F wt, G bias, Cnv *C, int cmaj = 0) {
     const int NT = N / 16, KS = k * k * Cin / 32;
     std::vector<f16> stream((size_t)KS * NT * 512 + 8192, (f16)0.f);
-    for (int ks = 0; ks < KS; ++ks)
-        for (int nt = 0; nt < NT; ++nt)
-            put_frag(stream, (size_t)ks * NT + nt, nt, ks, [&](int n, int kk) { return wt(n, kk / Cin, kk % Cin); });
+    if (cmaj) {
+        // chunk-major (conv3_lds_cm_kernel): [chunk of `cmaj` channels][tap][32-channel half][n-tile]
+        size_t frag = 0;
+        for (int q = 0; q < Cin / cmaj; ++q)
+            for (int tap = 0; tap < k * k; ++tap)
+                for (int c = 0; c < cmaj / 32; ++c)
+                    for (int nt = 0; nt < NT; ++nt, ++frag)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j)
+                                stream[(frag * 64 + l) * 8 + j] = (f16)wt(nt * 16 + (l & 15), tap, q * cmaj + c * 32 + (l >> 4) * 8 + j);
+    } else {
+        for (int ks = 0; ks < KS; ++ks)
+            for (int nt = 0; nt < NT; ++nt)
+                put_frag(stream, (size_t)ks * NT + nt, nt, ks, [&](int n, int kk) { return wt(n, kk / Cin, kk % Cin); });
+    }
     std::vector<float> b(N);
     for (int n = 0; n < N; ++n) b[n] = bias(n);
-    C->N = N; C->Cin = Cin; C->k = k;
+    C->N = N; C->Cin = Cin; C->k = k; C->cmaj = cmaj;
     int rc = upload(h, stream, &C->w);
     return rc ? rc : upload(h, b, &C->b);
 }
 int conv_from(nunif_depth_anything *h, const TMap &m, const std::string &key, int cout, int cin, int cin_pad, int k, bool has_bias,
-              Cnv *C) {
+              Cnv *C, int cmaj = 0) {
     const HostT *w, *b = nullptr;
     int rc;
     if ((rc = find(m, key + ".weight", &w)) || (has_bias && (rc = find(m, key + ".bias", &b)))) return rc;
     NUNIF_REQUIRE(w->numel == (int64_t)cout * cin * k * k, "%s: unexpected shape", key.c_str());
     const float *wd = w->data, *bd = b ? b->data : nullptr;
     return make_cnv(h, cout, cin_pad, k, [=](int n, int tap, int ci) { return ci < cin ? wd[((size_t)n * cin + ci) * k * k + tap] : 0.f; },
-                    [=](int n) { return bd ? bd[n] : 0.f; }, C);
+                    [=](int n) { return bd ? bd[n] : 0.f; }, C, cmaj);
 }
 
 int run_lin(const Lin &L, const f16 *a, int B, int Wi, int Wo, int ox, int act, const f16 *res, f16 *out, hipStream_t s,
@@ -529,13 +541,13 @@ int run_tok(const Lin &L, const f16 *a, long T, int act, const f16 *res, f16 *ou
     return run_lin(L, a, 1, (int)T, (int)T, 0, act, res, out, s, tag);
 }
 int run_cnv(const Cnv &C, const f16 *a, int B, int Hi, int Wi, int stride, int zpad, int relu_in, int act, const f16 *res,
-            const f16 *res2, f16 *out, hipStream_t s, int ldo = 0) {
+            const f16 *res2, f16 *out, hipStream_t s, int ldo = 0, float *part32 = nullptr) {
     ConvArgs c;
     memset(&c, 0, sizeof(c));
     c.a = a; c.B = B; c.Hi = Hi; c.Wi = Wi; c.Cin = C.Cin; c.stride = stride; c.kh = C.k; c.kw = C.k;
     c.Ho = (Hi + 2 * zpad - C.k) / stride + 1; c.Wo = (Wi + 2 * zpad - C.k) / stride + 1;
     c.wstream = C.w; c.bias = C.b; c.N = C.N; c.n_real = C.N; c.act = act; c.out = out; c.zpad = zpad; c.relu_in = relu_in;
-    c.res = res; c.res2 = res2; c.ldo = ldo;
+    c.res = res; c.res2 = res2; c.ldo = ldo; c.cmaj = C.cmaj; c.part32 = part32;
     return launch_conv(c, s);
 }
 }  // namespace
@@ -666,7 +678,12 @@ extern "C" int nunif_hip_depth_anything_create_ex(const nunif_tensor_desc *tenso
             if ((rc = make_lin(h, ocp, kD, [=](int n, int k) { return n < oc ? wd[(size_t)n * kD + k] : 0.f; },
                                [=](int n) { return n < oc ? bd[n] : 0.f; }, &h->proj[i])))
                 break;
-            rc = conv_from(h, m, H + "scratch.layer" + std::to_string(i + 1) + "_rn", F, oc, ocp, 3, false, &h->rn[i]);
+            // wide inputs (> 128 channels, a multiple of 64): chunk-major stream for conv3_lds_cm_kernel
+            const bool cm_off = (getenv("NUNIF_CONV3_LDS") && atoi(getenv("NUNIF_CONV3_LDS")) == 0) ||
+                                (getenv("NUNIF_CONV3_CM") && atoi(getenv("NUNIF_CONV3_CM")) == 0);      // read per engine (tests)
+            // (chunks of 64 channels; 32 for the 128-wide fusion maps: 72 KiB of weights per workgroup either way)
+            const int cmaj = (!cm_off && ocp > 128 && ocp % 64 == 0 && (F == 64 || F == 128)) ? (F == 128 ? 32 : 64) : 0;
+            rc = conv_from(h, m, H + "scratch.layer" + std::to_string(i + 1) + "_rn", F, oc, ocp, 3, false, &h->rn[i], cmaj);
         }
         if (rc) break;
         {   // resize_layers.0: ConvTranspose2d(oc0, oc0, 4, 4): N = (i*4+j)*ocp0 + co, K = ci (padded); weight [ci][co][4][4]
@@ -735,7 +752,7 @@ extern "C" void nunif_hip_depth_anything_destroy(nunif_depth_anything *h) {
     if (!h) return;
     for (void *p : h->owned) (void)hipFree(p);
     Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->vt, &h->att, &h->hid, &h->feat[0], &h->feat[1], &h->feat[2],
-                   &h->feat[3], &h->rnb[0], &h->rnb[1], &h->rnb[2], &h->rnb[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5};
+                   &h->feat[3], &h->rnb[0], &h->rnb[1], &h->rnb[2], &h->rnb[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5, &h->part};
     for (Buf *b : bufs) b->release();
     delete h;
 }
@@ -839,7 +856,12 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
                 if ((rc = run_cnv(h->rs3[c], m1, B, gh, gw, 2, 1, 0, 0, nullptr, nullptr, m2 + c * chunk, s, h->OCP[3]))) return rc;
             src = m2;
         }
-        if ((rc = run_cnv(h->rn[i], src, B, Hs[i], Ws[i], 1, 1, 0, 0, nullptr, nullptr, rn[i], s))) return rc;
+        float *part = nullptr;
+        if (h->rn[i].cmaj) {
+            if ((rc = h->part.ensure((size_t)(h->rn[i].Cin / h->rn[i].cmaj) * B * Hs[i] * Ws[i] * h->rn[i].N * sizeof(float)))) return rc;
+            part = (float *)h->part.p;
+        }
+        if ((rc = run_cnv(h->rn[i], src, B, Hs[i], Ws[i], 1, 1, 0, 0, nullptr, nullptr, rn[i], s, 0, part))) return rc;
     }
     // refinenet k: x = path (+ RCU1(skip)); x = RCU2(x); upsample; out_conv
     auto rcu = [&](const Rcu &r, const f16 *in, int Hc, int Wc, const f16 *extra, f16 *tmp, f16 *out) -> int {

@@ -140,6 +140,10 @@ struct ConvArgs {
     const f16 *res2;          // optional second residual (same indexing as res)
     int ldo;                  // > 0: channel stride of the NHWC output / residual pixels (default n_real): lets a conv write a
                               //      channel slice of a wider map (out pre-offset by the slice's first channel)
+    int cmaj;                 // 64 / 32: wstream is packed CHUNK-MAJOR ([cmaj-channel chunk][tap][32-channel part][n-tile]) and the
+                              //     contraction of a 3x3 stride-1 conv with Cin > 128 is split over workgroups (conv3_lds.hip);
+                              //     0: tap-major (k = tap * Cin + ci)
+    float *part32;            // cmaj: scratch for the fp32 partials, (Cin / cmaj) * B * Ho * Wo * N floats
 };
 int launch_conv(const ConvArgs &g, hipStream_t s);
 // 3x3 stride-1 same conv with the input tile staged in LDS (conv3_lds.hip); launch_conv takes it when it applies

@@ -118,14 +118,21 @@ def test_resident_weight_conv_is_bit_identical_to_the_ring_form(hiplib, monkeypa
 def test_lds_staged_conv_is_bit_identical_to_the_gather_form(hiplib, monkeypatch):
     """conv3_lds_kernel (input halo staged in LDS once, resident or ringed weights) issues the same MFMAs in the same order as
     conv_kernel's per-tap gathers: the whole DPT head must not change by a bit, on maps that are not multiples of its 8 x 32
-    patch (5 x 7 ... 80 x 112) and with 64- and 128-wide fusion maps (ViT-S / ViT-B)."""
+    patch (5 x 7 ... 80 x 112) and with 64- and 128-wide fusion maps (ViT-S / ViT-B).  The chunk-major form of the wide-input
+    convs (conv3_lds_cm_kernel: layer3_rn / layer4_rn) contracts in a different order, so it is held to a tolerance instead."""
     from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
     for enc, shape in (("vits", (2, 3, 70, 98)), ("vits", (1, 3, 154, 266)), ("vitb", (1, 3, 84, 126))):
-        net = HipDepthAnythingV2(ODA.random_state_dict(630, grid=8, encoder=enc), "cuda:0")
+        sd = ODA.random_state_dict(630, grid=8, encoder=enc)
         x = _norm(torch.stack([synth_image(290 + i, 3, shape[2], shape[3]) for i in range(shape[0])])).to("cuda:0")
+        monkeypatch.setenv("NUNIF_CONV3_CM", "0")
+        net = HipDepthAnythingV2(sd, "cuda:0")              # tap-major streams everywhere
         monkeypatch.setenv("NUNIF_CONV3_LDS", "1")
         a = net(x).cpu()
         monkeypatch.setenv("NUNIF_CONV3_LDS", "0")
         b = net(x).cpu()
-        monkeypatch.setenv("NUNIF_CONV3_RESW", "0")
         assert float(a.std()) > 0 and torch.equal(a, b), (enc, shape)
+        monkeypatch.delenv("NUNIF_CONV3_CM")
+        monkeypatch.setenv("NUNIF_CONV3_LDS", "1")
+        c = HipDepthAnythingV2(sd, "cuda:0")(x).cpu()       # chunk-major layer{3,4}_rn
+        span = float(a.max() - a.min())
+        assert float((c - a).abs().max()) < 2e-3 * span, (enc, shape, float((c - a).abs().max()), span)
