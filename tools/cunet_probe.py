@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""waifu2x cunet / upcunet whole-frame render of a 1080p frame (tile 256): ms per frame."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nunif_amd.nunif.models import create_model  # noqa: E402
+from nunif_amd.nunif.utils.render import tiled_render  # noqa: E402
+import nunif_amd.waifu2x.utils  # noqa: E402,F401
+from nunif_amd.synthetic import cunet_state_dict  # noqa: E402
+
+torch.set_grad_enabled(False)
+x = torch.rand(3, 1080, 1920, device="cuda:0")
+for name, up in (("waifu2x.cunet", False), ("waifu2x.upcunet", True)):
+    m = create_model(name).eval()
+    m.load_state_dict(cunet_state_dict(7, up=up))
+    m = m.to("cuda:0")
+    for _ in range(3):
+        tiled_render(x, m, tile_size=256, batch_size=16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        tiled_render(x, m, tile_size=256, batch_size=16)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    print(f"{name}: {dt * 1e3:.3f} ms per 1080p frame = {1080 * 1920 / dt / 1e6:.1f} MPix/s")
