@@ -99,16 +99,15 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
     // reuse load-destination registers across the arms and guard every arm with vmcnt(0)): tap coordinate = pixel * stride +
     // tap - pad, clamped into the map; replicate padding keeps the clamped value, zero padding remembers which lanes were outside.
     const int pad = g.rpad ? g.rpad : g.zpad;
-    auto load_x = [&](int ks, f16x8 (&dst)[MF], unsigned &inb_mask) {
+    auto load_x = [&](int ks, f16x8 (&dst)[MF], f16x8 (&dst2)[A2 ? MF : 1], unsigned &inb_mask) {
         const int tap = ks / cpt, c0 = (ks - tap * cpt) << 5;
         const int dy = tap / g.kw, dx = tap - dy * g.kw;
         inb_mask = 0u;
-        if constexpr (A2) {         // second input added element-wise (cropped U-Net skip; VALID, stride as given): eager
+        if constexpr (A2) {         // second input (cropped U-Net skip; VALID, stride as given): both raw, added by finish_x
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
-                f16x8 v = *reinterpret_cast<const f16x8 *>(g.a + base[f] + ((long)dy * g.Wi + dx) * g.Cin + c0);
-                v += *reinterpret_cast<const f16x8 *>(g.a2 + base2[f] + ((long)dy * g.W2 + dx) * g.Cin + c0);
-                dst[f] = v;
+                dst[f] = *reinterpret_cast<const f16x8 *>(g.a + base[f] + ((long)dy * g.Wi + dx) * g.Cin + c0);
+                dst2[f] = *reinterpret_cast<const f16x8 *>(g.a2 + base2[f] + ((long)dy * g.W2 + dx) * g.Cin + c0);
             }
             return;
         }
@@ -120,8 +119,13 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
             inb_mask |= ((yy == yc && xx == xc) ? 1u : 0u) << f;
         }
     };
-    auto finish_x = [&](f16x8 (&x)[MF], unsigned inb_mask) {
-        if (A2 || !(g.zpad || g.relu_in) || g.rpad) return;
+    auto finish_x = [&](f16x8 (&x)[MF], const f16x8 (&x2)[A2 ? MF : 1], unsigned inb_mask) {
+        if constexpr (A2) {
+#pragma unroll
+            for (int f = 0; f < MF; ++f) x[f] += x2[f];
+            return;
+        }
+        if (!(g.zpad || g.relu_in) || g.rpad) return;
         const f16x8 z8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
@@ -144,18 +148,19 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs g) {
     // With NT x MF <= 16 MFMAs per k-step a one-step distance is ~256 cycles — far less than an L2 / HBM round trip, and the
     // small maps these shapes run on (DPT head, side nets) leave 1-2 waves per SIMD to hide it: three steps ahead there.
     constexpr int NB = (NT * MF <= 16) ? 4 : 2;
-    f16x8 xq[NB][MF];
+    f16x8 xq[NB][MF], xq2[NB][A2 ? MF : 1];
     unsigned xm[NB];
 #pragma unroll
     for (int j = 0; j < NB - 1; ++j)
-        if (j < ksteps) load_x(j, xq[j], xm[j]);
+        if (j < ksteps) load_x(j, xq[j], xq2[j], xm[j]);
 #pragma unroll 1
     for (int ks = 0; ks < ksteps; ks += NB) {        // NB k-steps per trip: statically named register buffers
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (ks + j < ksteps) {
-                if (ks + j + NB - 1 < ksteps) load_x(ks + j + NB - 1, xq[(j + NB - 1) % NB], xm[(j + NB - 1) % NB]);
-                finish_x(xq[j], xm[j]);
+                if (ks + j + NB - 1 < ksteps)
+                    load_x(ks + j + NB - 1, xq[(j + NB - 1) % NB], xq2[(j + NB - 1) % NB], xm[(j + NB - 1) % NB]);
+                finish_x(xq[j], xq2[j], xm[j]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const f16x8 w = wfrag((ks + j) * NT + nt);
