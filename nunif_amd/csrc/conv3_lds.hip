@@ -36,16 +36,16 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
     // split contraction (g.cmaj, grid.y = chunks): this workgroup convolves channels [cmaj * blockIdx.y, + cmaj) of rows that are
     // lda channels wide and writes an fp32 partial; otherwise cin = lda = g.Cin
     const int cin = g.cmaj ? g.cmaj : g.Cin, lda = g.Cin;
+    const int pad = (g.zpad || g.rpad) ? 1 : 0;                          // 0: VALID 3x3 (Ho = Hi - 2), the waifu2x conv nets
     const int pstride = cin * 2 + 16;
     const int tiles_x = (g.Wo + kC3TW - 1) / kC3TW, tiles_y = (g.Ho + kC3TH - 1) / kC3TH;
-    const int n_tiles = g.B * tiles_x * tiles_y;
     const int cpt = cin >> 5;
     const f16 *a_in = g.a + (g.cmaj ? (int)blockIdx.y * cin : 0);
     const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.wstream) +    // zero-padded by 16 KiB on the host
                         (g.cmaj ? (long)blockIdx.y * 9 * cpt * NT * 64 : 0);
     const int ksteps = 9 * cpt;
     const int n_chunks = (ksteps * NT + CH - 1) / CH;
-    constexpr int UW = 6, UH = 6;                                        // loads in flight per thread and batch: weights, halo
+    constexpr int UW = 4, UH = 4;                                        // loads in flight per thread and batch: weights, halo
     const int w_total = ksteps * NT * 64;                                // 16-byte items of the weight stream
     const int segs = cin >> 3;                                           // 16-byte segments per pixel
     const int h_items = kC3HH * kC3HW * segs;
@@ -60,20 +60,22 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
     };
     // halo: (pixel, 16-byte segment) = work item; zero / replicate padding and the pre-activation ReLU are applied while it is
     // written to LDS, once per element
-    auto h_load = [&](int i0, int b, int ty0, int tx0, f16x8 (&v)[UH], unsigned &inb) {
+    auto h_load = [&](int i0, int b, int ty0, int tx0, f16x8 (&v)[UH], f16x8 (&v2)[UH], unsigned &inb) {
         inb = 0u;
 #pragma unroll
         for (int u = 0; u < UH; ++u) {
             const int i = min(i0 + u * 256 + tid, h_items - 1);
             const int p = i / segs, sg = i - p * segs;
             const int hy = p / kC3HW, hx = p - hy * kC3HW;
-            const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
+            const int yy = ty0 + hy - pad, xx = tx0 + hx - pad;         // pad 0 (VALID): rows beyond the map only feed masked outputs
             const int yc = min(max(yy, 0), g.Hi - 1), xc = min(max(xx, 0), g.Wi - 1);
-            inb |= ((g.rpad || (yy == yc && xx == xc)) ? 1u : 0u) << u;
+            inb |= ((!g.zpad || (yy == yc && xx == xc)) ? 1u : 0u) << u;
             v[u] = *reinterpret_cast<const f16x8 *>(a_in + (((long)b * g.Hi + yc) * g.Wi + xc) * lda + sg * 8);
+            if (g.a2)               // second input (cropped U-Net skip, VALID convs only): added while staging
+                v2[u] = *reinterpret_cast<const f16x8 *>(g.a2 + (((long)b * g.H2 + yc + g.crop2) * g.W2 + xc + g.crop2) * lda + sg * 8);
         }
     };
-    auto h_store = [&](int i0, const f16x8 (&v)[UH], unsigned inb) {
+    auto h_store = [&](int i0, const f16x8 (&v)[UH], const f16x8 (&v2)[UH], unsigned inb) {
         const f16x8 z8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
 #pragma unroll
         for (int u = 0; u < UH; ++u) {
@@ -81,6 +83,7 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
             if (i >= h_items) continue;
             const int p = i / segs, sg = i - p * segs;
             f16x8 w = ((inb >> u) & 1u) ? v[u] : z8;
+            if (g.a2) w += v2[u];
             if (g.relu_in) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) w[j] = w[j] > (f16)0.f ? w[j] : (f16)0.f;
@@ -88,30 +91,29 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
             *reinterpret_cast<f16x8 *>(halo + (long)p * pstride + sg * 16) = w;
         }
     };
-    // (the patch loop runs once per workgroup with the grids launch_c3 uses; a persistent RESW grid is supported but not faster)
-#pragma unroll 1
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // One patch per workgroup.  (A persistent loop over patches — resident weights copied once — was not faster on large grids
+    // and its loop-carried state cost 70 VGPRs, i.e. two resident waves per SIMD: 155 vs 84 registers for NT = 4.)
+    const int tile = blockIdx.x;
     const int tx0 = (tile % tiles_x) * kC3TW;
     const int ty0 = ((tile / tiles_x) % tiles_y) * kC3TH;
     const int b = tile / (tiles_x * tiles_y);
     f16x8 st0, st1, sq0, sq1, sr0, sr1;
     {
-        f16x8 hv[UH];
+        f16x8 hv[UH], hv2[UH];
         unsigned hin;
-        if (RESW && tile == (int)blockIdx.x) {
-            // first patch: the first batches of BOTH streams are requested before anything is waited for: one round trip
+        if (RESW) {
+            // the first batches of BOTH streams are requested before anything is waited for: one round trip
             f16x8 wv[UW];
             w_load(0, wv);
-            h_load(0, b, ty0, tx0, hv, hin);
+            h_load(0, b, ty0, tx0, hv, hv2, hin);
             w_store(0, wv);
-            h_store(0, hv, hin);
+            h_store(0, hv, hv2, hin);
             for (int i0 = 256 * UW; i0 < w_total; i0 += 256 * UW) { w_load(i0, wv); w_store(i0, wv); }
         } else {
-            if (RESW) __syncthreads();                                   // every wave is done with the previous patch's halo
-            h_load(0, b, ty0, tx0, hv, hin);
-            h_store(0, hv, hin);
+            h_load(0, b, ty0, tx0, hv, hv2, hin);
+            h_store(0, hv, hv2, hin);
         }
-        for (int i0 = 256 * UH; i0 < h_items; i0 += 256 * UH) { h_load(i0, b, ty0, tx0, hv, hin); h_store(i0, hv, hin); }
+        for (int i0 = 256 * UH; i0 < h_items; i0 += 256 * UH) { h_load(i0, b, ty0, tx0, hv, hv2, hin); h_store(i0, hv, hv2, hin); }
     }
     if constexpr (!RESW) {
         const int c1 = min(1, n_chunks), c2 = min(2, n_chunks);
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
                 if (oy >= g.Ho || ox >= g.Wo) continue;
                 *reinterpret_cast<f32x4 *>(part + (((long)b * g.Ho + oy) * g.Wo + ox) * g.N + nt * 16 + grp * 4) = acc[nt][f];
             }
-        continue;
+        return;
     }
     const int ldo = g.ldo > 0 ? g.ldo : g.n_real;
 #pragma unroll
@@ -207,7 +209,6 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
             *reinterpret_cast<f16x4 *>(g.out + off) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
         }
     }
-    }   // patches
 }
 
 // Wide inputs (Cin > 128: the layer{3,4}_rn convs of the DPT head read 192 ... 1024 channels on 14 x 25 / 28 x 49 maps, 6-22
@@ -258,9 +259,12 @@ static inline int conv3_lds_enabled() { const char *e = getenv("NUNIF_CONV3_LDS"
 
 bool conv3_lds_applies(const ConvArgs &g) {
     const int nt = g.N / 16;
-    const bool shape = g.kh == 3 && g.kw == 3 && g.stride == 1 && !g.a2 && !g.out32 && g.Ho == g.Hi && g.Wo == g.Wi &&
-                       (g.zpad == 1 || g.rpad == 1) && !(g.zpad && g.rpad) && g.N % 16 == 0 && (nt == 2 || nt == 4 || nt == 8);
+    const int pad = (g.zpad || g.rpad) ? 1 : 0;
+    const bool shape = g.kh == 3 && g.kw == 3 && g.stride == 1 && (!g.a2 || (!pad && !g.cmaj)) && !g.out32 && g.Ho == g.Hi + 2 * pad - 2 &&
+                       g.Wo == g.Wi + 2 * pad - 2 && g.zpad <= 1 && g.rpad <= 1 && !(g.zpad && g.rpad) && g.N % 16 == 0 &&
+                       (nt == 2 || nt == 4 || nt == 8);
     if (!conv3_lds_enabled() || !shape) return false;
+    if (g.a2 && getenv("NUNIF_CONV3_A2") && atoi(getenv("NUNIF_CONV3_A2")) == 0) return false;      // A/B switch
     if (g.cmaj) return (g.cmaj == 64 || g.cmaj == 32) && g.Cin % g.cmaj == 0;     // a chunk-major stream: the split form only
     return g.Cin % 32 == 0 && g.Cin <= 128;
 }
