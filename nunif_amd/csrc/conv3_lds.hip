@@ -195,6 +195,19 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
+            if (g.out32) {
+                // image head: planar fp32, optional `+ crop(add32)` and clamp  (cunet.py:183-196), as in conv_kernel
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + r;
+                    if (n >= g.n_real) continue;
+                    float o = v[r];
+                    if (g.add32) o += g.add32[(((long)b * g.n_real + n) * g.addH + oy + g.add_crop) * g.addW + ox + g.add_crop];
+                    if (g.clamp01) o = fminf(fmaxf(o, 0.f), 1.f);
+                    g.out32[(((long)b * g.n_real + n) * g.Ho + oy) * g.Wo + ox] = o;
+                }
+                continue;
+            }
             const long off = (((long)b * g.Ho + oy) * g.Wo + ox) * ldo + n0;
             if (g.res) {
                 const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
@@ -260,12 +273,12 @@ static inline int conv3_lds_enabled() { const char *e = getenv("NUNIF_CONV3_LDS"
 bool conv3_lds_applies(const ConvArgs &g) {
     const int nt = g.N / 16;
     const int pad = (g.zpad || g.rpad) ? 1 : 0;
-    const bool shape = g.kh == 3 && g.kw == 3 && g.stride == 1 && (!g.a2 || (!pad && !g.cmaj)) && !g.out32 && g.Ho == g.Hi + 2 * pad - 2 &&
+    const bool shape = g.kh == 3 && g.kw == 3 && g.stride == 1 && (!g.a2 || (!pad && !g.cmaj)) && (!g.out32 || !g.cmaj) && g.Ho == g.Hi + 2 * pad - 2 &&
                        g.Wo == g.Wi + 2 * pad - 2 && g.zpad <= 1 && g.rpad <= 1 && !(g.zpad && g.rpad) && g.N % 16 == 0 &&
-                       (nt == 2 || nt == 4 || nt == 8);
+                       (nt == 1 || nt == 2 || nt == 4 || nt == 8);
     if (!conv3_lds_enabled() || !shape) return false;
     if (g.a2 && getenv("NUNIF_CONV3_A2") && atoi(getenv("NUNIF_CONV3_A2")) == 0) return false;      // A/B switch
-    if (g.cmaj) return (g.cmaj == 64 || g.cmaj == 32) && g.Cin % g.cmaj == 0;     // a chunk-major stream: the split form only
+    if (g.cmaj) return nt != 1 && (g.cmaj == 64 || g.cmaj == 32) && g.Cin % g.cmaj == 0;     // a chunk-major stream: the split form only
     return g.Cin % 32 == 0 && g.Cin <= 128;
 }
 
@@ -328,6 +341,7 @@ int launch_conv3_lds(const ConvArgs &g, hipStream_t s) {
         }
     }
     switch (g.N / 16) {
+        case 1: return launch_c3<1>(g, s, "conv3_lds_kernel<1>");
         case 2: return launch_c3<2>(g, s, "conv3_lds_kernel<2>");
         case 4: return launch_c3<4>(g, s, "conv3_lds_kernel<4>");
         case 8: return launch_c3<8>(g, s, "conv3_lds_kernel<8>");
