@@ -368,6 +368,26 @@ __global__ void __launch_bounds__(512) da_attn_lds_kernel(const f16 *__restrict_
     }
 }
 
+// resize_layers.3 (3x3, stride 2, padding 1, C -> C on the patch grid: 364 output pixels per 4 x 1080p batch, K = 9 C up to 9 216):
+// as a conv it is a chain of 108+ k-steps for a handful of workgroups (160 us); as im2col + the output-stationary Linear the
+// same contraction is spread over M / 32 x C / 128 workgroups.  a: [B,H,W,C] -> col: [B*Ho*Wo][9*C], k = tap * C + c
+__global__ void __launch_bounds__(256) da_im2col_s2_kernel(const f16 *__restrict__ a, f16 *__restrict__ col, int B, int H, int W,
+                                                           int C, int Ho, int Wo) {
+    const int c8 = C / 8;
+    const long total = (long)B * Ho * Wo * 9 * c8;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int sg = (int)(id % c8);
+    long t = id / c8;
+    const int tap = (int)(t % 9); t /= 9;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    const int yy = 2 * oy + tap / 3 - 1, xx = 2 * ox + tap % 3 - 1;
+    f16x8 v = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *reinterpret_cast<const f16x8 *>(a + (((long)b * H + yy) * W + xx) * C + sg * 8);
+    *reinterpret_cast<f16x8 *>(col + (((long)b * Ho + oy) * Wo + ox) * 9 * C + (long)tap * C + sg * 8) = v;
+}
+
 // F.interpolate(bilinear, align_corners=True) on NHWC fp16; one thread = 8 channels of one output pixel
 __global__ void __launch_bounds__(256) da_upsample_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int B, int Hi,
                                                           int Wi, int Ho, int Wo, int C) {
@@ -446,8 +466,8 @@ struct nunif_depth_anything {
     float max_depth = 0.f;                 // > 0: metric head (Sigmoid * max_depth)
     Lin patch; float *cls = nullptr, *norm_g = nullptr, *norm_b = nullptr;
     std::vector<Blk> blk;
-    Lin proj[4], rs0, rs1; std::vector<Cnv> rs3; Cnv rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
-    Buf a_col, pe, t, y, qkv, vt, att, hid, feat[4], rnb[4], m1, m2, m3, m4, m5, part;
+    Lin proj[4], rs0, rs1, rs3g; std::vector<Cnv> rs3; Cnv rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
+    Buf a_col, pe, t, y, qkv, vt, att, hid, feat[4], rnb[4], m1, m2, m3, m4, m5, part, col;
 };
 
 namespace {
@@ -706,11 +726,16 @@ extern "C" int nunif_hip_depth_anything_create_ex(const nunif_tensor_desc *tenso
             if ((rc = find(m, H + "resize_layers.3.weight", &w)) || (rc = find(m, H + "resize_layers.3.bias", &b))) break;
             const int o3 = h->OC[3];
             if (o3 % 32 || h->OC[2] % 32 || w->numel != (int64_t)o3 * o3 * 9) { set_error("depth_head.resize_layers.3: unexpected shape"); rc = NUNIF_HIP_EINVAL; break; }
+            if (gemm_os_supported(1, o3, 9 * o3)) {         // im2col + output-stationary Linear (k = tap * C + ci)
+                const float *w3g = w->data, *b3g = b->data;
+                if ((rc = make_lin(h, o3, 9 * o3, [=](int n, int k) { const int tap = k / o3, ci = k % o3; return w3g[((size_t)n * o3 + ci) * 9 + tap]; },
+                                   [=](int n) { return b3g[n]; }, &h->rs3g))) break;
+            }
             const int chunk = o3 <= 384 ? o3 : 256;
             if (o3 % chunk) { set_error("depth_head.resize_layers.3: %d channels unsupported", o3); rc = NUNIF_HIP_EUNSUPPORTED; break; }
-            h->rs3.resize(o3 / chunk);
+            if (!h->rs3g.w) h->rs3.resize(o3 / chunk);
             const float *w3 = w->data, *b3 = b->data;
-            for (int c = 0; c < o3 / chunk && !rc; ++c)
+            for (int c = 0; c < (int)h->rs3.size() && !rc; ++c)
                 rc = make_cnv(h, chunk, o3, 3, [=](int n, int tap, int ci) { return w3[((size_t)(c * chunk + n) * o3 + ci) * 9 + tap]; },
                               [=](int n) { return b3[c * chunk + n]; }, &h->rs3[c]);
             if (rc) break;
@@ -752,7 +777,7 @@ extern "C" void nunif_hip_depth_anything_destroy(nunif_depth_anything *h) {
     if (!h) return;
     for (void *p : h->owned) (void)hipFree(p);
     Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->vt, &h->att, &h->hid, &h->feat[0], &h->feat[1], &h->feat[2],
-                   &h->feat[3], &h->rnb[0], &h->rnb[1], &h->rnb[2], &h->rnb[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5, &h->part};
+                   &h->feat[3], &h->rnb[0], &h->rnb[1], &h->rnb[2], &h->rnb[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5, &h->part, &h->col};
     for (Buf *b : bufs) b->release();
     delete h;
 }
@@ -851,9 +876,18 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         if (i == 0) { if ((rc = run_lin(h->rs0, m1, B, gw, gw, 0, 0, nullptr, m2, s, "da_resize0", 1, h->OCP[0], 4, gh))) return rc; src = m2; }
         else if (i == 1) { if ((rc = run_lin(h->rs1, m1, B, gw, gw, 0, 0, nullptr, m2, s, "da_resize1", 1, h->OCP[1], 2, gh))) return rc; src = m2; }
         else if (i == 3) {
-            const int chunk = h->rs3[0].N;
-            for (size_t c = 0; c < h->rs3.size(); ++c)
-                if ((rc = run_cnv(h->rs3[c], m1, B, gh, gw, 2, 1, 0, 0, nullptr, nullptr, m2 + c * chunk, s, h->OCP[3]))) return rc;
+            if (h->rs3g.w) {
+                const int C3 = h->OCP[3];
+                const long M4 = (long)B * H4 * W4;
+                if ((rc = h->col.ensure((size_t)M4 * 9 * C3 * e2))) return rc;
+                da_im2col_s2_kernel<<<blocks(M4 * 9 * (C3 / 8)), 256, 0, s>>>(m1, (f16 *)h->col.p, B, gh, gw, C3, H4, W4);
+                NUNIF_LAUNCH_CHECK();
+                if ((rc = run_tok(h->rs3g, (const f16 *)h->col.p, M4, 0, nullptr, m2, s, "da_resize3"))) return rc;
+            } else {
+                const int chunk = h->rs3[0].N;
+                for (size_t c = 0; c < h->rs3.size(); ++c)
+                    if ((rc = run_cnv(h->rs3[c], m1, B, gh, gw, 2, 1, 0, 0, nullptr, nullptr, m2 + c * chunk, s, h->OCP[3]))) return rc;
+            }
             src = m2;
         }
         float *part = nullptr;
