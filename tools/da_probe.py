@@ -28,7 +28,7 @@ for enc in (sys.argv[1:] or ["vits", "vitb", "vitl"]):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
     print(f"{enc}: {4 / dt:.1f} fps  ({dt * 1e3:.2f} ms per batch of 4)")
-    if enc == "vits":
+    if enc == os.environ.get("DA_PROF", "vits"):
         _hip.profile_read(reset=True)
         _hip.profile_enable(True)
         for _ in range(3):
