@@ -1,4 +1,5 @@
-"""Oracle: Depth-Anything V1 / V2 / V2-metric (DINOv2 ViT-S / B / L /14 encoder + DPT head), torch CPU fp32 — **parity unpinned**.
+"""Oracle: Depth-Anything V1 / V2 / V2-metric (DINOv2 ViT-S / B / L /14 encoder + DPT head), torch CPU fp32 — pinned against
+HuggingFace ``transformers`` (an independent implementation), not against the hub repository the reference loads.
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
@@ -9,8 +10,12 @@ neither that repository nor its weights exist offline.  This file restates the P
 through the final norm without the class token; DPT head with out_channels 48/96/192/384 and 64 fusion features) from
 the call-site contract in SURVEY.md §8c: input B x 3 x h x w ImageNet-normalised with h, w multiples of 14, output
 B x h x w (ReLU'd inverse depth).  State-dict key names follow the public checkpoint (``pretrained.*``, ``depth_head.*``)
-so that a real ``depth_anything_v2_vits.pth`` can be tried as soon as one is available; until then nothing here is
-pinned against the real network, and tests compare the HIP engine with THIS restatement only.
+so that a real ``depth_anything_v2_vits.pth`` can be tried as soon as one is available.  Pinning:
+``tests/test_depth_anything_vs_hf.py`` loads the same weights into ``transformers.DepthAnythingForDepthEstimation``
+(``oracle/hf_pin.py``; ViT-S / ViT-B, V1 taps, metric head: max |diff| <= 5e-5) and ``tests/golden/depth_anything_hf.npz``
+holds HuggingFace outputs that the GPU test compares the HIP engine with.  One divergence between upstream and HuggingFace
+exists — the position-embedding resize (``scale_factor=(g + 0.1) / 37`` upstream vs ``size=``) — this file follows upstream
+(what the reference's hub fork wraps); see ``oracle/hf_pin.py``.  The hub fork itself has never been run against this.
 
 The geometry is read from the state dict (``config_of``): embed 384 / 768 / 1024 with heads of 64, 12 / 24 blocks, DPT
 out_channels (48-96-192-384 / 96-192-384-768 / 256-512-1024-1024) and fusion width (64 / 128 / 256) as published for vits /

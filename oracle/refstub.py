@@ -61,7 +61,7 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def create_module(self, spec):
         m = _StubModule(spec.name)
         m.__path__ = []
-        m.__version__ = "0.0.0-stub"
+        m.__version__ = "0.0.0+stub"
         return m
 
     def exec_module(self, module):
@@ -75,10 +75,17 @@ def reference_available():
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "nunif"))
 
 
-def install():
-    """Make ``import nunif / waifu2x / iw3`` resolve to the reference. Idempotent."""
+def install(swin_block="oracle"):
+    """Make ``import nunif / waifu2x / iw3`` resolve to the reference. Idempotent.
+
+    ``swin_block``: which class stands in for ``torchvision.models.swin_transformer.SwinTransformerBlock`` —
+    ``"oracle"`` = :mod:`oracle.tv_swin_block` (the restatement), ``"hf"`` = :class:`oracle.hf_pin.HFSwinTransformerBlock`
+    (HuggingFace's ``SwinLayer`` behind torchvision's constructor and key layout; the independent pin).  Must be chosen
+    before the reference's ``waifu2x.models.swin_unet`` is first imported."""
     global _installed
     if _installed:
+        if swin_block != _installed:
+            raise RuntimeError(f"refstub already installed with swin_block={_installed!r}")
         return
     if not reference_available():
         raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
@@ -90,8 +97,12 @@ def install():
     importlib.import_module("torchvision")
     importlib.import_module("torchvision.models")
     mod = types.ModuleType("torchvision.models.swin_transformer")
-    mod.SwinTransformerBlock = tv_swin_block.SwinTransformerBlock
+    if swin_block == "hf":
+        from . import hf_pin
+        mod.SwinTransformerBlock = hf_pin.HFSwinTransformerBlock
+    else:
+        mod.SwinTransformerBlock = tv_swin_block.SwinTransformerBlock
     sys.modules["torchvision.models.swin_transformer"] = mod
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
-    _installed = True
+    _installed = swin_block

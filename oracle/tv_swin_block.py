@@ -6,10 +6,14 @@ The reference imports this class from torchvision (pinned ``torchvision==0.22.1`
 ``requirements-torch.txt``; call site ``waifu2x/models/swin_unet.py:9-12,26-36``); torchvision is not
 installed in this image and is not vendored under ``/root/reference``, so the published algorithm of
 torchvision 0.22 ``ShiftedWindowAttention`` / ``shifted_window_attention`` is restated here (SURVEY.md
-Appendix A).  **Parity status: unpinned** against a real torchvision install — the reference holds no
-test or golden vector for this block.  What *is* pinned: the parameter names/shapes that the reference's
-own ``SwinUNetBase`` produces on top of this class (3 757 431 / 3 758 304 / 4 302 852 parameters for the
-1x/2x/4x nets — asserted in tests/test_oracle_vs_reference.py).
+Appendix A).  **Parity status: pinned against an independent implementation** — HuggingFace ``transformers``
+``SwinLayer`` carrying the same weights (``tests/test_tv_swin_block_vs_hf.py``: max |diff| <= 2e-5 for 6 / 12 heads,
+C = 96 / 192, no shift / shift 3, padded and non-square maps, LayerNormNoBias; a wrong shift is shown to fail), and the
+reference's own ``SwinUNetBase`` run over that HuggingFace layer reproduces the fixtures made over this class to 7e-7
+(``tests/golden/make_golden_hf.py`` -> ``swin_unet_hf.npz``, which the GPU tests read).  Still not compared with a real
+torchvision install (none exists where this code runs; ``tests/test_tv_swin_block_live.py`` does it wherever one does).
+Also pinned: the parameter names/shapes that the reference's own ``SwinUNetBase`` produces on top of this class
+(3 757 431 / 3 758 304 / 4 302 852 parameters for the 1x/2x/4x nets — asserted in tests/test_oracle_vs_reference.py).
 
 State-dict keys (per block): ``norm1.*``, ``attn.qkv.{weight,bias}``, ``attn.proj.{weight,bias}``,
 ``attn.relative_position_bias_table`` [(2w-1)^2, heads], ``attn.relative_position_index`` [w^4] (buffer),

@@ -42,6 +42,12 @@ def golden_swin():
 
 
 @pytest.fixture(scope="session")
+def golden_swin_hf():
+    """The reference's SwinUNet* over HuggingFace's SwinLayer (tests/golden/make_golden_hf.py): an oracle-independent pin."""
+    return dict(np.load(os.path.join(GOLDEN, "swin_unet_hf.npz")))
+
+
+@pytest.fixture(scope="session")
 def hiplib():
     """The built C-ABI library (built on demand; hipcc cross-compiles without a GPU)."""
     from nunif_amd import _hip, build

@@ -1,7 +1,8 @@
 """Depth-Anything-V2 ViT-S backbone: HIP engine vs the architecture restatement (oracle/depth_anything_v2.py).
 
-PARITY UNPINNED: the real network lives in an external hub repository that is not available offline;
-these tests compare the engine with our restatement of the published architecture only."""
+The real network lives in an external hub repository that is not available offline.  The restatement is
+pinned against HuggingFace's independent ``DepthAnythingForDepthEstimation`` (tests/test_depth_anything_vs_hf.py), and
+``test_hip_backbone_vs_huggingface_fixture`` compares the engine with HF-produced outputs directly."""
 import pytest
 import torch
 
@@ -59,6 +60,38 @@ def test_hip_backbone_vs_restatement(hiplib):
     assert torch.equal(net(x.to("cuda:0")).cpu(), y)                        # deterministic
     with pytest.raises(ValueError):
         net(torch.zeros(1, 3, 50, 56))
+
+
+@pytest.mark.gpu
+def test_hip_backbone_vs_huggingface_fixture(hiplib):
+    """The HIP backbone against ``tests/golden/depth_anything_hf.npz`` — outputs of ``transformers``'
+    ``DepthAnythingForDepthEstimation`` (``oracle/hf_pin.py``, ``tests/golden/make_golden_hf.py``), an implementation our
+    restatement had no part in: the 2 x 56 x 70 batch, the 392 x 686 map of a 1080p frame, the metric head and V1's taps."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN, sd_checksum
+    from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+    z = np.load(os.path.join(GOLDEN, "depth_anything_hf.npz"))
+    sd = ODA.random_state_dict(601)
+    assert sd_checksum(sd) == pytest.approx(float(z["sdsum"]), rel=1e-12)
+    net = HipDepthAnythingV2(sd, "cuda:0")
+
+    def check(y, ref, rel_max=1e-2):
+        ref = torch.from_numpy(ref)
+        assert y.shape == ref.shape
+        span = float(ref.max() - ref.min())
+        p = psnr(y / span, ref / span)
+        rel = ((y - ref).pow(2).mean().sqrt() / ref.std()).item()
+        assert float(ref.std()) > 1e-3 and p >= 50.0 and rel < rel_max, (p, rel)
+
+    check(net(torch.from_numpy(z["x_small"]).to("cuda:0")).cpu(), z["y_small"])
+    x = _norm(synth_image(95, 3, 392, 686)[None])
+    check(net(x.to("cuda:0")).cpu(), z["y_392x686_seed95"])
+    sd8 = ODA.random_state_dict(620, grid=8, encoder="vits")
+    assert sd_checksum(sd8) == pytest.approx(float(z["sdsum8"]), rel=1e-12)
+    x = _norm(torch.stack([synth_image(190 + i, 3, 70, 98) for i in range(2)])).to("cuda:0")
+    check(HipDepthAnythingV2(sd8, "cuda:0", max_depth=80.0)(x).cpu(), z["y_metric80"], 1.5e-2)
+    check(HipDepthAnythingV2(sd8, "cuda:0", taps=(8, 9, 10, 11))(x).cpu(), z["y_v1taps"], 1.5e-2)
 
 
 @pytest.mark.gpu

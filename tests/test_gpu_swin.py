@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import psnr, synth_image
+from conftest import psnr, sd_checksum, synth_image
 from oracle import seam_blending as OS
 from oracle import swin_unet as O
 
@@ -106,6 +106,21 @@ def test_forward_matches_golden_and_oracle(hiplib, golden_swin, sf, tag):
     assert float(y.min()) >= 0.0 and float(y.max()) <= 1.0
     assert psnr(y, ref) >= PSNR_MIN, f"PSNR vs reference fixture {psnr(y, ref):.2f} dB"
     assert psnr(y, O.model_forward(sd, x, NAMES[sf])) >= PSNR_MIN
+
+
+@pytest.mark.parametrize("sf,tag", [(1, "1x"), (2, "2x"), (4, "4x")])
+def test_forward_matches_the_hf_backed_reference_fixture(hiplib, golden_swin_hf, sf, tag):
+    """The same nets against ``swin_unet_hf.npz``: the reference's own ``SwinUNetBase`` over HuggingFace's ``SwinLayer``
+    (``oracle/hf_pin.py``) — no line of ``oracle/tv_swin_block.py`` took part in producing the expected output."""
+    m, sd = make_model(sf, 100 + sf)
+    assert sd_checksum(sd) == pytest.approx(float(golden_swin_hf["sdsum_" + tag]), rel=1e-12)
+    y = m(torch.from_numpy(golden_swin_hf["x"]).to("cuda:0")).cpu()
+    ref = torch.from_numpy(golden_swin_hf["y_" + tag])
+    assert y.shape == ref.shape and 0.05 < ref.std().item() < 0.45
+    assert psnr(y, ref) >= PSNR_MIN, f"PSNR vs HF-backed reference fixture {psnr(y, ref):.2f} dB"
+    if sf == 2:
+        y = m(torch.from_numpy(golden_swin_hf["x_112"]).to("cuda:0")).cpu()
+        assert psnr(y, torch.from_numpy(golden_swin_hf["y_2x_112"])) >= PSNR_MIN
 
 
 def test_downscaled_4x_to_2x_and_1x(hiplib, golden_swin):

@@ -51,6 +51,18 @@ def test_swin_forward_matches_reference(golden_swin, tag, sf):
     assert 0.05 < ref.std().item() < 0.45, "fixture is saturated; PSNR would be meaningless"
 
 
+@pytest.mark.parametrize("tag,sf", [("1x", 1), ("2x", 2), ("4x", 4)])
+def test_swin_forward_matches_hf_backed_reference(golden_swin_hf, tag, sf):
+    """``swin_unet_hf.npz`` = the reference's U-Net over HuggingFace's ``SwinLayer`` instead of ``oracle/tv_swin_block.py``
+    (tests/golden/make_golden_hf.py): the oracle's whole-net restatement agrees with an output that our block restatement
+    did not produce."""
+    sd = O.random_state_dict(100 + sf, sf)
+    assert sd_checksum(sd) == pytest.approx(float(golden_swin_hf["sdsum_" + tag]), rel=1e-12)
+    name = {1: "waifu2x.swin_unet_1x", 2: "waifu2x.swin_unet_2x", 4: "waifu2x.swin_unet_4x"}[sf]
+    y = O.model_forward(sd, torch.from_numpy(golden_swin_hf["x"]), name)
+    assert (y - torch.from_numpy(golden_swin_hf["y_" + tag])).abs().max().item() < TOL
+
+
 def test_swin_downscaled_matches_reference(golden_swin):
     sd = O.random_state_dict(104, 4)
     x = torch.from_numpy(golden_swin["x"])
