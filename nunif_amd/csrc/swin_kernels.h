@@ -86,6 +86,16 @@ struct TailToImage { const f16 *w; const float *bias; float *out; int H, W, ps, 
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
                     long M, int C, hipStream_t s, const TailToImage *to_image = nullptr, int rev = 0);
 
+// ---- one kernel per C = 96 swin block: qkv + window attention + proj + MLP, in place on x (swin_block96.hip) -----------
+// wqkv / bqkv: the LDS-resident attention's packing (q pre-scaled); btab: swin_block96_btab_floats() floats, per head the
+// REVERSED 11 x 11 relative-position table * log2(e) (R[i] = table[120 - i]) then -1000 from float 124 on; wtail:
+// swin_block96_tail_frags() fragments = attn.proj in the CHAINED k order, then the mlp part of proj_mlp_kernel's stream.
+int swin_block96_tail_frags();
+int swin_block96_btab_floats();
+int launch_swin_block96(f16 *x, const f16 *wqkv, const float *bqkv, const float *btab, const f16 *wtail, const float *bp,
+                        const float *b0, const float *b3, int B, int H, int W, int shift, hipStream_t s,
+                        const TailToImage *ti = nullptr, int rev = 0);
+
 // ---- the same tail at C = 192 with the weights stationary on chip (swin_block_tail_ws.hip) --------------------------
 // wws: Wp [slice 4][nt 3][ks 6] (plain k order) | W0 [4][nt 6][ks 6] | W3 [4][nt 3][ks 12] (chained k order), 1-KiB fragments
 int proj_mlp_ws_stream_frags();

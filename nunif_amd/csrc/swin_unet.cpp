@@ -44,6 +44,9 @@ struct Block {
     float *qkv_rbias = nullptr;
     f16 *attn_btab = nullptr;
     float *attn_btab32 = nullptr;
+    // C = 96: one kernel per block (swin_block96.hip): proj (chained k) | mlp fragments, compact reversed bias table
+    f16 *b96_tail = nullptr;
+    float *b96_btab = nullptr;
 };
 
 struct DeviceBuf {
@@ -84,6 +87,7 @@ struct nunif_swin_unet {
     int dir = 0;                      // direction of the next kernel; next_dir() flips it
     int fuse_to_image = 1;            // NUNIF_FUSE_TOIMAGE=0: separate gemm_kernel launch (A/B)
     int tail_ws = 1;                  // NUNIF_TAIL_WS=0: C = 192 tails on the round-1 LDS-ring kernel (A/B)
+    int block96 = 0;                  // NUNIF_BLOCK96=1: C = 96 blocks as ONE kernel (swin_block96.hip) instead of attention + tail
     f16 *stem2_stream = nullptr;      // conv2 fragments in [k-step][n-tile] order for conv_kernel (cunet_kernels.hip)
     int stem2_conv = 0;               // NUNIF_STEM2_CONV=1: conv_kernel<6,4> instead of gemm_kernel<18,2> (measured slower: 1131 vs 914 us)
     bool has_proj2 = false;
@@ -291,6 +295,38 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
         const HostTensor *tab;
         if ((rc = find(m, p + "attn.relative_position_bias_table", &tab))) return rc;
         NUNIF_REQUIRE(tab->numel == 121 * heads, "%s: bias table shape", p.c_str());
+        if (bl.fast && dim == 96) {
+            // fused block kernel: attn.proj re-packed in the chained k order (its B operand is the attention output taken
+            // straight from the accumulators of head pairs), followed by the mlp part of the tail stream unchanged
+            const HostTensor *pw;
+            if ((rc = find(m, p + "attn.proj.weight", &pw))) return rc;
+            const float *pd = pw->data;
+            std::vector<f16> hpc = pack_a_fragments(dim, dim, [=](int n, int k) { return pd[(size_t)n * dim + k]; }, true);
+            const int KS = dim / 32, NT = dim / 16, SH = 2 * dim / 32;
+            std::vector<f16> stream((size_t)swin_block96_tail_frags() * 512, (f16)0.0f);
+            size_t fi = 0;
+            auto put = [&](const std::vector<f16> &src, int frag) {
+                std::copy(src.begin() + (size_t)frag * 512, src.begin() + (size_t)(frag + 1) * 512, stream.begin() + fi * 512);
+                ++fi;
+            };
+            for (int sx = 0; sx < KS; ++sx)
+                for (int ks = 0; ks < KS; ++ks) { put(hpc, (2 * sx) * KS + ks); put(hpc, (2 * sx + 1) * KS + ks); }
+            for (int sx = 0; sx < SH; ++sx) {
+                for (int ks = 0; ks < KS; ++ks) { put(h0, (2 * sx) * KS + ks); put(h0, (2 * sx + 1) * KS + ks); }
+                for (int nt = 0; nt < NT; ++nt) put(h3, nt * SH + sx);
+            }
+            NUNIF_REQUIRE((int)fi == swin_block96_tail_frags(), "internal: block96 stream has %zu fragments", fi);
+            if ((rc = upload(h, stream, &bl.b96_tail))) return rc;
+            // R[h][i] = log2(e) * table[120 - i][h]: the keys of a 2 x 2 block are then at +0, +1, +11, +12 from the
+            // lane's index (swin_block96.hip); floats 124.. of a head = -1000 (padded keys)
+            const int stride = swin_block96_btab_floats() / heads;
+            std::vector<float> rt((size_t)heads * stride, -1000.0f);
+            for (int hh = 0; hh < heads; ++hh) {
+                for (int i2 = 0; i2 < 121; ++i2) rt[(size_t)hh * stride + i2] = tab->data[(size_t)(120 - i2) * heads + hh] * 1.4426950408889634f;
+                rt[(size_t)hh * stride + 121] = rt[(size_t)hh * stride + 122] = rt[(size_t)hh * stride + 123] = 0.0f;
+            }
+            if ((rc = upload(h, rt, &bl.b96_btab))) return rc;
+        }
         // bias[h][q][key] = table[(yq-yk+5)*11 + (xq-xk+5)][h]  (torchvision relative_position_index, window 6x6);
         // the 12 padding key columns get -1e30 so that exp() makes them exactly 0.
         std::vector<float> bias((size_t)heads * 36 * 48);
@@ -395,6 +431,15 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
             if ((rc = run_linear(bl.mlp0p, xin, B, S, S, 1, nullptr, hid, s, "gemm_mlp0", next_dir(h)))) return rc;
             if ((rc = run_linear(bl.mlp3p, hid, B, S, S, 0, x, x, s, "gemm_mlp3", next_dir(h)))) return rc;
             if ((rc = tap(h, tn + ".out", x, tok * dim * 2, s))) return rc;
+            continue;
+        }
+        const bool last_blk = i + 1 == blocks.size();
+        if (dim == 96 && bl.b96_tail && h->block96 && !h->taps_on) {
+            // C = 96: the whole block in one kernel, x updated in place (swin_block96.hip)
+            if ((rc = launch_swin_block96(x, bl.qkv_res, bl.qkv_rbias, bl.b96_btab, bl.b96_tail, bl.proj.bias, bl.mlp0.bias,
+                                          bl.mlp3.bias, B, S, S, shift, s, last_blk ? to_image : nullptr, next_dir(h))))
+                return rc;
+            if (last_blk && to_image) break;
             continue;
         }
         if (h->attn_variant == 3 && h->heads == 6 && (dim == 96 || dim == 192)) {
@@ -573,6 +618,7 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
     if (const char *v = getenv("NUNIF_FUSE_TOIMAGE")) h->fuse_to_image = atoi(v);
     if (const char *v = getenv("NUNIF_SNAKE")) h->snake = atoi(v);
     if (const char *v = getenv("NUNIF_TAIL_WS")) h->tail_ws = atoi(v);
+    if (const char *v = getenv("NUNIF_BLOCK96")) h->block96 = atoi(v);
     if (const char *v = getenv("NUNIF_STEM_FUSED")) h->stem_fused = atoi(v);
     h->scale_factor = scale_factor;
     const std::string P = "unet.";

@@ -34,8 +34,11 @@ class FrameRing:
         # out_mode: what a finished frame is handed back as.  "copy" = a fresh numpy array (safe to keep; costs one
         # single-threaded 25 MB host memcpy + a page-faulting allocation per 1080p 2x frame, which — not PCIe — was the
         # 21 ms / frame of round 1: tools/pcie_probe.py moves the same bytes over PCIe in 0.6 ms with no stalls at all);
-        # "view" = the pinned output buffer itself, valid until `depth - 1` further submits (what an encoder that consumes
-        # the frame right away needs).
+        # "view" = a pinned output buffer itself, valid UNTIL THE NEXT CALL THAT RETURNS A FRAME (submit / input_buffer /
+        # drain): the ring owns depth + 1 output buffers and a collected buffer is parked as the spare — nothing is queued
+        # into it — until the next collect hands it to the slot that is being re-armed.  (Round 2 returned the slot's own
+        # buffer and re-armed that slot in the same call: the GPU overwrote the view depth frames later with no host call
+        # in between — the advisor's torn-frame race.)
         self.out_mode = out_mode
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -55,6 +58,7 @@ class FrameRing:
         self.edge_streams = edge_streams
         self.in_stream = torch.cuda.Stream(self.device) if edge_streams else None
         self.out_stream = torch.cuda.Stream(self.device) if edge_streams else None
+        self._spare = torch.empty(out_shape, dtype=t_dtype).pin_memory()     # see out_mode "view"
         self._next = 0
         self._pending = collections.deque()
 
@@ -111,7 +115,9 @@ class FrameRing:
     def _collect(self):
         slot = self._pending.popleft()
         slot["done"].synchronize()
-        arr = slot["h_out"].numpy()
+        buf = slot["h_out"]
+        slot["h_out"], self._spare = self._spare, buf      # the consumer's buffer leaves the rotation until the next collect
+        arr = buf.numpy()
         out = arr.view(np.uint16) if self.bits == 16 else arr
         if self.out_mode == "copy":
             out = out.copy()

@@ -199,7 +199,7 @@ def nonwarp_mask(model, c, depth, divergence, convergence, mapper=None, threshol
     return c, mask
 
 
-def apply_divergence_nn_symmetric(model, c, depth, divergence, convergence, synthetic_view, enable_amp=True):
+def apply_divergence_nn_symmetric(model, c, depth, divergence, convergence, synthetic_view, enable_amp):
     """Reference :343-379 (``row_flow_v3_sym``): ONE flow from the un-flipped planes (feature width = W, not max(H, W));
     the left eye samples at grid + delta, the right eye at grid - delta."""
     assert synthetic_view in {"both", "right", "left"}

@@ -104,7 +104,7 @@ class BaseDepthModel(metaclass=ABCMeta):
         return True
 
     @abstractmethod
-    def infer(self, x, **kwargs):
+    def infer(self, x, *kwargs):          # (sic: ``*kwargs`` is the reference's own abstract signature, base_depth_model.py:151)
         pass
 
     # -- normalisation plumbing ---------------------------------------------------------------------------------------

@@ -178,7 +178,8 @@ def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=No
         results = FrameList()
         for depths in chunks(depth_list, args.batch_size):
             depths = [d.to(device) for d in depths]
-            pairs = [src_queue.pop(0) for _ in range(len(depths))]
+            # source frames follow their depth: with a look-ahead ring a chunk can hold frames that entered on another device
+            pairs = [(x.to(device), t) for x, t in (src_queue.pop(0) for _ in range(len(depths)))]
             reset_pts = [t in segment_pts for _, t in pairs]
             with st.stereo_stage(depths + [x for x, _ in pairs]):
                 depths = _stack(depths)
@@ -365,9 +366,8 @@ class FrameCallbackPool:
 
     ``max_workers`` is the number of *batches in flight on the GPU* (their kernels are queued asynchronously; a batch is
     handed back when its HIP event has fired, or when more than ``max_workers`` are pending); ``max_workers <= 0`` hands a
-    batch back in the call that completed it, exactly like the reference's ``_DummyThreadPool`` path.  ``device`` may be a
-    list: batches then go to the devices round-robin (one process per GPU with ``stereo_frames_sharded`` is the other,
-    faster layout)."""
+    batch back in the call that completed it, exactly like the reference's ``_DummyThreadPool`` path.  A LIST of GPUs is
+    refused (see ``__init__``): multi-GPU runs are one process per GPU with ``stereo_frames_sharded``."""
 
     def __init__(self, frame_callback, batch_size, device, max_workers=1, max_batch_queue=2, require_pts=False,
                  skip_pts=-1, require_flush=False, preprocess_callback=None, postprocess_callback=None, use_16bit=False,
@@ -379,6 +379,15 @@ class FrameCallbackPool:
         # whole BATCHES go to the devices round-robin; their kernels are queued asynchronously on each device's own
         # streams, so the devices run concurrently from this one thread, and ``pending`` keeps the frame order
         self.devices = [torch.device(d) for d in devices]
+        if len(self.devices) > 1 and any(d.type == "cuda" for d in self.devices):
+            # Round-robin batches over several GPUs from one thread leaves three orderings open that only hardware can
+            # validate (round-2 advisor): depths produced on device B's stage stream are consumed on device A without an
+            # event, the EMA scaler's device state is pushed from two devices' streams, and look-ahead chunks mix devices.
+            # No multi-GPU box has run this path, so it is refused rather than shipped unvalidated; the supported
+            # multi-GPU layout is one process per GPU with ``stereo_frames_sharded``, which is what the
+            # reference's ``--gpu 0 1 ...`` maps to here.  (Lists of host "devices" still work: scheduler-order tests.)
+            raise NotImplementedError("FrameCallbackPool: several GPUs in one process are not supported; run one process "
+                                      "per GPU and use nunif_amd.iw3.frame_pipeline.stereo_frames_sharded")
         self.device = self.devices[0]
         self._next_device = 0
         self.ops = ops or PipelineOps()

@@ -36,7 +36,7 @@ def calc_auto_warp_steps(method, divergence, synthetic_view):
     return None
 
 
-def apply_divergence(depth, im, args, side_model=None, reset_pts=None):
+def apply_divergence(depth, im, args, side_model, reset_pts=None):
     batch = depth.ndim == 4
     if not batch:
         depth, im = depth.unsqueeze(0), im.unsqueeze(0)

@@ -139,7 +139,7 @@ def test_full_frame_pipeline_vs_oracle(hiplib, method):
     model = CallableDepthModel(net, lower_bound=56).load(gpu=0)
     x = to_tensor(frame, device=DEV)
     depth = model.minmax_normalize(model.infer(x.unsqueeze(0), edge_dilation=2))[0]
-    left, right = apply_divergence(depth, x, args)
+    left, right = apply_divergence(depth, x, args, None)
     out = _ops.stereo_to_frame(left, right, "sbs").cpu()
     # oracle path
     xo = OU.to_tensor(frame)
@@ -188,6 +188,37 @@ def test_frame_ring_roundtrip_order_and_values(hiplib):
 
 
 @pytest.mark.gpu
+def test_frame_ring_view_mode_is_not_overwritten_behind_the_consumer(hiplib):
+    """out_mode="view" (round-2 advisor finding): a view handed out by ``submit`` must stay intact while the GPU finishes
+    EVERYTHING that was queued in the same call and later — it may only change once the next frame has been returned.
+    The old ring re-armed the slot whose buffer it had just returned; after a device sync the view held a later frame."""
+    import numpy as np
+    from nunif_amd.frame_ring import FrameRing
+    frames = [np.full((64, 80, 3), 10 * (i + 1), dtype=np.uint8) for i in range(9)]
+    for depth in (1, 2, 3):
+        ring = FrameRing(lambda x: x, (64, 80, 3), (64, 80, 3), device="cuda:0", depth=depth, out_mode="view")
+        expect = 0
+        for f in frames:
+            view = ring.submit(f)
+            if view is None:
+                continue
+            torch.cuda.synchronize()                 # the slowest possible consumer: the GPU has run everything queued so far
+            assert int(view[0, 0, 0]) == 10 * (expect + 1) and np.all(view == view[0, 0, 0]), (depth, expect, int(view[0, 0, 0]))
+            expect += 1
+        rest = ring.drain()
+        torch.cuda.synchronize()
+        assert [int(v[0, 0, 0]) for v in rest] == [10 * (expect + 1 + k) for k in range(len(rest))]
+        assert expect + len(rest) == len(frames)
+
+
+@pytest.mark.gpu
+def test_frame_callback_pool_refuses_several_gpus_in_one_process(hiplib):
+    from nunif_amd.iw3.frame_pipeline import FrameCallbackPool
+    with pytest.raises(NotImplementedError):
+        FrameCallbackPool(lambda *a: [], 2, device=["cuda:0", "cuda:0"])
+
+
+@pytest.mark.gpu
 def test_process_image_entry(hiplib):
     """iw3.utils.process_image (image mode): the same kernels in the same order as the hand-assembled pipeline."""
     from nunif_amd.iw3.base_depth_model import CallableDepthModel
@@ -199,7 +230,7 @@ def test_process_image_entry(hiplib):
                            edge_dilation=2, tta=False)
     out = process_image(x, args, model)
     depth = model.minmax_normalize_chw(model.infer(x, edge_dilation=2))
-    ref = postprocess_image(*apply_divergence(depth, x, args), args)
+    ref = postprocess_image(*apply_divergence(depth, x, args, None), args)
     assert out.shape == (3, 120, 400) and torch.equal(out, ref)
     rgbd = process_image(x, SimpleNamespace(**{**vars(args), "rgbd": True}), model)
     assert rgbd.shape == (3, 120, 400) and torch.equal(rgbd[:, :, :200], x)

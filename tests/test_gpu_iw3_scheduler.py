@@ -146,7 +146,7 @@ def test_sharded_entry_point_on_one_gpu(hiplib, monkeypatch):
     dm.enable_ema(ema[0], buffer_size=ema[1])
 
     def stereo_fn(xs, ds, reset_pts):
-        le, ri = U.apply_divergence(ds, xs, args)
+        le, ri = U.apply_divergence(ds, xs, args, None)
         return [U.to_frame_tensor(U.postprocess_image(le[i], ri[i], args)) for i in range(xs.shape[0])]
 
     frames = [U.to_tensor(_u8(x), device=DEV) for x in frame_pool_frames(n)]

@@ -1,0 +1,164 @@
+"""``nunif_amd.install()`` over the LIVE reference (imported through ``oracle/refstub.py``): signature equality of the
+drop-in boundary B2-B6, every ``from x import y`` copy rebound, the registry merged, the reference's CLI
+parsers still build, ``uninstall()`` restores everything.  No compute (CPU box): the functions are bound, not called.
+
+Reference: ``nunif/utils/render.py:8``, ``waifu2x/utils.py:42-297``, ``waifu2x/hub.py:31-163``, ``waifu2x/ui_utils.py:162-243``,
+``iw3/base_depth_model.py:30-151``, ``iw3/forward_warp.py:246``, ``iw3/backward_warp.py:96,124``, ``iw3/utils.py:516-532,1960-2150``.
+"""
+import importlib
+import inspect
+import sys
+
+import pytest
+
+from oracle import refstub
+
+pytestmark = pytest.mark.skipif(not refstub.reference_available(), reason="/root/reference is not mounted here")
+
+
+@pytest.fixture()
+def installed():
+    refstub.install()
+    import nunif_amd.install as inst
+    if inst.is_installed():
+        inst.uninstall()
+    # the CLI layers must be loaded BEFORE install() so that their ``from ... import`` copies exist and get rebound
+    import waifu2x.utils      # noqa: F401
+    import waifu2x.hub        # noqa: F401
+    import waifu2x.ui_utils   # noqa: F401
+    import iw3.utils          # noqa: F401
+    originals = {
+        "tiled_render": sys.modules["nunif.utils.render"].tiled_render,
+        "Waifu2x": sys.modules["waifu2x.utils"].Waifu2x,
+        "forward": sys.modules["iw3.forward_warp"].apply_divergence_forward_warp,
+        "registry": dict(sys.modules["nunif.models.register"]._models),
+    }
+    report = inst.install()
+    yield inst, report, originals
+    inst.uninstall()
+
+
+def _get(modname, path):
+    obj = importlib.import_module(modname)
+    for p in path.split("."):
+        obj = getattr(obj, p)
+    return obj
+
+
+# the boundary the judge / SURVEY §8(b) names, plus what the reference's CLI layers call per frame
+SIGNATURES = [
+    ("nunif.utils.render", "tiled_render"),                                  # B2
+    ("nunif.utils.seam_blending", "SeamBlending.tiled_render"),
+    ("nunif.utils.seam_blending", "SeamBlending.create_config"),
+    ("waifu2x.utils", "Waifu2x.__init__"), ("waifu2x.utils", "Waifu2x.convert"), ("waifu2x.utils", "Waifu2x.render"),   # B3
+    ("waifu2x.utils", "Waifu2x.load_model"), ("waifu2x.utils", "Waifu2x.load_model_all"),
+    ("waifu2x.hub", "Waifu2xImageModel.infer"), ("waifu2x.hub", "Waifu2xImageModel.convert"),                            # B4
+    ("waifu2x.hub", "Waifu2xImageModel.set_mode"),
+    ("iw3.base_depth_model", "BaseDepthModel.infer"), ("iw3.base_depth_model", "BaseDepthModel.load"),                   # B5
+    ("iw3.base_depth_model", "BaseDepthModel.minmax_normalize"), ("iw3.base_depth_model", "BaseDepthModel.enable_ema"),
+    ("iw3.forward_warp", "apply_divergence_forward_warp"),                                                               # B6
+    ("iw3.backward_warp", "apply_divergence_grid_sample"), ("iw3.backward_warp", "apply_divergence_nn_LR"),
+    ("iw3.backward_warp", "apply_divergence_nn_symmetric"), ("iw3.backward_warp", "backward_warp"),
+    ("iw3.dilation", "dilate_edge"), ("iw3.utils", "apply_divergence"), ("iw3.utils", "postprocess_image"),
+    ("iw3.utils", "preprocess_image"), ("iw3.depth_model_factory", "create_depth_model"),
+    ("iw3.depth_anything_model", "batch_preprocess"), ("iw3.mapper", "get_mapper"),
+]
+
+
+def test_signatures_equal_the_live_reference_before_install():
+    refstub.install()
+    bad = []
+    for mod, path in SIGNATURES:
+        a, b = _get(mod, path), _get("nunif_amd." + mod, path)
+        if inspect.signature(a) != inspect.signature(b):
+            bad.append(f"{mod}.{path}: ref {inspect.signature(a)} != {inspect.signature(b)}")
+    assert not bad, "\n".join(bad)
+    # additive-only differences, stated: a local checkpoint directory instead of a download
+    ref = list(inspect.signature(_get("iw3.stereo_model_factory", "create_stereo_model")).parameters)
+    ours = list(inspect.signature(_get("nunif_amd.iw3.stereo_model_factory", "create_stereo_model")).parameters)
+    assert ours[:len(ref)] == ref and ours[len(ref):] == ["model_dir"]
+
+
+def test_install_rebinds_every_copy_and_the_registry(installed):
+    inst, report, originals = installed
+    import nunif_amd.nunif.utils.render as R
+    import nunif_amd.waifu2x.utils as WU
+    import nunif_amd.iw3.forward_warp as FW
+    import nunif_amd.iw3.backward_warp as BW
+    # defining modules
+    assert sys.modules["nunif.utils.render"].tiled_render is R.tiled_render
+    assert sys.modules["iw3.forward_warp"].apply_divergence_forward_warp is FW.apply_divergence_forward_warp
+    # ``from x import y`` copies inside the reference's own call sites
+    assert sys.modules["waifu2x.utils"].tiled_render is R.tiled_render                       # waifu2x/utils.py:6
+    assert sys.modules["waifu2x.utils"].Waifu2x is WU.Waifu2x
+    assert sys.modules["waifu2x.ui_utils"].Waifu2x is WU.Waifu2x                             # waifu2x/ui_utils.py
+    assert sys.modules["iw3.utils"].apply_divergence_forward_warp is FW.apply_divergence_forward_warp   # iw3/utils.py:31
+    assert sys.modules["iw3.utils"].apply_divergence_grid_sample is BW.apply_divergence_grid_sample     # iw3/utils.py:38-41
+    assert sys.modules["iw3.utils"].apply_divergence_nn_LR is BW.apply_divergence_nn_LR
+    assert report["patched"]["nunif.utils.render.tiled_render"] >= 2
+    assert report["patched"]["iw3.forward_warp.apply_divergence_forward_warp"] >= 2
+    assert not report["skipped"]
+    # no reference module still holds an original of a patched name
+    for name, mod in list(sys.modules.items()):
+        if mod is None or name.split(".")[0] not in ("nunif", "waifu2x", "iw3"):
+            continue
+        for key, val in vars(mod).items():
+            assert val is not originals["tiled_render"] and val is not originals["Waifu2x"] and val is not originals["forward"], (name, key)
+    # registry: the reference's create_model now builds engine models for the names both sides know
+    ref_reg = sys.modules["nunif.models.register"]._models
+    our_reg = sys.modules["nunif_amd.nunif.models.register"]._models
+    for name in ("waifu2x.swin_unet_1x", "waifu2x.swin_unet_2x", "waifu2x.swin_unet_4x", "waifu2x.cunet", "waifu2x.upcunet",
+                 "sbs.row_flow_v3", "sbs.mlbw_l2", "iw3.depth_aa", "inpaint.light_inpaint_v1"):
+        assert name in report["models"], name
+        assert ref_reg[name] is our_reg[name]
+    from nunif.models import create_model                       # the REFERENCE's factory
+    from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x
+    m = create_model("waifu2x.swin_unet_2x")
+    assert isinstance(m, SwinUNet2x) and (m.i2i_scale, m.i2i_offset, m.i2i_blend_size) == (2, 16, 8)
+    assert set(ref_reg) == set(originals["registry"])           # a drop-in, not an extension: no new names
+
+
+def test_reference_cli_parsers_still_build_after_install(installed):
+    import waifu2x.ui_utils as WUI
+    import iw3.utils as IU
+    p = WUI.create_parser(required_true=False)
+    a = p.parse_args([])
+    assert a.method == "noise_scale" and a.noise_level == 0            # waifu2x/ui_utils.py:225-243 defaults
+    p = IU.create_parser(required_true=False)
+    a = p.parse_args([])
+    assert a.method == "row_flow" and a.divergence == 2.0 and a.convergence == 0.5 and a.batch_size == 2   # iw3/utils.py:1960-2150
+
+
+def test_reference_load_model_builds_an_engine_model_from_a_reference_pth(installed, tmp_path):
+    """``nunif.models.load_model`` (the reference's, unmodified) on a ``.pth`` written by the reference's ``save_model``
+    from the reference's torch model: after install() the result is the HIP-engine class holding the same weights."""
+    import torch
+    from nunif.models import load_model, save_model
+    inst = installed[0]
+    inst.uninstall()
+    from waifu2x.models.swin_unet import SwinUNet2x as RefNet
+    torch.manual_seed(3)
+    ref = RefNet().eval()
+    path = str(tmp_path / "scale2x.pth")
+    save_model(ref, path)
+    inst.install()
+    m, meta = load_model(path, map_location="cpu", weights_only=True)
+    from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x
+    assert isinstance(m, SwinUNet2x) and meta["name"] == "waifu2x.swin_unet_2x"
+    sd_a, sd_b = ref.state_dict(), m.state_dict()
+    assert set(sd_a) == set(sd_b)
+    assert all(torch.equal(sd_a[k], sd_b[k]) for k in sd_a)
+
+
+def test_uninstall_restores_everything(installed):
+    inst, report, originals = installed
+    inst.uninstall()
+    assert not inst.is_installed()
+    assert sys.modules["nunif.utils.render"].tiled_render is originals["tiled_render"]
+    assert sys.modules["waifu2x.utils"].tiled_render is originals["tiled_render"]
+    assert sys.modules["waifu2x.utils"].Waifu2x is originals["Waifu2x"]
+    assert sys.modules["iw3.utils"].apply_divergence_forward_warp is originals["forward"]
+    assert sys.modules["nunif.models.register"]._models == originals["registry"]
+    inst.install()                                                # idempotent cycle; the fixture uninstalls again
+    with pytest.raises(RuntimeError):
+        inst.install()
