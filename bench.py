@@ -27,8 +27,12 @@ Rank 0 prints ONE JSON line with the contract fields plus
                   geometry -> forward_fill / row_flow_v3 -> SBS uint8, with the forward-warp kernel's own HBM roofline
                   (40 B / pixel) and the CPU oracle of forward_fill + dilate_edge timed beside it
   scale4x_4k    — BASELINE config 3 on one GPU: swin_unet 4x on a 4K frame (170 tiles of 256)
-  cpu_baseline  — the CPU oracle (oracle/, a torch-fp32 port of the reference path) on the host cores: warm-up, then the
-                  median of 3 passes over a stated crop, thread count = physical cores
+  cunet         — north_star's second waifu2x generator: BASELINE configs[0] geometry (512 x 512, 9 tiles) and a 1080p frame,
+                  dominant conv kernel's roofline, PSNR vs the CPU oracle
+  config5       — BASELINE configs[4] shape on one GPU: 4K, VDA-streaming wrapper (per-frame ViT-S stand-in, named as such) +
+                  mask-MLBW backward warp + 12-frame video inpaint
+  cpu_baseline  — the CPU oracle (oracle/, a torch-fp32 port of the reference path) on the host cores: thread count and tile
+                  minibatch swept over {8, 32, physical} x {1, 4}, then warm-up + median of 3 with the best
 """
 import argparse
 import json
@@ -64,6 +68,8 @@ def parse_args():
                     help="skip the extra (reported, never `value`) PCIe-inclusive measurement through the pinned frame ring")
     ap.add_argument("--no-iw3", action="store_true", help="skip the iw3 (config 4) sub-record")
     ap.add_argument("--no-4k", action="store_true", help="skip the 4K 4x (config 3) sub-record")
+    ap.add_argument("--no-cunet", action="store_true", help="skip the cunet (config 1 geometry) sub-record")
+    ap.add_argument("--no-config5", action="store_true", help="skip the 4K VDA-wrapper + mask-MLBW + video-inpaint (config 5) sub-record")
     return ap.parse_args()
 
 
@@ -113,18 +119,35 @@ def median_time(fn, repeats=3):
 
 
 def cpu_baseline(sd, frame):
-    """The oracle's tiled_render on a crop of the same frame: 4 tiles of 256 in ONE minibatch, all physical cores."""
+    """The oracle's tiled_render on a crop of the same frame (4 tiles of 256).  128 threads on 36-token ``bmm``s is
+    oversubscription (round-2 verdict), so the thread count and the tile minibatch are SWEPT first — one warm-up + one timed
+    pass each over {8, 32, physical cores} x {minibatch 1, 4} — and the best setting is then timed as the median of 3."""
     import torch
     from oracle import seam_blending as OS
     from oracle import swin_unet as O
-    cores = physical_cores()
-    torch.set_num_threads(cores)
+    phys = physical_cores()
     crop = frame[:, :476, :476].contiguous()        # 2x2 tiles of 256 (input step 236 + 2 x 8 offset rows), same tile size
     fn = lambda mb: O.model_forward(sd, mb)         # noqa: E731
-    dt, out = median_time(lambda: OS.tiled_render(crop, fn, 2, 16, 8, TILE, 4), repeats=3)
-    return {"value": round(crop.shape[1] * crop.shape[2] / 1e6 / dt, 5), "unit": "MPix/s", "cores": cores, "kind": "port",
-            "sample": f"oracle tiled_render of a 476x476 crop of the bench frame (4 tiles of 256 in one minibatch of 4), "
-                      f"1 warm-up + median of 3 passes, {dt:.2f} s per pass, torch threads = physical cores"}, crop, out
+    sweep = {}
+    for threads in sorted({min(8, phys), min(32, phys), phys}):
+        for mb in (1, 4):
+            torch.set_num_threads(threads)
+            OS.tiled_render(crop, fn, 2, 16, 8, TILE, mb)
+            t0 = time.perf_counter()
+            OS.tiled_render(crop, fn, 2, 16, 8, TILE, mb)
+            sweep[(threads, mb)] = time.perf_counter() - t0
+    (threads, mb), _ = min(sweep.items(), key=lambda kv: kv[1])
+    torch.set_num_threads(threads)
+    dt, out = median_time(lambda: OS.tiled_render(crop, fn, 2, 16, 8, TILE, mb), repeats=3)
+    frame_s = dt / 4 * 45
+    return {"value": round(crop.shape[1] * crop.shape[2] / 1e6 / dt, 5), "unit": "MPix/s", "cores": threads, "kind": "port",
+            "physical_cores": phys, "tile_minibatch": mb,
+            "sweep_s_per_pass": {f"{t}thr_mb{b}": round(v, 2) for (t, b), v in sorted(sweep.items())},
+            "whole_1080p_frame_estimate_s": round(frame_s, 1),
+            "sample": f"oracle tiled_render of a 476x476 crop of the bench frame (4 tiles of 256, minibatch {mb}), best of a "
+                      f"threads x minibatch sweep ({threads} threads), 1 warm-up + median of 3 passes, {dt:.2f} s per pass "
+                      f"(= {frame_s:.0f} s per 1080p frame of 45 tiles, above the 120-s budget for timing it whole when > 120); "
+                      "tools/cpu_ref_vs_port.py gives the reference / port ratio measured in the build container"}, crop, out
 
 
 def pmc_traffic_bytes(symbol):
@@ -243,7 +266,8 @@ def iw3_record(dev, with_cpu):
         return dt / n
 
     rec = {"config": "BASELINE configs[3]: uint8 1080p frames in HBM -> FrameCallbackPool -> bind_batch_frame_callback "
-                     f"(batch {batch}, Depth-Anything-V2 ViT-S geometry with random-init weights — parity unpinned, "
+                     f"(batch {batch}, Depth-Anything-V2 ViT-S geometry with random-init weights — engine pinned against HuggingFace "
+                     "transformers' DepthAnythingForDepthEstimation, tests/golden/depth_anything_hf.npz, "
                      "EMA 0.75 x 4-frame look-ahead, one scene cut, edge_dilation 2) -> stereo -> SBS uint8",
            "frame": [H, W], "frames": n_frames, "batch": batch, "unit": "input MPix/s"}
     for method in ("forward_fill", "row_flow_v3"):
@@ -334,6 +358,140 @@ def scale4x_record(dev):
             "output_mpix_per_s": round(16 * 2160 * 3840 / dt / 1e6, 1)}
 
 
+def cunet_record(dev, with_cpu):
+    """north_star names "swin_unet / cunet": BASELINE configs[0] geometry (waifu2x cunet, one 512 x 512 image, tile 256 = 9 tiles)
+    and a 1080p frame through ``tiled_render``; per-kernel roofline of the dominant conv kernel (algorithmic 28 GFLOP / tile over
+    all conv launches), PSNR of the 512 x 512 render against the CPU oracle (``oracle/cunet.py``)."""
+    import torch
+    from nunif_amd import _hip
+    from nunif_amd.nunif.models import create_model
+    from nunif_amd.nunif.utils.render import tiled_render
+    import nunif_amd.waifu2x.models.cunet  # noqa: F401
+    from nunif_amd.synthetic import cunet_state_dict
+    sd = cunet_state_dict(201)
+    m = create_model("waifu2x.cunet").eval()
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    rec = {"config": "BASELINE configs[0] geometry on the GPU: waifu2x cunet (noise geometry, random-init), tile 256, batch 16: "
+                     "one 512 x 512 image (9 tiles) and a 1080p frame (66 tiles)", "unit": "input MPix/s"}
+    img = synth_frame(31, 512, 512).to(dev)
+    frame = synth_frame(32, FRAME_H, FRAME_W).to(dev)
+    for key, x, n in (("image_512", img, 60), ("frame_1080p", frame, 30)):
+        for _ in range(3):
+            tiled_render(x, m, tile_size=TILE, batch_size=16)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            y = tiled_render(x, m, tile_size=TILE, batch_size=16)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / n
+        rec[key] = {"ms": round(dt * 1e3, 3), "value": round(x.shape[1] * x.shape[2] / dt / 1e6, 1)}
+    _hip.profile_read(reset=True)
+    _hip.profile_enable(True)
+    for _ in range(3):
+        tiled_render(frame, m, tile_size=TILE, batch_size=16)
+    torch.cuda.synchronize(dev)
+    recs = _hip.profile_read(reset=True)
+    _hip.profile_enable(False)
+    if recs:
+        rec["kernel_classes"] = kernel_table(recs, 3)[:6]
+        dom = max(recs, key=lambda r: r["total_ms"])
+        rec["roofline"] = roofline_of(dom, with_pmc=False)
+        conv_ms = sum(r["total_ms"] for r in recs if r["flops"] > 0) / 3
+        tiles = 66
+        rec["model_tflops"] = round(tiles * 28e9 / (rec["frame_1080p"]["ms"] * 1e-3) / 1e12, 1)
+        rec["model_mfma_frac"] = round(rec["model_tflops"] / MFMA_PEAK_TFLOPS, 4)
+        rec["conv_kernel_ms_per_frame"] = round(conv_ms, 3)
+    if with_cpu:
+        from oracle import cunet as OC
+        from oracle import seam_blending as OS
+        torch.set_num_threads(min(32, physical_cores()))
+        t0 = time.perf_counter()
+        ref = OS.tiled_render(img.cpu(), lambda mb: OC.model_forward(sd, mb), 1, 28, 0, TILE, 4)
+        dt = time.perf_counter() - t0
+        got = tiled_render(img, m, tile_size=TILE, batch_size=16).cpu()
+        mse = torch.mean((got.double() - ref.double()) ** 2).item()
+        rec["psnr_vs_oracle_db"] = round(10 * math.log10(1.0 / (mse + 1e-6)), 2)
+        rec["cpu_baseline"] = {"value": round(512 * 512 / 1e6 / dt, 4), "unit": "MPix/s", "cores": min(32, physical_cores()),
+                               "kind": "port", "sample": f"oracle cunet tiled_render of the 512 x 512 image, one pass, {dt:.2f} s"}
+    del m
+    return rec
+
+
+def config5_record(dev):
+    """BASELINE configs[4] shape on ONE GPU: 4K frames in batches of 3 -> ``VideoDepthAnythingStreamingModel`` wrapper (pre / post
+    kernels of the reference's wrapper around a PER-FRAME ViT-S STAND-IN: the external streaming network's temporal head is not
+    restated) -> min-max -> mask-MLBW backward warp (``sbs.mask_mlbw_l2``) -> 12-frame ``FrameQueue`` ->
+    ``inpaint.light_video_inpaint_v1`` on both eyes -> SBS uint8.  Reference call sites: iw3/mlbw_inpaint.py:296-360."""
+    import torch
+    from nunif_amd import _hip
+    from nunif_amd.iw3 import _ops
+    from nunif_amd.iw3.base_depth_model import CallableDepthModel
+    from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+    from nunif_amd.iw3.mlbw_inpaint import MLBWInpaint
+    from nunif_amd.iw3.models.light_inpaint_v1 import LightInpaintV1
+    from nunif_amd.iw3.models.light_video_inpaint_v1 import LightVideoInpaintV1
+    from nunif_amd.iw3.models.mlbw import MLBW
+    from nunif_amd.iw3.video_depth_anything_streaming_model import VideoDepthAnythingStreamingModel
+    from nunif_amd.synthetic import (depth_anything_v2_state_dict, light_inpaint_state_dict, light_video_inpaint_state_dict,
+                                     mlbw_state_dict)
+    H5, W5, batch = 2160, 3840, 3
+    depth_model = CallableDepthModel(HipDepthAnythingV2(depth_anything_v2_state_dict(601), str(dev)))
+    depth_model.load(gpu=dev.index or 0)
+    vda = VideoDepthAnythingStreamingModel("VDA_Stream_S", backbone=depth_model.model).load(gpu=dev.index or 0)
+    inp = LightInpaintV1().eval()
+    inp.load_state_dict(light_inpaint_state_dict(701))
+    mm = MLBW(num_layers=2, base_dim=32, hole_mask=True).eval()
+    mm.load_state_dict(mlbw_state_dict(431, 2, False, hole_mask=True))
+    vid = LightVideoInpaintV1().eval()
+    vid.load_state_dict(light_video_inpaint_state_dict(801))
+    side = MLBWInpaint(inp.to(dev), mm.to(dev), video_model=vid.to(dev))
+    side.set_mode("video")
+    frames5 = [synth_frame(950 + i, H5, W5).to(dev) for i in range(3)]
+    n_out = [0]
+
+    def step(i):
+        x = torch.stack([frames5[(i + k) % 3] for k in range(batch)])
+        d = torch.stack(vda.minmax_normalize(vda.infer(x, edge_dilation=2)))
+        left, right = side.infer(x, d, divergence=2.0, convergence=0.5, synthetic_view="both", inner_dilation=1, outer_dilation=1)
+        if left is None:                          # the 12-frame queue is still filling
+            return
+        for k in range(left.shape[0]):
+            _ops.stereo_to_frame(left[k], right[k], "sbs")
+            n_out[0] += 1
+
+    for i in range(4):
+        step(i)
+    torch.cuda.synchronize(dev)
+    n_out[0] = 0
+    n_calls = 8
+    t0 = time.perf_counter()
+    for i in range(n_calls):
+        step(i)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    n_in = n_calls * batch
+    rec = {"config": "BASELINE configs[4] shape on one GPU: 4K frames (batches of 3) -> VideoDepthAnythingStreaming WRAPPER around a "
+                     "per-frame ViT-S stand-in (temporal head not restated; random-init) -> min-max -> sbs.mask_mlbw_l2 backward "
+                     "warp -> 12-frame queue -> inpaint.light_video_inpaint_v1 (both eyes) -> SBS uint8",
+           "frame": [H5, W5], "frames_in": n_in, "frames_out": n_out[0], "ms_per_frame": round(1e3 * dt / n_in, 2),
+           "fps": round(n_in / dt, 1), "value": round(H5 * W5 * n_in / dt / 1e6, 1), "unit": "input MPix/s",
+           "target": "4K @ 30 fps on 8 GPUs (BASELINE configs[4]); this is one GPU"}
+    _hip.profile_read(reset=True)
+    _hip.profile_enable(True)
+    for i in range(4):
+        step(i)
+    torch.cuda.synchronize(dev)
+    recs = _hip.profile_read(reset=True)
+    _hip.profile_enable(False)
+    if recs:
+        rec["kernel_classes"] = kernel_table(recs, 4 * batch)[:8]
+        dom = max(recs, key=lambda r: r["total_ms"])
+        rec["roofline"] = roofline_of(dom, with_pmc=False)
+    side.reset()
+    return rec
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -353,6 +511,21 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    # self-evidence for the driver's N > 1 runs: how many ranks took part in a collective and which physical devices they
+    # hold (one distinct PCI bus id per rank, or the run was not N GPUs)
+    multi_gpu = None
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device": props.name,
+                "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xff,
+                                                  getattr(props, "pci_device_id", 0)),
+                "hbm_gib": round(props.total_memory / 2 ** 30, 1)}
+        table = [None] * world
+        dist.all_gather_object(table, mine)
+        multi_gpu = {"ranks_seen": int(ones.item()), "world_size": world, "backend": dist.get_backend(),
+                     "distinct_pci_bus_ids": len({t["pci_bus_id"] for t in table}), "devices": table}
 
     from nunif_amd import _hip
     from nunif_amd.nunif.utils.render import tiled_render
@@ -457,6 +630,10 @@ def main():
             "model_mfma_frac": round(45 * 98e9 * args.steps * n_streams * world / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
             "roofline": roofline, "kernel_classes": classes,
         }
+        if multi_gpu is not None:
+            result["multi_gpu"] = multi_gpu
+            if multi_gpu["ranks_seen"] != world or multi_gpu["distinct_pci_bus_ids"] != world:
+                result.setdefault("errors", []).append("ranks / devices do not add up to --gpus")
         if single is not None:
             result["single_stream"] = single        # one frame at a time on one stream, same build, same run
         if not args.no_host_frames and world == 1:
@@ -489,8 +666,15 @@ def main():
             result["host_frames"] = hf
         if not args.no_4k and world == 1:
             result["scale4x_4k"] = scale4x_record(dev)
+        if not args.no_cunet and world == 1:
+            result["cunet"] = cunet_record(dev, with_cpu=not args.no_cpu_baseline)
         if not args.no_iw3 and world == 1:
             result["iw3"] = iw3_record(dev, with_cpu=not args.no_cpu_baseline)
+        if not args.no_config5 and world == 1:
+            try:
+                result["config5"] = config5_record(dev)
+            except Exception as e:                       # a sub-record must never cost the headline line
+                result["config5"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
             base, crop, ref = cpu_baseline(sd, frames[0].cpu())
             got = tiled_render(crop.to(dev), model, tile_size=TILE, batch_size=args.batch_size).cpu()
@@ -507,6 +691,7 @@ def main():
             if rank == 0:
                 result["gathered"] = {"error": f"the delivery leg did not finish within {GATHER_TIMEOUT_S} s; value / roofline "
                                                "above are unaffected (they contain no collective)"}
+                result.setdefault("errors", []).append("delivery leg hung (watchdog)")
                 print(json.dumps(result), flush=True)
             os._exit(0)
 
@@ -531,6 +716,8 @@ def main():
             dtg = float(tg.item())
             done.set()
             if rank == 0:
+                if delivered[0] != n_g:
+                    result.setdefault("errors", []).append(f"delivery leg: {delivered[0]} of {n_g} frames arrived on rank 0")
                 result["gathered"] = {
                     "value": round(FRAME_H * FRAME_W / 1e6 * n_g / dtg, 2), "unit": "MPix/s", "frames": n_g,
                     "frames_delivered": delivered[0],
@@ -546,6 +733,7 @@ def main():
             print(f"[bench rank {rank}] delivery leg failed: {e!r}", file=sys.stderr, flush=True)
             if rank == 0:
                 result["gathered"] = {"error": repr(e)}
+                result.setdefault("errors", []).append("delivery leg raised")
                 print(json.dumps(result), flush=True)
                 os._exit(0)
             threading.Event().wait()            # the watchdog ends this rank with exit code 0

@@ -232,7 +232,7 @@ proj_mlp_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wst
 template <int C, int MF, int WAVES, bool PF = false>
 __global__ void __launch_bounds__(WAVES * 64)
 proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wstream, const float *__restrict__ bp,
-                  const float *__restrict__ b0, const float *__restrict__ b3, long M, TailToImage ti, int rev) {
+                  const float *__restrict__ b0, const float *__restrict__ b3, long M, TailToImage ti, int rev, WinMap wm) {
     constexpr int KS = C / 32, NT = C / 16, SH = 2 * C / 32;
     constexpr int NF = 2 * KS * KS + SH * (2 * KS + NT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
@@ -278,25 +278,45 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
     // wave exposes one full HBM latency per group and the kernel sits at ~3.3 TB/s however cheap the math is
     // (bytes in flight per CU ~ 20 KB; Little's law wants >= 40 KB for 5 TB/s).
     auto gmap = [&](long g) { return rev ? n_groups - 1 - g : g; };          // snake order between kernels
-    auto load_group = [&](long g, f16x8 (&of)[MF][KS], f16x8 (&xr)[MF][KS]) {
+    // pixn[f]: row of x (and of the image head) that token f*16 + r16 of the group lives at.  Plain map: the token index.
+    // Window map (wm.on): token n = window * 36 + t of the SHIFTED 6x6 windows, t row-major in the window — the order
+    // qkv_attn_r_kernel writes its window-major att map in; att is then [window][head 6][36][16].
+    const int nwx = wm.on ? wm.W / 6 : 1, nwy = wm.on ? wm.H / 6 : 1;
+    auto load_group = [&](long g, f16x8 (&of)[MF][KS], f16x8 (&xr)[MF][KS], long (&pixn)[MF]) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             const long m = gmap(g) * (MF * 16) + f * 16 + r16;
             const long r = m < M ? m : M - 1;
-            const f16 *p = att + r * C + grp * 8;
-            const f16 *px = x + r * C + grp * 8;
+            const f16 *p;
+            if (wm.on) {
+                const int w = (int)(r / 36), t = (int)(r - 36L * w);
+                const int wx = w % nwx, t2 = w / nwx;
+                const int wy = t2 % nwy, b = t2 / nwy;
+                const int iy = t / 6, ix = t - 6 * iy;
+                int yy = wy * 6 + iy + wm.shift, xx = wx * 6 + ix + wm.shift;
+                if (yy >= wm.H) yy -= wm.H;
+                if (xx >= wm.W) xx -= wm.W;
+                pixn[f] = ((long)b * wm.H + yy) * wm.W + xx;
+                // lane group g holds channels 32 ks + 8 g .. + 7 = head 2 ks + (g >> 1), dims 8 (g & 1) ..
+                p = att + (((long)w * 6 + (grp >> 1)) * 36 + t) * 16 + 8 * (grp & 1);
+            } else {
+                pixn[f] = r;
+                p = att + r * C + grp * 8;
+            }
+            const f16 *px = x + pixn[f] * C + grp * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                of[f][ks] = *reinterpret_cast<const f16x8 *>(p + ks * 32);
+                of[f][ks] = *reinterpret_cast<const f16x8 *>(p + (wm.on ? ks * (2 * 36 * 16) : ks * 32));
                 xr[f][ks] = *reinterpret_cast<const f16x8 *>(px + ks * 32);      // B-operand layout: the residual rides an MFMA
             }
         }
     };
     f16x8 ofn[PF ? MF : 1][PF ? KS : 1];
     f16x8 xrn[PF ? MF : 1][PF ? KS : 1];
+    long pixnn[MF];
     const long g_first = (long)blockIdx.x * WAVES + wave;
     if constexpr (PF) {
-        if (g_first < n_groups) load_group(g_first, ofn, xrn);
+        if (g_first < n_groups) load_group(g_first, ofn, xrn, pixnn);
     }
 #pragma unroll 1
     for (long g = g_first; g < n_groups; g += gstride) {
@@ -314,16 +334,17 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
             for (int f = 0; f < MF; ++f) {
                 const long m = m_base + f * 16 + r16;
                 valid[f] = m < M;
-                row[f] = m < M ? m : M - 1;
             }
             if constexpr (PF) {
 #pragma unroll
-                for (int f = 0; f < MF; ++f)
+                for (int f = 0; f < MF; ++f) {
+                    row[f] = pixnn[f];
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) { of[f][ks] = ofn[f][ks]; xr[f][ks] = xrn[f][ks]; }
-                load_group(g + gstride < n_groups ? g + gstride : g, ofn, xrn);
+                }
+                load_group(g + gstride < n_groups ? g + gstride : g, ofn, xrn, pixnn);
             } else {
-                load_group(g, of, xr);
+                load_group(g, of, xr, row);
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -455,10 +476,11 @@ int proj_mlp_stream_frags(int C) {
 }
 
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
-                    long M, int C, hipStream_t s, const TailToImage *to_image, int rev) {
+                    long M, int C, hipStream_t s, const TailToImage *to_image, int rev, const WinMap *wmap) {
     if (M == 0) return NUNIF_HIP_OK;
     NUNIF_REQUIRE(!to_image || (C == 96 && !getenv("NUNIF_TAIL_RING") && to_image->n_real <= 16),
                   "proj_mlp: the fused image head needs the resident C = 96 kernel");
+    NUNIF_REQUIRE(!(wmap && wmap->on) || (C == 96 && !getenv("NUNIF_TAIL_RING")), "proj_mlp: the window map needs the resident C = 96 kernel");
     static const bool ring96 = getenv("NUNIF_TAIL_RING") != nullptr;     // A/B switch: the round-1 ring version
     static const int variant = getenv("NUNIF_TAIL_VARIANT") ? atoi(getenv("NUNIF_TAIL_VARIANT")) : 6;
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
@@ -471,6 +493,10 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
         TailToImage ti;
         memset(&ti, 0, sizeof(ti));
         if (to_image) ti = *to_image;
+        WinMap wm;
+        memset(&wm, 0, sizeof(wm));
+        if (wmap) wm = *wmap;
+        NUNIF_REQUIRE(!wm.on || (wm.H % 6 == 0 && wm.W % 6 == 0 && M % ((long)wm.H * wm.W) == 0), "proj_mlp: window map geometry");
         auto go = [&](auto kern, int mf, int waves) -> int {
             static bool configured[8] = {false};
             if (!configured[variant & 7]) {
@@ -479,7 +505,7 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
             }
             const long groups = (M + mf * 16 - 1) / (mf * 16);
             const unsigned blocks = (unsigned)std::min<long>((groups + waves - 1) / waves, 256);
-            kern<<<blocks, waves * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti, rev);
+            kern<<<blocks, waves * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti, rev, wm);
             return NUNIF_HIP_OK;
         };
         int rc;

@@ -83,8 +83,13 @@ int proj_mlp_stream_frags(int C);
 // ToImage (Linear C -> 3*ps*ps, pixel_shuffle, clamp(0,1); swin_unet.py:85-116) to the fp16-rounded result and writes
 // planar fp32.  w: KS fragments of a 16-row tile in the chained k order; tokens are (b, y, x) over [B, H, W].
 struct TailToImage { const f16 *w; const float *bias; float *out; int H, W, ps, n_real; };
+// WinMap (C = 96 resident kernel only): tokens are walked in WINDOW order (n = window * 36 + t, the shifted 6x6 windows of
+// launch_qkv_attn_r) and att is the window-major map that kernel writes with window_major = 1; x rows / image pixels are
+// addressed through the same window -> pixel map.  The per-token arithmetic is unchanged (bit-identical results).
+struct WinMap { int on, H, W, shift; };
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
-                    long M, int C, hipStream_t s, const TailToImage *to_image = nullptr, int rev = 0);
+                    long M, int C, hipStream_t s, const TailToImage *to_image = nullptr, int rev = 0,
+                    const WinMap *wm = nullptr);
 
 // ---- one kernel per C = 96 swin block: qkv + window attention + proj + MLP, in place on x (swin_block96.hip) -----------
 // wqkv / bqkv: the LDS-resident attention's packing (q pre-scaled); btab: swin_block96_btab_floats() floats, per head the
@@ -112,8 +117,10 @@ int launch_qkv_attn(const f16 *x, f16 *att, const f16 *wqkv, const float *bqkv, 
 int qkv_attn_w_stream_frags(int C);
 // ---- same, qkv weights resident in LDS, no barrier in the window loop (swin_qkv_attn_r.hip) -------------------------
 // btab: fp16 [heads][36][48] one-hot-MFMA bias table (NUNIF_ATTN_CBIAS=0); btab32: fp32 [heads][36][52] C-operand table
+// window_major = 1 (C = 96): att is written as [window][head][36][16] — every store instruction covers one contiguous
+// 512-byte run; launch_proj_mlp's WinMap reads it back in the same order
 int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, const float *btab32,
-                      int B, int H, int W, int C, int heads, int shift, hipStream_t s, int rev = 0);
+                      int B, int H, int W, int C, int heads, int shift, hipStream_t s, int rev = 0, int window_major = 0);
 int launch_qkv_attn_w(const f16 *x, f16 *att, const f16 *wstream, const float *bqkv, const float *bias, int B, int H,
                       int W, int C, int heads, int shift, hipStream_t s);
 

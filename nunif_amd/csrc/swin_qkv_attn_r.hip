@@ -36,6 +36,7 @@ struct QkvAttnRArgs {
     const float *btab32;     // CBIAS: [heads][36][52] fp32: log2e * bias, cols 36..47 = -1000 (padded keys), 48..51 unused
     int B, H, W, shift, n_windows;
     int rev;                 // 1: walk the windows from the last to the first (snake order, see launch_qkv_attn_r)
+    int wm;                  // 1: att is written WINDOW-major / head-major, [window][head][36 tokens][HD] (C = 96 tail reads it so)
 #ifdef NUNIF_ABLATIONS
     int abl;                 // timing-only (NUNIF_ATTN_ABL): 1 = x is loaded for the first window of a wave only, 2 = no att stores
 #endif
@@ -293,7 +294,11 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     } else {
                         // head_dim 16: pairing with the neighbouring head's tile (held across one trip of the head loop)
                         // was measured slower (504 vs 457 us): plain 8-byte stores
-                        if (store) *reinterpret_cast<f16x4 *>(a.att + pix[qt] * C + head * HD + 4 * grp) = ov[0];
+                        // window-major map (a.wm): the 64 lanes of this store cover ONE contiguous 512-byte run (16 tokens x 32 B)
+                        // instead of sixteen 8-byte pieces 192 B apart (1.48x write amplification in the r02 counters)
+                        f16 *dst = a.wm ? a.att + ((long)(wmap(wi) * HEADS + head) * 36 + 16 * qt + r16) * HD + 4 * grp
+                                        : a.att + pix[qt] * C + head * HD + 4 * grp;
+                        if (store) *reinterpret_cast<f16x4 *>(dst) = ov[0];
                     }
                 }
             }
@@ -332,7 +337,7 @@ static int launch_r(const QkvAttnRArgs &a, int grid, hipStream_t s) {
 }
 
 int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, const float *btab32,
-                      int B, int H, int W, int C, int heads, int shift, hipStream_t s, int rev) {
+                      int B, int H, int W, int C, int heads, int shift, hipStream_t s, int rev, int window_major) {
     NUNIF_REQUIRE(H % 6 == 0 && W % 6 == 0, "qkv_attn: %dx%d not a multiple of the 6x6 window", H, W);
     NUNIF_REQUIRE(heads == 6 && (C == 96 || C == 192), "qkv_attn: C=%d heads=%d unsupported", C, heads);
     if (H <= 6) shift = 0;                 // torchvision disables the shift when the window covers the map
@@ -341,6 +346,8 @@ int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv
     a.B = B; a.H = H; a.W = W; a.shift = shift;
     a.n_windows = B * (H / 6) * (W / 6);
     a.rev = rev;            // snake order between consecutive kernels (swin_unet.cpp next_dir)
+    a.wm = window_major;
+    NUNIF_REQUIRE(!window_major || C == 96, "qkv_attn: the window-major att map exists for C = 96 only");
 #ifdef NUNIF_ABLATIONS
     static const int attn_abl = getenv("NUNIF_ATTN_ABL") ? atoi(getenv("NUNIF_ATTN_ABL")) : 0;
     a.abl = attn_abl;

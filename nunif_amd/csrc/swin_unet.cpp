@@ -87,6 +87,7 @@ struct nunif_swin_unet {
     int dir = 0;                      // direction of the next kernel; next_dir() flips it
     int fuse_to_image = 1;            // NUNIF_FUSE_TOIMAGE=0: separate gemm_kernel launch (A/B)
     int tail_ws = 1;                  // NUNIF_TAIL_WS=0: C = 192 tails on the round-1 LDS-ring kernel (A/B)
+    int att_wm = 1;                   // NUNIF_ATT_WM=0: C = 96 att map pixel-major (8-byte partial-line stores) as in round 2
     int block96 = 0;                  // NUNIF_BLOCK96=1: C = 96 blocks as ONE kernel (swin_block96.hip) instead of attention + tail
     f16 *stem2_stream = nullptr;      // conv2 fragments in [k-step][n-tile] order for conv_kernel (cunet_kernels.hip)
     int stem2_conv = 0;               // NUNIF_STEM2_CONV=1: conv_kernel<6,4> instead of gemm_kernel<18,2> (measured slower: 1131 vs 914 us)
@@ -442,9 +443,12 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
             if (last_blk && to_image) break;
             continue;
         }
+        // C = 96: att travels in window-major order (full-line stores in the attention kernel, the tail walks its tokens in
+        // window order); debug taps want the pixel-major map the oracle has
+        const bool att_wm = dim == 96 && h->att_wm && h->attn_variant == 3 && !h->taps_on && !getenv("NUNIF_TAIL_RING");
         if (h->attn_variant == 3 && h->heads == 6 && (dim == 96 || dim == 192)) {
             if ((rc = launch_qkv_attn_r(x, att, bl.qkv_res, bl.qkv_rbias, bl.attn_btab, bl.attn_btab32, B, S, S, dim, h->heads, shift, s,
-                                        next_dir(h))))
+                                        next_dir(h), att_wm ? 1 : 0)))
                 return rc;
         } else if (h->attn_variant == 2 && h->heads == 6 && (dim == 96 || dim == 192)) {
             if ((rc = launch_qkv_attn_w(x, att, bl.qkv_stream, bl.qkv.bias, bl.attn_bias, B, S, S, dim, h->heads, shift, s)))
@@ -465,9 +469,12 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
             // C = 192: weights stationary in registers / LDS (swin_block_tail_ws.hip); NUNIF_TAIL_WS=0 restores the ring kernel
             if ((rc = launch_proj_mlp_ws(att, x, bl.tail_ws, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, s, next_dir(h))))
                 return rc;
-        } else if ((rc = launch_proj_mlp(att, x, bl.tail_stream, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, dim, s,
-                                         last ? to_image : nullptr, next_dir(h))))
-            return rc;
+        } else {
+            const WinMap wmap = {att_wm ? 1 : 0, S, S, S <= 6 ? 0 : shift};
+            if ((rc = launch_proj_mlp(att, x, bl.tail_stream, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, dim, s,
+                                      last ? to_image : nullptr, next_dir(h), &wmap)))
+                return rc;
+        }
         if (last && to_image) break;               // x of the last block is not materialised
         if ((rc = tap(h, tn + ".out", x, tok * dim * 2, s))) return rc;
     }
@@ -619,6 +626,7 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
     if (const char *v = getenv("NUNIF_SNAKE")) h->snake = atoi(v);
     if (const char *v = getenv("NUNIF_TAIL_WS")) h->tail_ws = atoi(v);
     if (const char *v = getenv("NUNIF_BLOCK96")) h->block96 = atoi(v);
+    if (const char *v = getenv("NUNIF_ATT_WM")) h->att_wm = atoi(v);
     if (const char *v = getenv("NUNIF_STEM_FUSED")) h->stem_fused = atoi(v);
     h->scale_factor = scale_factor;
     const std::string P = "unet.";

@@ -119,8 +119,10 @@ class DataParallelInference:
     forward = __call__
 
     def __getattr__(self, name):
-        if name == "render_frame":
-            raise AttributeError(name)
+        # (copy.deepcopy / pickle probe ``__deepcopy__`` / ``__getstate__`` on an instance whose __init__ has not run:
+        #  that must be an AttributeError, not a KeyError)
+        if name == "render_frame" or "module" not in self.__dict__ or (name.startswith("__") and name.endswith("__")):
+            raise AttributeError(name)      # dunder probes (__deepcopy__, __getstate__) are about the WRAPPER, never delegated
         return getattr(self.__dict__["module"], name)
 
     def get_device(self):
@@ -146,12 +148,17 @@ class DeviceSwitchInference:
         self._replicas = replicate(self._module, self._devices)
 
     def _replica(self, device):
-        return self._replicas[self._devices.index(torch.device(device))]
+        device = torch.device(device)
+        if device not in self._devices:
+            raise ValueError(f"DeviceSwitchInference: tensor on {device}, replicas exist on {[str(d) for d in self._devices]}")
+        return self._replicas[self._devices.index(device)]
 
     def __call__(self, x, *args, **kwargs):
         return self._replica(x.device)(x, *args, **kwargs)
 
     def __getattr__(self, name):
+        if "_module" not in self.__dict__ or (name.startswith("__") and name.endswith("__")):
+            raise AttributeError(name)
         attr = getattr(self.__dict__["_module"], name)
         if callable(attr) and hasattr(attr, "__self__") and attr.__self__ is self.__dict__["_module"]:
             # a method of the wrapped model that takes tensors (``infer_delta``, ``infer``, ...): same dispatch as __call__

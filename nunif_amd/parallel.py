@@ -55,6 +55,10 @@ def render_sharded(frames, render_fn, group=None, dst=0, bits=8, on_frame=None):
         return None if on_frame is not None else out
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n = len(frames)
+    # dst sizes its receive buffers from ITS OWN frames: unequal frame sizes would corrupt silently, so refuse them up front
+    shapes = {tuple(f.shape) for f in frames if f is not None}
+    if len(shapes) > 1:
+        raise ValueError(f"render_sharded: all frames must have one shape, got {sorted(shapes)}")
     rounds = (n + world - 1) // world
     mine = shard_indices(n, rank, world)
     out = [None] * n

@@ -173,3 +173,38 @@ def test_render_rows_sharded_is_bit_identical_to_the_whole_render(tmp_path):
         got = torch.load(path)
         assert got.shape == ref.shape == (3, 2 * H, 2 * W)
         assert torch.equal(got, ref), (H, W, world)
+
+
+def _nccl_worker(rank, world, port, n_frames, result_path, dst):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    g = torch.Generator().manual_seed(7)
+    frames = [torch.rand(3, 10, 12, generator=g).to(f"cuda:{rank}") for _ in range(n_frames)]
+    out = render_sharded(frames, _fake_render, dst=dst)
+    if rank == dst:
+        torch.save([o.cpu() for o in out], result_path)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_render_sharded_two_gpus_nccl(tmp_path):
+    """The same delivery path under RCCL (lazy per-pair communicators, grouped receives against single sends, buffer lifetime
+    after ``wait``): needs two GPUs, skipped on the one-GPU test box; n not divisible by the world and a dst that owns 0 frames."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    for n_frames, dst in ((5, 0), (1, 1)):
+        path = str(tmp_path / f"nccl_{n_frames}_{dst}.pt")
+        mp.spawn(_nccl_worker, args=(2, _free_port(), n_frames, path, dst), nprocs=2, join=True)
+        got = torch.load(path)
+        g = torch.Generator().manual_seed(7)
+        ref = [to_frame(_fake_render(torch.rand(3, 10, 12, generator=g))) for _ in range(n_frames)]
+        assert len(got) == n_frames and all(torch.equal(a, b) for a, b in zip(got, ref))
