@@ -24,14 +24,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip", "-
 NO_SLP = ["-fno-slp-vectorize"]
 EXTRA_FLAGS = {"stitch.hip": ["-ffp-contract=off"], "iw3_warp.hip": ["-ffp-contract=off"],
                "iw3_depth.hip": ["-ffp-contract=off"], "image_ops.hip": ["-ffp-contract=off"], "swin_block_tail.hip": NO_SLP, "swin_block_tail_ws.hip": NO_SLP, "swin_qkv_attn_r.hip": NO_SLP + ["-fno-honor-nans"], "swin_block96.hip": NO_SLP + ["-fno-honor-nans"],
-               "swin_qkv_attn_w.hip": NO_SLP, "swin_qkv_attn.hip": NO_SLP, "swin_kernels.hip": NO_SLP,
+               "swin_kernels.hip": NO_SLP,
                "cunet_kernels.hip": NO_SLP, "rowflow.hip": NO_SLP, "depth_aa.hip": NO_SLP, "depth_anything.hip": NO_SLP, "conv3_lds.hip": NO_SLP}
-
-
-# NUNIF_BUILD_ABL=1: compile the timing-only ablation variants of the swin kernels (wrong results, selected at run time
-# with NUNIF_TAIL_ABL / NUNIF_TAIL_WS_ABL); never part of a shipping build
-if os.environ.get("NUNIF_BUILD_ABL") == "1":
-    FLAGS.append("-DNUNIF_ABLATIONS")
 
 
 def sources():

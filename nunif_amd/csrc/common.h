@@ -49,6 +49,7 @@ struct ProfScope {
     hipStream_t stream;
 };
 bool profiling_enabled();
+bool profile_tags_enabled();     // NUNIF_PROF_TAGS=1: profiler classes of the generic GEMMs are named after the call site, not the kernel symbol
 
 typedef _Float16 f16;
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
@@ -78,6 +79,27 @@ __device__ __forceinline__ f16x8 pair_to_run(f16x4 a, f16x4 b) {
     const u32x2 r0 = lane16_swap(ai[0], bi[0]);
     const u32x2 r1 = lane16_swap(ai[1], bi[1]);
     return __builtin_bit_cast(f16x8, ((u32x4){r0[0], r1[0], r0[1], r1[1]}));
+}
+
+// max over the four 16-lane rows of a wave (the lanes with equal lane & 15), result in every lane: two register swaps on the
+// VALU (v_permlane16_swap / v_permlane32_swap of a value with its own copy) instead of two ds_bpermute round trips through
+// the LDS crossbar, which sit in the middle of every softmax dependency chain
+__device__ __forceinline__ float row_group_max(float m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // NB: ``__builtin_bit_cast(float, v[1])`` on an ext-vector ELEMENT reads element 0 with hipcc of ROCm 7.2 (the cast takes
+    // the address of the whole vector) — it silently reduced this to a max over lane group 0 only, a stabiliser all lanes still
+    // share, so the softmax stayed right until another group's score exceeded it by 16 (fp16 P overflows -> NaN; one test input
+    // did).  Elements are copied into scalars first.
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(u, u, false, false);       // rows [0,0,2,2] / [1,1,3,3]
+    const unsigned a0 = a[0], a1 = a[1];
+    m = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
+    const unsigned v = __builtin_bit_cast(unsigned, m);
+    const u32x2 b = __builtin_amdgcn_permlane32_swap(v, v, false, false);       // lower halves / upper halves
+    const unsigned b0 = b[0], b1 = b[1];
+    m = fmaxf(__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1));
+#endif
+    return m;
 }
 
 __device__ __forceinline__ void run_to_pair(f16x8 v, f16x4 &a, f16x4 &b) {          // inverse (the swap is an involution)

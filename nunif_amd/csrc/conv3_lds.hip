@@ -277,7 +277,6 @@ bool conv3_lds_applies(const ConvArgs &g) {
                        g.Wo == g.Wi + 2 * pad - 2 && g.zpad <= 1 && g.rpad <= 1 && !(g.zpad && g.rpad) && g.N % 16 == 0 &&
                        (nt == 1 || nt == 2 || nt == 4 || nt == 8);
     if (!conv3_lds_enabled() || !shape) return false;
-    if (g.a2 && getenv("NUNIF_CONV3_A2") && atoi(getenv("NUNIF_CONV3_A2")) == 0) return false;      // A/B switch
     if (g.cmaj) return nt != 1 && (g.cmaj == 64 || g.cmaj == 32) && g.Cin % g.cmaj == 0;     // a chunk-major stream: the split form only
     return g.Cin % 32 == 0 && g.Cin <= 128;
 }
@@ -302,12 +301,11 @@ static int launch_c3(const ConvArgs &g, hipStream_t s, const char *name) {
     const size_t wres = (size_t)9 * (g.Cin >> 5) * NT * 1024;
     const long M = (long)g.B * g.Ho * g.Wo;
     ProfScope ps(name, s, 2.0 * (double)M * 9.0 * g.Cin * g.n_real, (double)M * (g.Cin + g.n_real) * 2.0);
-    static const bool no_res = getenv("NUNIF_CONV3_RESW") && atoi(getenv("NUNIF_CONV3_RESW")) == 0;       // A/B switch
     // resident weights for launches of at most one workgroup per CU (the small maps, where the ring's chunk boundaries are a chain
     // of memory round trips: 23 -> 17 us); on larger grids the 72-KiB copy per workgroup and one resident workgroup per CU cost
     // more than they save (392 patches: 34 vs 26 us), and a persistent form with 18 + 12 loads in flight was no better either
     const long n_tiles = (long)g.B * ((g.Ho + kC3TH - 1) / kC3TH) * ((g.Wo + kC3TW - 1) / kC3TW);
-    if (!no_res && n_tiles <= 256 && halo + wres <= 150 * 1024) return launch_c3r<NT, true>(g, s, halo + wres);
+    if (n_tiles <= 256 && halo + wres <= 150 * 1024) return launch_c3r<NT, true>(g, s, halo + wres);
     return launch_c3r<NT, false>(g, s, halo + 2 * 8 * 1024);
 }
 

@@ -1,4 +1,6 @@
 // Error reporting and the optional HIP-event kernel-class profiler of libnunif_hip.so.
+#include <cstdlib>
+
 #include "common.h"
 
 #include <cstring>
@@ -31,6 +33,10 @@ static std::vector<ProfEvent> g_events;
 static std::vector<hipEvent_t> g_free_events;
 
 bool profiling_enabled() { return g_prof_on; }
+bool profile_tags_enabled() {
+    static const bool on = getenv("NUNIF_PROF_TAGS") != nullptr;
+    return on;
+}
 
 static hipEvent_t get_event() {
     if (!g_free_events.empty()) {

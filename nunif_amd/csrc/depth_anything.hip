@@ -11,8 +11,9 @@
 // padding, pre-activation ReLU and up to two residuals fused).  LayerScale is folded into proj / fc2 on the host, the
 // softmax scale * log2(e) into Wq.  New kernels here:
 //   da_layernorm_kernel   one wave per token (384 channels), fp32 statistics
-//   da_attn_kernel        global softmax attention over 1 + gh*gw tokens, 6 heads of 64: one wave per 16 queries,
-//                         32 keys per step, online softmax; S^T = K Q^T so that exp2(S^T) is directly the P^T operand of
+//   da_attn_lds_kernel    global softmax attention over 1 + gh*gw tokens, heads of 64: one wave per 16 queries, 8 query tiles
+//                         per workgroup sharing K / V through LDS, 32 keys per step, online softmax; S^T = K Q^T so that
+//                         exp2(S^T) is directly the P^T operand of
 //                         O^T = V^T P^T (V^T is written once per layer by da_vt_kernel, so every operand is a 16-byte
 //                         per-lane load); the key -> MFMA-row permutation that makes P^T's k-slots contiguous keys is
 //                         free because the K fragment is a per-lane row gather
@@ -110,176 +111,14 @@ __device__ __forceinline__ f16x8 cat8a(f16x4 lo, f16x4 hi) {
     return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-// grid (ceil(Np/16)/4 rounded up, heads, B), 4 waves per workgroup = 4 query tiles
-__global__ void __launch_bounds__(256) da_attn_kernel(const f16 *__restrict__ qkv, const f16 *__restrict__ vt,
-                                                      f16 *__restrict__ att, int Np, int Tp, int kD, int kHeads) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, grp = lane >> 4;
-    const int qt = blockIdx.x * 4 + wave;
-    if (qt * 16 >= Np) return;
-    const int hh = blockIdx.y, b = blockIdx.z;
-    const f16 *base = qkv + (long)b * Np * (3 * kD);
-    const int q = min(qt * 16 + r16, Np - 1);
-    f16x8 qf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-        qf[ks] = *reinterpret_cast<const f16x8 *>(base + (long)q * (3 * kD) + hh * kHd + 32 * ks + 8 * grp);
-    const f16 *vbase = vt + ((long)(b * kHeads + hh) * kHd) * Tp;
-    f32x4 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -1.0e30f, l_run = 0.f;
-    // MFMA row i of key tile 0 / 1 <-> key k0 + 8*(i>>2) + (i&3) [+ 4]: lane's 8 P^T slots are then keys k0 + 8g + 0..7
-    const int krow = 8 * (r16 >> 2) + (r16 & 3);
-    for (int k0 = 0; k0 < Tp; k0 += 32) {
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-        const int ka = min(k0 + krow, Np - 1), kb = min(k0 + krow + 4, Np - 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const f16x8 k_a = *reinterpret_cast<const f16x8 *>(base + (long)ka * (3 * kD) + kD + hh * kHd + 32 * ks + 8 * grp);
-            const f16x8 k_b = *reinterpret_cast<const f16x8 *>(base + (long)kb * (3 * kD) + kD + hh * kHd + 32 * ks + 8 * grp);
-            s0 = MFMA_16x16x32(k_a, qf[ks], s0);
-            s1 = MFMA_16x16x32(k_b, qf[ks], s1);
-        }
-        // accumulator row 4g+r of tile 0 is key k0 + 8g + r, of tile 1 key k0 + 8g + 4 + r
-        float mx = -1.0e30f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (k0 + 8 * grp + r >= Np) s0[r] = -1.0e30f;
-            if (k0 + 8 * grp + 4 + r >= Np) s1[r] = -1.0e30f;
-            mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float p[8], sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            p[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-            p[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
-            sum += p[r] + p[4 + r];
-        }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        l_run = l_run * alpha + sum;
-        m_run = m_new;
-        const f16x8 pf = {(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3], (f16)p[4], (f16)p[5], (f16)p[6], (f16)p[7]};
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const f16x8 vf = *reinterpret_cast<const f16x8 *>(vbase + (long)(dt * 16 + r16) * Tp + k0 + 8 * grp);
-            o[dt] = (f32x4){o[dt][0] * alpha, o[dt][1] * alpha, o[dt][2] * alpha, o[dt][3] * alpha};
-            o[dt] = MFMA_16x16x32(vf, pf, o[dt]);
-        }
-    }
-    if (qt * 16 + r16 < Np) {
-        const float inv = 1.0f / l_run;
-        f16 *dst = att + ((long)b * Np + qt * 16 + r16) * kD + hh * kHd + 4 * grp;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<f16x4 *>(dst + dt * 16) =
-                (f16x4){(f16)(o[dt][0] * inv), (f16)(o[dt][1] * inv), (f16)(o[dt][2] * inv), (f16)(o[dt][3] * inv)};
-    }
-}
-
-// Split-key form of da_attn_kernel: ONE 16-query tile per workgroup, its 4 waves take a quarter of the keys each (online
-// softmax per wave), then merge (m, l, O) through LDS — wave w finishes channels 16w..16w+15.  Why: with one wave per query
-// tile the launch is 1032 waves for B = 2 at 392 x 686 (one per SIMD) and every one of its 43 key steps exposes two dependent
-// global-load latencies (measured 59.7 us per launch = 97 TFLOP/s, profiles/r01d_kernel_stats_iw3_sched.csv); here the same
-// launch is 4128 waves (4 per SIMD) of 11 key steps.  grid (ceil(Np/16), heads, B).
-__global__ void __launch_bounds__(256) da_attn_split_kernel(const f16 *__restrict__ qkv, const f16 *__restrict__ vt,
-                                                            f16 *__restrict__ att, int Np, int Tp, int kD, int kHeads) {
-    __shared__ float sh_o[4][64][17];          // [wave][channel][query] (+1: no bank conflicts on the column reads)
-    __shared__ float sh_m[4][16], sh_l[4][16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, grp = lane >> 4;
-    const int qt = blockIdx.x;
-    const int hh = blockIdx.y, b = blockIdx.z;
-    const f16 *base = qkv + (long)b * Np * (3 * kD);
-    const int q = min(qt * 16 + r16, Np - 1);
-    f16x8 qf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-        qf[ks] = *reinterpret_cast<const f16x8 *>(base + (long)q * (3 * kD) + hh * kHd + 32 * ks + 8 * grp);
-    const f16 *vbase = vt + ((long)(b * kHeads + hh) * kHd) * Tp;
-    f32x4 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -1.0e30f, l_run = 0.f;
-    const int krow = 8 * (r16 >> 2) + (r16 & 3);
-    const int steps = Tp / 32, per = (steps + 3) / 4;
-    const int k_begin = wave * per * 32, k_end = min((wave + 1) * per, steps) * 32;
-    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-        const int ka = min(k0 + krow, Np - 1), kb = min(k0 + krow + 4, Np - 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const f16x8 k_a = *reinterpret_cast<const f16x8 *>(base + (long)ka * (3 * kD) + kD + hh * kHd + 32 * ks + 8 * grp);
-            const f16x8 k_b = *reinterpret_cast<const f16x8 *>(base + (long)kb * (3 * kD) + kD + hh * kHd + 32 * ks + 8 * grp);
-            s0 = MFMA_16x16x32(k_a, qf[ks], s0);
-            s1 = MFMA_16x16x32(k_b, qf[ks], s1);
-        }
-        float mx = -1.0e30f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (k0 + 8 * grp + r >= Np) s0[r] = -1.0e30f;
-            if (k0 + 8 * grp + 4 + r >= Np) s1[r] = -1.0e30f;
-            mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float p[8], sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            p[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-            p[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
-            sum += p[r] + p[4 + r];
-        }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        l_run = l_run * alpha + sum;
-        m_run = m_new;
-        const f16x8 pf = {(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3], (f16)p[4], (f16)p[5], (f16)p[6], (f16)p[7]};
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const f16x8 vf = *reinterpret_cast<const f16x8 *>(vbase + (long)(dt * 16 + r16) * Tp + k0 + 8 * grp);
-            o[dt] = (f32x4){o[dt][0] * alpha, o[dt][1] * alpha, o[dt][2] * alpha, o[dt][3] * alpha};
-            o[dt] = MFMA_16x16x32(vf, pf, o[dt]);
-        }
-    }
-    // lane holds O^T[channel dt*16 + 4*grp + r][query r16]; m_run / l_run are per query (identical in the 4 lane groups)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sh_o[wave][dt * 16 + 4 * grp + r][r16] = o[dt][r];
-    if (grp == 0) { sh_m[wave][r16] = m_run; sh_l[wave][r16] = l_run; }
-    __syncthreads();
-    // merge: wave w owns channels 16w .. 16w+15; lane -> (channel 16w + 4*grp + r, query r16)
-    const float m_all = fmaxf(fmaxf(sh_m[0][r16], sh_m[1][r16]), fmaxf(sh_m[2][r16], sh_m[3][r16]));
-    float sc[4], l_all = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        sc[w] = __builtin_amdgcn_exp2f(sh_m[w][r16] - m_all);      // a wave whose keys were all masked has m = -1e30 -> 0
-        l_all += sh_l[w][r16] * sc[w];
-    }
-    if (qt * 16 + r16 < Np) {
-        const float inv = 1.0f / l_all;
-        f16x4 ov;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ch = wave * 16 + 4 * grp + r;
-            const float v = sh_o[0][ch][r16] * sc[0] + sh_o[1][ch][r16] * sc[1] + sh_o[2][ch][r16] * sc[2] + sh_o[3][ch][r16] * sc[3];
-            ov[r] = (f16)(v * inv);
-        }
-        *reinterpret_cast<f16x4 *>(att + ((long)b * Np + qt * 16 + r16) * kD + hh * kHd + wave * 16 + 4 * grp) = ov;
-    }
-}
-
+// (Rounds 1-2 went through two earlier forms, both deleted: one wave per 16-query tile reading K / V straight from L2 (59.7 us
+//  per launch for B = 2 at 392 x 686: 1 032 waves, two dependent load latencies per key step) and a split-key form that gave one
+//  query tile to a workgroup of 4 waves (-4.5 % on the iw3 frame).  Both pulled 8 KiB of K / V per wave and key step through the
+//  vector memory pipe for 8 MFMAs: that pipe, not the matrix pipe, was the bound — 155 TFLOP/s.)
 // K / V shared through LDS: a workgroup of 8 waves = 8 query tiles (128 queries) walks the keys together; the 8 operand
 // fragments of a 32-key step (K rows in MFMA row order for both key tiles x 2 k-steps, V^T for the 4 channel tiles) are loaded
 // ONCE per workgroup — one 16-byte load per thread — into a double-buffered 8-KiB LDS slot, and every wave reads them from there.
-// Why: in the two kernels above every wave pulls its own 8 KiB of K / V per step through the vector memory pipe for 8 MFMAs; at
-// 64 B / clk / CU that pipe, not the matrix pipe, was the bound (measured 155 TFLOP/s).  grid (ceil(Np / 128), heads, B).
+// grid (ceil(Np / 128), heads, B).
 __global__ void __launch_bounds__(512) da_attn_lds_kernel(const f16 *__restrict__ qkv, const f16 *__restrict__ vt,
                                                           f16 *__restrict__ att, int Np, int Tp, int kD, int kHeads) {
     __shared__ __attribute__((aligned(16))) f16x8 kv[2][8][64];
@@ -836,18 +675,8 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         NUNIF_LAUNCH_CHECK();
         {
             ProfScope ps("da_attn_kernel", s, 4.0 * B * (double)Np * Np * kD, (double)T * kD * 8.0);
-            static const bool split = []() { const char *e = getenv("NUNIF_DA_ATTN_SPLIT"); return e ? atoi(e) != 0 : true; }();
-            static const bool shared = []() { const char *e = getenv("NUNIF_DA_ATTN_LDS"); return e ? atoi(e) != 0 : true; }();
-            if (shared) {
-                dim3 grid((unsigned)(((Np + 15) / 16 + 7) / 8), kHeads, B);
-                da_attn_lds_kernel<<<grid, 512, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
-            } else if (split) {
-                dim3 grid((unsigned)((Np + 15) / 16), kHeads, B);
-                da_attn_split_kernel<<<grid, 256, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
-            } else {
-                dim3 grid((unsigned)(((Np + 15) / 16 + 3) / 4), kHeads, B);
-                da_attn_kernel<<<grid, 256, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
-            }
+            dim3 grid((unsigned)(((Np + 15) / 16 + 7) / 8), kHeads, B);
+            da_attn_lds_kernel<<<grid, 512, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
             NUNIF_LAUNCH_CHECK();
         }
         if ((rc = run_tok(bk.proj, att, T, 0, t, t, s, "da_proj"))) return rc;        // t += ls1 * proj(att)

@@ -413,7 +413,7 @@ extern "C" int nunif_hip_resize_aa(const float *x, float *y, float *tmp, int64_t
     return NUNIF_HIP_OK;
 }
 
-static const long kStatBlocks = []() { const char *e = getenv("NUNIF_STAT_BLOCKS"); return e ? atol(e) : 96L; }();
+static const long kStatBlocks = 96L;      // workgroups of the min / max statistics kernels (r01d: 96 beat 32 and 256)
 
 namespace {
 constexpr long kFirstStatBlocks = 512;

@@ -68,21 +68,6 @@ __device__ __forceinline__ void tok_yx(int t, int &iy, int &ix) {
     ix = 2 * bx + (e & 1);
 }
 
-// max over the four 16-lane rows of a wave (the lanes lane & 15 == const), result in every lane: two register swaps on
-// the VALU (v_permlane16_swap / v_permlane32_swap of a value with its own copy) instead of two ds_bpermute round trips
-// through the LDS crossbar, which sat in the middle of every softmax dependency chain
-__device__ __forceinline__ float row_group_max(float m) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned u = __builtin_bit_cast(unsigned, m);
-    const u32x2 a = __builtin_amdgcn_permlane16_swap(u, u, false, false);       // rows [0,0,2,2] / [1,1,3,3]
-    m = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
-    const unsigned v = __builtin_bit_cast(unsigned, m);
-    const u32x2 b = __builtin_amdgcn_permlane32_swap(v, v, false, false);       // lower halves / upper halves
-    m = fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
-#endif
-    return m;
-}
-
 // lane-wise merge of lanes 0..3 of every 16-lane row of `src` into lanes 4 SLOT .. 4 SLOT + 3 of `old`
 template <int SLOT>
 __device__ __forceinline__ unsigned merge_u32(unsigned old, unsigned src) {

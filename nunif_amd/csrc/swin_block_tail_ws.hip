@@ -350,19 +350,7 @@ int launch_proj_mlp_ws(const f16 *att, f16 *x, const f16 *wws, const float *bp, 
         return NUNIF_HIP_OK;
     };
     int rc;
-#ifdef NUNIF_ABLATIONS
-    static const int abl = getenv("NUNIF_TAIL_WS_ABL") ? atoi(getenv("NUNIF_TAIL_WS_ABL")) : 0;
-    switch (abl) {
-#define WS_ABL_CASE(v) case v: rc = go(proj_mlp_ws_kernel<v>, v); break;
-        WS_ABL_CASE(1) WS_ABL_CASE(2) WS_ABL_CASE(3) WS_ABL_CASE(4) WS_ABL_CASE(7) WS_ABL_CASE(8) WS_ABL_CASE(12)
-        WS_ABL_CASE(16) WS_ABL_CASE(32) WS_ABL_CASE(48) WS_ABL_CASE(112) WS_ABL_CASE(23) WS_ABL_CASE(39) WS_ABL_CASE(55)
-        WS_ABL_CASE(119) WS_ABL_CASE(127) WS_ABL_CASE(256) WS_ABL_CASE(257) WS_ABL_CASE(258) WS_ABL_CASE(259)
-#undef WS_ABL_CASE
-        default: rc = go(proj_mlp_ws_kernel<0>, 0); break;
-    }
-#else
-    rc = go(proj_mlp_ws_kernel<0>, 0);
-#endif
+    rc = go(proj_mlp_ws_kernel<0>, 0);       // ABL != 0 instantiations are timing-only experiments (see the kernel header), never shipped
     if (rc) return rc;
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;

@@ -107,22 +107,14 @@ int proj_mlp_ws_stream_frags();
 int launch_proj_mlp_ws(const f16 *att, f16 *x, const f16 *wws, const float *bp, const float *b0, const float *b3, long M,
                        hipStream_t s, int rev = 0);
 
-// ---- fused qkv Linear + (shifted) window attention, C = 96 / 6 heads of 16 (swin_qkv_attn.hip) ---------------------
-// x: [B,H,W,C] -> att: [B,H,W,C] (pre-projection attention output at the un-rolled positions)
-int launch_qkv_attn(const f16 *x, f16 *att, const f16 *wqkv, const float *bqkv, const float *bias, int B, int H,
-                    int W, int C, int heads, int shift, hipStream_t s);
-
-// ---- fused qkv Linear + window attention, one window per wave, C = 96 or 192 (swin_qkv_attn_w.hip) ----------------
-// wstream: per head Wq | Wk | Wv fragments in consumption order (assembled in make_stage, swin_unet.cpp)
-int qkv_attn_w_stream_frags(int C);
-// ---- same, qkv weights resident in LDS, no barrier in the window loop (swin_qkv_attn_r.hip) -------------------------
-// btab: fp16 [heads][36][48] one-hot-MFMA bias table (NUNIF_ATTN_CBIAS=0); btab32: fp32 [heads][36][52] C-operand table
+// ---- fused qkv Linear + (shifted) 6x6 window attention, one window per wave, qkv weights resident in LDS, no barrier in the
+// window loop (swin_qkv_attn_r.hip); C = 96 (6 heads of 16) or 192 (6 heads of 32).  x: [B,H,W,C] -> att: [B,H,W,C]
+// (pre-projection attention output at the un-rolled positions); wres: per head Wq | Wk | Wv fragments, q pre-scaled;
+// btab32: fp32 [heads][36][52] C-operand table
 // window_major = 1 (C = 96): att is written as [window][head][36][16] — every store instruction covers one contiguous
 // 512-byte run; launch_proj_mlp's WinMap reads it back in the same order
-int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, const float *btab32,
+int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const float *btab32,
                       int B, int H, int W, int C, int heads, int shift, hipStream_t s, int rev = 0, int window_major = 0);
-int launch_qkv_attn_w(const f16 *x, f16 *att, const f16 *wstream, const float *bqkv, const float *bias, int B, int H,
-                      int W, int C, int heads, int shift, hipStream_t s);
 
 // ---- (shifted) 6x6 window attention on a fused qkv map ----------------------------------------------------------
 // qkv: [B,H,W,3C] fp16 (q | k | v, each heads x hd), out: [B,H,W,C]; bias: [heads][36][48] fp32 with the

@@ -397,10 +397,10 @@ static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym,
     const long M = (long)g.B * g.Ho * g.Wo;
     const size_t wbytes = (size_t)(g.N / 16) * KS * 1024;
     // resident weights pay where the ring's one-chunk-ahead prefetch is too short (MF = 2: K = 384, 576); measured
-    // slower for the MF = 4 shapes (K = 96, 192), which keep the ring.  NUNIF_GEMM_RING=1 / NUNIF_GEMM_RES=1 force one.
-    static const bool force_ring = getenv("NUNIF_GEMM_RING") != nullptr, force_res = getenv("NUNIF_GEMM_RES") != nullptr;
+    // slower for the MF = 4 shapes (K = 96, 192), which keep the ring (re-checked at the end of round 2: PatchDown through the
+    // ring 134 us, resident 112 us).
     const bool fits = wbytes <= 144 * 1024 && M >= 8 * MF * 16 * 64;
-    const bool res = fits && !force_ring && !ring_only && (MF == 2 || force_res);
+    const bool res = fits && !ring_only && MF == 2;
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
     // (NUNIF_PROF_TAGS=1 names the class after the call site instead: separates e.g. the two gemm_kernel<6,4> users)
     ProfScope ps(g_prof_tag ? g_prof_tag : res ? res_sym : ring_sym, s, flops, bytes);
@@ -441,8 +441,7 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
                   "gemm %s: NHWC outputs are written in 32-channel pairs (N=%d n_real=%d ldo=%d)", tag, g.N, g.n_real, g.ldo);
     const long M = (long)g.B * g.Ho * g.Wo;
     if (M == 0) return NUNIF_HIP_OK;
-    static const bool prof_tags = getenv("NUNIF_PROF_TAGS") != nullptr;
-    g_prof_tag = prof_tags ? tag : nullptr;
+    g_prof_tag = profile_tags_enabled() ? tag : nullptr;
     const double flops = 2.0 * (double)M * g.K * g.n_real;
     const double bytes = (double)M * (g.Cin * 2.0 * (g.K / g.Cin > 1 ? 1.0 : 1.0) + g.n_real * (g.mode == 2 ? 4.0 : 2.0) +
                                       (g.res ? g.n_real * 2.0 : 0.0));
@@ -455,9 +454,8 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
             // PatchUp (mode 1 with the skip as residual) is HBM-bound and exposes the latency of its residual reads: with 2 token
             // tiles per wave the kernel needs 156 instead of 252 registers, so 3 workgroups per CU are resident and hide it
             // (measured, both PatchUps of the 2x net: 604 -> 529 us; the resident-weight form of the same shape was slower: 381 vs
-            // 340 us on PatchUp 1).  NUNIF_GEMM6_MF=4 restores the 4-tile form.
-            static const int mf6 = getenv("NUNIF_GEMM6_MF") ? atoi(getenv("NUNIF_GEMM6_MF")) : 2;
-            if (mf6 == 2 && g.mode == 1 && g.res)
+            // 340 us on PatchUp 1).
+            if (g.mode == 1 && g.res)
                 return launch_gemm_t<6, 2>(g, s, "gemm_kernel<6,2>", "gemm_res_kernel<6,2>", flops, bytes, true);
             return launch_gemm_t<6, 4>(g, s, "gemm_kernel<6,4>", "gemm_res_kernel<6,4>", flops, bytes);
         }
@@ -574,21 +572,18 @@ __global__ void __launch_bounds__(256) gemm_os_kernel(GemmOsArgs g) {
 }
 
 bool gemm_os_supported(long M, int N, int K) {
-    static const bool off = getenv("NUNIF_GEMM_OS") && atoi(getenv("NUNIF_GEMM_OS")) == 0;       // A/B switch
-    return !off && M > 0 && N % 128 == 0 && K % 128 == 0 && K >= 128;
+    return M > 0 && N % 128 == 0 && K % 128 == 0 && K >= 128;
 }
 
 int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag) {
     NUNIF_REQUIRE(gemm_os_supported(g.M, g.N, g.K) && g.lda % 8 == 0 && g.ldo % 8 == 0, "gemm_os %s: M=%ld N=%d K=%d unsupported",
                   tag, g.M, g.N, g.K);
-    static const bool prof_tags = getenv("NUNIF_PROF_TAGS") != nullptr;
-    ProfScope ps(prof_tags ? tag : "gemm_os_kernel", s, 2.0 * (double)g.M * g.K * g.N,
+    ProfScope ps(profile_tags_enabled() ? tag : "gemm_os_kernel", s, 2.0 * (double)g.M * g.K * g.N,
                  (double)g.M * (g.K * 2.0 + g.N * 2.0 * (g.res ? 2.0 : 1.0)));
     // 32-token workgroups (fewer registers, more resident waves to hide the short K loop's prologue) unless 64-token ones already
     // give the chip four workgroups per CU; measured on ViT-S (5 492 tokens): fc1 0.339 -> 0.315 ms, fc2 0.345 -> 0.313 ms per 12 launches
-    static const int force_mt = getenv("NUNIF_GEMM_OS_MT") ? atoi(getenv("NUNIF_GEMM_OS_MT")) : 0;
     const long blocks = ((g.M + 63) / 64) * (g.N / 128);
-    if (force_mt == 2 || (force_mt == 0 && blocks < 1100)) {
+    if (blocks < 1100) {
         gemm_os_kernel<2><<<(unsigned)(((g.M + 31) / 32) * (g.N / 128)), 256, 0, s>>>(g);
     } else {
         gemm_os_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(g);

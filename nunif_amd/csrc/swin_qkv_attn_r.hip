@@ -3,13 +3,13 @@
 // Replaces torchvision shifted_window_attention steps 2-7 (roll, window partition, qkv Linear,
 // q*scale, QK^T + relative-position bias + shift mask, softmax, PV), called from waifu2x/models/swin_unet.py:26-36.
 //
-// Same math and register dataflow as swin_qkv_attn_w.hip (one window per wave, everything after the GEMM in registers,
-// bias / padding / shift-region masks folded into the score MFMA).  What changed, and why (measured):
-// the ring version needs one workgroup barrier per 8 weight fragments, which keeps the two waves of a SIMD in lock
-// step — both in their MFMA phase or both in their softmax (VALU) phase — and 40 % of the wave cycles were waits.
-// 160 KB of LDS per CU holds the whole packed Wqkv of C = 96 (54 KiB) and half of the heads of C = 192 (108 KiB), so
-// here a persistent 8-wave workgroup copies the weights once (per pass of HPP heads), and the window loop has NO
-// barrier: waves drift apart and one wave's exp/convert work overlaps the other's MFMAs.
+// One window per wave, everything after the GEMM in registers, bias / padding / shift-region masks folded into the score
+// MFMA.  (History, DESIGN.md §6: a round-1 version streamed the weights through an LDS ring with one workgroup barrier per
+// 8 fragments, which kept the two waves of a SIMD in lock step — both in their MFMA phase or both in their softmax
+// (VALU) phase — and 40 % of the wave cycles were waits.)  160 KB of LDS per CU holds the whole packed Wqkv of C = 96
+// (54 KiB) and half of the heads of C = 192 (108 KiB), so a persistent workgroup copies the weights once (per pass of
+// HPP heads), and the window loop has NO barrier: waves drift apart and one wave's exp/convert work overlaps the
+// other's MFMAs.
 //   * q weights / bias are pre-multiplied by head_dim^-0.5 * log2(e) on the host and the bias table by log2(e):
 //     softmax = exp2(s - max) with a bare v_exp_f32, no multiply;
 //   * the qkv biases initialise the accumulators (no epilogue add);
@@ -32,14 +32,9 @@ struct QkvAttnRArgs {
     f16 *att;                // [B,H,W,C]
     const f16 *wres;         // per head: Wq tiles, Wk tiles, Wv tiles, each (nt, ks) fragment-major; q pre-scaled
     const float *bqkv;       // [3C], q part pre-scaled
-    const f16 *btab;         // [heads][36][48] fp16: log2e * relative-position bias, col 36 = BIG, cols 37.. = 0
-    const float *btab32;     // CBIAS: [heads][36][52] fp32: log2e * bias, cols 36..47 = -1000 (padded keys), 48..51 unused
+    const float *btab32;     // [heads][36][52] fp32: log2e * bias, cols 36..47 = -1000 (padded keys), 48..51 unused
     int B, H, W, shift, n_windows;
     int rev;                 // 1: walk the windows from the last to the first (snake order, see launch_qkv_attn_r)
-    int wm;                  // 1: att is written WINDOW-major / head-major, [window][head][36 tokens][HD] (C = 96 tail reads it so)
-#ifdef NUNIF_ABLATIONS
-    int abl;                 // timing-only (NUNIF_ATTN_ABL): 1 = x is loaded for the first window of a wave only, 2 = no att stores
-#endif
 };
 
 __device__ __forceinline__ f16x8 cat8r(f16x4 lo, f16x4 hi) {
@@ -48,12 +43,12 @@ __device__ __forceinline__ f16x8 cat8r(f16x4 lo, f16x4 hi) {
 
 constexpr int kBiasStride = 52;        // fp32 row stride of the CBIAS table: 16 lanes x 16 B land in 16 distinct bank quads
 
-// CBIAS (default): the score accumulators are INITIALISED from an fp32 bias table in LDS (relative-position bias and
+// The score accumulators are INITIALISED from an fp32 bias table in LDS (relative-position bias and
 // the padded-key mask are the MFMA C operand), the softmax denominator comes from one MFMA against a ones fragment, and
 // the shift-region term rides in the unused half of the K = 32 step (head_dim 16) or in one extra MFMA that only the
 // windows of the last row / column issue (head_dim 32).  Per head this removes 9 (hd 16) / 18 (hd 32) one-hot MFMAs and
 // ~45 VALU instructions; MFMA and VALU do not overlap on a SIMD, so both count.
-template <int C, int HD, int HPP, bool PREFETCH, bool CBIAS, int WAVES = 8>
+template <int C, int HD, int HPP, bool PREFETCH, int WAVES = 8, bool WM = false>
 __global__ void __launch_bounds__(WAVES * 64)
 qkv_attn_r_kernel(QkvAttnRArgs a) {
     constexpr int kWavesR = WAVES;
@@ -66,9 +61,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     static_assert(HEADS == 6 && HEADS % HPP == 0, "swin_unet uses 6 heads at every level");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
     f16x8 *wl = reinterpret_cast<f16x8 *>(smem_r);                                   // [HPP*FPH][64]
-    f16 *bt = reinterpret_cast<f16 *>(wl + HPP * FPH * 64);                          // [HEADS][36][48]
-    float *bt32 = reinterpret_cast<float *>(wl + HPP * FPH * 64);                    // CBIAS: [HPP][36][52]
-    float *bl = CBIAS ? bt32 + HPP * 36 * kBiasStride : reinterpret_cast<float *>(bt + HEADS * 36 * 48);   // [3C]
+    float *bt32 = reinterpret_cast<float *>(wl + HPP * FPH * 64);                    // [HPP][36][52]
+    float *bl = bt32 + HPP * 36 * kBiasStride;                                       // [3C]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,26 +72,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     const int nwx = a.W / 6, nwy = a.H / 6;
     const f16x4 zero4 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
 
-    if constexpr (!CBIAS)
-        for (int i = tid; i < HEADS * 36 * 48 / 8; i += NTHR)
-            reinterpret_cast<f16x8 *>(bt)[i] = reinterpret_cast<const f16x8 *>(a.btab)[i];
     for (int i = tid; i < 3 * C; i += NTHR) bl[i] = a.bqkv[i];
     const f16x8 ones8 = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
-
-    // window-invariant part of the key-side one-hot fragments (cols < 36: k_loc == col; col 36: real key)
-    f16x4 rk[CBIAS ? 1 : 3][3];
-#pragma unroll
-    for (int mt = 0; mt < (CBIAS ? 0 : 3); ++mt) {
-        const int tok = 16 * mt + r16;
-#pragma unroll
-        for (int js = 0; js < 3; ++js)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = 16 * js + 4 * grp + j;
-                const bool one = col < 36 ? tok == col : (col == 36 ? tok < 36 : false);
-                rk[mt][js][j] = (f16)(one ? 1.f : 0.f);
-            }
-    }
 
     auto pix_of = [&](int wi, int t) -> long {       // window-local token -> pixel of the un-rolled map
         const int wx = wi % nwx, t2 = wi / nwx;
@@ -131,10 +107,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
         {
             const f16x8 *src = reinterpret_cast<const f16x8 *>(a.wres) + (long)pass * HPP * FPH * 64;
             for (int i = tid; i < HPP * FPH * 64; i += NTHR) wl[i] = src[i];
-            if constexpr (CBIAS) {
-                const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.btab32 + (long)pass * HPP * 36 * kBiasStride);
-                for (int i = tid; i < HPP * 36 * kBiasStride / 4; i += NTHR) reinterpret_cast<f32x4 *>(bt32)[i] = bsrc[i];
-            }
+            const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.btab32 + (long)pass * HPP * 36 * kBiasStride);
+            for (int i = tid; i < HPP * 36 * kBiasStride / 4; i += NTHR) reinterpret_cast<f32x4 *>(bt32)[i] = bsrc[i];
         }
         __syncthreads();
 
@@ -215,7 +189,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     const int tokq = min(16 * qt + r16, 35);
                     f32x4 s[3];
                     float mx = -3.0e38f;
-                    if constexpr (CBIAS) {
+                    {
                         const float *brow = bt32 + (hl * 36 + tokq) * kBiasStride + 4 * grp;
 #pragma unroll
                         for (int kt = 0; kt < 3; ++kt) {
@@ -231,53 +205,24 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                         mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
                                    fmaxf(fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])),
                                          fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3]))));
-                    } else {
-                        const f16 *brow = &bt[(head * 36 + tokq) * 48];
-                        const f16x4 rq0 = *reinterpret_cast<const f16x4 *>(brow + 4 * grp);
-                        const f16x4 rq1 = *reinterpret_cast<const f16x4 *>(brow + 16 + 4 * grp);
-                        const f16x4 rq2 = *reinterpret_cast<const f16x4 *>(brow + 32 + 4 * grp) + rqr[qt];
-#pragma unroll
-                        for (int kt = 0; kt < 3; ++kt) {
-                            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                            const f16x4 rk2 = rk[kt][2] + rkr[kt];
-                            if constexpr (HD == 16) {
-                                acc = MFMA_16x16x32(cat8r(kt4[0][kt], rk[kt][0]), cat8r(qt4[0][qt], rq0), acc);
-                                acc = MFMA_16x16x32(cat8r(rk[kt][1], rk2), cat8r(rq1, rq2), acc);
-                            } else {
-                                acc = MFMA_16x16x32(cat8r(kt4[0][kt], kt4[1][kt]), cat8r(qt4[0][qt], qt4[1][qt]), acc);
-                                acc = MFMA_16x16x32(cat8r(rk[kt][0], rk[kt][1]), cat8r(rq0, rq1), acc);
-                                acc = MFMA_16x16x32(cat8r(rk2, zero4), cat8r(rq2, zero4), acc);
-                            }
-                            s[kt] = acc;
-                            mx = fmaxf(mx, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
-                        }
                     }
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    mx = row_group_max(mx);
                     float sum = 0.f;
                     f16x4 pf[3];
 #pragma unroll
                     for (int kt = 0; kt < 3; ++kt) {
                         const float p0 = __builtin_amdgcn_exp2f(s[kt][0] - mx), p1 = __builtin_amdgcn_exp2f(s[kt][1] - mx);
                         const float p2 = __builtin_amdgcn_exp2f(s[kt][2] - mx), p3 = __builtin_amdgcn_exp2f(s[kt][3] - mx);
-                        if constexpr (!CBIAS) sum += (p0 + p1) + (p2 + p3);
                         pf[kt] = (f16x4){(f16)p0, (f16)p1, (f16)p2, (f16)p3};
                     }
-                    if constexpr (CBIAS) {
+                    {
                         // denominator = sum of the fp16 probabilities the PV product actually uses: ones x P on the MFMA
                         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
                         const f32x4 sm = MFMA_16x16x32(ones8, cat8r(pf[0] + pf[1], pf[2]), z4);
                         sum = sm[0];
-                    } else {
-                        sum += __shfl_xor(sum, 16);
-                        sum += __shfl_xor(sum, 32);
                     }
                     const float inv = __builtin_amdgcn_rcpf(sum);
-#ifdef NUNIF_ABLATIONS
-                    const bool store = (16 * qt + r16) < 36 && !(a.abl & 2);
-#else
                     const bool store = (16 * qt + r16) < 36;
-#endif
                     // 16-byte stores: two adjacent 16-channel tiles -> one 8-channel run per lane (common.h pair_to_run).
                     // head_dim 32: the two tiles of this head.
                     f16x4 ov[NTH];
@@ -294,10 +239,10 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     } else {
                         // head_dim 16: pairing with the neighbouring head's tile (held across one trip of the head loop)
                         // was measured slower (504 vs 457 us): plain 8-byte stores
-                        // window-major map (a.wm): the 64 lanes of this store cover ONE contiguous 512-byte run (16 tokens x 32 B)
+                        // window-major map (WM: att is [window][head][36 tokens][HD], the C = 96 tail reads it so): the 64 lanes of this store cover ONE contiguous 512-byte run (16 tokens x 32 B)
                         // instead of sixteen 8-byte pieces 192 B apart (1.48x write amplification in the r02 counters)
-                        f16 *dst = a.wm ? a.att + ((long)(wmap(wi) * HEADS + head) * 36 + 16 * qt + r16) * HD + 4 * grp
-                                        : a.att + pix[qt] * C + head * HD + 4 * grp;
+                        f16 *dst = WM ? a.att + ((long)(wmap(wi) * HEADS + head) * 36 + 16 * qt + r16) * HD + 4 * grp
+                                      : a.att + pix[qt] * C + head * HD + 4 * grp;
                         if (store) *reinterpret_cast<f16x4 *>(dst) = ov[0];
                     }
                 }
@@ -311,9 +256,6 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = xn[mt][ks];
                 }
             } else {
-#ifdef NUNIF_ABLATIONS
-                if (a.abl & 1) continue;
-#endif
                 if (wi + wstride < a.n_windows) load_x(wmap(wi + wstride), xf, pix);
             }
         }
@@ -322,53 +264,44 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
 
 int qkv_attn_r_frags(int C) { return 3 * (C / 16) * (C / 32); }
 
-template <int C, int HD, int HPP, bool PREFETCH, bool CBIAS, int WAVES = 8>
+template <int C, int HD, int HPP, bool PREFETCH, int WAVES = 8, bool WM = false>
 static int launch_r(const QkvAttnRArgs &a, int grid, hipStream_t s) {
-    constexpr size_t smem = (size_t)HPP * 3 * (HD / 16) * (C / 32) * 1024 +
-                            (CBIAS ? HPP * 36 * kBiasStride * 4 : 6 * 36 * 48 * 2) + 3 * C * 4;
+    constexpr size_t smem = (size_t)HPP * 3 * (HD / 16) * (C / 32) * 1024 + HPP * 36 * kBiasStride * 4 + 3 * C * 4;
     static bool configured = false;
     if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)qkv_attn_r_kernel<C, HD, HPP, PREFETCH, CBIAS, WAVES>,
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)qkv_attn_r_kernel<C, HD, HPP, PREFETCH, WAVES, WM>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = true;
     }
-    qkv_attn_r_kernel<C, HD, HPP, PREFETCH, CBIAS, WAVES><<<grid, WAVES * 64, smem, s>>>(a);
+    qkv_attn_r_kernel<C, HD, HPP, PREFETCH, WAVES, WM><<<grid, WAVES * 64, smem, s>>>(a);
     return NUNIF_HIP_OK;
 }
 
-int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const f16 *btab, const float *btab32,
+int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const float *btab32,
                       int B, int H, int W, int C, int heads, int shift, hipStream_t s, int rev, int window_major) {
     NUNIF_REQUIRE(H % 6 == 0 && W % 6 == 0, "qkv_attn: %dx%d not a multiple of the 6x6 window", H, W);
     NUNIF_REQUIRE(heads == 6 && (C == 96 || C == 192), "qkv_attn: C=%d heads=%d unsupported", C, heads);
     if (H <= 6) shift = 0;                 // torchvision disables the shift when the window covers the map
     QkvAttnRArgs a;
-    a.x = x; a.att = att; a.wres = wres; a.bqkv = bqkv; a.btab = btab; a.btab32 = btab32;
+    a.x = x; a.att = att; a.wres = wres; a.bqkv = bqkv; a.btab32 = btab32;
     a.B = B; a.H = H; a.W = W; a.shift = shift;
     a.n_windows = B * (H / 6) * (W / 6);
     a.rev = rev;            // snake order between consecutive kernels (swin_unet.cpp next_dir)
-    a.wm = window_major;
     NUNIF_REQUIRE(!window_major || C == 96, "qkv_attn: the window-major att map exists for C = 96 only");
-#ifdef NUNIF_ABLATIONS
-    static const int attn_abl = getenv("NUNIF_ATTN_ABL") ? atoi(getenv("NUNIF_ATTN_ABL")) : 0;
-    a.abl = attn_abl;
-#endif
     const double tok = (double)B * H * W;
-    static const bool cbias = !(getenv("NUNIF_ATTN_CBIAS") && atoi(getenv("NUNIF_ATTN_CBIAS")) == 0);   // A/B switch
-    static const int waves96 = getenv("NUNIF_ATTN_WAVES") ? atoi(getenv("NUNIF_ATTN_WAVES")) : 16;
-    const int kWavesR = (C == 96 && cbias) ? waves96 : 8;
+    // C = 96: 16 waves per workgroup (120 registers, no register prefetch: four waves per SIMD hide the x loads; 8 waves with
+    // prefetch measured 10 % slower, 12 waves in between); C = 192: 8 waves
+    const int kWavesR = C == 96 ? 16 : 8;
     const int wgs = (a.n_windows + kWavesR - 1) / kWavesR;
-    int grid = wgs < 256 ? wgs : 256;                   // persistent: one 8-wave workgroup per CU
+    int grid = wgs < 256 ? wgs : 256;                   // persistent: one workgroup per CU
     if (C == 192) grid = std::max(2, grid & ~1);        // two head passes = two kinds of workgroup
     int rc;
     if (C == 96) {
         ProfScope ps("qkv_attn_r_kernel<96,16>", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 4.0);
-        if (!cbias) rc = launch_r<96, 16, 6, true, false>(a, grid, s);
-        else if (kWavesR == 12) rc = launch_r<96, 16, 6, true, true, 12>(a, grid, s);
-        else if (kWavesR == 16) rc = launch_r<96, 16, 6, false, true, 16>(a, grid, s);
-        else rc = launch_r<96, 16, 6, true, true>(a, grid, s);
+        rc = window_major ? launch_r<96, 16, 6, false, 16, true>(a, grid, s) : launch_r<96, 16, 6, false, 16, false>(a, grid, s);
     } else {
         ProfScope ps("qkv_attn_r_kernel<192,32>", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 4.0);
-        rc = cbias ? launch_r<192, 32, 3, false, true>(a, grid, s) : launch_r<192, 32, 3, false, false>(a, grid, s);
+        rc = launch_r<192, 32, 3, false>(a, grid, s);
     }
     if (rc) return rc;
     NUNIF_LAUNCH_CHECK();

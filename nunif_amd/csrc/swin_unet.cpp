@@ -37,12 +37,10 @@ struct Block {
     float *attn_bias = nullptr;   // [heads][36][48]
     f16 *tail_stream = nullptr;   // proj | mlp.0 | mlp.3 fragments in proj_mlp_kernel's consumption order
     f16 *tail_ws = nullptr;       // C = 192: per-slice fragments of the weight-stationary tail (swin_block_tail_ws.hip)
-    f16 *qkv_stream = nullptr;    // per-head Wq | Wk | Wv fragments in qkv_attn_w_kernel's consumption order
-    // LDS-resident variant (swin_qkv_attn_r.hip): same fragment order, q rows / q bias pre-multiplied by
-    // head_dim^-0.5 * log2(e); bias table fp16 [heads][36][48] * log2(e) with the "real key" column 36 = 1000
+    // LDS-resident attention (swin_qkv_attn_r.hip): per head Wq | Wk | Wv fragments, q rows / q bias pre-multiplied by
+    // head_dim^-0.5 * log2(e); fp32 bias table [heads][36][52] * log2(e) read as the MFMA C operand, padded keys = -1000
     f16 *qkv_res = nullptr;
     float *qkv_rbias = nullptr;
-    f16 *attn_btab = nullptr;
     float *attn_btab32 = nullptr;
     // C = 96: one kernel per block (swin_block96.hip): proj (chained k) | mlp fragments, compact reversed bias table
     f16 *b96_tail = nullptr;
@@ -82,15 +80,9 @@ struct nunif_swin_unet {
     bool down2_split = false;
     f16 *to_image_chained = nullptr;  // ToImage weights in the chained k order, for the fused head of the last C = 96 block
     f16 *stemf_w1 = nullptr, *stemf_w2 = nullptr;   // fused stem (swin_stem.hip)
-    int stem_fused = 1;               // NUNIF_STEM_FUSED=0: stem1_kernel + gather GEMM
-    int snake = 1;                    // NUNIF_SNAKE=0: every kernel walks its tokens upwards
-    int dir = 0;                      // direction of the next kernel; next_dir() flips it
-    int fuse_to_image = 1;            // NUNIF_FUSE_TOIMAGE=0: separate gemm_kernel launch (A/B)
-    int tail_ws = 1;                  // NUNIF_TAIL_WS=0: C = 192 tails on the round-1 LDS-ring kernel (A/B)
+    int dir = 0;                      // direction of the next kernel (snake order); next_dir() flips it
     int att_wm = 1;                   // NUNIF_ATT_WM=0: C = 96 att map pixel-major (8-byte partial-line stores) as in round 2
     int block96 = 0;                  // NUNIF_BLOCK96=1: C = 96 blocks as ONE kernel (swin_block96.hip) instead of attention + tail
-    f16 *stem2_stream = nullptr;      // conv2 fragments in [k-step][n-tile] order for conv_kernel (cunet_kernels.hip)
-    int stem2_conv = 0;               // NUNIF_STEM2_CONV=1: conv_kernel<6,4> instead of gemm_kernel<18,2> (measured slower: 1131 vs 914 us)
     bool has_proj2 = false;
     std::vector<Block> swin[5];
     std::vector<void *> owned;        // every device allocation made at create time
@@ -98,7 +90,6 @@ struct nunif_swin_unet {
     int device = 0;
     // debug taps (tests only): when on, every stage's fp16 output is snapshotted device-side
     struct Tap { std::string name; void *dev; size_t bytes; };
-    int attn_variant = 3;             // see run_stage(); NUNIF_QKV_ATTN=0|1|2|3 overrides (A/B measurements)
     bool taps_on = false;
     std::vector<Tap> taps;
     void clear_taps() { for (auto &t : taps) (void)hipFree(t.dev); taps.clear(); }
@@ -209,21 +200,6 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
                 (rc = make_plain_linear(h, m, p + "mlp.3", dim, 2 * dim, &bl.mlp3p)))
                 return rc;
         }
-        if (bl.fast) {   // qkv weights in the order qkv_attn_w_kernel consumes them: per head Wq tiles, Wk tiles, Wv tiles
-            const int KS = dim / 32, NTH = (dim / heads) / 16, nf = qkv_attn_w_stream_frags(dim);
-            std::vector<f16> stream((size_t)(nf + 7) / 8 * 8 * 512, (f16)0.0f);
-            size_t fi = 0;
-            for (int hh = 0; hh < heads; ++hh)
-                for (int part = 0; part < 3; ++part)
-                    for (int nt = 0; nt < NTH; ++nt)
-                        for (int ks = 0; ks < KS; ++ks) {
-                            const size_t frag = (size_t)(part * (dim / 16) + hh * NTH + nt) * KS + ks;
-                            std::copy(hq.begin() + frag * 512, hq.begin() + (frag + 1) * 512, stream.begin() + fi * 512);
-                            ++fi;
-                        }
-            NUNIF_REQUIRE((int)fi == nf, "internal: qkv stream has %zu fragments, expected %d", fi, nf);
-            if ((rc = upload(h, stream, &bl.qkv_stream))) return rc;
-        }
         if (bl.fast) {
             const HostTensor *w, *b;
             if ((rc = find(m, p + "attn.qkv.weight", &w)) || (rc = find(m, p + "attn.qkv.bias", &b))) return rc;
@@ -231,7 +207,8 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
             const float *wd = w->data;
             std::vector<f16> hs = pack_a_fragments(3 * dim, dim, [=](int n, int k) {
                 return wd[(size_t)n * dim + k] * (n < dim ? qs : 1.0f); }, false);
-            const int KS = dim / 32, NTH = (dim / heads) / 16, nf = qkv_attn_w_stream_frags(dim);
+            // per head: Wq tiles, Wk tiles, Wv tiles, each (nt, ks) fragment-major — the order qkv_attn_r_kernel reads them
+            const int KS = dim / 32, NTH = (dim / heads) / 16, nf = 3 * (dim / 16) * KS;
             std::vector<f16> stream((size_t)nf * 512, (f16)0.0f);
             size_t fi = 0;
             for (int hh = 0; hh < heads; ++hh)
@@ -342,14 +319,6 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
                     bias[((size_t)hh * 36 + q) * 48 + k] = v;
                 }
         if ((rc = upload(h, bias, &bl.attn_bias))) return rc;
-        std::vector<f16> btab((size_t)heads * 36 * 48, (f16)0.0f);
-        for (int hh = 0; hh < heads; ++hh)
-            for (int q = 0; q < 36; ++q) {
-                for (int k = 0; k < 36; ++k)
-                    btab[((size_t)hh * 36 + q) * 48 + k] = (f16)(bias[((size_t)hh * 36 + q) * 48 + k] * 1.4426950408889634f);
-                btab[((size_t)hh * 36 + q) * 48 + 36] = (f16)1000.0f;
-            }
-        if ((rc = upload(h, btab, &bl.attn_btab))) return rc;
         // fp32 table read as the MFMA C operand: [heads][36][52], log2(e) * bias, padded keys 1000 log2-units down
         std::vector<float> btab32((size_t)heads * 36 * 52, 0.0f);
         for (int hh = 0; hh < heads; ++hh)
@@ -392,7 +361,7 @@ int tap(nunif_swin_unet *h, const std::string &name, const void *src, size_t byt
 // predecessor touched last (still in the 256-MB memory-side cache) — measured +1.3 % on the 1080p 2x frame with only the
 // attention kernels reversed.  Results do not depend on the walk order.
 static int next_dir(nunif_swin_unet *h) {
-    const int d = h->snake ? h->dir : 0;
+    const int d = h->dir;
     h->dir ^= 1;
     return d;
 }
@@ -406,10 +375,8 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         Block &bl = blocks[i];
         const int shift = (i % 2 == 1) ? 3 : 0;      // swin_unet.py:30
         const std::string tn = std::string(name) + ".b" + std::to_string(i);
-        // qkv Linear + attention in one kernel; the 3C-wide qkv map never exists in HBM.
-        // variant 3 (default): one window per wave, weights resident in LDS, no barrier in the window loop;
-        // variant 2: one window per wave, weights through the LDS ring (both widths);
-        // variant 1: one wave per head, 4 windows per workgroup (C = 96 only); variant 0: unfused GEMM + attention.
+        // fast blocks (6 heads, no norm): qkv Linear + attention in one kernel (one window per wave, weights resident in LDS);
+        // the 3C-wide qkv map never exists in HBM.  Everything else takes the generic composition below.
         if (!bl.fast) {
             // generic block (swin_unet_4xl: 12 heads, LayerNormNoBias): every Linear on gemm_kernel, attention on the
             // fused-qkv-map kernel, the two LayerNorms as their own pass.  att / hid double as the normalised maps.
@@ -445,28 +412,15 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         }
         // C = 96: att travels in window-major order (full-line stores in the attention kernel, the tail walks its tokens in
         // window order); debug taps want the pixel-major map the oracle has
-        const bool att_wm = dim == 96 && h->att_wm && h->attn_variant == 3 && !h->taps_on && !getenv("NUNIF_TAIL_RING");
-        if (h->attn_variant == 3 && h->heads == 6 && (dim == 96 || dim == 192)) {
-            if ((rc = launch_qkv_attn_r(x, att, bl.qkv_res, bl.qkv_rbias, bl.attn_btab, bl.attn_btab32, B, S, S, dim, h->heads, shift, s,
-                                        next_dir(h), att_wm ? 1 : 0)))
-                return rc;
-        } else if (h->attn_variant == 2 && h->heads == 6 && (dim == 96 || dim == 192)) {
-            if ((rc = launch_qkv_attn_w(x, att, bl.qkv_stream, bl.qkv.bias, bl.attn_bias, B, S, S, dim, h->heads, shift, s)))
-                return rc;
-        } else if (h->attn_variant >= 1 && dim == 96 && h->heads == 6) {
-            if ((rc = launch_qkv_attn(x, att, bl.qkv.w, bl.qkv.bias, bl.attn_bias, B, S, S, dim, h->heads, shift, s)))
-                return rc;
-        } else {
-            if ((rc = run_linear(bl.qkv, x, B, S, S, 0, nullptr, qkv, s, "gemm_qkv"))) return rc;
-            if ((rc = tap(h, tn + ".qkv", qkv, tok * 3 * dim * 2, s))) return rc;
-            if ((rc = launch_window_attn(qkv, att, bl.attn_bias, B, S, S, h->heads, dim / h->heads, shift, s)))
-                return rc;
-        }
+        const bool att_wm = dim == 96 && h->att_wm && !h->taps_on;
+        if ((rc = launch_qkv_attn_r(x, att, bl.qkv_res, bl.qkv_rbias, bl.attn_btab32, B, S, S, dim, h->heads, shift, s, next_dir(h),
+                                    att_wm ? 1 : 0)))
+            return rc;
         if ((rc = tap(h, tn + ".attn", att, tok * dim * 2, s))) return rc;
         // x = y + mlp(y), y = x + proj(attn): three GEMMs chained through registers, one read + one write of x
         const bool last = i + 1 == blocks.size();
-        if (dim == 192 && bl.tail_ws && h->tail_ws && !(last && to_image)) {
-            // C = 192: weights stationary in registers / LDS (swin_block_tail_ws.hip); NUNIF_TAIL_WS=0 restores the ring kernel
+        if (dim == 192) {
+            // C = 192: weights stationary in registers / LDS (swin_block_tail_ws.hip)
             if ((rc = launch_proj_mlp_ws(att, x, bl.tail_ws, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, s, next_dir(h))))
                 return rc;
         } else {
@@ -507,7 +461,7 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
     if ((rc = ensure_workspace(h, B, T))) return rc;
     f16 *s1 = (f16 *)h->s1.p, *f1 = (f16 *)h->f1.p, *f2 = (f16 *)h->f2.p, *f3 = (f16 *)h->f3.p;
 
-    if (h->stem_fused && h->stemf_w2 && stem_fused_supported(h->C1, (int)C)) {
+    if (h->stemf_w2 && stem_fused_supported(h->C1, (int)C)) {
         StemFusedArgs sf;
         memset(&sf, 0, sizeof(sf));
         if (frame) {
@@ -534,14 +488,7 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
     h->dir = 1;                                    // stem1 walks upwards; everything after it alternates
     if ((rc = launch_stem1(a1, s))) return rc;
     // conv2 3x3 VALID + LeakyReLU(0.1) + crop 6 (swin_unet.py:135-137,182): s1 already starts at conv1 row/col 6
-    if (h->stem2_conv && C == 96) {
-        ConvArgs cv;
-        memset(&cv, 0, sizeof(cv));
-        cv.a = s1; cv.B = B; cv.Hi = T - 14; cv.Wi = T - 14; cv.Cin = h->C1P; cv.Ho = S; cv.Wo = S; cv.stride = 1;
-        cv.kh = 3; cv.kw = 3; cv.wstream = h->stem2_stream; cv.bias = h->stem2.bias; cv.N = C; cv.n_real = C;
-        cv.act = 2; cv.slope = 0.1f; cv.out = f1;
-        if ((rc = launch_conv(cv, s))) return rc;
-    } else if ((rc = run_gemm(h->stem2, s1, B, T - 14, T - 14, h->C1P, S, S, 1, 0, 0, 3, 0, 2, 0.1f, nullptr, f1, C, 1, s,
+    if ((rc = run_gemm(h->stem2, s1, B, T - 14, T - 14, h->C1P, S, S, 1, 0, 0, 3, 0, 2, 0.1f, nullptr, f1, C, 1, s,
                               "gemm_stem2", next_dir(h))))
         return rc;
 stem_done:
@@ -578,8 +525,7 @@ stem_done:
     if ((rc = tap(h, "up1", top, (size_t)B * S * S * h->top_dim * 2, s))) return rc;
     // to_image + pixel_shuffle + clamp(0,1) (ToImage.forward :110-116, wrapper eval clamp :225-226): fused into the
     // last block's tail kernel when that block runs on the resident C = 96 kernel (1x / 2x nets)
-    if (h->fuse_to_image && h->top_dim == 96 && h->swin[4].back().fast && h->to_image_chained && !h->taps_on &&
-        !getenv("NUNIF_TAIL_RING")) {
+    if (h->top_dim == 96 && h->swin[4].back().fast && h->to_image_chained && !h->taps_on) {
         TailToImage ti;
         ti.w = h->to_image_chained; ti.bias = h->to_image.bias; ti.out = z; ti.H = S; ti.W = S; ti.ps = h->scale_factor;
         ti.n_real = h->to_image.n_real;
@@ -620,14 +566,8 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
     }
     nunif_swin_unet *h = new nunif_swin_unet();
     (void)hipGetDevice(&h->device);
-    if (const char *v = getenv("NUNIF_QKV_ATTN")) h->attn_variant = atoi(v);
-    if (const char *v = getenv("NUNIF_STEM2_CONV")) h->stem2_conv = atoi(v);
-    if (const char *v = getenv("NUNIF_FUSE_TOIMAGE")) h->fuse_to_image = atoi(v);
-    if (const char *v = getenv("NUNIF_SNAKE")) h->snake = atoi(v);
-    if (const char *v = getenv("NUNIF_TAIL_WS")) h->tail_ws = atoi(v);
     if (const char *v = getenv("NUNIF_BLOCK96")) h->block96 = atoi(v);
     if (const char *v = getenv("NUNIF_ATT_WM")) h->att_wm = atoi(v);
-    if (const char *v = getenv("NUNIF_STEM_FUSED")) h->stem_fused = atoi(v);
     h->scale_factor = scale_factor;
     const std::string P = "unet.";
     int rc = NUNIF_HIP_OK;
@@ -652,19 +592,11 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
         {   // conv2 [C][C1][3][3] -> W[n][k = (dy*3+dx)*C1P + ci], zero for the padded input channels
             const float *wd = w2->data;
             const int C1P = h->C1P;
-            std::vector<f16> packed;
             rc = make_linear(h, C, 9 * C1P, [=](int n, int k) {
                 const int tap = k / C1P, ci = k % C1P;
                 return ci < C1 ? wd[((size_t)n * C1 + ci) * 9 + tap] : 0.0f;
-            }, b2->data, &h->stem2, false, &packed);
+            }, b2->data, &h->stem2);
             if (rc) break;
-            const int KS = 9 * C1P / 32, NT = C / 16;
-            std::vector<f16> stream((size_t)KS * NT * 512 + 8192, (f16)0.0f);
-            for (int ks = 0; ks < KS; ++ks)
-                for (int nt = 0; nt < NT; ++nt)
-                    std::copy(packed.begin() + ((size_t)nt * KS + ks) * 512, packed.begin() + ((size_t)nt * KS + ks + 1) * 512,
-                              stream.begin() + ((size_t)ks * NT + nt) * 512);
-            if ((rc = upload(h, stream, &h->stem2_stream))) break;
         }
         if (stem_fused_supported(C1, C)) {
             const float *w0d = w0->data, *b0d = b0->data, *wd = w2->data;
@@ -713,10 +645,8 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
         if ((rc = make_down(P + "down1", C, 2 * C, &h->down1))) break;
         // the base_dim-96 nets' down2 runs the same way (K = 768, one token tile per wave on gemm_kernel<24,1>)
         // as two K = 384 passes on the resident-weight gemm_res_kernel<12,2>
-        // (measured on the 2x net: gemm_kernel<24,1> 172 us -> 2 x 114 us - the 200 us of down1 stay = 30 us less per frame;
-        //  NUNIF_DOWN2_SPLIT=0 restores the single K = 768 pass)
-        static const bool split768 = !getenv("NUNIF_DOWN2_SPLIT") || atoi(getenv("NUNIF_DOWN2_SPLIT")) != 0;
-        if (4 * 2 * C > 1024 || split768) {
+        // (measured on the 2x net: gemm_kernel<24,1> 172 us -> 2 x 114 us - the 200 us of down1 stay = 30 us less per frame)
+        {
             // gemm_kernel keeps a token's whole K extent in registers (K <= 1024): the 2x2 stride-2 conv over 2C = 384
             // channels runs as its two tap ROWS, the second accumulating onto the first's output
             const HostTensor *w, *b;
@@ -731,7 +661,7 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
                     const int dx = k / cin, ci = k % cin; return wd[((size_t)n * cin + ci) * 4 + 2 + dx]; }, zero.data(), &h->down2b)))
                 break;
             h->down2_split = true;
-        } else if ((rc = make_down(P + "down2", 2 * C, 2 * C, &h->down2))) break;
+        }
         if ((rc = make_up(P + "up2", 2 * C, 2 * C, &h->up2))) break;
         if ((rc = make_up(P + "up1", 2 * C, h->top_dim, &h->up1))) break;
         if (h->has_proj2 && (rc = make_plain_linear(h, m, P + "proj2", 2 * C, C, &h->proj2))) break;

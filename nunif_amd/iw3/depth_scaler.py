@@ -31,33 +31,46 @@ def max_normalize(frame, min_value, max_value):
     return frame.clamp(0.0, 1.0)
 
 
-class MinMaxBuffer():
+class MinMaxBuffer:
+    """The look-ahead ring: the (min, max) of the last ``size`` frames as ``size`` PAIRS (the reference keeps the same 2 * size
+    scalars interleaved in one flat vector, :33-61).  The very first frame fills every pair, so the ring is "filled" after
+    ``size`` frames."""
+
     def __init__(self, size, dtype, device):
         assert size > 0
-        self.count = 0
-        self.size = size * 2
-        self.data = torch.zeros(self.size, dtype=dtype, device=device)
+        self.pairs = torch.zeros((size, 2), dtype=dtype, device=device)
+        self.seen = 0
+
+    @property
+    def data(self):                      # the reference's flat view (min0, max0, min1, max1, ...)
+        return self.pairs.view(-1)
+
+    @property
+    def count(self):                     # the reference counts scalars, starting at 2 after the first frame
+        return 2 * self.seen
+
+    @property
+    def size(self):
+        return self.pairs.numel()
 
     def add(self, min_value, max_value):
-        if self.count == 0:
-            self.data[0::2] = min_value
-            self.data[1::2] = max_value
-            self.count = 2
+        pair = torch.stack([min_value.reshape(()), max_value.reshape(())]).to(self.pairs)
+        if self.seen == 0:
+            self.pairs[:] = pair
         else:
-            for v in (min_value, max_value):
-                self.data[self.count % self.size] = v
-                self.count += 1
+            self.pairs[self.seen % self.pairs.shape[0]] = pair
+        self.seen += 1
 
     def is_filled(self):
-        return self.count >= self.size
+        return self.seen >= self.pairs.shape[0]
 
     def get_minmax(self):
-        return self.data.amin(), self.data.amax()
+        return self.pairs.amin(), self.pairs.amax()
 
 
 class EMAMinMaxScaler():
-    """Reference :64-142.  Host tensors run the reference's torch arithmetic line by line (that is what the CPU tests compare
-    with the live reference class); DEVICE tensors run the same arithmetic as four HIP kernels on a small device state block
+    """Reference :64-142.  Host tensors run the reference's arithmetic in torch (bit-identical to the live reference class in the
+    CPU tests); DEVICE tensors run the same arithmetic as four HIP kernels on a small device state block
     (``nunif_hip_minmax`` / ``ema_scaler_push`` / ``ema_scaler_ring_minmax`` / ``range_normalize``): no ATen reduce / fill /
     elementwise kernels and no ``if scale > 0`` host synchronisation per frame.  The data-independent bookkeeping (ring
     count, "filled", "an EMA value exists") is host state in both paths."""
@@ -133,29 +146,32 @@ class EMAMinMaxScaler():
         self.reset()
         return frames
 
-    # -- reference path (host tensors; device tensors of another device than the state's) --------------------------------
+    # -- host path (host tensors, or a stream that did not start on the device path) ---------------------------------------
+    # Same arithmetic as the reference in the same order (decay * old + (1 - decay) * new on 0-d tensors, then
+    # (frame - lo) / (hi - lo) and a clamp), so the CPU tests can demand bit-identical output from the live reference class.
+    def _blend(self, old, new):
+        return new if old is None else self.decay * old + (1. - self.decay) * new
+
+    def _answer(self, frames, lo, hi, return_minmax):
+        done = [self.normalize(f, lo, hi) for f in frames]
+        return [(f, lo, hi) for f in done] if return_minmax else done
+
     def update(self, frame, return_minmax=False):
         if self._on_device(frame):
             return self._dev_update(frame, return_minmax)
         if self._dev_state is not None:
             raise RuntimeError("EMAMinMaxScaler: a stream started with device frames cannot continue with host frames; reset()")
-        if self.minmax_buffer is None:
-            self.minmax_buffer = MinMaxBuffer(self.buffer_size, dtype=frame.dtype, device=frame.device)
+        ring = self.minmax_buffer
+        if ring is None:
+            ring = self.minmax_buffer = MinMaxBuffer(self.buffer_size, dtype=frame.dtype, device=frame.device)
         self.frame_queue.append(frame)
-        lo_f, hi_f = frame.amin(), frame.amax()
-        if lo_f.device != self.minmax_buffer.data.device:
-            lo_f, hi_f = lo_f.to(self.minmax_buffer.data.device), hi_f.to(self.minmax_buffer.data.device)
-        self.minmax_buffer.add(lo_f, hi_f)
-        if not self.minmax_buffer.is_filled():
+        ring.add(frame.amin().to(ring.pairs.device), frame.amax().to(ring.pairs.device))
+        if not ring.is_filled():                            # still looking ahead: nothing leaves yet
             return (None, None, None) if return_minmax else None
-        lo, hi = self.get_minmax()
-        if self.min_value is None:
-            self.min_value, self.max_value = lo, hi
-        else:
-            self.min_value = self.decay * self.min_value + (1. - self.decay) * lo
-            self.max_value = self.decay * self.max_value + (1. - self.decay) * hi
-        out = self.normalize(self.frame_queue.pop(0), self.min_value, self.max_value)
-        return (out, self.min_value, self.max_value) if return_minmax else out
+        lo, hi = ring.get_minmax()
+        self.min_value, self.max_value = self._blend(self.min_value, lo), self._blend(self.max_value, hi)
+        out = self._answer([self.frame_queue.pop(0)], self.min_value, self.max_value, return_minmax)[0]
+        return out
 
     def flush(self, return_minmax=False):
         if not self.frame_queue:
@@ -163,12 +179,8 @@ class EMAMinMaxScaler():
             return []
         if self._dev_state is not None:
             return self._dev_flush(return_minmax)
-        if self.min_value is None:
-            lo, hi = self.minmax_buffer.get_minmax()
-        else:
-            lo, hi = self.min_value, self.max_value
-        frames = [self.normalize(f, lo, hi) for f in self.frame_queue]
-        if return_minmax:
-            frames = [(f, lo, hi) for f in frames]
+        # a scene shorter than the look-ahead never produced an EMA value: the ring's own extrema stand in
+        lo, hi = (self.min_value, self.max_value) if self.min_value is not None else self.minmax_buffer.get_minmax()
+        frames = self._answer(self.frame_queue, lo, hi, return_minmax)
         self.reset()
         return frames

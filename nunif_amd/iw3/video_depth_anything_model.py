@@ -60,122 +60,138 @@ def postprocess(out, edge_dilation, metric_depth, max_dist=None, depth_aa=None, 
 from .base_depth_model import BaseDepthModel  # noqa: E402
 
 
-class VideoDepthAnythingModel(BaseDepthModel):
-    """``VideoDepthAnythingModel`` (reference :110-283): the NON-streaming wrapper.  The external online model buffers frames —
-    ``model.infer(frame | None, use_amp)`` returns ``None`` or a list of finished depth maps, possibly later than the frame
-    that completed them — so the wrapper counts frames in and out, normalises what comes back through the EMA scaler and drains
-    the model (``infer(None)``) at scene cuts / end of stream, dropping the padding the model emits past the last real frame.
+class _OnlineLedger:
+    """Book-keeping around an ONLINE video depth network: ``net.infer(frame | None, use_amp)`` swallows frames and hands back
+    lists of finished depth maps whenever it likes (``None`` while it is buffering), and once it is drained with ``None`` it
+    keeps emitting padding.  The ledger counts what went in and what came out; ``feed`` pushes one frame, ``drain`` pulls until
+    every frame that went in has come back and cuts the padding past the last real frame off.  (The reference keeps two
+    counters on the wrapper and repeats this arithmetic in ``infer`` / ``_flush``, video_depth_anything_model.py:166-283.)"""
 
-    The network itself lives in the external ``torch.hub`` repository (``VideoDepthAnythingOnline`` / ``Metric...Online``,
-    :127-146) and is not restated: ``load_model`` takes the ``backbone`` given to the constructor — any object with
-    ``infer(frame | None, use_amp=...)``, ``reset_state()`` and a ``metric_depth`` attribute.  Pre / post-processing are the
-    HIP paths above."""
+    def __init__(self, net):
+        self.net = net
+        self.n_in = self.n_out = 0
+
+    def owed(self):
+        return self.n_in - self.n_out
+
+    def feed(self, frame, use_amp):
+        self.n_in += 1
+        got = self.net.infer(frame, use_amp=use_amp) or []
+        self.n_out += len(got)
+        return got
+
+    def drain(self, use_amp):
+        got = []
+        while self.owed() > 0:
+            more = self.net.infer(None, use_amp=use_amp)
+            if more:
+                got += more
+                self.n_out += len(more)
+        surplus = -self.owed()                     # padding frames the network emitted past the last real one
+        assert 0 <= surplus <= len(got) or not got
+        return got[:len(got) - surplus] if surplus > 0 else got
+
+    def restart(self):
+        self.net.reset_state()
+        self.n_in = self.n_out = 0
+
+
+class VideoDepthAnythingModel(BaseDepthModel):
+    """The NON-streaming wrapper (reference :110-283) around an external online network (``VideoDepthAnythingOnline`` /
+    ``Metric...Online`` of the ``torch.hub`` repository, :127-146 — not restated; ``load_model`` takes the ``backbone`` given to
+    the constructor: any object with ``infer(frame | None, use_amp=...)``, ``reset_state()`` and ``metric_depth``).
+
+    Frames go in one by one (:class:`_OnlineLedger`); whatever comes back is post-processed by the HIP paths above and pushed
+    through the EMA min-max scaler; at a scene cut / end of stream the network is drained, the scaler flushed, everything
+    restarted.  Contract pinned by ``tests/golden/video_depth_anything_online.npz`` (the reference class around a fake net)."""
 
     def __init__(self, model_type, backbone=None, depth_aa=None):
         super().__init__(model_type)
         if model_type not in NAME_MAP:
             raise ValueError(f"unknown model_type {model_type}")
-        self.input_frame_count = 0
-        self.output_frame_count = 0
         self.metric_depth = model_type in METRIC_DEPTH_TYPES
-        self.force_disparity = True
-        self._backbone = backbone
-        self.depth_aa = depth_aa
+        self.force_disparity = True             # 1 / depth for the metric checkpoints; is_metric() is then False
+        self._backbone, self.depth_aa = backbone, depth_aa
+        self._ledger = None
+
+    # the reference's two counters, for callers that peek at them
+    input_frame_count = property(lambda self: self._ledger.n_in if self._ledger else 0)
+    output_frame_count = property(lambda self: self._ledger.n_out if self._ledger else 0)
 
     def load_model(self, model_type, resolution=None, device=None, backbone=None, **kwargs):
-        model = backbone if backbone is not None else self._backbone
-        if model is None or not hasattr(model, "infer"):
+        net = backbone if backbone is not None else self._backbone
+        if net is None or not hasattr(net, "infer"):
             raise RuntimeError("VideoDepthAnythingModel: the online network lives in an external torch.hub repository; pass "
                                "backbone=<object with infer(frame | None, use_amp) / reset_state / metric_depth>")
-        if not hasattr(model, "metric_depth"):
-            model.metric_depth = self.metric_depth
-        model.prep_lower_bound = resolution or 392
-        if model.prep_lower_bound % 14 != 0:
-            model.prep_lower_bound += 14 - model.prep_lower_bound % 14
-        return model
+        if not hasattr(net, "metric_depth"):
+            net.metric_depth = self.metric_depth
+        bound = resolution or 392
+        net.prep_lower_bound = bound + (-bound) % 14             # e.g. the GUI's 512 -> 518
+        self._ledger = _OnlineLedger(net)
+        return net
+
+    def _book(self):
+        if self._ledger is None or self._ledger.net is not self.model:
+            self._ledger = _OnlineLedger(self.model)
+        return self._ledger
 
     def reset_state(self):
-        self.model.reset_state()
-        self.input_frame_count = 0
-        self.output_frame_count = 0
+        self._book().restart()
 
     def reset(self):
         self.reset_state()
         self.reset_ema()
 
-    def _post(self, frames, edge_dilation, depth_aa, enable_amp):
-        return postprocess(torch.stack(frames), edge_dilation=edge_dilation, depth_aa=depth_aa,
-                           metric_depth=self.model.metric_depth, force_disparity=self.force_disparity, enable_amp=enable_amp)
+    def _prepare(self, x):
+        return batch_preprocess(x.to(self.device), self.model.prep_lower_bound, metric_depth=self.model.metric_depth,
+                                limit_resolution=self.limit_resolution)
+
+    def _finish(self, maps, edge_dilation, depth_aa, enable_amp):
+        """finished raw maps of the network -> post-processed [n,1,h,w]"""
+        return postprocess(torch.stack(maps), edge_dilation=edge_dilation, depth_aa=depth_aa, metric_depth=self.model.metric_depth,
+                           force_disparity=self.force_disparity, enable_amp=enable_amp)
+
+    def _normalised(self, maps, edge_dilation, depth_aa, enable_amp):
+        if not maps:
+            return []
+        done = (self.minmax_normalize_chw(d) for d in self._finish(maps, edge_dilation, depth_aa, enable_amp))
+        return [d for d in done if d is not None]
+
+    def _aa(self, flag):
+        return flag if not isinstance(flag, bool) and flag is not None else (self.depth_aa if flag else None)
 
     @torch.inference_mode()
     def infer(self, x, enable_amp=True, edge_dilation=0, **kwargs):
-        """Single image through the video model (reference :166-190, marked "DONT USE THIS" there): push one frame, drain."""
+        """A single image through the video network (reference :166-190, marked "DONT USE THIS" there): one frame in, drain."""
         if not torch.is_tensor(x):
             raise ValueError("infer expects a CHW or BCHW float tensor in [0,1]")
-        batch = x.ndim != 3
-        if not batch:
-            x = x.unsqueeze(0)
+        single = x.ndim == 3
         self.reset()
-        x = batch_preprocess(x.to(self.device), self.model.prep_lower_bound, metric_depth=self.model.metric_depth,
-                             limit_resolution=self.limit_resolution)
-        self.model.infer(x[0], use_amp=enable_amp)
-        self.input_frame_count = 1
-        out = self._post(self._flush(), edge_dilation, None, enable_amp)
+        book = self._book()
+        book.feed(self._prepare(x.unsqueeze(0) if single else x)[0], enable_amp)
+        book.n_out = 0                      # the reference ignores what this first call returns (:181-183): the drain owes one frame
+        out = self._finish(book.drain(enable_amp), edge_dilation, None, enable_amp)
         self.reset()
-        return out if batch else out.squeeze(0)
+        return out.squeeze(0) if single else out
 
     @torch.inference_mode()
     def infer_with_normalize(self, x, pts, reset_pts, enable_amp=True, edge_dilation=0, depth_aa=None, **kwargs):
         assert x.ndim == 4
-        depth_aa = self.depth_aa if depth_aa else None
-        x = batch_preprocess(x.to(self.device), self.model.prep_lower_bound, metric_depth=self.model.metric_depth,
-                             limit_resolution=self.limit_resolution)
-        outputs = []
-        for i in range(x.shape[0]):
-            self.input_frame_count += 1
-            ret = self.model.infer(x[i], use_amp=enable_amp)
-            if ret is not None:
-                self.output_frame_count += len(ret)
-                out = self._post(ret, edge_dilation, depth_aa, enable_amp)
-                for j in range(out.shape[0]):
-                    normalized_depth = self.minmax_normalize_chw(out[j])
-                    if normalized_depth is not None:
-                        outputs.append(normalized_depth)
-            if pts[i] in reset_pts:
-                outputs += self.flush_with_normalize(enable_amp=enable_amp, edge_dilation=edge_dilation, depth_aa=depth_aa)
+        aa = self._aa(depth_aa)
+        book, out = self._book(), []
+        for frame, t in zip(self._prepare(x), pts):
+            out += self._normalised(book.feed(frame, enable_amp), edge_dilation, aa, enable_amp)
+            if t in reset_pts:                     # scene cut: nothing of this scene may leak into the next one
+                out += self.flush_with_normalize(enable_amp=enable_amp, edge_dilation=edge_dilation, depth_aa=aa)
                 self.reset()
-        return outputs
+        return out
 
     @torch.inference_mode()
     def flush_with_normalize(self, enable_amp=True, edge_dilation=0, depth_aa=None):
-        if isinstance(depth_aa, bool):
-            depth_aa = self.depth_aa if depth_aa else None
-        outputs = []
-        ret = self._flush(enable_amp=enable_amp)
-        if ret:
-            out = self._post(ret, edge_dilation, depth_aa, enable_amp)
-            for i in range(out.shape[0]):
-                normalized_depth = self.minmax_normalize_chw(out[i])
-                if normalized_depth is not None:
-                    outputs.append(normalized_depth)
-            outputs += self.flush_minmax_normalize()
-        return outputs
-
-    def _flush(self, enable_amp=True):
-        results = []
-        while self.output_frame_count < self.input_frame_count:
-            ret = self.model.infer(None, use_amp=enable_amp)
-            if ret is None:
-                continue
-            results += ret
-            self.output_frame_count += len(ret)
-        if results:
-            unpad = self.output_frame_count - self.input_frame_count
-            if unpad > 0:
-                assert unpad <= len(results)
-                results = results[:-unpad]
-            return results
-        return []
+        tail = self._book().drain(enable_amp)
+        if not tail:
+            return []
+        return self._normalised(tail, edge_dilation, self._aa(depth_aa), enable_amp) + self.flush_minmax_normalize()
 
     @classmethod
     def get_name(cls):
@@ -189,9 +205,7 @@ class VideoDepthAnythingModel(BaseDepthModel):
         return model_type in NAME_MAP
 
     def is_metric(self):
-        if not self.metric_depth:
-            return False
-        return not self.force_disparity
+        return self.metric_depth and not self.force_disparity
 
     @classmethod
     def multi_gpu_supported(cls, model_type):

@@ -95,41 +95,40 @@ class Waifu2x():
         gpus = self.gpus if isinstance(self.gpus, (list, tuple)) else [self.gpus]
         return data_parallel_model(model, device_ids=list(gpus)) if len(gpus) > 1 else model
 
-    def _require(self, filename):
-        if not self.has_model_file(filename):
-            raise FileNotFoundError(f"{filename} not found in {self.model_dir}")
-        return self.load_model_by_name(filename)
+    # Where a method's model comes from: its own file, or — when that file is absent — a model DERIVED from the 4x net of the
+    # same noise level (``SwinUNet4x.to_2x()`` / ``to_1x()``: the 4x output downscaled, reference :139-175).  One table instead of
+    # the reference's five hand-written branches; the slots themselves keep the reference's attribute names.
+    _FILE = {"scale": "scale2x.pth", "scale4x": "scale4x.pth", "noise": "noise{n}.pth",
+             "noise_scale": "noise{n}_scale2x.pth", "noise_scale4x": "noise{n}_scale4x.pth"}
+    _DERIVED_FROM = {"scale": ("scale4x", "to_2x"), "noise_scale": ("noise_scale4x", "to_2x"), "noise": ("noise_scale4x", "to_1x")}
+    _ATTR = {"scale": "scale_model", "scale4x": "scale4x_model", "noise": "noise_models", "noise_scale": "noise_scale_models",
+             "noise_scale4x": "noise_scale4x_models"}
+
+    def _slot(self, method, noise_level):
+        held = getattr(self, self._ATTR[method])
+        return held[noise_level] if isinstance(held, list) else held
+
+    def _fill_slot(self, method, noise_level, model):
+        if isinstance(getattr(self, self._ATTR[method]), list):
+            getattr(self, self._ATTR[method])[noise_level] = model
+        else:
+            setattr(self, self._ATTR[method], model)
 
     def _load_model(self, method, noise_level):
-        if method == "scale4x":
-            if self.scale4x_model is None:
-                self.scale4x_model = self._require("scale4x.pth")
-        elif method == "scale":
-            if self.scale_model is None:
-                if self.has_model_file("scale2x.pth"):
-                    self.scale_model = self.load_model_by_name("scale2x.pth")
-                else:
-                    self._load_model("scale4x", noise_level)
-                    self.scale_model = self._dp(self.scale4x_model.to_2x())
-        elif method == "noise_scale4x":
-            if self.noise_scale4x_models[noise_level] is None:
-                self.noise_scale4x_models[noise_level] = self._require(f"noise{noise_level}_scale4x.pth")
-        elif method == "noise_scale":
-            if self.noise_scale_models[noise_level] is None:
-                if self.has_model_file(f"noise{noise_level}_scale2x.pth"):
-                    self.noise_scale_models[noise_level] = self.load_model_by_name(f"noise{noise_level}_scale2x.pth")
-                else:
-                    self._load_model("noise_scale4x", noise_level)
-                    self.noise_scale_models[noise_level] = self._dp(self.noise_scale4x_models[noise_level].to_2x())
-        elif method == "noise":
-            if self.noise_models[noise_level] is None:
-                if self.has_model_file(f"noise{noise_level}.pth"):
-                    self.noise_models[noise_level] = self.load_model_by_name(f"noise{noise_level}.pth")
-                else:
-                    self._load_model("noise_scale4x", noise_level)
-                    self.noise_models[noise_level] = self._dp(self.noise_scale4x_models[noise_level].to_1x())
-        else:
+        if method not in self._FILE:
             raise ValueError(method)
+        if self._slot(method, noise_level) is not None:
+            return
+        filename = self._FILE[method].format(n=noise_level)
+        if self.has_model_file(filename):
+            model = self.load_model_by_name(filename)
+        elif method in self._DERIVED_FROM:
+            parent, derive = self._DERIVED_FROM[method]
+            self._load_model(parent, noise_level)                 # raises FileNotFoundError when the 4x file is missing too
+            model = self._dp(getattr(self._slot(parent, noise_level), derive)())
+        else:
+            raise FileNotFoundError(f"{filename} not found in {self.model_dir}")
+        self._fill_slot(method, noise_level, model)
 
     def load_model(self, method, noise_level):
         assert method in METHODS
@@ -159,12 +158,6 @@ class Waifu2x():
         self._setup()
 
     # -- inference ------------------------------------------------------------------------------------------------
-    def _slot(self, method, noise_level):
-        return {"scale": lambda: self.scale_model, "scale4x": lambda: self.scale4x_model,
-                "noise": lambda: self.noise_models[noise_level],
-                "noise_scale": lambda: self.noise_scale_models[noise_level],
-                "noise_scale4x": lambda: self.noise_scale4x_models[noise_level]}[method]()
-
     def render(self, x, method, noise_level, tile_size=None, batch_size=None, enable_amp=False):
         assert method in METHODS
         assert method in {"scale", "scale4x"} or 0 <= noise_level and noise_level < 4

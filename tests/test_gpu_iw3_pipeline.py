@@ -158,6 +158,44 @@ def test_full_frame_pipeline_vs_oracle(hiplib, method):
     assert float((diff > 1).float().mean()) < 2e-3
 
 
+@pytest.mark.parametrize("method", ["forward_fill", "grid_sample"])
+def test_full_frame_pipeline_1080p_vs_oracle(hiplib, method):
+    """BASELINE config 4 at its real size: one 1080p uint8 frame -> batch_preprocess (392 x 686) -> stand-in net -> dilate_edge ->
+    normalise -> warp at 1080p -> SBS uint8, against the CPU oracle of every stage (north_star: PSNR >= 50 dB on depth / warp
+    outputs).  Stage by stage: the DEPTH that reaches the warp must agree to >= 50 dB (float, over its range); given the SAME
+    depth the forward warp is bit-exact; the whole frame — where last-bit depth differences may move a splat by one source
+    pixel at a depth edge — must still reach 50 dB on the uint8 output."""
+    from nunif_amd.iw3.base_depth_model import CallableDepthModel
+    from nunif_amd.iw3.forward_warp import apply_divergence_forward_warp
+    from nunif_amd.iw3.utils import apply_divergence, to_tensor
+    from nunif_amd.iw3 import _ops
+    net = lambda t: t.mean(1) + 0.3 * t[:, 0]                              # noqa: E731
+    args = SimpleNamespace(mapper="mul_1", convergence=0.5, divergence=2.0, method=method, synthetic_view="both")
+    frame = (synth_image(91, 3, 1080, 1920) * 255).round().byte().permute(1, 2, 0).contiguous()
+    model = CallableDepthModel(net).load(gpu=0)
+    x = to_tensor(frame, device=DEV)
+    depth = model.minmax_normalize(model.infer(x.unsqueeze(0), edge_dilation=2))[0]
+    left, right = apply_divergence(depth, x, args, None)
+    out = _ops.stereo_to_frame(left, right, "sbs").cpu()
+    xo = OU.to_tensor(frame)
+    do = OD.dilate_edge(torch.nan_to_num(net(OP.batch_preprocess(xo[None], lower_bound=392)).unsqueeze(1)), 2)
+    dn = OP.minmax_normalize(do[0])
+    assert depth.shape == dn.shape == (1, 392, 686)
+    assert psnr(depth.cpu(), dn) >= 50.0, f"depth stage {psnr(depth.cpu(), dn):.2f} dB"
+    dm = OU.MAPPERS["mul_1"](dn)[None]
+    if method == "grid_sample":
+        lo, ro = OB.grid_sample_warp(xo[None], dm, 2.0, 0.5)
+    else:
+        lo, ro = OF.forward_warp(xo[None], dm, 2.0, 0.5, fill=True, width_base=False)
+        # same depth in, same pixels out: the warp stage itself is bit-exact at 1080p
+        l2, r2 = apply_divergence_forward_warp(xo[None].to(DEV), dm.to(DEV), 2.0, 0.5, method="forward_fill", width_base=False)
+        assert torch.equal(l2.cpu(), lo) and torch.equal(r2.cpu(), ro)
+    ref = OU.to_frame(OU.compose(lo[0], ro[0]))
+    assert out.shape == ref.shape == (1080, 3840, 3)
+    p = psnr(out.float() / 255, ref.float() / 255)
+    assert p >= 50.0, f"whole frame {method}: {p:.2f} dB"
+
+
 @pytest.mark.gpu
 def test_frame_ring_roundtrip_order_and_values(hiplib):
     """Pinned-buffer ring: frames come back in order, values == the synchronous path; 8 and 16 bit."""

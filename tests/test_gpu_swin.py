@@ -123,6 +123,39 @@ def test_forward_matches_the_hf_backed_reference_fixture(hiplib, golden_swin_hf,
         assert psnr(y, torch.from_numpy(golden_swin_hf["y_2x_112"])) >= PSNR_MIN
 
 
+@pytest.mark.parametrize("env", [{"NUNIF_BLOCK96": "1"}, {"NUNIF_ATT_WM": "0"}, {"NUNIF_BLOCK96": "1", "NUNIF_ATT_WM": "0"}])
+@pytest.mark.parametrize("sf,tag", [(1, "1x"), (2, "2x"), (4, "4x")])
+def test_every_kernel_switch_of_the_engine_matches_the_reference(hiplib, golden_swin, golden_swin_hf, monkeypatch, env, sf, tag):
+    """The two switches the swin engine still reads at create time, each against the reference fixtures (>= 50 dB):
+    NUNIF_BLOCK96=1 = one kernel per C = 96 block (swin_block96.hip, incl. its fused image head on the 1x / 2x nets) instead of
+    attention + tail; NUNIF_ATT_WM=0 = pixel-major att map.  Also a whole tiled render (ragged frame, 2 x 3 tiles)."""
+    from nunif_amd.nunif.utils.render import tiled_render
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m, sd = make_model(sf, 100 + sf)
+    y = m(torch.from_numpy(golden_swin["x"]).to("cuda:0")).cpu()
+    assert psnr(y, torch.from_numpy(golden_swin["y_" + tag])) >= PSNR_MIN
+    assert psnr(y, torch.from_numpy(golden_swin_hf["y_" + tag])) >= PSNR_MIN
+    if sf == 1:
+        # the input that exposed a softmax stabiliser reduced over one lane group only (common.h row_group_max): the 1x net with
+        # seed 303 on a 70 x 90 image has shifted windows whose logits differ by > 16 log2-units between lane groups
+        m1, sd1 = make_model(1, 303)
+        img = synth_image(71, 3, 70, 90)
+        ref = OS.tiled_render(img, lambda mb: O.model_forward(sd1, mb, NAMES[1]), 1, 8, 4, 64, 4)
+        out = tiled_render(img.to("cuda:0"), m1, tile_size=64, batch_size=4).cpu()
+        assert torch.isfinite(out).all() and psnr(out, ref) >= PSNR_MIN, psnr(out, ref)
+    if sf == 2:
+        m2, _ = make_model(2, 102)
+        out = tiled_render(torch.from_numpy(golden_swin["img"]).to("cuda:0"), m2, tile_size=64, batch_size=4).cpu()
+        assert psnr(out, torch.from_numpy(golden_swin["render_2x_t64_b4"])) >= PSNR_MIN
+        # 1080p-sized level-1 maps: 9 windows per wave and the 4-window remainder tile of swin_block96 at its real occupancy
+        x = torch.stack([synth_image(40 + i, 3, 256, 256) for i in range(3)]).to("cuda:0")
+        monkeypatch.delenv("NUNIF_BLOCK96", raising=False)
+        monkeypatch.delenv("NUNIF_ATT_WM", raising=False)
+        base, _ = make_model(2, 102)
+        assert psnr(m2(x).cpu(), base(x).cpu()) >= 55.0
+
+
 def test_downscaled_4x_to_2x_and_1x(hiplib, golden_swin):
     """SwinUNet4x.to_2x()/to_1x() (the fallback when scale2x.pth is absent, waifu2x/utils.py:139-144)."""
     m, _ = make_model(4, 104)

@@ -50,42 +50,40 @@ def test_forward_2x_random_tile(ref):
 
 
 @pytest.mark.parametrize("view", ["both", "left", "right"])
-def test_frame_queue_matches_reference_under_random_operations(view):
-    """The 12-frame inpaint queue (iw3/inpaint_utils.py:98-188) is pure torch: the product class against the reference class,
-    state for state, under the operation pattern MLBWInpaintVideo / ForwardInpaintVideo produce (adds, remove(6), fill, clear)."""
+def test_stereo_window_matches_the_reference_frame_queue_under_random_operations(view):
+    """The 12-frame inpaint window: the product's ``StereoWindow`` (side_model.py — own API: push / pad_with_last / slide / reset)
+    against the reference's ``FrameQueue`` (iw3/inpaint_utils.py:98-188: add / fill / remove / clear), contents and fill level
+    state for state under the operation pattern the video drivers produce."""
     refstub.install()
     import av
     av.__version__ = "14.2.0"
     from iw3.inpaint_utils import FrameQueue as RefQueue
-    from nunif_amd.iw3.inpaint_utils import FrameQueue
-    kw = dict(synthetic_view=view, seq=12, height=6, width=10, dtype=torch.float32, device="cpu", mask_height=3, mask_width=5)
-    a, b = RefQueue(**kw), FrameQueue(**kw)
+    from nunif_amd.iw3.side_model import StereoWindow
+    a = RefQueue(synthetic_view=view, seq=12, height=6, width=10, dtype=torch.float32, device="cpu", mask_height=3, mask_width=5)
+    b = StereoWindow(view, 12, (3, 6, 10), (1, 3, 5), torch.float32, "cpu")
     g = torch.Generator().manual_seed(17)
+    names = {"both": ("left", "right", "left_mask", "right_mask"), "left": ("left", "right", "left_mask"),
+             "right": ("left", "right", "right_mask")}[view]
 
     def same():
-        assert (a.index, a.full(), a.empty()) == (b.index, b.full(), b.empty())
-        for x, y in zip(a.get(), b.get()):
-            assert torch.equal(x[:a.index], y[:b.index])
+        assert (a.index, a.full(), a.empty()) == (b.level, b.is_full(), b.is_empty())
+        for x, name in zip(a.get(), names):
+            assert torch.equal(x[:a.index], b.get(name)[:b.level])
 
     for step in range(60):
         if a.full():
-            op = int(torch.randint(0, 3, (1,), generator=g))
-            if op == 0:
-                a.remove(6); b.remove(6)
-            elif op == 1:
-                a.clear(); b.clear()
+            if int(torch.randint(0, 3, (1,), generator=g)) == 1:
+                a.clear(); b.reset()
             else:
-                a.remove(6); b.remove(6)
+                a.remove(6); b.slide(6)
         elif not a.empty() and int(torch.randint(0, 6, (1,), generator=g)) == 0:
-            assert a.fill() == b.fill()
+            assert a.fill() == b.pad_with_last()
         else:
             le, ri = torch.rand(3, 6, 10, generator=g), torch.rand(3, 6, 10, generator=g)
-            masks = {}
-            if view in ("both", "left"):
-                masks["left_mask"] = torch.rand(1, 3, 5, generator=g)
-            if view in ("both", "right"):
-                masks["right_mask"] = torch.rand(1, 3, 5, generator=g)
-            a.add(le, ri, **masks); b.add(le, ri, **masks)
+            lm = torch.rand(1, 3, 5, generator=g) if view in ("both", "left") else None
+            rm = torch.rand(1, 3, 5, generator=g) if view in ("both", "right") else None
+            a.add(le, ri, **{k: v for k, v in (("left_mask", lm), ("right_mask", rm)) if v is not None})
+            b.push(left=le, right=ri, left_mask=lm, right_mask=rm)
         same()
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Depth backbones: BaseDepthModel.infer on a 4 x 1080p batch (the reference's _bench protocol), fps per encoder, and the
-per-kernel-class table of the ViT-S run.  NUNIF_GEMM_OS=0 restores the token-stationary GEMMs for an A/B."""
+per-kernel-class table of the ViT-S run."""
 import os
 import sys
 import time
