@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # --streams 1: per-kernel durations must not be overlapped with a second frame (bench.py measures its roofline leg the same way)
-BENCH="python $REPO/bench.py --batch-size 45 --no-cpu-baseline --no-host-frames --no-iw3 --no-4k --streams 1"
+BENCH="python $REPO/bench.py --batch-size 45 --no-cpu-baseline --no-host-frames --no-iw3 --no-4k --no-cunet --no-config5 --streams 1"
 
 rm -rf /tmp/p1 /tmp/p2 /tmp/p3
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o ks -- $BENCH --steps 6 --warmup 2 > "$OUT/${TAG}_prof_bench.log" 2>&1
