@@ -33,7 +33,7 @@ namespace nunif {
 // Waves drift apart (no barrier in the group loop), so one wave's GELU / convert (VALU) phase overlaps its SIMD partner's
 // MFMA phase (same finding as swin_qkv_attn_r.hip).  MF = 2 token tiles per group, 8 waves, next-group prefetch: the fastest
 // of the eight (MF, waves, prefetch) combinations measured in rounds 1-2.
-template <int C, int MF, int WAVES, bool PF = false>
+template <int C, int MF, int WAVES, bool PF = false, bool WM = false>
 __global__ void __launch_bounds__(WAVES * 64)
 proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wstream, const float *__restrict__ bp,
                   const float *__restrict__ b0, const float *__restrict__ b3, long M, TailToImage ti, int rev, WinMap wm) {
@@ -85,22 +85,23 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
     // pixn[f]: row of x (and of the image head) that token f*16 + r16 of the group lives at.  Plain map: the token index.
     // Window map (wm.on): token n = window * 36 + t of the SHIFTED 6x6 windows, t row-major in the window — the order
     // qkv_attn_r_kernel writes its window-major att map in; att is then [window][head 6][36][16].
-    const int nwx = wm.on ? wm.W / 6 : 1, nwy = wm.on ? wm.H / 6 : 1;
+    const int nwx = WM ? wm.W / 6 : 1, nwy = WM ? wm.H / 6 : 1;
     auto load_group = [&](long g, f16x8 (&of)[MF][KS], f16x8 (&xr)[MF][KS], long (&pixn)[MF]) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             const long m = gmap(g) * (MF * 16) + f * 16 + r16;
             const long r = m < M ? m : M - 1;
             const f16 *p;
-            if (wm.on) {
-                const int w = (int)(r / 36), t = (int)(r - 36L * w);
+            if constexpr (WM) {
+                const int ri = (int)r;                                   // M < 2^31 in this mode (checked by the launcher): 32-bit divides
+                const int w = ri / 36, t = ri - 36 * w;
                 const int wx = w % nwx, t2 = w / nwx;
                 const int wy = t2 % nwy, b = t2 / nwy;
                 const int iy = t / 6, ix = t - 6 * iy;
                 int yy = wy * 6 + iy + wm.shift, xx = wx * 6 + ix + wm.shift;
                 if (yy >= wm.H) yy -= wm.H;
                 if (xx >= wm.W) xx -= wm.W;
-                pixn[f] = ((long)b * wm.H + yy) * wm.W + xx;
+                pixn[f] = (b * wm.H + yy) * wm.W + xx;
                 // lane group g holds channels 32 ks + 8 g .. + 7 = head 2 ks + (g >> 1), dims 8 (g & 1) ..
                 p = att + (((long)w * 6 + (grp >> 1)) * 36 + t) * 16 + 8 * (grp & 1);
             } else {
@@ -110,7 +111,7 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
             const f16 *px = x + pixn[f] * C + grp * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                of[f][ks] = *reinterpret_cast<const f16x8 *>(p + (wm.on ? ks * (2 * 36 * 16) : ks * 32));
+                of[f][ks] = *reinterpret_cast<const f16x8 *>(p + (WM ? ks * (2 * 36 * 16) : ks * 32));
                 xr[f][ks] = *reinterpret_cast<const f16x8 *>(px + ks * 32);      // B-operand layout: the residual rides an MFMA
             }
         }
@@ -293,17 +294,21 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
     WinMap wm;
     memset(&wm, 0, sizeof(wm));
     if (wmap) wm = *wmap;
-    NUNIF_REQUIRE(!wm.on || (wm.H % 6 == 0 && wm.W % 6 == 0 && M % ((long)wm.H * wm.W) == 0), "proj_mlp: window map geometry");
+    NUNIF_REQUIRE(!wm.on || (wm.H % 6 == 0 && wm.W % 6 == 0 && M % ((long)wm.H * wm.W) == 0 && M < (1L << 31)),
+                  "proj_mlp: window map geometry");
     constexpr int MF = 2, WAVES = 8;
     static bool configured = false;
     if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)proj_mlp_r_kernel<96, MF, WAVES, true>,
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)proj_mlp_r_kernel<96, MF, WAVES, true, false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)proj_mlp_r_kernel<96, MF, WAVES, true, true>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = true;
     }
     const long groups = (M + MF * 16 - 1) / (MF * 16);
     const unsigned blocks = (unsigned)std::min<long>((groups + WAVES - 1) / WAVES, 256);
-    proj_mlp_r_kernel<96, MF, WAVES, true><<<blocks, WAVES * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti, rev, wm);
+    if (wm.on) proj_mlp_r_kernel<96, MF, WAVES, true, true><<<blocks, WAVES * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti, rev, wm);
+    else proj_mlp_r_kernel<96, MF, WAVES, true, false><<<blocks, WAVES * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti, rev, wm);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }

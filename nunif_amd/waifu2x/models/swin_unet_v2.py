@@ -15,7 +15,7 @@ from collections import OrderedDict
 
 import torch
 
-from ...nunif.models import I2IBaseModel, register_model
+from ...nunif.models import register_model_factory, I2IBaseModel, register_model
 from ... import _hip
 from ...synthetic import window_score_bias_input
 from .swin_unet import _FlatWeightsModel, tile_size_validator
@@ -196,6 +196,17 @@ class SwinUNet4xV2(_HipSwinUNetV2Model):
     def to_1x(self, shared=True):
         unet = self if shared else copy.deepcopy(self)
         return SwinUNetV2Downscaled(unet, downscale_factor=4, in_channels=self.i2i_in_channels, out_channels=self.out_channels)
+
+
+def _swin_unet_v2_1xs(**kwargs):
+    """``waifu2x.swin_unet_v2_1xs`` (reference :528-530: base_dim 32, one first / last layer, mlp ratios 1) — an experimental
+    geometry without released weights that the HIP engine does not carry (its kernels are instantiated for base_dim 64 / 96 /
+    128 with lv1_mlp_ratio 2).  Registered so that the name is KNOWN and fails with the reason instead of "Unknown model name"."""
+    raise NotImplementedError("waifu2x.swin_unet_v2_1xs (base_dim 32, lv1_mlp_ratio 1) is not on the HIP engine: it carries the "
+                              "registered 1x / 2x / 4x geometries (base_dim 64 / 96 / 128, lv1_mlp_ratio 2)")
+
+
+register_model_factory("waifu2x.swin_unet_v2_1xs", _swin_unet_v2_1xs)
 
 
 @register_model
