@@ -171,8 +171,7 @@ __global__ void __launch_bounds__(512) da_attn_lds_kernel(const f16 *__restrict_
                 if (k0 + 8 * grp + 4 + r >= Np) s1[r] = -1.0e30f;
                 mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = row_group_max(mx);                  // the four lane groups of a query column must share the stabiliser
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             float p[8], sum = 0.f;
@@ -182,8 +181,8 @@ __global__ void __launch_bounds__(512) da_attn_lds_kernel(const f16 *__restrict_
                 p[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
                 sum += p[r] + p[4 + r];
             }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            // the denominator stays a per-LANE partial (alpha is the same in all four lane groups of a column): one cross-group
+            // reduction after the key loop instead of two shuffles through the LDS crossbar per 32-key step
             l_run = l_run * alpha + sum;
             m_run = m_new;
             const f16x8 pf = {(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3], (f16)p[4], (f16)p[5], (f16)p[6], (f16)p[7]};
@@ -197,6 +196,8 @@ __global__ void __launch_bounds__(512) da_attn_lds_kernel(const f16 *__restrict_
         __syncthreads();
         buf ^= 1;
     }
+    l_run += __shfl_xor(l_run, 16);              // all lanes take part (the exchange partners share r16, not the branch below)
+    l_run += __shfl_xor(l_run, 32);
     if (has_q && qt * 16 + r16 < Np) {
         const float inv = 1.0f / l_run;
         f16 *dst = att + ((long)b * Np + qt * 16 + r16) * kD + hh * kHd + 4 * grp;
