@@ -119,92 +119,138 @@ __device__ __forceinline__ f16x8 cat8a(f16x4 lo, f16x4 hi) {
 // fragments of a 32-key step (K rows in MFMA row order for both key tiles x 2 k-steps, V^T for the 4 channel tiles) are loaded
 // ONCE per workgroup — one 16-byte load per thread — into a double-buffered 8-KiB LDS slot, and every wave reads them from there.
 // grid (ceil(Np / 128), heads, B).
-__global__ void __launch_bounds__(512) da_attn_lds_kernel(const f16 *__restrict__ qkv, const f16 *__restrict__ vt,
+// QT query tiles per wave, WAVES waves per workgroup.  Round 3 measured (same box, ms per 12 launches at B = 4): <1, 8> 0.52,
+// <2, 4> (a fragment read feeds two MFMAs, the same 128 queries per workgroup) 0.69, <2, 8> (256 queries, 144 workgroups) 0.58 —
+// with about one workgroup per CU, fewer waves or fewer workgroups cost more than the halved LDS reads give; <1, 8> stays.
+template <int QT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) da_attn_lds_kernel(const f16 *__restrict__ qkv, const f16 *__restrict__ vt,
                                                           f16 *__restrict__ att, int Np, int Tp, int kD, int kHeads) {
     __shared__ __attribute__((aligned(16))) f16x8 kv[2][8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, grp = lane >> 4;
-    const int qt = blockIdx.x * 8 + wave;
-    const bool has_q = qt * 16 < Np;
+    const int qt0 = (blockIdx.x * WAVES + wave) * QT;
+    const bool has_q = qt0 * 16 < Np;
     const int hh = blockIdx.y, b = blockIdx.z;
     const f16 *base = qkv + (long)b * Np * (3 * kD);
-    const int q = min(qt * 16 + r16, Np - 1);
-    f16x8 qf[2];
+    f16x8 qf[QT][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-        qf[ks] = *reinterpret_cast<const f16x8 *>(base + (long)q * (3 * kD) + hh * kHd + 32 * ks + 8 * grp);
+    for (int t = 0; t < QT; ++t) {
+        const int q = min((qt0 + t) * 16 + r16, Np - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[t][ks] = *reinterpret_cast<const f16x8 *>(base + (long)q * (3 * kD) + hh * kHd + 32 * ks + 8 * grp);
+    }
     const f16 *vbase = vt + ((long)(b * kHeads + hh) * kHd) * Tp;
     // MFMA row i of key tile 0 / 1 <-> key k0 + 8*(i>>2) + (i&3) [+ 4]: lane's 8 P^T slots are then keys k0 + 8g + 0..7
     const int krow = 8 * (r16 >> 2) + (r16 & 3);
-    // this thread's share of the staging: fragment `wave` of the step (0, 1: key tile 0, k-step 0 / 1; 2, 3: key tile 1; 4..7: V^T)
-    auto stage = [&](int k0) -> f16x8 {
-        if (wave < 4) {
-            const int key = min(k0 + krow + (wave >= 2 ? 4 : 0), Np - 1);
-            return *reinterpret_cast<const f16x8 *>(base + (long)key * (3 * kD) + kD + hh * kHd + 32 * (wave & 1) + 8 * grp);
-        }
-        return *reinterpret_cast<const f16x8 *>(vbase + (long)((wave - 4) * 16 + r16) * Tp + k0 + 8 * grp);
+    // staging: fragment f of a step (0, 1: key tile 0, k-step 0 / 1; 2, 3: key tile 1; 4..7: V^T); with 8 waves wave w stages
+    // fragment w, with 4 waves fragments w and w + 4
+    static_assert(WAVES == 4 || WAVES == 8, "staging is written for 4 or 8 waves");
+    auto stage_k = [&](int k0, int f) -> f16x8 {
+        const int key = min(k0 + krow + (f >= 2 ? 4 : 0), Np - 1);
+        return *reinterpret_cast<const f16x8 *>(base + (long)key * (3 * kD) + kD + hh * kHd + 32 * (f & 1) + 8 * grp);
     };
-    f32x4 o[4];
+    auto stage_v = [&](int k0, int f) -> f16x8 {
+        return *reinterpret_cast<const f16x8 *>(vbase + (long)(f * 16 + r16) * Tp + k0 + 8 * grp);
+    };
+    auto stage_a = [&](int k0) -> f16x8 {        // first piece of this thread
+        if (WAVES == 4 || wave < 4) return stage_k(k0, wave & 3);
+        return stage_v(k0, wave - 4);
+    };
+    f32x4 o[QT][4];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -1.0e30f, l_run = 0.f;
-    kv[0][wave][lane] = stage(0);
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -1.0e30f; l_run[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    kv[0][wave][lane] = stage_a(0);
+    if constexpr (WAVES == 4) kv[0][4 + wave][lane] = stage_v(0, wave);
     __syncthreads();
     int buf = 0;
-    // (64 keys per barrier — two staged steps — measured slower: 0.69 vs 0.64 ms per 12 launches)
 #pragma unroll 1
     for (int k0 = 0; k0 < Tp; k0 += 32) {
         const bool more = k0 + 32 < Tp;
-        f16x8 st;
-        if (more) st = stage(k0 + 32);
+        f16x8 stk, stv;
+        if (more) {
+            stk = stage_a(k0 + 32);
+            if constexpr (WAVES == 4) stv = stage_v(k0 + 32, wave);
+        }
         if (has_q) {
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            f16x8 kf[4];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                s0 = MFMA_16x16x32(kv[buf][ks][lane], qf[ks], s0);
-                s1 = MFMA_16x16x32(kv[buf][2 + ks][lane], qf[ks], s1);
-            }
-            // accumulator row 4g+r of tile 0 is key k0 + 8g + r, of tile 1 key k0 + 8g + 4 + r
-            float mx = -1.0e30f;
+            for (int f = 0; f < 4; ++f) kf[f] = kv[buf][f][lane];
+            f16x8 pf[QT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (k0 + 8 * grp + r >= Np) s0[r] = -1.0e30f;
-                if (k0 + 8 * grp + 4 + r >= Np) s1[r] = -1.0e30f;
-                mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-            }
-            mx = row_group_max(mx);                  // the four lane groups of a query column must share the stabiliser
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            float p[8], sum = 0.f;
+            for (int t = 0; t < QT; ++t) {
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-                p[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
-                sum += p[r] + p[4 + r];
+                for (int ks = 0; ks < 2; ++ks) {
+                    s0 = MFMA_16x16x32(kf[ks], qf[t][ks], s0);
+                    s1 = MFMA_16x16x32(kf[2 + ks], qf[t][ks], s1);
+                }
+                // accumulator row 4g+r of tile 0 is key k0 + 8g + r, of tile 1 key k0 + 8g + 4 + r
+                if (k0 + 32 > Np) {                      // only the last step has keys beyond the sequence (wave-uniform branch)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (k0 + 8 * grp + r >= Np) s0[r] = -1.0e30f;
+                        if (k0 + 8 * grp + 4 + r >= Np) s1[r] = -1.0e30f;
+                    }
+                }
+                float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+                mx = row_group_max(mx);                  // the four lane groups of a query column must share the stabiliser
+                const float m_new = fmaxf(m_run[t], mx);
+                // Online-softmax rescale only when some query of this tile saw a new maximum: after the first few key steps that
+                // is rare, and the 16 multiplies + the exp were a fifth of the step's VALU work.  alpha = exp2(0) = 1 exactly
+                // otherwise, so skipping is bit-identical.
+                if (__any(m_new > m_run[t])) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        o[t][dt] = (f32x4){o[t][dt][0] * alpha, o[t][dt][1] * alpha, o[t][dt][2] * alpha, o[t][dt][3] * alpha};
+                    l_run[t] *= alpha;
+                }
+                float p[8], sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+                    p[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+                    sum += p[r] + p[4 + r];
+                }
+                // the denominator stays a per-LANE partial (alpha is the same in all four lane groups of a column): one
+                // cross-group reduction after the key loop instead of two shuffles through the LDS crossbar per 32-key step
+                l_run[t] += sum;
+                m_run[t] = m_new;
+                pf[t] = (f16x8){(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3], (f16)p[4], (f16)p[5], (f16)p[6], (f16)p[7]};
             }
-            // the denominator stays a per-LANE partial (alpha is the same in all four lane groups of a column): one cross-group
-            // reduction after the key loop instead of two shuffles through the LDS crossbar per 32-key step
-            l_run = l_run * alpha + sum;
-            m_run = m_new;
-            const f16x8 pf = {(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3], (f16)p[4], (f16)p[5], (f16)p[6], (f16)p[7]};
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                o[dt] = (f32x4){o[dt][0] * alpha, o[dt][1] * alpha, o[dt][2] * alpha, o[dt][3] * alpha};
-                o[dt] = MFMA_16x16x32(kv[buf][4 + dt][lane], pf, o[dt]);
+                const f16x8 vf = kv[buf][4 + dt][lane];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) o[t][dt] = MFMA_16x16x32(vf, pf[t], o[t][dt]);
             }
         }
-        if (more) kv[buf ^ 1][wave][lane] = st;
+        if (more) {
+            kv[buf ^ 1][wave][lane] = stk;
+            if constexpr (WAVES == 4) kv[buf ^ 1][4 + wave][lane] = stv;
+        }
         __syncthreads();
         buf ^= 1;
     }
-    l_run += __shfl_xor(l_run, 16);              // all lanes take part (the exchange partners share r16, not the branch below)
-    l_run += __shfl_xor(l_run, 32);
-    if (has_q && qt * 16 + r16 < Np) {
-        const float inv = 1.0f / l_run;
-        f16 *dst = att + ((long)b * Np + qt * 16 + r16) * kD + hh * kHd + 4 * grp;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<f16x4 *>(dst + dt * 16) =
-                (f16x4){(f16)(o[dt][0] * inv), (f16)(o[dt][1] * inv), (f16)(o[dt][2] * inv), (f16)(o[dt][3] * inv)};
+    for (int t = 0; t < QT; ++t) {
+        float l = l_run[t];
+        l += __shfl_xor(l, 16);                  // all lanes take part (the exchange partners share r16, not the branch below)
+        l += __shfl_xor(l, 32);
+        const int qrow = (qt0 + t) * 16 + r16;
+        if (has_q && qrow < Np) {
+            const float inv = 1.0f / l;
+            f16 *dst = att + ((long)b * Np + qrow) * kD + hh * kHd + 4 * grp;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<f16x4 *>(dst + dt * 16) = (f16x4){(f16)(o[t][dt][0] * inv), (f16)(o[t][dt][1] * inv),
+                                                                    (f16)(o[t][dt][2] * inv), (f16)(o[t][dt][3] * inv)};
+        }
     }
 }
 
@@ -676,8 +722,8 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         NUNIF_LAUNCH_CHECK();
         {
             ProfScope ps("da_attn_kernel", s, 4.0 * B * (double)Np * Np * kD, (double)T * kD * 8.0);
-            dim3 grid((unsigned)(((Np + 15) / 16 + 7) / 8), kHeads, B);
-            da_attn_lds_kernel<<<grid, 512, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
+            dim3 grid((unsigned)(((Np + 15) / 16 + 7) / 8), kHeads, B);           // 8 waves x 1 query tile = 128 queries per workgroup
+            da_attn_lds_kernel<1, 8><<<grid, 512, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
             NUNIF_LAUNCH_CHECK();
         }
         if ((rc = run_tok(bk.proj, att, T, 0, t, t, s, "da_proj"))) return rc;        // t += ls1 * proj(att)
