@@ -492,6 +492,26 @@ def config5_record(dev):
     return rec
 
 
+def collect_multi_gpu(dist, world, rank, local_rank, dev):
+    """Self-evidence for the driver's N > 1 runs: how many ranks took part in a collective and which physical devices they hold
+    (one distinct PCI bus id per rank, or the run was not N GPUs).  ``dev`` may be a CPU device in the gloo unit test."""
+    import torch
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    if dev.type == "cuda":
+        props = torch.cuda.get_device_properties(dev)
+        name, hbm = props.name, round(props.total_memory / 2 ** 30, 1)
+        bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xff,
+                                  getattr(props, "pci_device_id", 0))
+    else:
+        name, hbm, bus = "cpu", 0.0, f"host-rank-{rank}"
+    mine = {"rank": rank, "local_rank": local_rank, "device": name, "pci_bus_id": bus, "hbm_gib": hbm}
+    table = [None] * world
+    dist.all_gather_object(table, mine)
+    return {"ranks_seen": int(ones.item()), "world_size": world, "backend": dist.get_backend(),
+            "distinct_pci_bus_ids": len({t["pci_bus_id"] for t in table}), "devices": table}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -511,21 +531,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
-    # self-evidence for the driver's N > 1 runs: how many ranks took part in a collective and which physical devices they
-    # hold (one distinct PCI bus id per rank, or the run was not N GPUs)
-    multi_gpu = None
-    if world > 1:
-        ones = torch.ones(1, device=dev)
-        dist.all_reduce(ones)
-        props = torch.cuda.get_device_properties(dev)
-        mine = {"rank": rank, "local_rank": local_rank, "device": props.name,
-                "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xff,
-                                                  getattr(props, "pci_device_id", 0)),
-                "hbm_gib": round(props.total_memory / 2 ** 30, 1)}
-        table = [None] * world
-        dist.all_gather_object(table, mine)
-        multi_gpu = {"ranks_seen": int(ones.item()), "world_size": world, "backend": dist.get_backend(),
-                     "distinct_pci_bus_ids": len({t["pci_bus_id"] for t in table}), "devices": table}
+    multi_gpu = collect_multi_gpu(dist, world, rank, local_rank, dev) if world > 1 else None
 
     from nunif_amd import _hip
     from nunif_amd.nunif.utils.render import tiled_render

@@ -208,3 +208,28 @@ def test_render_sharded_two_gpus_nccl(tmp_path):
         g = torch.Generator().manual_seed(7)
         ref = [to_frame(_fake_render(torch.rand(3, 10, 12, generator=g))) for _ in range(n_frames)]
         assert len(got) == n_frames and all(torch.equal(a, b) for a, b in zip(got, ref))
+
+
+def _evidence_worker(rank, world, port, path):
+    import importlib.util
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ev = bench.collect_multi_gpu(dist, world, rank, rank, torch.device("cpu"))
+    if rank == 0:
+        torch.save(ev, path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_evidence_block_on_two_gloo_ranks(tmp_path):
+    """bench.py --gpus N prints which ranks / devices took part (the driver's SCALE runs are the only N > 1 executions this code
+    ever gets): the collecting function on two CPU ranks."""
+    path = str(tmp_path / "ev.pt")
+    mp.spawn(_evidence_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    ev = torch.load(path)
+    assert ev["ranks_seen"] == 2 and ev["world_size"] == 2 and ev["distinct_pci_bus_ids"] == 2 and ev["backend"] == "gloo"
+    assert [d["rank"] for d in ev["devices"]] == [0, 1]
