@@ -5,7 +5,7 @@ TAG=${1:-sq}; shift || true
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
-BENCH="python $REPO/bench.py --batch-size 45 --no-cpu-baseline --steps 2 --warmup 1"
+BENCH="python $REPO/bench.py --batch-size 45 --no-cpu-baseline --no-host-frames --no-iw3 --no-4k --no-cunet --no-config5 --streams 1 --steps 2 --warmup 1"
 : > "$OUT/${TAG}_sq.txt"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" \
