@@ -93,164 +93,155 @@ __global__ void __launch_bounds__(256) da_layernorm_kernel(const f16 *__restrict
     }
 }
 
-// vt[b][h][ch][t] = V[b][t][h*64 + ch]; zero for t >= Np (t < Tp)
-__global__ void __launch_bounds__(256) da_vt_kernel(const f16 *__restrict__ qkv, f16 *__restrict__ vt, int B, int Np, int Tp,
-                                                    int kD, int kHeads) {
-    const long total = (long)B * kHeads * kHd * Tp;
-    const long id = (long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= total) return;
-    const int t = (int)(id % Tp);
-    const long r = id / Tp;
-    const int ch = (int)(r % kHd);
-    const long r2 = r / kHd;
-    const int hh = (int)(r2 % kHeads), b = (int)(r2 / kHeads);
-    vt[id] = t < Np ? qkv[((long)b * Np + t) * (3 * kD) + 2 * kD + hh * kHd + ch] : (f16)0.f;
-}
-
-__device__ __forceinline__ f16x8 cat8a(f16x4 lo, f16x4 hi) {
-    return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
 // (Rounds 1-2 went through two earlier forms, both deleted: one wave per 16-query tile reading K / V straight from L2 (59.7 us
 //  per launch for B = 2 at 392 x 686: 1 032 waves, two dependent load latencies per key step) and a split-key form that gave one
 //  query tile to a workgroup of 4 waves (-4.5 % on the iw3 frame).  Both pulled 8 KiB of K / V per wave and key step through the
 //  vector memory pipe for 8 MFMAs: that pipe, not the matrix pipe, was the bound — 155 TFLOP/s.)
 // K / V shared through LDS: a workgroup of 8 waves = 8 query tiles (128 queries) walks the keys together; the 8 operand
 // fragments of a 32-key step (K rows in MFMA row order for both key tiles x 2 k-steps, V^T for the 4 channel tiles) are loaded
-// ONCE per workgroup — one 16-byte load per thread — into a double-buffered 8-KiB LDS slot, and every wave reads them from there.
+// ONCE per workgroup — one 16-byte load per thread — into an 8-KiB LDS slot, and every wave reads them from there.
 // grid (ceil(Np / 128), heads, B).
-// QT query tiles per wave, WAVES waves per workgroup.  Round 3 measured (same box, ms per 12 launches at B = 4): <1, 8> 0.52,
-// <2, 4> (a fragment read feeds two MFMAs, the same 128 queries per workgroup) 0.69, <2, 8> (256 queries, 144 workgroups) 0.58 —
-// with about one workgroup per CU, fewer waves or fewer workgroups cost more than the halved LDS reads give; <1, 8> stays.
-template <int QT, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) da_attn_lds_kernel(const f16 *__restrict__ qkv, const f16 *__restrict__ vt,
-                                                          f16 *__restrict__ att, int Np, int Tp, int kD, int kHeads) {
-    __shared__ __attribute__((aligned(16))) f16x8 kv[2][8][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, grp = lane >> 4;
-    const int qt0 = (blockIdx.x * WAVES + wave) * QT;
+//
+// Round 3, second form.  The first LDS form fetched step i + 1 while computing step i behind a __syncthreads(), which drains
+// vmcnt: one exposed L2 / MALL latency per 32 keys — 1.0 us per step for ~0.3 us of issue work.  Now the slots are a ring of
+// THREE and the fetch runs two steps ahead in two register sets (the loop is unrolled by two so that they are static): the
+// load of step i + 3 is issued in front of step i's MFMAs and lands in LDS behind step i + 1's; the barrier is
+// `s_waitcnt lgkmcnt(0); s_barrier` — it must not wait for the loads in flight.
+// V is read in its natural [key][channel] layout (128 contiguous bytes per key and head) and transposed on the way INTO LDS
+// (8 ds_write_b16 per staging thread and step), which removed the separate V^T kernel and its 2-byte gathers (11 us per layer);
+// the 16 lanes of a V fragment are stored at r16 ^ 2f so that the 8 channels x 4 fragments of one write fall into different banks.
+// (QT query tiles per wave were measured on the first form, ms per 12 launches at B = 4: <1, 8 waves> 0.52, <2, 4> 0.69, <2, 8>
+//  0.58 — with about one workgroup per CU, fewer waves or fewer workgroups cost more than the halved LDS reads give.)
+template <int WAVES>                                // query tiles (= waves) per workgroup; waves 0..7 stage K / V for all of them
+__global__ void __launch_bounds__(WAVES * 64) da_attn_kernel(const f16 *__restrict__ qkv, f16 *__restrict__ att, int Np, int kD,
+                                                             int kHeads) {
+    __shared__ __attribute__((aligned(16))) f16x8 kv[3][8][64];
+    // the wave index as an SGPR: the K / V staging arms become scalar branches, so that both carry their vmcnt wait on every path
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, grp = lane >> 4;
+    const int qt0 = blockIdx.x * WAVES + wave;
     const bool has_q = qt0 * 16 < Np;
     const int hh = blockIdx.y, b = blockIdx.z;
     const f16 *base = qkv + (long)b * Np * (3 * kD);
-    f16x8 qf[QT][2];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const int q = min((qt0 + t) * 16 + r16, Np - 1);
+    const int steps = (Np + 31) >> 5;
+    f16x8 qf[2];
+    {
+        const int q = min(qt0 * 16 + r16, Np - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            qf[t][ks] = *reinterpret_cast<const f16x8 *>(base + (long)q * (3 * kD) + hh * kHd + 32 * ks + 8 * grp);
+            qf[ks] = *reinterpret_cast<const f16x8 *>(base + (long)q * (3 * kD) + hh * kHd + 32 * ks + 8 * grp);
     }
-    const f16 *vbase = vt + ((long)(b * kHeads + hh) * kHd) * Tp;
-    // MFMA row i of key tile 0 / 1 <-> key k0 + 8*(i>>2) + (i&3) [+ 4]: lane's 8 P^T slots are then keys k0 + 8g + 0..7
-    const int krow = 8 * (r16 >> 2) + (r16 & 3);
-    // staging: fragment f of a step (0, 1: key tile 0, k-step 0 / 1; 2, 3: key tile 1; 4..7: V^T); with 8 waves wave w stages
-    // fragment w, with 4 waves fragments w and w + 4
-    static_assert(WAVES == 4 || WAVES == 8, "staging is written for 4 or 8 waves");
-    auto stage_k = [&](int k0, int f) -> f16x8 {
-        const int key = min(k0 + krow + (f >= 2 ? 4 : 0), Np - 1);
-        return *reinterpret_cast<const f16x8 *>(base + (long)key * (3 * kD) + kD + hh * kHd + 32 * (f & 1) + 8 * grp);
+    // staging piece of this thread.  Waves 0..3: K fragment f = wave (key tile f >> 1, k-step f & 1); MFMA row i of key tile 0 / 1
+    // <-> key k0 + 8*(i>>2) + (i&3) [+ 4], so that a lane's 8 P^T slots are keys k0 + 8g + 0..7.  Waves 4..7: 8 keys x 128 B of V,
+    // lane = 8 * (key & 7) + channel block.
+    const bool is_k = wave < 4;
+    const int key_off = is_k ? 8 * (r16 >> 2) + (r16 & 3) + (wave >= 2 ? 4 : 0) : 8 * (wave - 4) + (lane >> 3);
+    const f16 *src = base + (is_k ? kD + hh * kHd + 32 * (wave & 1) + 8 * grp : 2 * kD + hh * kHd + 8 * (lane & 7));
+    auto stage = [&](int step) -> f16x8 {
+        const int key = min(step * 32 + key_off, Np - 1);              // clamped keys are masked (K) / meet P = 0 (V)
+        return *reinterpret_cast<const f16x8 *>(src + (long)key * (3 * kD));
     };
-    auto stage_v = [&](int k0, int f) -> f16x8 {
-        return *reinterpret_cast<const f16x8 *>(vbase + (long)(f * 16 + r16) * Tp + k0 + 8 * grp);
-    };
-    auto stage_a = [&](int k0) -> f16x8 {        // first piece of this thread
-        if (WAVES == 4 || wave < 4) return stage_k(k0, wave & 3);
-        return stage_v(k0, wave - 4);
-    };
-    f32x4 o[QT][4];
-    float m_run[QT], l_run[QT];
+    // V element i of this thread: channel 8c + i = 16 f + r16v -> fragment f = c >> 1, lane (r16v, grp = wave - 4), slot e = key & 7
+    const int vc = lane & 7;
+    f16 *vdst = reinterpret_cast<f16 *>(&kv[0][4 + (vc >> 1)][(wave & 3) * 16]) + (lane >> 3);
+    const int vr0 = 8 * (vc & 1), vx = 2 * (vc >> 1);
+    auto publish = [&](int slot, f16x8 v) {
+        if (WAVES > 8 && wave >= 8) return;
+        if (is_k) {
+            kv[slot][wave][lane] = v;
+        } else {
+            f16 *d = vdst + slot * (8 * 64 * 8);
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        m_run[t] = -1.0e30f; l_run[t] = 0.f;
+            for (int i = 0; i < 8; ++i) d[((vr0 + i) ^ vx) * 8] = v[i];
+        }
+    };
+    f32x4 o[4];
+    float m_run = -1.0e30f, l_run = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    kv[0][wave][lane] = stage_a(0);
-    if constexpr (WAVES == 4) kv[0][4 + wave][lane] = stage_v(0, wave);
-    __syncthreads();
-    int buf = 0;
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int vrd = grp * 16;                               // reader side of the V swizzle
+    auto compute = [&](int step, int slot) {
+        const int k0 = step * 32;
+        f16x8 kf[4], vf[4];                        // V fragments are read HERE: their LDS latency hides beneath the softmax
+#pragma unroll
+        for (int f = 0; f < 4; ++f) kf[f] = kv[slot][f][lane];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vf[dt] = kv[slot][4 + dt][vrd + (r16 ^ (2 * dt))];
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            s0 = MFMA_16x16x32(kf[ks], qf[ks], s0);
+            s1 = MFMA_16x16x32(kf[2 + ks], qf[ks], s1);
+        }
+        // accumulator row 4g+r of tile 0 is key k0 + 8g + r, of tile 1 key k0 + 8g + 4 + r
+        if (k0 + 32 > Np) {                      // only the last step has keys beyond the sequence (wave-uniform branch)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k0 + 8 * grp + r >= Np) s0[r] = -1.0e30f;
+                if (k0 + 8 * grp + 4 + r >= Np) s1[r] = -1.0e30f;
+            }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        mx = row_group_max(mx);                  // the four lane groups of a query column must share the stabiliser
+        const float m_new = fmaxf(m_run, mx);
+        // Online-softmax rescale only when some query of this tile saw a new maximum: after the first few key steps that
+        // is rare, and the 16 multiplies + the exp were a fifth of the step's VALU work.  alpha = exp2(0) = 1 exactly
+        // otherwise, so skipping is bit-identical.
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){o[dt][0] * alpha, o[dt][1] * alpha, o[dt][2] * alpha, o[dt][3] * alpha};
+            l_run *= alpha;
+        }
+        float p[8], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            p[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            sum += p[r] + p[4 + r];
+        }
+        // the denominator stays a per-LANE partial (alpha is the same in all four lane groups of a column): one
+        // cross-group reduction after the key loop instead of two shuffles through the LDS crossbar per 32-key step
+        l_run += sum;
+        m_run = m_new;
+        const f16x8 pf = {(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3], (f16)p[4], (f16)p[5], (f16)p[6], (f16)p[7]};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = MFMA_16x16x32(vf[dt], pf, o[dt]);
+    };
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // one half of the unrolled loop: computes `step` from `slot`; st_old holds step + 2 (fetched one half earlier), st_new takes step + 3
+    auto half_step = [&](int step, int slot, f16x8 &st_new, const f16x8 &st_old) {
+        st_new = stage(step + 3);                 // unconditional (keys are clamped): a conditional load makes hipcc wait vmcnt(0)
+        if (has_q && step < steps) compute(step, slot);
+        // slot (slot + 2) % 3; unconditional as well (behind the last steps it rewrites a slot nobody reads again): a skipped
+        // publish is a path without its vmcnt wait, and hipcc then drains vmcnt(0) at the loop header
+        publish(slot >= 1 ? slot - 1 : 2, st_old);
+        lds_barrier();
+    };
+    f16x8 sa, sb;
+    publish(0, stage(0));
+    if (steps > 1) publish(1, stage(1));
+    sb = stage(2);
+    lds_barrier();
+    int slot = 0;
 #pragma unroll 1
-    for (int k0 = 0; k0 < Tp; k0 += 32) {
-        const bool more = k0 + 32 < Tp;
-        f16x8 stk, stv;
-        if (more) {
-            stk = stage_a(k0 + 32);
-            if constexpr (WAVES == 4) stv = stage_v(k0 + 32, wave);
-        }
-        if (has_q) {
-            f16x8 kf[4];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) kf[f] = kv[buf][f][lane];
-            f16x8 pf[QT];
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    s0 = MFMA_16x16x32(kf[ks], qf[t][ks], s0);
-                    s1 = MFMA_16x16x32(kf[2 + ks], qf[t][ks], s1);
-                }
-                // accumulator row 4g+r of tile 0 is key k0 + 8g + r, of tile 1 key k0 + 8g + 4 + r
-                if (k0 + 32 > Np) {                      // only the last step has keys beyond the sequence (wave-uniform branch)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (k0 + 8 * grp + r >= Np) s0[r] = -1.0e30f;
-                        if (k0 + 8 * grp + 4 + r >= Np) s1[r] = -1.0e30f;
-                    }
-                }
-                float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-                mx = row_group_max(mx);                  // the four lane groups of a query column must share the stabiliser
-                const float m_new = fmaxf(m_run[t], mx);
-                // Online-softmax rescale only when some query of this tile saw a new maximum: after the first few key steps that
-                // is rare, and the 16 multiplies + the exp were a fifth of the step's VALU work.  alpha = exp2(0) = 1 exactly
-                // otherwise, so skipping is bit-identical.
-                if (__any(m_new > m_run[t])) {
-                    const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-                        o[t][dt] = (f32x4){o[t][dt][0] * alpha, o[t][dt][1] * alpha, o[t][dt][2] * alpha, o[t][dt][3] * alpha};
-                    l_run[t] *= alpha;
-                }
-                float p[8], sum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-                    p[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
-                    sum += p[r] + p[4 + r];
-                }
-                // the denominator stays a per-LANE partial (alpha is the same in all four lane groups of a column): one
-                // cross-group reduction after the key loop instead of two shuffles through the LDS crossbar per 32-key step
-                l_run[t] += sum;
-                m_run[t] = m_new;
-                pf[t] = (f16x8){(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3], (f16)p[4], (f16)p[5], (f16)p[6], (f16)p[7]};
-            }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const f16x8 vf = kv[buf][4 + dt][lane];
-#pragma unroll
-                for (int t = 0; t < QT; ++t) o[t][dt] = MFMA_16x16x32(vf, pf[t], o[t][dt]);
-            }
-        }
-        if (more) {
-            kv[buf ^ 1][wave][lane] = stk;
-            if constexpr (WAVES == 4) kv[buf ^ 1][4 + wave][lane] = stv;
-        }
-        __syncthreads();
-        buf ^= 1;
+    for (int step = 0; step < steps; step += 2) {
+        half_step(step, slot, sa, sb);
+        slot = slot == 2 ? 0 : slot + 1;
+        half_step(step + 1, slot, sb, sa);        // always (it only skips its MFMAs behind the last step): a path around it would
+                                                  // reach the loop header with sa's load in flight, i.e. another vmcnt(0)
+        slot = slot == 2 ? 0 : slot + 1;
     }
+    float l = l_run;
+    l += __shfl_xor(l, 16);                      // all lanes take part (the exchange partners share r16, not the branch below)
+    l += __shfl_xor(l, 32);
+    const int qrow = qt0 * 16 + r16;
+    if (has_q && qrow < Np) {
+        const float inv = 1.0f / l;
+        f16 *dst = att + ((long)b * Np + qrow) * kD + hh * kHd + 4 * grp;
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        float l = l_run[t];
-        l += __shfl_xor(l, 16);                  // all lanes take part (the exchange partners share r16, not the branch below)
-        l += __shfl_xor(l, 32);
-        const int qrow = (qt0 + t) * 16 + r16;
-        if (has_q && qrow < Np) {
-            const float inv = 1.0f / l;
-            f16 *dst = att + ((long)b * Np + qrow) * kD + hh * kHd + 4 * grp;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<f16x4 *>(dst + dt * 16) = (f16x4){(f16)(o[t][dt][0] * inv), (f16)(o[t][dt][1] * inv),
-                                                                    (f16)(o[t][dt][2] * inv), (f16)(o[t][dt][3] * inv)};
-        }
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<f16x4 *>(dst + dt * 16) = (f16x4){(f16)(o[dt][0] * inv), (f16)(o[dt][1] * inv),
+                                                                (f16)(o[dt][2] * inv), (f16)(o[dt][3] * inv)};
     }
 }
 
@@ -353,7 +344,7 @@ struct nunif_depth_anything {
     Lin patch; float *cls = nullptr, *norm_g = nullptr, *norm_b = nullptr;
     std::vector<Blk> blk;
     Lin proj[4], rs0, rs1, rs3g; std::vector<Cnv> rs3; Cnv rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
-    Buf a_col, pe, t, y, qkv, vt, att, hid, feat[4], rnb[4], m1, m2, m3, m4, m5, part, col;
+    Buf a_col, pe, t, y, qkv, att, hid, feat[4], rnb[4], m1, m2, m3, m4, m5, part, col;
 };
 
 namespace {
@@ -662,7 +653,7 @@ extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors,
 extern "C" void nunif_hip_depth_anything_destroy(nunif_depth_anything *h) {
     if (!h) return;
     for (void *p : h->owned) (void)hipFree(p);
-    Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->vt, &h->att, &h->hid, &h->feat[0], &h->feat[1], &h->feat[2],
+    Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->att, &h->hid, &h->feat[0], &h->feat[1], &h->feat[2],
                    &h->feat[3], &h->rnb[0], &h->rnb[1], &h->rnb[2], &h->rnb[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5, &h->part, &h->col};
     for (Buf *b : bufs) b->release();
     delete h;
@@ -676,7 +667,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
                   "depth_anything_forward: h, w must be multiples of 14 (>= 28)");
     hipStream_t s = (hipStream_t)stream;
     const int kD = h->D, kHeads = h->heads, F = h->feat_ch;
-    const int gh = hh / kPatch, gw = ww / kPatch, N = gh * gw, Np = N + 1, Tp = (Np + 31) / 32 * 32;
+    const int gh = hh / kPatch, gw = ww / kPatch, N = gh * gw, Np = N + 1;
     const long T = (long)B * Np;
     const size_t e2 = sizeof(f16);
     // DPT map sizes
@@ -691,14 +682,14 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     int rc;
     if ((rc = h->a_col.ensure((size_t)B * N * kKp * e2)) || (rc = h->pe.ensure((size_t)B * N * kD * e2)) ||
         (rc = h->t.ensure(T * kD * e2)) || (rc = h->y.ensure(T * kD * e2)) || (rc = h->qkv.ensure(T * 3 * kD * e2)) ||
-        (rc = h->vt.ensure((size_t)B * kHeads * kHd * Tp * e2)) || (rc = h->att.ensure(T * kD * e2)) ||
+        (rc = h->att.ensure(T * kD * e2)) ||
         (rc = h->hid.ensure(T * 4 * kD * e2)) || (rc = h->m1.ensure(big * e2)) || (rc = h->m2.ensure(big * e2)) ||
         (rc = h->m3.ensure(big * e2)) || (rc = h->m4.ensure(big * e2)) || (rc = h->m5.ensure(big * e2)))
         return rc;
     for (int i = 0; i < 4; ++i)
         if ((rc = h->feat[i].ensure(T * kD * e2)) || (rc = h->rnb[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2))) return rc;
     f16 *a_col = (f16 *)h->a_col.p, *pe = (f16 *)h->pe.p, *t = (f16 *)h->t.p, *y = (f16 *)h->y.p, *qkv = (f16 *)h->qkv.p;
-    f16 *vt = (f16 *)h->vt.p, *att = (f16 *)h->att.p, *hid = (f16 *)h->hid.p;
+    f16 *att = (f16 *)h->att.p, *hid = (f16 *)h->hid.p;
     auto blocks = [](long n) { return (unsigned)((n + 255) / 256); };
 
     {   // patch embedding
@@ -718,12 +709,21 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             if ((rc = launch_da_layernorm(t, bk.g1, bk.b1, y, T, kD, s))) return rc;
         }
         if ((rc = run_tok(bk.qkv, y, T, 0, nullptr, qkv, s, "da_qkv"))) return rc;
-        da_vt_kernel<<<blocks((long)B * kHeads * kHd * Tp), 256, 0, s>>>(qkv, vt, B, Np, Tp, kD, kHeads);
-        NUNIF_LAUNCH_CHECK();
         {
             ProfScope ps("da_attn_kernel", s, 4.0 * B * (double)Np * Np * kD, (double)T * kD * 8.0);
-            dim3 grid((unsigned)(((Np + 15) / 16 + 7) / 8), kHeads, B);           // 8 waves x 1 query tile = 128 queries per workgroup
-            da_attn_lds_kernel<1, 8><<<grid, 512, 0, s>>>(qkv, vt, att, Np, Tp, kD, kHeads);
+            // One wave = one 16-query tile over ALL keys, so the chip's time is (workgroups per CU) x (waves per SIMD) wave-passes:
+            // ViT-S at B = 4 is 24 (frame, head) pairs x 86 tiles = 264 workgroups of 8 — eight more than CUs, and the CUs that
+            // get two run four waves per SIMD for twice as long while the other 248 idle (SQ_WAVE_CYCLES: 1.34 waves per SIMD on
+            // average).  12 tiles per workgroup are 192 workgroups of 3 waves per SIMD: 3 passes instead of 4 (measured on one box:
+            // 0.530 -> 0.435 ms per 12 launches; 16 tiles: 0.506).
+            const int tiles = (Np + 15) / 16, pairs = kHeads * B;
+            auto passes = [&](int w) { return (long)((pairs * ((tiles + w - 1) / w) + 255) / 256) * ((w + 3) / 4); };
+            int w = passes(12) < passes(8) ? 12 : 8;
+            if (passes(16) < passes(w)) w = 16;
+            dim3 grid((unsigned)((tiles + w - 1) / w), kHeads, B);
+            if (w == 8) da_attn_kernel<8><<<grid, 512, 0, s>>>(qkv, att, Np, kD, kHeads);
+            else if (w == 12) da_attn_kernel<12><<<grid, 768, 0, s>>>(qkv, att, Np, kD, kHeads);
+            else da_attn_kernel<16><<<grid, 1024, 0, s>>>(qkv, att, Np, kD, kHeads);
             NUNIF_LAUNCH_CHECK();
         }
         if ((rc = run_tok(bk.proj, att, T, 0, t, t, s, "da_proj"))) return rc;        // t += ls1 * proj(att)

@@ -527,11 +527,14 @@ __global__ void __launch_bounds__(256) gemm_os_kernel(GemmOsArgs g) {
 #pragma unroll 1
     for (int k0 = 0; k0 < KS; k0 += PF) {
         const bool more = k0 + PF < KS;
-        if (more) load_act(k0 + PF);
+        // every load of the loop is UNCONDITIONAL (indices clamped instead): with a conditional load in flight hipcc has to
+        // wait vmcnt(0) at the next use, which serialises the weight prefetch; and the barrier below is lgkmcnt-only for the
+        // same reason — __syncthreads() drains vmcnt, i.e. the three weight k-steps fetched ahead for the next group
+        load_act(more ? k0 + PF : k0);
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             const int kn = k0 + j + PF - 1;
-            if (kn < KS) load_w(kn, (j + PF - 1) % PF);
+            load_w(kn < KS ? kn : KS - 1, (j + PF - 1) % PF);
             f16x8 bq[MT];
 #pragma unroll
             for (int f = 0; f < MT; ++f) bq[f] = act[buf][j][f][lane];
@@ -544,7 +547,7 @@ __global__ void __launch_bounds__(256) gemm_os_kernel(GemmOsArgs g) {
 #pragma unroll
             for (int f = 0; f < MT; ++f) act[buf ^ 1][wave][f][lane] = st[f];
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         buf ^= 1;
     }
     const int np = nt0 * 16;                                      // the wave's two tiles = one 32-channel pair
