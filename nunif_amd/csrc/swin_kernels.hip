@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "swin_kernels.h"
+#include "swin_gelu.h"
 
 namespace nunif {
 
@@ -474,17 +475,24 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag) {
 }
 
 // =================================================================================================================
-// Output-stationary Linear (swin_kernels.h GemmOsArgs).  Workgroup = 4 waves = 64 tokens x 128 channels; wave w owns channel
-// tiles 2w, 2w + 1 of the workgroup's 8 and all 4 token tiles: acc[4][2].  K loop in groups of 4 k-steps over 4 register
-// buffers: the loads of step k + 3 are issued in front of the MFMAs of step k (static buffer indices, nothing dynamic).
+// Output-stationary Linear (swin_kernels.h GemmOsArgs).  Workgroup = 4 waves = MT x 16 tokens x 128 channels; wave w owns channel
+// tiles 2w, 2w + 1 of the workgroup's 8 and all MT token tiles: acc[MT][2].  The K loop runs in groups of PF k-steps over PF
+// register buffers (refilled PF k-steps ahead, right behind the MFMAs that read them) for the weights (direct loads, static indices) and an LDS image of the group's activations (shared by the
+// four waves: once through the vector memory pipe instead of four times).
+//
+// These are SHORT-K products (the depth ViT: 5 492 tokens, K = 384 or 1 536): a workgroup lives for a few thousand cycles, and
+// round 2's form (PF = 4: weights three k-steps = ~200 MFMA-cycles ahead, the residual read in the epilogue, libm erff for the
+// GELU) was a chain of exposed memory latencies — SQ counters of the ViT-S run: 53 % of all wave-cycles in s_waitcnt, 10 VALU
+// per MFMA, 2.05 waves per SIMD on average.  Now: PF = 12 (8 where K is not a multiple of 384) puts a whole K = 384 product's
+// loads in flight at once — one latency per workgroup; the residual tile is fetched with them; every load of the loop is
+// unconditional and the barrier is lgkmcnt-only (a conditional load or __syncthreads() makes hipcc drain vmcnt, which
+// serialises the prefetch); the last group is peeled so that nothing is fetched twice; GELU is swin_gelu.h's polynomial.
 // =================================================================================================================
-template <int MT>                                   // token tiles per workgroup: 4 (64 tokens) or 2 (32 tokens, narrow N)
+template <int MT, int PF, int NB>                   // NB = 2 LDS buffers; 1 when the whole K is one group (KS == PF)
 __global__ void __launch_bounds__(256) gemm_os_kernel(GemmOsArgs g) {
-    constexpr int NTW = 2, PF = 4;
-    // the activation tile of a k-group (64 tokens x 128 k = 16 KiB) is shared by the four waves: it goes through LDS once
-    // (fragment-major, double-buffered, one barrier per 4 k-steps) instead of four times through the vector memory pipe, which
-    // at 64 B / clk / CU was the bound of the all-global form (24 KiB of loads per 32 MFMAs); the weights stay direct loads
-    __shared__ __attribute__((aligned(16))) f16x8 act[2][PF][MT][64];
+    constexpr int NTW = 2, SW = PF / 4;              // a wave stages k-steps w, w + 4, .. of every group
+    static_assert(PF % 4 == 0, "four waves share the staging of a group");
+    __shared__ __attribute__((aligned(16))) f16x8 act[NB][PF][MT][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, grp = lane >> 4;
     const int KS = g.K >> 5;
@@ -493,18 +501,33 @@ __global__ void __launch_bounds__(256) gemm_os_kernel(GemmOsArgs g) {
     const long mb = blockIdx.x / n_blocks;
     const long m0 = mb * (MT * 16);
     const int nt0 = nb * 8 + wave * NTW;                          // first 16-channel tile of this wave
-    const f16 *arow[MT];                                          // wave w stages k-step w of every group
+    const int np = nt0 * 16;                                      // the wave's two tiles = one 32-channel pair
+    const f16 *arow[MT];
+    f16x8 rres[MT];
+    bool live[MT];
+    long ooff[MT];
 #pragma unroll
     for (int f = 0; f < MT; ++f) {
-        long m = m0 + f * 16 + r16;
-        m = m < g.M ? m : g.M - 1;
-        arow[f] = g.a + m * g.lda + grp * 8 + wave * 32;
+        const long m = m0 + f * 16 + r16;
+        live[f] = m < g.M;
+        const long mc = live[f] ? m : g.M - 1;
+        arow[f] = g.a + mc * g.lda + grp * 8 + wave * 32;
+        ooff[f] = mc * g.ldo + np + pair_run_channel(grp);
+        if (g.res) rres[f] = *reinterpret_cast<const f16x8 *>(g.res + ooff[f]);
     }
     const f16x8 *wbase = reinterpret_cast<const f16x8 *>(g.w) + (long)nt0 * KS * 64 + lane;
-    f16x8 st[MT], aq[PF][NTW];
+    f16x8 st[SW][MT], aq[PF][NTW];
     auto load_act = [&](int k0) {
 #pragma unroll
-        for (int f = 0; f < MT; ++f) st[f] = *reinterpret_cast<const f16x8 *>(arow[f] + k0 * 32);
+        for (int i = 0; i < SW; ++i)
+#pragma unroll
+            for (int f = 0; f < MT; ++f) st[i][f] = *reinterpret_cast<const f16x8 *>(arow[f] + (k0 + 4 * i) * 32);
+    };
+    auto store_act = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < SW; ++i)
+#pragma unroll
+            for (int f = 0; f < MT; ++f) act[buf][wave + 4 * i][f][lane] = st[i][f];
     };
     auto load_w = [&](int ks, int buf) {
 #pragma unroll
@@ -519,58 +542,62 @@ __global__ void __launch_bounds__(256) gemm_os_kernel(GemmOsArgs g) {
     }
     load_act(0);
 #pragma unroll
-    for (int j = 0; j < PF - 1; ++j) load_w(j, j);
-#pragma unroll
-    for (int f = 0; f < MT; ++f) act[0][wave][f][lane] = st[f];
-    __syncthreads();
+    for (int j = 0; j < PF; ++j) load_w(j, j);
+    store_act(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int buf = 0;
+    auto mfma_step = [&](int j) {
+        f16x8 bq[MT];
+#pragma unroll
+        for (int f = 0; f < MT; ++f) bq[f] = act[NB == 1 ? 0 : buf][j][f][lane];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int f = 0; f < MT; ++f) acc[f][n] = MFMA_16x16x32(aq[j][n], bq[f], acc[f][n]);
+    };
+    if constexpr (NB == 2) {
 #pragma unroll 1
-    for (int k0 = 0; k0 < KS; k0 += PF) {
-        const bool more = k0 + PF < KS;
-        // every load of the loop is UNCONDITIONAL (indices clamped instead): with a conditional load in flight hipcc has to
-        // wait vmcnt(0) at the next use, which serialises the weight prefetch; and the barrier below is lgkmcnt-only for the
-        // same reason — __syncthreads() drains vmcnt, i.e. the three weight k-steps fetched ahead for the next group
-        load_act(more ? k0 + PF : k0);
+        for (int k0 = 0; k0 + PF < KS; k0 += PF) {               // every group but the last: the next group is fetched behind it
+            load_act(k0 + PF);
 #pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            const int kn = k0 + j + PF - 1;
-            load_w(kn < KS ? kn : KS - 1, (j + PF - 1) % PF);
-            f16x8 bq[MT];
-#pragma unroll
-            for (int f = 0; f < MT; ++f) bq[f] = act[buf][j][f][lane];
-#pragma unroll
-            for (int n = 0; n < NTW; ++n)
-#pragma unroll
-                for (int f = 0; f < MT; ++f) acc[f][n] = MFMA_16x16x32(aq[j][n], bq[f], acc[f][n]);
+            for (int j = 0; j < PF; ++j) {
+                mfma_step(j);
+                load_w(k0 + PF + j, j);                           // buffer j is free again: PF k-steps ahead
+            }
+            store_act(buf ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            buf ^= 1;
         }
-        if (more) {
-#pragma unroll
-            for (int f = 0; f < MT; ++f) act[buf ^ 1][wave][f][lane] = st[f];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        buf ^= 1;
     }
-    const int np = nt0 * 16;                                      // the wave's two tiles = one 32-channel pair
+#pragma unroll
+    for (int j = 0; j < PF; ++j) mfma_step(j);
 #pragma unroll
     for (int f = 0; f < MT; ++f) {
-        const long m = m0 + f * 16 + r16;
-        float v0[4] = {acc[f][0][0], acc[f][0][1], acc[f][0][2], acc[f][0][3]};
-        float v1[4] = {acc[f][1][0], acc[f][1][1], acc[f][1][2], acc[f][1][3]};
+        f16x4 o0, o1;
         if (g.act == 1) {
+            const f16x8 h = gelu8(acc[f][0], acc[f][1]);
+            o0 = (f16x4){h[0], h[1], h[2], h[3]};
+            o1 = (f16x4){h[4], h[5], h[6], h[7]};
+            if (g.res) {                                          // (no caller today: GELU is fc1, the residual proj / fc2)
+                f16x4 ra, rb;
+                run_to_pair(rres[f], ra, rb);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf(v0[r]); v1[r] = gelu_erf(v1[r]); }
-        }
-        const bool live = m < g.M;
-        const long off = (live ? m : 0) * g.ldo + np + pair_run_channel(grp);
-        if (g.res) {
-            f16x4 ra, rb;
-            run_to_pair(*reinterpret_cast<const f16x8 *>(g.res + off), ra, rb);
+                for (int r = 0; r < 4; ++r) { o0[r] = (f16)((float)o0[r] + (float)ra[r]); o1[r] = (f16)((float)o1[r] + (float)rb[r]); }
+            }
+        } else {
+            float v0[4] = {acc[f][0][0], acc[f][0][1], acc[f][0][2], acc[f][0][3]};
+            float v1[4] = {acc[f][1][0], acc[f][1][1], acc[f][1][2], acc[f][1][3]};
+            if (g.res) {
+                f16x4 ra, rb;
+                run_to_pair(rres[f], ra, rb);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v0[r] += (float)ra[r]; v1[r] += (float)rb[r]; }
+                for (int r = 0; r < 4; ++r) { v0[r] += (float)ra[r]; v1[r] += (float)rb[r]; }
+            }
+            o0 = (f16x4){(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3]};
+            o1 = (f16x4){(f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]};
         }
-        const f16x8 ov = pair_to_run((f16x4){(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3]},
-                                     (f16x4){(f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]});
-        if (live) *reinterpret_cast<f16x8 *>(g.out + off) = ov;
+        const f16x8 ov = pair_to_run(o0, o1);
+        if (live[f]) *reinterpret_cast<f16x8 *>(g.out + ooff[f]) = ov;
     }
 }
 
@@ -578,19 +605,27 @@ bool gemm_os_supported(long M, int N, int K) {
     return M > 0 && N % 128 == 0 && K % 128 == 0 && K >= 128;
 }
 
+template <int MT, int PF>
+static void launch_gemm_os_t(const GemmOsArgs &g, hipStream_t s) {
+    const unsigned blocks = (unsigned)(((g.M + MT * 16 - 1) / (MT * 16)) * (g.N / 128));
+    if (g.K == PF * 32) gemm_os_kernel<MT, PF, 1><<<blocks, 256, 0, s>>>(g);
+    else gemm_os_kernel<MT, PF, 2><<<blocks, 256, 0, s>>>(g);
+}
+
 int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag) {
     NUNIF_REQUIRE(gemm_os_supported(g.M, g.N, g.K) && g.lda % 8 == 0 && g.ldo % 8 == 0, "gemm_os %s: M=%ld N=%d K=%d unsupported",
                   tag, g.M, g.N, g.K);
     ProfScope ps(profile_tags_enabled() ? tag : "gemm_os_kernel", s, 2.0 * (double)g.M * g.K * g.N,
                  (double)g.M * (g.K * 2.0 + g.N * 2.0 * (g.res ? 2.0 : 1.0)));
-    // 32-token workgroups (fewer registers, more resident waves to hide the short K loop's prologue) unless 64-token ones already
-    // give the chip four workgroups per CU; measured on ViT-S (5 492 tokens): fc1 0.339 -> 0.315 ms, fc2 0.345 -> 0.313 ms per 12 launches
-    const long blocks = ((g.M + 63) / 64) * (g.N / 128);
-    if (blocks < 1100) {
-        gemm_os_kernel<2><<<(unsigned)(((g.M + 31) / 32) * (g.N / 128)), 256, 0, s>>>(g);
-    } else {
-        gemm_os_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(g);
-    }
+    // 32-token workgroups (fewer registers, more resident waves) unless 64-token ones already give the chip four workgroups per CU
+    // (those keep the round-2 shape: 64 tokens, four k-steps per group)
+    const bool wide = ((g.M + 63) / 64) * (g.N / 128) >= 1100;
+    // (64-token tiles with PF = 12 — 40 % less operand traffic — measured on ViT-S: fc1 0.272 -> 0.262, qkv 0.219 -> 0.220, fc2
+    //  0.334 -> 0.404 ms per 12 launches: these launches are not bound by operand bytes either)
+    if (wide) launch_gemm_os_t<4, 4>(g, s);
+    else if (g.K % 384 == 0) launch_gemm_os_t<2, 12>(g, s);
+    else if (g.K % 256 == 0) launch_gemm_os_t<2, 8>(g, s);
+    else launch_gemm_os_t<2, 4>(g, s);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
