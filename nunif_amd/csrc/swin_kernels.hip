@@ -612,11 +612,158 @@ static void launch_gemm_os_t(const GemmOsArgs &g, hipStream_t s) {
     else gemm_os_kernel<MT, PF, 2><<<blocks, 256, 0, s>>>(g);
 }
 
+// ---- the same Linear with the weights STATIONARY in registers (K = 32 KS <= 384 with two channel tiles per wave) --------------
+// A short-K product is all prologue and epilogue when every 32 x 128 output tile is its own workgroup (gemm_os_kernel above: 2 064
+// workgroups that each fetch 96 KiB of weights to run 48 MFMAs per wave, §4.10c).  Here a workgroup keeps its 128 channels'
+// weights in registers (KS x NTW fragments per wave) for its whole life and walks the token blocks g, g + G, ..: per tile it
+// fetches only the 32 tokens' rows (through LDS, shared by the four waves) and the residual tile, ONE TILE AHEAD of the MFMAs, so
+// that in steady state no load latency is exposed and the weight traffic falls by the number of tiles per workgroup.  The grid is
+// sized to what is RESIDENT (occupancy x CUs): a persistent kernel with a few workgroups too many runs a second pass for them.
+template <int KS, int NTW, int MT, bool RES, bool GELU>           // compile-time residual / GELU: a load under a run-time `if` costs vmcnt(0)
+__global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, int G) {
+    constexpr int SW = KS / 4;
+    static_assert(KS % 4 == 0, "four waves share the staging of a tile");
+    __shared__ __attribute__((aligned(16))) f16x8 act[2][KS][MT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, grp = lane >> 4;
+    const int n_blocks = g.N / (64 * NTW);
+    const int nb = blockIdx.x % n_blocks;                         // neighbours in the grid share their token blocks (L2)
+    const int g0 = blockIdx.x / n_blocks;
+    const int nt0 = nb * 4 * NTW + wave * NTW;
+    const int np = nt0 * 16;
+    const int acol = grp * 8 + wave * 32;
+    static_assert(NTW == 2, "the epilogue writes 32-channel pairs");
+    const int ocol = np + pair_run_channel(grp);
+    f16x8 aq[KS][NTW];
+    {
+        const f16x8 *wbase = reinterpret_cast<const f16x8 *>(g.w) + (long)nt0 * KS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) aq[ks][n] = wbase[((long)n * KS + ks) * 64];
+    }
+    float4 bv[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) bv[n] = *reinterpret_cast<const float4 *>(g.bias + (nt0 + n) * 16 + grp * 4);
+    f16x8 st[SW][MT];
+    f16x8 rres[MT];
+    auto load_tile = [&](int t) {                                 // rows clamped, never conditional (vmcnt, §4.10c)
+#pragma unroll
+        for (int f = 0; f < MT; ++f) {
+            long m = (long)t * (MT * 16) + f * 16 + r16;
+            m = m < g.M ? m : g.M - 1;
+            const f16 *row = g.a + m * g.lda + acol;
+#pragma unroll
+            for (int i = 0; i < SW; ++i) st[i][f] = *reinterpret_cast<const f16x8 *>(row + 128 * i);
+            if constexpr (RES) rres[f] = *reinterpret_cast<const f16x8 *>(g.res + m * g.ldo + ocol);
+        }
+    };
+    auto store_act = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < SW; ++i)
+#pragma unroll
+            for (int f = 0; f < MT; ++f) act[buf][wave + 4 * i][f][lane] = st[i][f];
+    };
+    int t = g0;
+    load_tile(t);
+    store_act(0);
+    f16x8 rcur[MT];
+    if constexpr (RES) {
+#pragma unroll
+        for (int f = 0; f < MT; ++f) rcur[f] = rres[f];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int buf = 0;
+#pragma unroll 1
+    for (; t < tiles; t += G) {
+        const int tn = t + G < tiles ? t + G : t;
+        load_tile(tn);
+        f32x4 acc[MT][NTW];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int f = 0; f < MT; ++f) acc[f][n] = (f32x4){bv[n].x, bv[n].y, bv[n].z, bv[n].w};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            f16x8 bq[MT];
+#pragma unroll
+            for (int f = 0; f < MT; ++f) bq[f] = act[buf][ks][f][lane];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                for (int f = 0; f < MT; ++f) acc[f][n] = MFMA_16x16x32(aq[ks][n], bq[f], acc[f][n]);
+        }
+#pragma unroll
+        for (int f = 0; f < MT; ++f) {
+            const long m = (long)t * (MT * 16) + f * 16 + r16;
+            const bool live = m < g.M;
+            f16 *dst = g.out + (live ? m : 0) * g.ldo + ocol;
+            {
+                f16x4 o0, o1;
+                if constexpr (GELU) {
+                    const f16x8 h = gelu8(acc[f][0], acc[f][1]);
+                    o0 = (f16x4){h[0], h[1], h[2], h[3]};
+                    o1 = (f16x4){h[4], h[5], h[6], h[7]};
+                } else {
+                    float v0[4] = {acc[f][0][0], acc[f][0][1], acc[f][0][2], acc[f][0][3]};
+                    float v1[4] = {acc[f][1][0], acc[f][1][1], acc[f][1][2], acc[f][1][3]};
+                    if constexpr (RES) {
+                        f16x4 ra, rb;
+                        run_to_pair(rcur[f], ra, rb);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v0[r] += (float)ra[r]; v1[r] += (float)rb[r]; }
+                    }
+                    o0 = (f16x4){(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3]};
+                    o1 = (f16x4){(f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]};
+                }
+                const f16x8 ov = pair_to_run(o0, o1);
+                if (live) *reinterpret_cast<f16x8 *>(dst) = ov;
+            }
+        }
+        store_act(buf ^ 1);
+        if constexpr (RES) {
+#pragma unroll
+            for (int f = 0; f < MT; ++f) rcur[f] = rres[f];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        buf ^= 1;
+    }
+}
+
+// Measured on ViT-S (5 492 tokens, ms per 12 launches, against gemm_os_kernel<2, 12, 1>): fc1 (N = 1 536) 0.266 -> 0.226, qkv (N = 1 152)
+// 0.215 -> 0.204, proj (N = 384: 516 tiles are 258 workgroups of two tiles, one wave per SIMD) 0.139 -> 0.159 — so only N >= 768.
+static bool gemm_ws_shape(const GemmOsArgs &g) { return g.K == 384 && g.N % 128 == 0 && g.N >= 768 && !(g.act == 1 && g.res); }
+
+template <bool RES, bool GELU>
+static int launch_gemm_ws_t(const GemmOsArgs &g, hipStream_t s) {
+    static int resident = 0;                                      // workgroups the chip holds at once
+    if (!resident) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        NUNIF_HIP_CHECK(hipGetDevice(&dev));
+        NUNIF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        NUNIF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)gemm_ws_kernel<12, 2, 2, RES, GELU>, 256, 0));
+        resident = std::max(1, per_cu) * prop.multiProcessorCount;
+    }
+    const int tiles = (int)((g.M + 31) / 32), n_blocks = g.N / 128;
+    const int per_wg = (int)(((long)tiles * n_blocks + resident - 1) / resident);        // tiles per workgroup
+    const int G = (tiles + per_wg - 1) / per_wg;
+    gemm_ws_kernel<12, 2, 2, RES, GELU><<<(unsigned)(G * n_blocks), 256, 0, s>>>(g, tiles, G);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+static int launch_gemm_ws(const GemmOsArgs &g, hipStream_t s) {
+    if (g.res) return launch_gemm_ws_t<true, false>(g, s);
+    return g.act == 1 ? launch_gemm_ws_t<false, true>(g, s) : launch_gemm_ws_t<false, false>(g, s);
+}
+
 int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag) {
     NUNIF_REQUIRE(gemm_os_supported(g.M, g.N, g.K) && g.lda % 8 == 0 && g.ldo % 8 == 0, "gemm_os %s: M=%ld N=%d K=%d unsupported",
                   tag, g.M, g.N, g.K);
     ProfScope ps(profile_tags_enabled() ? tag : "gemm_os_kernel", s, 2.0 * (double)g.M * g.K * g.N,
                  (double)g.M * (g.K * 2.0 + g.N * 2.0 * (g.res ? 2.0 : 1.0)));
+    if (gemm_ws_shape(g)) return launch_gemm_ws(g, s);
     // 32-token workgroups (fewer registers, more resident waves) unless 64-token ones already give the chip four workgroups per CU
     // (those keep the round-2 shape: 64 tokens, four k-steps per group)
     const bool wide = ((g.M + 63) / 64) * (g.N / 128) >= 1100;
