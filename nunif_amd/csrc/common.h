@@ -111,6 +111,18 @@ __device__ __forceinline__ void run_to_pair(f16x8 v, f16x4 &a, f16x4 &b) {      
 }
 #endif
 
+// Workgroups of a 1-D grid are dealt round-robin to the 8 XCDs (blockIdx.x % 8), and every XCD has its OWN L2: neighbours in
+// blockIdx never share one.  xcd_contiguous() renumbers the grid so that XCD x owns a contiguous range of logical ids — use the
+// result wherever neighbouring ids share operands (the channel blocks of one token block, the query blocks of one head), or each
+// of the 8 L2s pulls its own copy of every shared tile through the fabric at the same moment.
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned n) {
+    constexpr unsigned kXcd = 8;
+    const unsigned x = b % kXcd, i = b / kXcd, base = n / kXcd, rem = n % kXcd;
+    return x * base + (x < rem ? x : rem) + i;
+}
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace nunif

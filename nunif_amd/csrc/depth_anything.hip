@@ -118,9 +118,12 @@ __global__ void __launch_bounds__(WAVES * 64) da_attn_kernel(const f16 *__restri
     __shared__ __attribute__((aligned(16))) f16x8 kv[3][8][64];
     // the wave index as an SGPR: the K / V staging arms become scalar branches, so that both carry their vmcnt wait on every path
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, grp = lane >> 4;
-    const int qt0 = blockIdx.x * WAVES + wave;
+    // 1-D grid, renumbered so that the query blocks of one (frame, head) — which all walk the same K / V — sit on one XCD's L2
+    const unsigned bid = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int qblocks = (Np + 16 * WAVES - 1) / (16 * WAVES);
+    const int qt0 = (int)(bid % qblocks) * WAVES + wave;
     const bool has_q = qt0 * 16 < Np;
-    const int hh = blockIdx.y, b = blockIdx.z;
+    const int hh = (int)(bid / qblocks) % kHeads, b = (int)(bid / qblocks) / kHeads;
     const f16 *base = qkv + (long)b * Np * (3 * kD);
     const int steps = (Np + 31) >> 5;
     f16x8 qf[2];
@@ -720,7 +723,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             auto passes = [&](int w) { return (long)((pairs * ((tiles + w - 1) / w) + 255) / 256) * ((w + 3) / 4); };
             int w = passes(12) < passes(8) ? 12 : 8;
             if (passes(16) < passes(w)) w = 16;
-            dim3 grid((unsigned)((tiles + w - 1) / w), kHeads, B);
+            const unsigned grid = (unsigned)((tiles + w - 1) / w) * kHeads * B;
             if (w == 8) da_attn_kernel<8><<<grid, 512, 0, s>>>(qkv, att, Np, kD, kHeads);
             else if (w == 12) da_attn_kernel<12><<<grid, 768, 0, s>>>(qkv, att, Np, kD, kHeads);
             else da_attn_kernel<16><<<grid, 1024, 0, s>>>(qkv, att, Np, kD, kHeads);

@@ -497,8 +497,9 @@ __global__ void __launch_bounds__(256) gemm_os_kernel(GemmOsArgs g) {
     const int r16 = lane & 15, grp = lane >> 4;
     const int KS = g.K >> 5;
     const int n_blocks = g.N >> 7;
-    const int nb = blockIdx.x % n_blocks;
-    const long mb = blockIdx.x / n_blocks;
+    const unsigned bid = xcd_contiguous(blockIdx.x, gridDim.x);  // the n_blocks channel blocks of a token block on ONE XCD's L2
+    const int nb = bid % n_blocks;
+    const long mb = bid / n_blocks;
     const long m0 = mb * (MT * 16);
     const int nt0 = nb * 8 + wave * NTW;                          // first 16-channel tile of this wave
     const int np = nt0 * 16;                                      // the wave's two tiles = one 32-channel pair
@@ -612,28 +613,29 @@ static void launch_gemm_os_t(const GemmOsArgs &g, hipStream_t s) {
     else gemm_os_kernel<MT, PF, 2><<<blocks, 256, 0, s>>>(g);
 }
 
-// ---- the same Linear with the weights STATIONARY in registers (K = 32 KS <= 384 with two channel tiles per wave) --------------
+// ---- the same Linear with the weights STATIONARY in registers (K = 384, two channel tiles per wave, no residual) ----------------
 // A short-K product is all prologue and epilogue when every 32 x 128 output tile is its own workgroup (gemm_os_kernel above: 2 064
-// workgroups that each fetch 96 KiB of weights to run 48 MFMAs per wave, §4.10c).  Here a workgroup keeps its 128 channels'
+// workgroups that each fetch 96 KiB of weights to run 48 MFMAs per wave).  Here a workgroup keeps its 128 channels'
 // weights in registers (KS x NTW fragments per wave) for its whole life and walks the token blocks g, g + G, ..: per tile it
-// fetches only the 32 tokens' rows (through LDS, shared by the four waves) and the residual tile, ONE TILE AHEAD of the MFMAs, so
-// that in steady state no load latency is exposed and the weight traffic falls by the number of tiles per workgroup.  The grid is
-// sized to what is RESIDENT (occupancy x CUs): a persistent kernel with a few workgroups too many runs a second pass for them.
-template <int KS, int NTW, int MT, bool RES, bool GELU>           // compile-time residual / GELU: a load under a run-time `if` costs vmcnt(0)
+// fetches only the 32 tokens' rows, by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a ring of three LDS images,
+// TWO TILES AHEAD of the MFMAs.  The loop has no compiler-visible vector load at all, so the only vmcnt wait in it is the
+// hand-counted one: `vmcnt(MT * SW)` behind the MFMAs = everything but the newest tile's DMAs has landed (loads return in order;
+// the stores of the previous tile, which may retire in any order, are a tile old by then and are simply waited for as well).
+// The grid is sized to what is RESIDENT (occupancy x CUs): a persistent kernel with a few workgroups too many runs a second pass.
+template <int KS, int NTW, int MT, bool GELU>
 __global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, int G) {
-    constexpr int SW = KS / 4;
-    static_assert(KS % 4 == 0, "four waves share the staging of a tile");
-    __shared__ __attribute__((aligned(16))) f16x8 act[2][KS][MT][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int SW = KS / 4;                                    // a wave stages k-steps w, w + 4, ..
+    static_assert(KS % 4 == 0 && NTW == 2 && MT * SW == 6, "vmcnt(6) below; the epilogue writes 32-channel pairs");
+    __shared__ __attribute__((aligned(16))) f16x8 act[3][KS][MT][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, grp = lane >> 4;
     const int n_blocks = g.N / (64 * NTW);
-    const int nb = blockIdx.x % n_blocks;                         // neighbours in the grid share their token blocks (L2)
-    const int g0 = blockIdx.x / n_blocks;
+    const unsigned bid = xcd_contiguous(blockIdx.x, gridDim.x);  // neighbours in `bid` share their token blocks: same XCD, same L2
+    const int nb = bid % n_blocks;
+    const int g0 = bid / n_blocks;
     const int nt0 = nb * 4 * NTW + wave * NTW;
-    const int np = nt0 * 16;
+    const int ocol = nt0 * 16 + pair_run_channel(grp);
     const int acol = grp * 8 + wave * 32;
-    static_assert(NTW == 2, "the epilogue writes 32-channel pairs");
-    const int ocol = np + pair_run_channel(grp);
     f16x8 aq[KS][NTW];
     {
         const f16x8 *wbase = reinterpret_cast<const f16x8 *>(g.w) + (long)nt0 * KS * 64 + lane;
@@ -645,39 +647,35 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, i
     float4 bv[NTW];
 #pragma unroll
     for (int n = 0; n < NTW; ++n) bv[n] = *reinterpret_cast<const float4 *>(g.bias + (nt0 + n) * 16 + grp * 4);
-    f16x8 st[SW][MT];
-    f16x8 rres[MT];
-    auto load_tile = [&](int t) {                                 // rows clamped, never conditional (vmcnt, §4.10c)
+    auto dma_tile = [&](int t, int slot) {                        // rows clamped, never conditional: always MT * SW DMAs
 #pragma unroll
         for (int f = 0; f < MT; ++f) {
             long m = (long)t * (MT * 16) + f * 16 + r16;
             m = m < g.M ? m : g.M - 1;
             const f16 *row = g.a + m * g.lda + acol;
 #pragma unroll
-            for (int i = 0; i < SW; ++i) st[i][f] = *reinterpret_cast<const f16x8 *>(row + 128 * i);
-            if constexpr (RES) rres[f] = *reinterpret_cast<const f16x8 *>(g.res + m * g.ldo + ocol);
+            for (int i = 0; i < SW; ++i) {
+                const unsigned lds_addr = (unsigned)reinterpret_cast<size_t>(&act[slot][wave + 4 * i][f][0]);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(row + 128 * i), "s"(lds_addr) : "memory");
+            }
         }
     };
-    auto store_act = [&](int buf) {
+    dma_tile(g0, 0);
+    dma_tile(g0 + G, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the weights and the bias have landed, and the compiler must KNOW it (an opaque use of each register): its own wait for a
+    // first use inside the loop would be vmcnt(0) on every trip, which drains the hand-counted DMAs as well
 #pragma unroll
-        for (int i = 0; i < SW; ++i)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int f = 0; f < MT; ++f) act[buf][wave + 4 * i][f][lane] = st[i][f];
-    };
-    int t = g0;
-    load_tile(t);
-    store_act(0);
-    f16x8 rcur[MT];
-    if constexpr (RES) {
+        for (int n = 0; n < NTW; ++n) asm volatile("" : "+v"(aq[ks][n]));
 #pragma unroll
-        for (int f = 0; f < MT; ++f) rcur[f] = rres[f];
-    }
+    for (int n = 0; n < NTW; ++n) asm volatile("" : "+v"(bv[n].x), "+v"(bv[n].y), "+v"(bv[n].z), "+v"(bv[n].w));
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    int buf = 0;
+    int slot = 0;
 #pragma unroll 1
-    for (; t < tiles; t += G) {
-        const int tn = t + G < tiles ? t + G : t;
-        load_tile(tn);
+    for (int t = g0; t < tiles; t += G) {
+        dma_tile(t + 2 * G, slot == 0 ? 2 : slot - 1);           // (slot + 2) % 3: read last in the previous trip, behind its barrier
         f32x4 acc[MT][NTW];
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
@@ -687,54 +685,39 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, i
         for (int ks = 0; ks < KS; ++ks) {
             f16x8 bq[MT];
 #pragma unroll
-            for (int f = 0; f < MT; ++f) bq[f] = act[buf][ks][f][lane];
+            for (int f = 0; f < MT; ++f) bq[f] = act[slot][ks][f][lane];
 #pragma unroll
             for (int n = 0; n < NTW; ++n)
 #pragma unroll
                 for (int f = 0; f < MT; ++f) acc[f][n] = MFMA_16x16x32(aq[ks][n], bq[f], acc[f][n]);
         }
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // tile t + G is in LDS; only tile t + 2G's six DMAs may be in flight
 #pragma unroll
         for (int f = 0; f < MT; ++f) {
             const long m = (long)t * (MT * 16) + f * 16 + r16;
-            const bool live = m < g.M;
-            f16 *dst = g.out + (live ? m : 0) * g.ldo + ocol;
-            {
-                f16x4 o0, o1;
-                if constexpr (GELU) {
-                    const f16x8 h = gelu8(acc[f][0], acc[f][1]);
-                    o0 = (f16x4){h[0], h[1], h[2], h[3]};
-                    o1 = (f16x4){h[4], h[5], h[6], h[7]};
-                } else {
-                    float v0[4] = {acc[f][0][0], acc[f][0][1], acc[f][0][2], acc[f][0][3]};
-                    float v1[4] = {acc[f][1][0], acc[f][1][1], acc[f][1][2], acc[f][1][3]};
-                    if constexpr (RES) {
-                        f16x4 ra, rb;
-                        run_to_pair(rcur[f], ra, rb);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { v0[r] += (float)ra[r]; v1[r] += (float)rb[r]; }
-                    }
-                    o0 = (f16x4){(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3]};
-                    o1 = (f16x4){(f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]};
-                }
-                const f16x8 ov = pair_to_run(o0, o1);
-                if (live) *reinterpret_cast<f16x8 *>(dst) = ov;
+            f16x4 o0, o1;
+            if constexpr (GELU) {
+                const f16x8 h = gelu8(acc[f][0], acc[f][1]);
+                o0 = (f16x4){h[0], h[1], h[2], h[3]};
+                o1 = (f16x4){h[4], h[5], h[6], h[7]};
+            } else {
+                o0 = (f16x4){(f16)acc[f][0][0], (f16)acc[f][0][1], (f16)acc[f][0][2], (f16)acc[f][0][3]};
+                o1 = (f16x4){(f16)acc[f][1][0], (f16)acc[f][1][1], (f16)acc[f][1][2], (f16)acc[f][1][3]};
             }
-        }
-        store_act(buf ^ 1);
-        if constexpr (RES) {
-#pragma unroll
-            for (int f = 0; f < MT; ++f) rcur[f] = rres[f];
+            const f16x8 ov = pair_to_run(o0, o1);
+            if (m < g.M) *reinterpret_cast<f16x8 *>(g.out + m * g.ldo + ocol) = ov;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        buf ^= 1;
+        slot = slot == 2 ? 0 : slot + 1;
     }
 }
 
-// Measured on ViT-S (5 492 tokens, ms per 12 launches, against gemm_os_kernel<2, 12, 1>): fc1 (N = 1 536) 0.266 -> 0.226, qkv (N = 1 152)
-// 0.215 -> 0.204, proj (N = 384: 516 tiles are 258 workgroups of two tiles, one wave per SIMD) 0.139 -> 0.159 — so only N >= 768.
-static bool gemm_ws_shape(const GemmOsArgs &g) { return g.K == 384 && g.N % 128 == 0 && g.N >= 768 && !(g.act == 1 && g.res); }
+// Measured on ViT-S (5 492 tokens, ms per 12 launches, against gemm_os_kernel<2, 12, 1>; register-staged first form of this kernel):
+// fc1 (N = 1 536) 0.266 -> 0.226, qkv (N = 1 152) 0.215 -> 0.204, proj (N = 384: 516 tiles are 258 workgroups of two tiles, one
+// wave per SIMD) 0.139 -> 0.159 — so only N >= 768, which also means no residual variant is needed.
+static bool gemm_ws_shape(const GemmOsArgs &g) { return g.K == 384 && g.N % 128 == 0 && g.N >= 768 && !g.res; }
 
-template <bool RES, bool GELU>
+template <bool GELU>
 static int launch_gemm_ws_t(const GemmOsArgs &g, hipStream_t s) {
     static int resident = 0;                                      // workgroups the chip holds at once
     if (!resident) {
@@ -742,20 +725,19 @@ static int launch_gemm_ws_t(const GemmOsArgs &g, hipStream_t s) {
         hipDeviceProp_t prop;
         NUNIF_HIP_CHECK(hipGetDevice(&dev));
         NUNIF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        NUNIF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)gemm_ws_kernel<12, 2, 2, RES, GELU>, 256, 0));
+        NUNIF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)gemm_ws_kernel<12, 2, 2, GELU>, 256, 0));
         resident = std::max(1, per_cu) * prop.multiProcessorCount;
     }
     const int tiles = (int)((g.M + 31) / 32), n_blocks = g.N / 128;
     const int per_wg = (int)(((long)tiles * n_blocks + resident - 1) / resident);        // tiles per workgroup
     const int G = (tiles + per_wg - 1) / per_wg;
-    gemm_ws_kernel<12, 2, 2, RES, GELU><<<(unsigned)(G * n_blocks), 256, 0, s>>>(g, tiles, G);
+    gemm_ws_kernel<12, 2, 2, GELU><<<(unsigned)(G * n_blocks), 256, 0, s>>>(g, tiles, G);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
 
 static int launch_gemm_ws(const GemmOsArgs &g, hipStream_t s) {
-    if (g.res) return launch_gemm_ws_t<true, false>(g, s);
-    return g.act == 1 ? launch_gemm_ws_t<false, true>(g, s) : launch_gemm_ws_t<false, false>(g, s);
+    return g.act == 1 ? launch_gemm_ws_t<true>(g, s) : launch_gemm_ws_t<false>(g, s);
 }
 
 int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag) {
