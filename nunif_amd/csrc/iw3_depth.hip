@@ -65,6 +65,103 @@ resize_aa_axis_kernel(const float *__restrict__ in, float *__restrict__ out, lon
     out[id] = acc;
 }
 
+// The generic kernel above evaluates the filter twice per tap and output (once for the normaliser, once for the weight): at
+// 1080p -> 392 x 686 bicubic that is 24 cubic evaluations for each of 8.9 M intermediate pixels — ~70 us of pure VALU work for
+// weights that only depend on the output COLUMN — and its 4-byte reads at a 2.8-element lane stride touch six cache lines per
+// wave-load.  The two kernels below do the same arithmetic in the same order (bit-identical results) with the weights
+// computed once: a persistent workgroup of the row pass builds the [len_out][K] weight table in LDS and then streams input rows
+// through LDS; a workgroup of the column pass owns one output row, whose <= K filter values are evaluated once, by K threads.
+__global__ void __launch_bounds__(256)
+resize_aa_rows_kernel(const float *__restrict__ in, float *__restrict__ out, long rows, int len_in, int len_out, float scale,
+                      int bicubic, int K) {
+    extern __shared__ float aa_sm[];
+    float *wtab = aa_sm;                                      // [len_out][K]
+    int *xm = reinterpret_cast<int *>(wtab + (long)len_out * K), *xs = xm + len_out;
+    float *row = reinterpret_cast<float *>(xs + len_out);     // [len_in]
+    const int tid = threadIdx.x;
+    const float interp = bicubic ? 4.f : 2.f;
+    const float support = scale >= 1.f ? (interp * 0.5f) * scale : interp * 0.5f;
+    const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    for (int o = tid; o < len_out; o += 256) {
+        const float center = scale * ((float)o + 0.5f);
+        int xmin = (int)(center - support + 0.5f);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5f);
+        if (xmax > len_in) xmax = len_in;
+        const int xsize = xmax - xmin;
+        float total_w = 0.f;
+        for (int j = 0; j < xsize; ++j) total_w += aa_filter(((float)(j + xmin) - center + 0.5f) * invscale, bicubic);
+        const float norm = total_w != 0.f ? 1.f / total_w : 0.f;
+        for (int j = 0; j < xsize; ++j) wtab[o * K + j] = aa_filter(((float)(j + xmin) - center + 0.5f) * invscale, bicubic) * norm;
+        xm[o] = xmin; xs[o] = xsize;
+    }
+    // the next row travels in registers (len_in <= 8 x 256, checked by the launcher) while this one is being filtered from LDS
+    float nxt[8];
+    auto fetch = [&](long r) {
+        const float *src = in + r * len_in;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u;
+            nxt[u] = src[i < len_in ? i : len_in - 1];
+        }
+    };
+    long r = blockIdx.x;
+    if (r < rows) fetch(r);
+    while (r < rows) {
+        __syncthreads();                                      // table ready / previous row consumed
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (tid + 256 * u < len_in) row[tid + 256 * u] = nxt[u];
+        __syncthreads();
+        const long rn = r + gridDim.x;
+        fetch(rn < rows ? rn : r);
+        float *dst = out + r * len_out;
+        for (int o = tid; o < len_out; o += 256) {
+            const float *w = wtab + o * K, *x = row + xm[o];
+            const int n = xs[o];
+            float acc = 0.f;
+            for (int j = 0; j < n; ++j) acc += w[j] * x[j];
+            dst[o] = acc;
+        }
+        r = rn;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+resize_aa_cols_kernel(const float *__restrict__ in, float *__restrict__ out, int len_in, int len_out, int other, float scale,
+                      int bicubic, int do_clamp, int norm_channels, float m0, float m1, float m2, float s0, float s1, float s2) {
+    __shared__ float f[256];
+    const int o = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    const long plane = blockIdx.z;
+    const float interp = bicubic ? 4.f : 2.f;
+    const float support = scale >= 1.f ? (interp * 0.5f) * scale : interp * 0.5f;
+    const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    const float center = scale * ((float)o + 0.5f);
+    int xmin = (int)(center - support + 0.5f);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5f);
+    if (xmax > len_in) xmax = len_in;
+    const int xsize = xmax - xmin;                            // <= 256: checked by the launcher
+    if ((int)threadIdx.x < xsize) f[threadIdx.x] = aa_filter(((float)((int)threadIdx.x + xmin) - center + 0.5f) * invscale, bicubic);
+    __syncthreads();
+    if (q >= other) return;
+    float total_w = 0.f;
+    for (int j = 0; j < xsize; ++j) total_w += f[j];
+    const float norm = total_w != 0.f ? 1.f / total_w : 0.f;
+    const float *src = in + (plane * len_in + xmin) * (long)other + q;
+    float acc = 0.f;
+    for (int j = 0; j < xsize; ++j) {
+        const float w = f[j] * norm;
+        acc += w * src[(long)j * other];
+    }
+    if (do_clamp) acc = fminf(fmaxf(acc, 0.f), 1.f);
+    if (norm_channels > 0) {    // x.sub_(mean).div_(std), depth_anything_model.py:107-109
+        const int c = (int)(plane % norm_channels);
+        acc = (acc - (c == 0 ? m0 : (c == 1 ? m1 : m2))) / (c == 0 ? s0 : (c == 1 ? s1 : s2));
+    }
+    out[(plane * len_out + o) * (long)other + q] = acc;
+}
+
 // ---- dilate_edge ------------------------------------------------------------------------------------------------------
 // Statistics of the 3x3 range map (edge_weight :101-113 needs its mean, std, min and max over the whole image) travel as
 // one PARTIAL per workgroup, reduced in a fixed order by every consumer workgroup: no atomics (round 1: 4 same-line atomics
@@ -396,13 +493,31 @@ extern "C" int nunif_hip_resize_aa(const float *x, float *y, float *tmp, int64_t
     hipStream_t s = (hipStream_t)stream;
     const double bytes = (double)planes * 4.0 * ((double)h_in * w_in + 2.0 * h_in * w_out + (double)h_out * w_out);
     ProfScope ps("resize_aa", s, 0.0, bytes);
+    auto taps = [&](float scale) {                               // upper bound of xsize = xmax - xmin
+        const float support = (bicubic ? 2.f : 1.f) * (scale >= 1.f ? scale : 1.f);
+        return (int)(2.f * support) + 3;
+    };
     {   // width first: [planes][h_in][w_in] -> tmp [planes][h_in][w_out]
-        const long total = planes * (long)h_in * w_out;
-        resize_aa_axis_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(
-            x, tmp, planes, w_in, w_out, h_in, 1, scale_of(w_in, w_out), bicubic, 0, 0, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
+        const float sc = scale_of(w_in, w_out);
+        const int K = taps(sc);
+        const size_t smem = ((size_t)w_out * K + 2 * (size_t)w_out + (size_t)w_in) * 4;
+        const long rows = planes * (long)h_in;
+        if (smem <= 64 * 1024 && rows >= 2048 && w_in <= 2048) {                 // the table is worth building when a workgroup streams several rows
+            resize_aa_rows_kernel<<<768, 256, smem, s>>>(x, tmp, rows, w_in, w_out, sc, bicubic, K);
+        } else {
+            const long total = planes * (long)h_in * w_out;
+            resize_aa_axis_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(
+                x, tmp, planes, w_in, w_out, h_in, 1, sc, bicubic, 0, 0, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
+        }
         NUNIF_LAUNCH_CHECK();
     }
-    {   // then height: tmp -> y [planes][h_out][w_out]
+    if (taps(scale_of(h_in, h_out)) <= 256 && planes <= 65535 && h_out <= 65535) {   // then height: tmp -> y [planes][h_out][w_out]
+        resize_aa_cols_kernel<<<dim3((unsigned)((w_out + 255) / 256), (unsigned)h_out, (unsigned)planes), 256, 0, s>>>(
+            tmp, y, h_in, h_out, w_out, scale_of(h_in, h_out), bicubic, clamp01, mean3 ? 3 : 0,
+            mean3 ? mean3[0] : 0.f, mean3 ? mean3[1] : 0.f, mean3 ? mean3[2] : 0.f, std3 ? std3[0] : 1.f,
+            std3 ? std3[1] : 1.f, std3 ? std3[2] : 1.f);
+        NUNIF_LAUNCH_CHECK();
+    } else {
         const long total = planes * (long)h_out * w_out;
         resize_aa_axis_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(
             tmp, y, planes, h_in, h_out, w_out, 0, scale_of(h_in, h_out), bicubic, clamp01, mean3 ? 3 : 0,
