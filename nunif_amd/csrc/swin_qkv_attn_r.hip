@@ -101,7 +101,12 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     // 4.4 units instead of 2.2 windows x 2 passes, i.e. the last-round quantisation loss drops from 36 % to 12 %.
     const int n_wg = gridDim.x / PASSES;
     const int wstride = kWavesR * n_wg;
-    const int w0 = (blockIdx.x / PASSES) * kWavesR + wave;
+    // With only a few units per wave (4.4 on the 60 x 60 level) the waves that get one more must not all sit in the same
+    // workgroups: numbering the slots wave-major gives every workgroup the same mix, so a SIMD (waves w and w + 4) runs 5 + 4
+    // units instead of 5 + 5 next to CUs with 4 + 4.  Long launches keep the workgroup-major numbering (16 neighbouring
+    // windows = one contiguous stretch of the window-major att map).
+    const bool spread = a.n_windows < 8 * wstride;
+    const int w0 = spread ? wave * n_wg + (int)(blockIdx.x / PASSES) : (int)(blockIdx.x / PASSES) * kWavesR + wave;
     {
         const int pass = blockIdx.x % PASSES;
         {
