@@ -167,8 +167,8 @@ def pmc_traffic_bytes(symbol):
                     return float(m.group(1)) * 1024.0
         return None
     pdir = os.path.join(ROOT, "profiles")
-    rounds = sorted({re.match(r"(r\d\d[a-z]?)_pmc_FETCH_SIZE", f).group(1) for f in os.listdir(pdir)
-                     if re.match(r"r\d\d[a-z]?_pmc_FETCH_SIZE", f)}) if os.path.isdir(pdir) else []
+    rounds = sorted({re.match(r"(r\d\d[a-z]{0,2})_pmc_FETCH_SIZE", f).group(1) for f in os.listdir(pdir)
+                     if re.match(r"r\d\d[a-z]{0,2}_pmc_FETCH_SIZE", f)}) if os.path.isdir(pdir) else []
     for r in reversed(rounds):
         fetch = per_launch(os.path.join(pdir, f"{r}_pmc_FETCH_SIZE.txt"))
         write = per_launch(os.path.join(pdir, f"{r}_pmc_WRITE_SIZE.txt"))
