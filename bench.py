@@ -86,6 +86,7 @@ def relaunch_as_ranks(args):
 
 
 GATHER_TIMEOUT_S = 240          # watchdog of the N > 1 delivery leg (see main)
+CPU_WHOLE_FRAME_BUDGET_S = 40   # cpu_baseline times a whole 1080p frame on the host when the crop predicts at most this
 
 
 def synth_frame(seed, h, w):
@@ -140,14 +141,25 @@ def cpu_baseline(sd, frame):
     torch.set_num_threads(threads)
     dt, out = median_time(lambda: OS.tiled_render(crop, fn, 2, 16, 8, TILE, mb), repeats=3)
     frame_s = dt / 4 * 45
-    return {"value": round(crop.shape[1] * crop.shape[2] / 1e6 / dt, 5), "unit": "MPix/s", "cores": threads, "kind": "port",
+    value, whole = crop.shape[1] * crop.shape[2] / 1e6 / dt, None
+    sample = (f"oracle tiled_render of a 476x476 crop of the bench frame (4 tiles of 256, minibatch {mb}), best of a threads x "
+              f"minibatch sweep ({threads} threads), 1 warm-up + median of 3 passes, {dt:.2f} s per pass "
+              f"(= {frame_s:.0f} s per 1080p frame of 45 tiles")
+    if frame_s <= CPU_WHOLE_FRAME_BUDGET_S:
+        # BASELINE.md section 4 asks for ONE WHOLE FRAME when it fits: a single timed pass (everything is warm after the sweep)
+        t0 = time.perf_counter()
+        OS.tiled_render(frame, fn, 2, 16, 8, TILE, mb)
+        whole = time.perf_counter() - t0
+        value = frame.shape[1] * frame.shape[2] / 1e6 / whole
+        sample += f"); `value` is the WHOLE 1080p frame (45 tiles) timed once with that setting: {whole:.1f} s"
+    else:
+        sample += f", above the {CPU_WHOLE_FRAME_BUDGET_S}-s budget for timing it whole: `value` is the crop's rate)"
+    return {"value": round(value, 5), "unit": "MPix/s", "cores": threads, "kind": "port",
             "physical_cores": phys, "tile_minibatch": mb,
             "sweep_s_per_pass": {f"{t}thr_mb{b}": round(v, 2) for (t, b), v in sorted(sweep.items())},
             "whole_1080p_frame_estimate_s": round(frame_s, 1),
-            "sample": f"oracle tiled_render of a 476x476 crop of the bench frame (4 tiles of 256, minibatch {mb}), best of a "
-                      f"threads x minibatch sweep ({threads} threads), 1 warm-up + median of 3 passes, {dt:.2f} s per pass "
-                      f"(= {frame_s:.0f} s per 1080p frame of 45 tiles, above the 120-s budget for timing it whole when > 120); "
-                      "tools/cpu_ref_vs_port.py gives the reference / port ratio measured in the build container"}, crop, out
+            "whole_1080p_frame_s": round(whole, 2) if whole is not None else None,
+            "sample": sample + "; tools/cpu_ref_vs_port.py gives the reference / port ratio measured in the build container"}, crop, out
 
 
 def pmc_traffic_bytes(symbol):

@@ -49,6 +49,19 @@ def main():
         t_port, y_port = med(lambda: OS.tiled_render(x, lambda mb: O.model_forward(sd, mb), 2, 16, 8, 256, bs))
         out[f"batch{bs}"] = {"reference_s": round(t_ref, 3), "port_s": round(t_port, 3), "port_over_reference": round(t_port / t_ref, 3),
                              "max_abs_diff": float((y_ref - y_port).abs().max())}
+    if "--whole-frame" in sys.argv:
+        # BASELINE.md section 4's protocol on the reference itself: ONE WHOLE 1080p frame (45 tiles), warm, timed once each
+        low = torch.rand(1, 3, 1080 // 16 + 1, 1920 // 16 + 1, generator=g)
+        frame = torch.nn.functional.interpolate(low, size=(1080, 1920), mode="bilinear", align_corners=False)[0].clamp(0, 1)
+        t0 = time.perf_counter()
+        y_ref = ref_render(frame, m, tile_size=256, batch_size=1)
+        t_ref = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        y_port = OS.tiled_render(frame, lambda mb: O.model_forward(sd, mb), 2, 16, 8, 256, 1)
+        t_port = time.perf_counter() - t0
+        out["frame_1080p"] = {"tiles": 45, "reference_s": round(t_ref, 2), "port_s": round(t_port, 2),
+                              "reference_mpix_per_s": round(1080 * 1920 / 1e6 / t_ref, 4), "port_over_reference": round(t_port / t_ref, 3),
+                              "max_abs_diff": float((y_ref - y_port).abs().max())}
     print(json.dumps(out))
 
 
