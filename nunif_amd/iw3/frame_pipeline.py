@@ -69,6 +69,15 @@ class PipelineOps:
         self.apply_rgbd = apply_rgbd or U.apply_rgbd
         self.postprocess_image = postprocess_image or U.postprocess_image
         self.to_frame = to_frame or U.to_frame_tensor
+        # with both defaults in place a stereo pair leaves through U.postprocess_to_frame (compose + quantise fused where the
+        # format allows); a caller's own postprocess_image / to_frame keep the two-step route
+        self._fused_out = U.postprocess_to_frame if (postprocess_image is None and to_frame is None) else None
+
+    def stereo_out(self, left_eye, right_eye, args, use_16bit=False):
+        """One stereo pair -> the output frame: ``to_frame(postprocess_image(left, right, args))``."""
+        if self._fused_out is not None:
+            return self._fused_out(left_eye, right_eye, args, use_16bit=use_16bit)
+        return self.to_frame(self.postprocess_image(left_eye, right_eye, args), use_16bit=use_16bit)
 
 
 def _frame_pixels(frame):
@@ -190,8 +199,7 @@ def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=No
                     left, right = ops.apply_divergence(depths, x_srcs, args, side_model, reset_pts=reset_pts)
                 if left is None:              # an inpaint side model whose 12-frame queue is still filling
                     continue
-                frames = [ops.postprocess_image(left[i], right[i], args) for i in range(left.shape[0])]
-                results += [ops.to_frame(f, use_16bit=use_16bit) for f in frames]
+                results += [ops.stereo_out(left[i], right[i], args, use_16bit=use_16bit) for i in range(left.shape[0])]
         if flush:
             # end of stream: frames still inside a side model with a temporal queue (the video inpaint FrameQueue) come
             # out here — the reference only sends inpaint methods through the single-frame route, which flushes the side
@@ -237,7 +245,7 @@ def _side_flush(side_model, args, ops, use_16bit):
     if hasattr(side_model, "flush"):
         left, right = side_model.flush(enable_amp=not getattr(args, "disable_amp", False))
         if left is not None:
-            out = [ops.to_frame(ops.postprocess_image(le, re, args), use_16bit=use_16bit) for le, re in zip(left, right)]
+            out = [ops.stereo_out(le, re, args, use_16bit=use_16bit) for le, re in zip(left, right)]
     return out
 
 
@@ -263,7 +271,7 @@ def bind_single_frame_callback(depth_model, side_model, segment_pts, args, ops=N
             if left is None:                  # a side model that is still filling its queue
                 continue
             pairs = [(left, right)] if left.ndim == 3 else list(zip(left, right))
-            frames += [ops.to_frame(ops.postprocess_image(le, re, args), use_16bit=use_16bit) for le, re in pairs]
+            frames += [ops.stereo_out(le, re, args, use_16bit=use_16bit) for le, re in pairs]
         if flush:
             frames += _side_flush(side_model, args, ops, use_16bit)
         return frames
@@ -309,8 +317,7 @@ def bind_vda_frame_callback(depth_model, side_model, segment_pts, args, ops=None
                 left, right = ops.apply_divergence(depths, x_srcs, args, side_model,
                                                    reset_pts=[t in segment_pts for _, t in pairs])
             if left is not None:
-                results += [ops.to_frame(ops.postprocess_image(left[i], right[i], args), use_16bit=use_16bit)
-                            for i in range(left.shape[0])]
+                results += [ops.stereo_out(left[i], right[i], args, use_16bit=use_16bit) for i in range(left.shape[0])]
         if flush:
             results += _side_flush(side_model, args, ops, use_16bit)
         return results

@@ -197,6 +197,28 @@ def postprocess_image(left_eye, right_eye, args):
     return _max_output_resize(sbs, args)
 
 
+def postprocess_to_frame(left_eye, right_eye, args, use_16bit=False):
+    """``to_frame_tensor(postprocess_image(left, right, args))`` — the frame's way out of the scheduler.  In the plain SBS / TB /
+    cross-eyed case (no IPD / aspect padding, no VR180 projection, no half-size or anaglyph format, no output-size cap that
+    bites) compose + clamp + quantise is ONE kernel (``stereo_to_frame``) and the fp32 side-by-side image is never written:
+    62 MB instead of 162 MB of traffic per 1080p frame; the bytes that come out are the same."""
+    g = lambda k, d=None: getattr(args, k, d)     # noqa: E731
+    h, w = left_eye.shape[-2:]
+    ipd_pad = int(abs(g("ipd_offset", 0) or 0) * 0.01 * max(h, w))
+    ipd_pad -= ipd_pad % 2
+    tb = bool(g("tb"))
+    out_h, out_w = (2 * h, w) if tb else (h, 2 * w)
+    plain = (left_eye.ndim == 3 and left_eye.shape == right_eye.shape and ipd_pad == 0
+             and g("pad") is None and g("pad_mode") != "16:9" and g("anaglyph") is None
+             and not (g("vr180") or g("half_sbs") or g("half_rgbd") or g("half_tb"))
+             and (g("max_output_height") is None or out_h <= g("max_output_height"))
+             and (g("max_output_width") is None or out_w <= g("max_output_width")))
+    if plain:
+        layout = "tb" if tb else ("cross_eyed" if g("cross_eyed") else "sbs")
+        return _ops.stereo_to_frame(left_eye.contiguous(), right_eye.contiguous(), layout, 16 if use_16bit else 8)
+    return to_frame_tensor(postprocess_image(left_eye, right_eye, args), use_16bit=use_16bit)
+
+
 def _max_output_resize(sbs, args):
     g = lambda k, d=None: getattr(args, k, d)     # noqa: E731
     h, w = sbs.shape[1:]

@@ -78,3 +78,22 @@ def test_hip_rgbd_and_errors(hiplib, g):
         apply_anaglyph_redcyan(left, left, "nope")
     with pytest.raises(RuntimeError):
         apply_anaglyph_redcyan(g["left"], g["right"], "color")      # CPU tensors: no fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(tb=True), dict(cross_eyed=True), dict(max_output_width=4096),
+                                dict(half_sbs=True), dict(pad=0.1), dict(anaglyph="dubois"), dict(ipd_offset=2),
+                                dict(max_output_width=100, keep_aspect_ratio=True)])
+@pytest.mark.parametrize("use_16bit", [False, True])
+def test_fused_leave_path_writes_the_same_bytes_as_compose_then_quantise(kw, use_16bit):
+    """``postprocess_to_frame`` (the scheduler's default way out: compose + quantise in one kernel where the format allows) against
+    ``to_frame_tensor(postprocess_image(...))`` on the same eyes: identical frames for plain and non-plain formats alike."""
+    from nunif_amd.iw3 import utils as U
+    gen = torch.Generator().manual_seed(77)
+    left = (torch.rand(3, 54, 96, generator=gen) * 1.2 - 0.1).cuda()       # values outside [0, 1] exercise the clamp
+    right = (torch.rand(3, 54, 96, generator=gen) * 1.2 - 0.1).cuda()
+    args = _args(**kw)
+    fused = U.postprocess_to_frame(left, right, args, use_16bit=use_16bit)
+    two_step = U.to_frame_tensor(U.postprocess_image(left, right, args), use_16bit=use_16bit)
+    assert fused.dtype == two_step.dtype and fused.shape == two_step.shape
+    assert torch.equal(fused, two_step)
