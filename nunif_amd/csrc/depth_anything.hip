@@ -332,9 +332,9 @@ struct Buf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
-struct Lin { f16 *w = nullptr; float *b = nullptr; int N = 0, K = 0; };              // gemm_kernel packing [nt][ks]
+struct Lin { f16 *w = nullptr; float *b = nullptr; int N = 0, K = 0; float *ws = nullptr; };     // gemm_kernel packing [nt][ks]; ws: row sums (LayerNorm-folded Linears)
 struct Cnv { f16 *w = nullptr; float *b = nullptr; int N = 0, Cin = 0, k = 3, cmaj = 0; };     // conv_kernel stream [ks][nt]
-struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2[4], fc2_full; int n_fc2; };   // fc2 (K = 4 D) = 2 or 4 GEMMs of K = 768 / 1024
+struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2[4], fc2_full, qkv_ln, fc1_ln; int n_fc2; };   // *_ln: norm1 / norm2 folded in (ViT-S)   // fc2 (K = 4 D) = 2 or 4 GEMMs of K = 768 / 1024
 struct Rcu { Cnv c1, c2; };
 struct Fus { Rcu r1, r2; Lin out; };
 }  // namespace
@@ -347,7 +347,7 @@ struct nunif_depth_anything {
     Lin patch; float *cls = nullptr, *norm_g = nullptr, *norm_b = nullptr;
     std::vector<Blk> blk;
     Lin proj[4], rs0, rs1, rs3g; std::vector<Cnv> rs3; Cnv rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
-    Buf a_col, pe, t, y, qkv, att, hid, feat[4], rnb[4], m1, m2, m3, m4, m5, part, col;
+    Buf a_col, pe, t, y, qkv, att, hid, lnstats, feat[4], rnb[4], m1, m2, m3, m4, m5, part, col;
 };
 
 namespace {
@@ -430,14 +430,16 @@ int run_lin(const Lin &L, const f16 *a, int B, int Wi, int Wo, int ox, int act, 
     return launch_gemm(g, s, tag);
 }
 // token-matrix Linear [T][K] -> [T][N]: the output-stationary kernel when the shape allows, else gemm_kernel
-int run_tok(const Lin &L, const f16 *a, long T, int act, const f16 *res, f16 *out, hipStream_t s, const char *tag) {
+int run_tok(const Lin &L, const f16 *a, long T, int act, const f16 *res, f16 *out, hipStream_t s, const char *tag,
+            float2 *stats_out = nullptr, const float2 *stats_in = nullptr) {
     if (gemm_os_supported(T, L.N, L.K)) {
         GemmOsArgs g;
         memset(&g, 0, sizeof(g));
         g.a = a; g.M = T; g.lda = L.K; g.K = L.K; g.w = L.w; g.bias = L.b; g.N = L.N; g.act = act; g.res = res; g.out = out;
-        g.ldo = L.N;
+        g.ldo = L.N; g.stats_out = stats_out; g.stats_in = stats_in; g.stats_parts = 12; g.wsum = L.ws; g.ln_eps = 1e-6f;
         return launch_gemm_os(g, s, tag);
     }
+    NUNIF_REQUIRE(!stats_out && !stats_in, "%s: LayerNorm statistics need the output-stationary Linear", tag);
     return run_lin(L, a, 1, (int)T, (int)T, 0, act, res, out, s, tag);
 }
 int run_cnv(const Cnv &C, const f16 *a, int B, int Hi, int Wi, int stride, int zpad, int relu_in, int act, const f16 *res,
@@ -545,6 +547,28 @@ extern "C" int nunif_hip_depth_anything_create_ex(const nunif_tensor_desc *tenso
             }
             d = w1->data; e = bb1->data;
             if ((rc = make_lin(h, 4 * kD, kD, [=](int n, int k) { return d[(size_t)n * kD + k]; }, [=](int n) { return e[n]; }, &bk.fc1))) break;
+            if (gemm_os_consumes_stats(1, 3 * kD, kD) && kD / 32 == 12) {
+                // norm1 / norm2 folded into their consumers: W (gamma xhat + beta) + b = (W diag(gamma)) xhat + (W beta + b), and
+                // xhat = (x - mu) r enters as r (W' x) - r mu wsum with wsum[n] = sum_k of the fp16 weights the MFMA really uses
+                auto fold = [&](const float *w, const float *b, const float *ga, const float *be, int N, float scale_upto, Lin *L) -> int {
+                    int rc2 = make_lin(h, N, kD, [=](int n, int k) { return w[(size_t)n * kD + k] * ga[k] * (n < kD ? scale_upto : 1.f); },
+                                       [=](int n) {
+                                           double acc = b[n];
+                                           for (int k = 0; k < kD; ++k) acc += (double)(float)(f16)w[(size_t)n * kD + k] * be[k];
+                                           return (float)acc * (n < kD ? scale_upto : 1.f);
+                                       }, L);
+                    if (rc2) return rc2;
+                    std::vector<float> ws(N);
+                    for (int n = 0; n < N; ++n) {
+                        double acc = 0.0;
+                        for (int k = 0; k < kD; ++k) acc += (double)(float)(f16)(w[(size_t)n * kD + k] * ga[k] * (n < kD ? scale_upto : 1.f));
+                        ws[n] = (float)acc;
+                    }
+                    return upload(h, ws, &L->ws);
+                };
+                if ((rc = fold(wq->data, bq->data, g1->data, b1->data, 3 * kD, qs, &bk.qkv_ln))) break;
+                if ((rc = fold(w1->data, bb1->data, g2->data, b2->data, 4 * kD, 1.f, &bk.fc1_ln))) break;
+            }
             {   // fc2 with LayerScale folded, split along K; the bias rides on the first slice
                 const float *wd = w2->data, *bd = bb2->data, *ls = ls2->data;
                 bk.n_fc2 = npiece;
@@ -656,7 +680,7 @@ extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors,
 extern "C" void nunif_hip_depth_anything_destroy(nunif_depth_anything *h) {
     if (!h) return;
     for (void *p : h->owned) (void)hipFree(p);
-    Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->att, &h->hid, &h->feat[0], &h->feat[1], &h->feat[2],
+    Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->att, &h->hid, &h->lnstats, &h->feat[0], &h->feat[1], &h->feat[2],
                    &h->feat[3], &h->rnb[0], &h->rnb[1], &h->rnb[2], &h->rnb[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5, &h->part, &h->col};
     for (Buf *b : bufs) b->release();
     delete h;
@@ -685,7 +709,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     int rc;
     if ((rc = h->a_col.ensure((size_t)B * N * kKp * e2)) || (rc = h->pe.ensure((size_t)B * N * kD * e2)) ||
         (rc = h->t.ensure(T * kD * e2)) || (rc = h->y.ensure(T * kD * e2)) || (rc = h->qkv.ensure(T * 3 * kD * e2)) ||
-        (rc = h->att.ensure(T * kD * e2)) ||
+        (rc = h->att.ensure(T * kD * e2)) || (rc = h->lnstats.ensure((size_t)((T + 31) / 32) * 32 * 12 * sizeof(float2))) ||
         (rc = h->hid.ensure(T * 4 * kD * e2)) || (rc = h->m1.ensure(big * e2)) || (rc = h->m2.ensure(big * e2)) ||
         (rc = h->m3.ensure(big * e2)) || (rc = h->m4.ensure(big * e2)) || (rc = h->m5.ensure(big * e2)))
         return rc;
@@ -693,6 +717,9 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         if ((rc = h->feat[i].ensure(T * kD * e2)) || (rc = h->rnb[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2))) return rc;
     f16 *a_col = (f16 *)h->a_col.p, *pe = (f16 *)h->pe.p, *t = (f16 *)h->t.p, *y = (f16 *)h->y.p, *qkv = (f16 *)h->qkv.p;
     f16 *att = (f16 *)h->att.p, *hid = (f16 *)h->hid.p;
+    float2 *lnstats = (float2 *)h->lnstats.p;
+    bool fuse_ln = kD / 32 == 12 && gemm_os_consumes_stats(T, 3 * kD, kD) && gemm_os_supported(T, kD, kD) && gemm_os_supported(T, kD, 4 * kD);
+    for (const Blk &bk : h->blk) fuse_ln = fuse_ln && bk.qkv_ln.w && bk.fc1_ln.w && bk.n_fc2 == 0;
     auto blocks = [](long n) { return (unsigned)((n + 255) / 256); };
 
     {   // patch embedding
@@ -707,11 +734,19 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     int tap = 0;
     for (int i = 0; i < h->depth; ++i) {
         const Blk &bk = h->blk[i];
-        {
-            ProfScope ps("da_layernorm_kernel", s, 0.0, (double)T * kD * 4.0);
-            if ((rc = launch_da_layernorm(t, bk.g1, bk.b1, y, T, kD, s))) return rc;
+        // ViT-S: norm1 (from the second block on) and norm2 have no kernel of their own — the Linear in front of them (fc2 of the
+        // previous block, proj) writes per-token partial sums of what it stores, the Linear behind them (qkv, fc1) multiplies the
+        // raw rows and finishes with r (W x - mu wsum) + b (GemmOsArgs::stats_out / stats_in)
+        const bool ln2 = fuse_ln, ln1 = fuse_ln && i > 0, ln1_next = fuse_ln && i + 1 < h->depth;
+        if (ln1) {
+            if ((rc = run_tok(bk.qkv_ln, t, T, 0, nullptr, qkv, s, "da_qkv", nullptr, lnstats))) return rc;
+        } else {
+            {
+                ProfScope ps("da_layernorm_kernel", s, 0.0, (double)T * kD * 4.0);
+                if ((rc = launch_da_layernorm(t, bk.g1, bk.b1, y, T, kD, s))) return rc;
+            }
+            if ((rc = run_tok(bk.qkv, y, T, 0, nullptr, qkv, s, "da_qkv"))) return rc;
         }
-        if ((rc = run_tok(bk.qkv, y, T, 0, nullptr, qkv, s, "da_qkv"))) return rc;
         {
             ProfScope ps("da_attn_kernel", s, 4.0 * B * (double)Np * Np * kD, (double)T * kD * 8.0);
             // One wave = one 16-query tile over ALL keys, so the chip's time is (workgroups per CU) x (waves per SIMD) wave-passes:
@@ -729,11 +764,15 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             else da_attn_kernel<16><<<grid, 1024, 0, s>>>(qkv, att, Np, kD, kHeads);
             NUNIF_LAUNCH_CHECK();
         }
-        if ((rc = run_tok(bk.proj, att, T, 0, t, t, s, "da_proj"))) return rc;        // t += ls1 * proj(att)
-        if ((rc = launch_da_layernorm(t, bk.g2, bk.b2, y, T, kD, s))) return rc;
-        if ((rc = run_tok(bk.fc1, y, T, 1, nullptr, hid, s, "da_fc1"))) return rc;      // GELU(erf)
+        if ((rc = run_tok(bk.proj, att, T, 0, t, t, s, "da_proj", ln2 ? lnstats : nullptr))) return rc;        // t += ls1 * proj(att)
+        if (ln2) {
+            if ((rc = run_tok(bk.fc1_ln, t, T, 1, nullptr, hid, s, "da_fc1", nullptr, lnstats))) return rc;
+        } else {
+            if ((rc = launch_da_layernorm(t, bk.g2, bk.b2, y, T, kD, s))) return rc;
+            if ((rc = run_tok(bk.fc1, y, T, 1, nullptr, hid, s, "da_fc1"))) return rc;      // GELU(erf)
+        }
         // t += ls2 * fc2(.): K-slices of the 4 D-wide hidden rows (lda = 4 D)
-        if (bk.n_fc2 == 0 && (rc = run_tok(bk.fc2_full, hid, T, 0, t, t, s, "da_fc2"))) return rc;
+        if (bk.n_fc2 == 0 && (rc = run_tok(bk.fc2_full, hid, T, 0, t, t, s, "da_fc2", ln1_next ? lnstats : nullptr))) return rc;
         for (int q = 0; q < bk.n_fc2; ++q)
             if ((rc = run_lin(bk.fc2[q], hid + (size_t)q * bk.fc2[q].K, 1, (int)T, (int)T, 0, 0, t, t, s, "da_fc2", 0, 0, 1, 1, 4 * kD)))
                 return rc;

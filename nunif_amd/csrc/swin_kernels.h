@@ -43,8 +43,16 @@ struct GemmOsArgs {
     int act;                  // 0 none, 1 GELU(erf)
     const f16 *res;           // optional residual [M][ldo] (may alias out)
     f16 *out; int ldo;
+    // LayerNorm without a LayerNorm kernel.  A PRODUCER (stats_out != nullptr) also writes, per token and per 32 output
+    // channels, the (sum, sum of squares) of the fp16 values it stored: stats_out[m][N / 32] float2.  A CONSUMER (stats_in != nullptr,
+    // weight-stationary launches only: gemm_os_consumes_stats()) multiplies the RAW rows and finishes with
+    //   out = r (W x - mu wsum) + bias,   mu / r from the stats_parts partials of its token, wsum[n] = sum_k W[n][k]
+    // which is W ((x - mu) r) + bias exactly; the caller folds the affine part of the norm into W / bias / wsum.
+    float2 *stats_out;
+    const float2 *stats_in; int stats_parts; const float *wsum; float ln_eps;
 };
 bool gemm_os_supported(long M, int N, int K);
+bool gemm_os_consumes_stats(long M, int N, int K);
 int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag);
 
 // ---- first conv of the stem (3 -> C1 real channels, stored padded to C1P), VALU ----------------------------------

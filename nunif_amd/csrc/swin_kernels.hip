@@ -599,6 +599,16 @@ __global__ void __launch_bounds__(256) gemm_os_kernel(GemmOsArgs g) {
         }
         const f16x8 ov = pair_to_run(o0, o1);
         if (live[f]) *reinterpret_cast<f16x8 *>(g.out + ooff[f]) = ov;
+        if (g.stats_out) {
+            // LayerNorm statistics of the NEXT norm, from the values as stored: this lane holds 8 of its token's channels, the four
+            // lane groups the wave's 32 — one (sum, sum of squares) partial per token and 32-channel pair
+            float su = 0.f, sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float v = (float)ov[e]; su += v; sq += v * v; }
+            su += __shfl_xor(su, 16); sq += __shfl_xor(sq, 16);
+            su += __shfl_xor(su, 32); sq += __shfl_xor(sq, 32);
+            if (grp == 0 && live[f]) g.stats_out[(m0 + f * 16 + r16) * (g.N >> 5) + (nt0 >> 1)] = make_float2(su, sq);
+        }
     }
 }
 
@@ -622,11 +632,14 @@ static void launch_gemm_os_t(const GemmOsArgs &g, hipStream_t s) {
 // hand-counted one: `vmcnt(MT * SW)` behind the MFMAs = everything but the newest tile's DMAs has landed (loads return in order;
 // the stores of the previous tile, which may retire in any order, are a tile old by then and are simply waited for as well).
 // The grid is sized to what is RESIDENT (occupancy x CUs): a persistent kernel with a few workgroups too many runs a second pass.
-template <int KS, int NTW, int MT, bool GELU>
+template <int KS, int NTW, int MT, bool GELU, bool LNF>          // LNF: rows normalised through GemmOsArgs::stats_in (12 partials per token)
 __global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, int G) {
     constexpr int SW = KS / 4;                                    // a wave stages k-steps w, w + 4, ..
-    static_assert(KS % 4 == 0 && NTW == 2 && MT * SW == 6, "vmcnt(6) below; the epilogue writes 32-channel pairs");
+    static_assert(KS % 4 == 0 && NTW == 2 && MT * SW == 6, "vmcnt(6 / 7) below; the epilogue writes 32-channel pairs");
+    constexpr int kParts = 12, kStatTile = MT * 16 * kParts;      // float2 per tile: 3 KiB, moved by one more DMA per wave
+    static_assert(!LNF || kStatTile * 8 == 3 * 1024, "the statistics tile is three 1-KiB DMAs (+ a fourth, discarded, so that every wave issues one)");
     __shared__ __attribute__((aligned(16))) f16x8 act[3][KS][MT][64];
+    __shared__ __attribute__((aligned(16))) float2 stl[LNF ? 2 : 1][LNF ? 3 * 128 : 1];      // 78 KiB in all: two workgroups per CU
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, grp = lane >> 4;
     const int n_blocks = g.N / (64 * NTW);
@@ -644,9 +657,21 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, i
 #pragma unroll
             for (int n = 0; n < NTW; ++n) aq[ks][n] = wbase[((long)n * KS + ks) * 64];
     }
-    float4 bv[NTW];
+    float4 bv[NTW], wsv[NTW];
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) bv[n] = *reinterpret_cast<const float4 *>(g.bias + (nt0 + n) * 16 + grp * 4);
+    for (int n = 0; n < NTW; ++n) {
+        bv[n] = *reinterpret_cast<const float4 *>(g.bias + (nt0 + n) * 16 + grp * 4);
+        if constexpr (LNF) wsv[n] = *reinterpret_cast<const float4 *>(g.wsum + (nt0 + n) * 16 + grp * 4);
+    }
+    // a tile's statistics: 32 tokens x 12 partials = 3 072 contiguous bytes (the buffer is padded to whole tiles), one DMA per wave
+    // (wave 3 repeats wave 2's piece onto the same KiB, so that every wave's vmcnt sees the same number of operations).  They travel
+    // ONE tile ahead in a ring of two: behind the next trip's vmcnt wait they are older than that trip's seven DMAs.
+    auto dma_stats = [&](int t, int sslot) {
+        const int tc = t < tiles ? t : tiles - 1, piece = wave < 3 ? wave : 2;
+        const char *src = reinterpret_cast<const char *>(g.stats_in) + (long)tc * (kStatTile * 8) + piece * 1024 + lane * 16;
+        const unsigned lds_addr = (unsigned)reinterpret_cast<size_t>(&stl[sslot][piece * 128]);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory");
+    };
     auto dma_tile = [&](int t, int slot) {                        // rows clamped, never conditional: always MT * SW DMAs
 #pragma unroll
         for (int f = 0; f < MT; ++f) {
@@ -662,6 +687,7 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, i
     };
     dma_tile(g0, 0);
     dma_tile(g0 + G, 1);
+    if constexpr (LNF) dma_stats(g0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the weights and the bias have landed, and the compiler must KNOW it (an opaque use of each register): its own wait for a
     // first use inside the loop would be vmcnt(0) on every trip, which drains the hand-counted DMAs as well
@@ -670,17 +696,22 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, i
 #pragma unroll
         for (int n = 0; n < NTW; ++n) asm volatile("" : "+v"(aq[ks][n]));
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) asm volatile("" : "+v"(bv[n].x), "+v"(bv[n].y), "+v"(bv[n].z), "+v"(bv[n].w));
+    for (int n = 0; n < NTW; ++n) {
+        asm volatile("" : "+v"(bv[n].x), "+v"(bv[n].y), "+v"(bv[n].z), "+v"(bv[n].w));
+        if constexpr (LNF) asm volatile("" : "+v"(wsv[n].x), "+v"(wsv[n].y), "+v"(wsv[n].z), "+v"(wsv[n].w));
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    int slot = 0;
+    int slot = 0, sslot = 0;
 #pragma unroll 1
     for (int t = g0; t < tiles; t += G) {
+        if constexpr (LNF) dma_stats(t + G, sslot ^ 1);
         dma_tile(t + 2 * G, slot == 0 ? 2 : slot - 1);           // (slot + 2) % 3: read last in the previous trip, behind its barrier
         f32x4 acc[MT][NTW];
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
-            for (int f = 0; f < MT; ++f) acc[f][n] = (f32x4){bv[n].x, bv[n].y, bv[n].z, bv[n].w};
+            for (int f = 0; f < MT; ++f)
+                acc[f][n] = LNF ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){bv[n].x, bv[n].y, bv[n].z, bv[n].w};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             f16x8 bq[MT];
@@ -691,10 +722,29 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, i
 #pragma unroll
                 for (int f = 0; f < MT; ++f) acc[f][n] = MFMA_16x16x32(aq[ks][n], bq[f], acc[f][n]);
         }
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // tile t + G is in LDS; only tile t + 2G's six DMAs may be in flight
+        // tile t + G is in LDS; only tile t + 2G's DMAs (six, seven with the statistics) may be in flight
+        if constexpr (LNF) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #pragma unroll
         for (int f = 0; f < MT; ++f) {
             const long m = (long)t * (MT * 16) + f * 16 + r16;
+            if constexpr (LNF) {
+                // W ((x - mu) r) + b = r (W x) + (b - r mu wsum): two FMAs per output, mu and r from the token's 12 partials
+                const float4 *pp = reinterpret_cast<const float4 *>(&stl[sslot][(f * 16 + r16) * kParts]);
+                float su = 0.f, sq = 0.f;
+#pragma unroll
+                for (int q = 0; q < kParts / 2; ++q) { const float4 v = pp[q]; su += v.x + v.z; sq += v.y + v.w; }
+                const float mu = su * (1.0f / (KS * 32));
+                const float var = fmaxf(sq * (1.0f / (KS * 32)) - mu * mu, 0.f);
+                const float r = rsqrtf(var + g.ln_eps), rm = r * mu;
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    acc[f][n][0] = fmaf(r, acc[f][n][0], fmaf(-rm, wsv[n].x, bv[n].x));
+                    acc[f][n][1] = fmaf(r, acc[f][n][1], fmaf(-rm, wsv[n].y, bv[n].y));
+                    acc[f][n][2] = fmaf(r, acc[f][n][2], fmaf(-rm, wsv[n].z, bv[n].z));
+                    acc[f][n][3] = fmaf(r, acc[f][n][3], fmaf(-rm, wsv[n].w, bv[n].w));
+                }
+            }
             f16x4 o0, o1;
             if constexpr (GELU) {
                 const f16x8 h = gelu8(acc[f][0], acc[f][1]);
@@ -709,6 +759,7 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, i
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         slot = slot == 2 ? 0 : slot + 1;
+        sslot ^= 1;
     }
 }
 
@@ -717,7 +768,9 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(GemmOsArgs g, int tiles, i
 // wave per SIMD) 0.139 -> 0.159 — so only N >= 768, which also means no residual variant is needed.
 static bool gemm_ws_shape(const GemmOsArgs &g) { return g.K == 384 && g.N % 128 == 0 && g.N >= 768 && !g.res; }
 
-template <bool GELU>
+bool gemm_os_consumes_stats(long M, int N, int K) { return M > 0 && K == 384 && N % 128 == 0 && N >= 768; }
+
+template <bool GELU, bool LNF>
 static int launch_gemm_ws_t(const GemmOsArgs &g, hipStream_t s) {
     static int resident = 0;                                      // workgroups the chip holds at once
     if (!resident) {
@@ -725,19 +778,20 @@ static int launch_gemm_ws_t(const GemmOsArgs &g, hipStream_t s) {
         hipDeviceProp_t prop;
         NUNIF_HIP_CHECK(hipGetDevice(&dev));
         NUNIF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        NUNIF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)gemm_ws_kernel<12, 2, 2, GELU>, 256, 0));
+        NUNIF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)gemm_ws_kernel<12, 2, 2, GELU, LNF>, 256, 0));
         resident = std::max(1, per_cu) * prop.multiProcessorCount;
     }
     const int tiles = (int)((g.M + 31) / 32), n_blocks = g.N / 128;
     const int per_wg = (int)(((long)tiles * n_blocks + resident - 1) / resident);        // tiles per workgroup
     const int G = (tiles + per_wg - 1) / per_wg;
-    gemm_ws_kernel<12, 2, 2, GELU><<<(unsigned)(G * n_blocks), 256, 0, s>>>(g, tiles, G);
+    gemm_ws_kernel<12, 2, 2, GELU, LNF><<<(unsigned)(G * n_blocks), 256, 0, s>>>(g, tiles, G);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
 
 static int launch_gemm_ws(const GemmOsArgs &g, hipStream_t s) {
-    return g.act == 1 ? launch_gemm_ws_t<true>(g, s) : launch_gemm_ws_t<false>(g, s);
+    if (g.stats_in) return g.act == 1 ? launch_gemm_ws_t<true, true>(g, s) : launch_gemm_ws_t<false, true>(g, s);
+    return g.act == 1 ? launch_gemm_ws_t<true, false>(g, s) : launch_gemm_ws_t<false, false>(g, s);
 }
 
 int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag) {
@@ -745,6 +799,9 @@ int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag) {
                   tag, g.M, g.N, g.K);
     ProfScope ps(profile_tags_enabled() ? tag : "gemm_os_kernel", s, 2.0 * (double)g.M * g.K * g.N,
                  (double)g.M * (g.K * 2.0 + g.N * 2.0 * (g.res ? 2.0 : 1.0)));
+    NUNIF_REQUIRE(!g.stats_in || (gemm_ws_shape(g) && g.stats_parts == 12 && g.wsum),
+                  "gemm_os %s: statistics-normalised rows need the weight-stationary launch (K = 384, N >= 768, 12 partials)", tag);
+    NUNIF_REQUIRE(!g.stats_out || (!gemm_ws_shape(g) && g.N % 32 == 0), "gemm_os %s: this launch does not write statistics", tag);
     if (gemm_ws_shape(g)) return launch_gemm_ws(g, s);
     // 32-token workgroups (fewer registers, more resident waves) unless 64-token ones already give the chip four workgroups per CU
     // (those keep the round-2 shape: 64 tokens, four k-steps per group)
