@@ -1,22 +1,25 @@
 // Depth-Anything (V1 / V2 / V2-metric; DINOv2 ViT-S / B / L /14 encoder + DPT head) on gfx950 — the depth backbone behind
-// BaseDepthModel.infer (iw3/depth_anything_model.py:113-119,200-230 loads it through torch.hub; the network itself is
-// NOT in the reference tree, see oracle/depth_anything_v2.py: parity is against that restatement of the published
-// architecture only — "parity unpinned").
+// BaseDepthModel.infer (iw3/depth_anything_model.py:113-119,200-230 loads it through torch.hub; the network itself is NOT in the
+// reference tree).  Parity: oracle/depth_anything_v2.py restates the published architecture and is pinned against HuggingFace
+// transformers' DepthAnythingForDepthEstimation (tests/test_depth_anything_vs_hf.py); the GPU tests read HF-produced fixtures
+// (tests/golden/depth_anything_hf.npz).
 //
 // Geometry is read from the checkpoint (embed 384 / 768 / 1024 = 6 / 12 / 16 heads of 64, 12 / 24 blocks, DPT out_channels and
 // fusion width from the head's own tensors); which four blocks feed the head and the metric head's max_depth are arguments.
 // Layout: tokens [B][1 + gh*gw][D] fp16 (class token first), DPT maps NHWC fp16.  GEMM-shaped work reuses the engine's
-// kernels: gemm_kernel (Linear with K <= 608: patch embed, qkv, proj, fc1, 1x1 convs, the k = stride ConvTranspose2d
-// resize layers as pixel-shuffle GEMMs), conv_kernel (K-looped: fc2 with K = 1536, every 3x3 of the head with zero
-// padding, pre-activation ReLU and up to two residuals fused).  LayerScale is folded into proj / fc2 on the host, the
-// softmax scale * log2(e) into Wq.  New kernels here:
-//   da_layernorm_kernel   one wave per token (384 channels), fp32 statistics
-//   da_attn_lds_kernel    global softmax attention over 1 + gh*gw tokens, heads of 64: one wave per 16 queries, 8 query tiles
-//                         per workgroup sharing K / V through LDS, 32 keys per step, online softmax; S^T = K Q^T so that
-//                         exp2(S^T) is directly the P^T operand of
-//                         O^T = V^T P^T (V^T is written once per layer by da_vt_kernel, so every operand is a 16-byte
-//                         per-lane load); the key -> MFMA-row permutation that makes P^T's k-slots contiguous keys is
-//                         free because the K fragment is a per-lane row gather
+// kernels: the token Linears on gemm_os_kernel / gemm_ws_kernel (swin_kernels.hip: output-stationary, and weight-stationary +
+// persistent for K = 384 with N >= 768), gemm_kernel for the patch embedding, the 1x1 convs and the k = stride ConvTranspose2d
+// resize layers (pixel-shuffle GEMMs), conv3_lds_kernel / conv_kernel for every 3x3 of the head (zero padding, pre-activation
+// ReLU and up to two residuals fused).  LayerScale is folded into proj / fc2 on the host, the softmax scale * log2(e) into Wq.
+// ViT-S: norm1 (from the second block on) and norm2 have no kernel — proj / fc2 write per-token partial sums of what they
+// store, qkv / fc1 multiply the raw rows and finish with r (W x - mu wsum) + b (GemmOsArgs::stats_out / stats_in).
+// New kernels here:
+//   da_layernorm_kernel   one wave per token, fp32 statistics (the first norm1, the four tap norms; every norm of ViT-B / L)
+//   da_attn_kernel<WAVES> global softmax attention over 1 + gh*gw tokens, heads of 64: one wave per 16 queries, 8 or 12 query tiles
+//                         per workgroup sharing K / V through a three-slot LDS ring fetched two steps ahead, 32 keys per step,
+//                         online softmax with lazy rescale; S^T = K Q^T so that exp2(S^T) is directly the P^T operand of
+//                         O^T = V^T P^T; V is read in its natural layout and transposed on the way into LDS; the key -> MFMA-row
+//                         permutation that makes P^T's k-slots contiguous keys is free because the K fragment is a row gather
 //   da_upsample_kernel    bilinear, align_corners=True, NHWC
 //   im2col / assemble / final 1x1 + ReLU
 #include <algorithm>
