@@ -34,9 +34,11 @@ int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag);
 // ---- output-stationary Linear for TOKEN matrices of a few thousand rows (the ViT encoders of the depth nets) -----------------
 // out[m][n] = act(sum_k a[m][k] W[n][k] + bias[n]) (+ res[m][n]); a: [M][lda] fp16, W in gemm_kernel's packing [nt][ks].
 // gemm_kernel is token-stationary (a wave keeps 16-32 tokens' whole K extent and sweeps all of N through the LDS ring): with
-// K >= 384 that is ONE MFMA per fragment read.  Here a wave owns 4 token tiles x 2 channel tiles, loops over K with both
-// operands read straight from L2 three k-steps ahead (no LDS, no barrier), 8 MFMAs per 6 fragment loads; a workgroup's four
-// waves share their tokens.  Needs N % 128 == 0 and (K / 32) % 4 == 0.
+// K >= 384 that is ONE MFMA per fragment read.  The token Linears of the depth ViTs use one of two other forms (swin_kernels.hip):
+// gemm_os_kernel<MT, PF, NB> — output-stationary: a workgroup owns MT x 16 tokens x 128 channels, the activations of a k-group go
+// through LDS once for its four waves, the weights are direct loads PF k-steps ahead — and, for K = 384 with N >= 768,
+// gemm_ws_kernel — weight-stationary and persistent: 128 channels' weights stay in registers, token tiles stream through an LDS
+// ring by LDS-DMA two tiles ahead.  Needs N % 128 == 0 and K % 128 == 0.
 struct GemmOsArgs {
     const f16 *a; long M; int lda, K;
     const f16 *w; const float *bias; int N;
