@@ -17,7 +17,7 @@
 //   da_layernorm_kernel   one wave per token, fp32 statistics (the first norm1, the four tap norms; every norm of ViT-B / L)
 //   da_attn_kernel<WAVES> global softmax attention over 1 + gh*gw tokens, heads of 64: one wave per 16 queries, 8 or 12 query tiles
 //                         per workgroup sharing K / V through a three-slot LDS ring fetched two steps ahead, 32 keys per step,
-//                         online softmax with lazy rescale; S^T = K Q^T so that exp2(S^T) is directly the P^T operand of
+//                         online softmax whose stabiliser moves only as an overflow guard; S^T = K Q^T so that exp2(S^T) is directly the P^T operand of
 //                         O^T = V^T P^T; V is read in its natural layout and transposed on the way into LDS; the key -> MFMA-row
 //                         permutation that makes P^T's k-slots contiguous keys is free because the K fragment is a row gather
 //   da_upsample_kernel    bilinear, align_corners=True, NHWC
@@ -187,12 +187,13 @@ __global__ void __launch_bounds__(WAVES * 64) da_attn_kernel(const f16 *__restri
             }
         }
         float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-        mx = row_group_max(mx);                  // the four lane groups of a query column must share the stabiliser
-        const float m_new = fmaxf(m_run, mx);
-        // Online-softmax rescale only when some query of this tile saw a new maximum: after the first few key steps that
-        // is rare, and the 16 multiplies + the exp were a fifth of the step's VALU work.  alpha = exp2(0) = 1 exactly
-        // otherwise, so skipping is bit-identical.
-        if (__any(m_new > m_run)) {
+        float m_new = m_run;
+        // The stabiliser only has to keep exp2(s - m) inside fp16, it need not be the maximum: m_run is left alone until some logit
+        // of the tile exceeds it by more than 8 (P <= 256), and only then is the column maximum looked up across the four lane groups
+        // (which must share one m) and the running sums rescaled — after the first key steps: never.  Against a maximum taken on
+        // every step (row_group_max + compare: ~10 of the step's 83 VALU instructions) 0.433 -> 0.389 ms per 12 launches, same box.
+        if (__any(mx > m_run + 8.0f)) {
+            m_new = fmaxf(m_run, row_group_max(mx));
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){o[dt][0] * alpha, o[dt][1] * alpha, o[dt][2] * alpha, o[dt][3] * alpha};
