@@ -97,3 +97,27 @@ def test_fused_leave_path_writes_the_same_bytes_as_compose_then_quantise(kw, use
     two_step = U.to_frame_tensor(U.postprocess_image(left, right, args), use_16bit=use_16bit)
     assert fused.dtype == two_step.dtype and fused.shape == two_step.shape
     assert torch.equal(fused, two_step)
+
+
+@pytest.mark.parametrize("kw,fused", [
+    (dict(), True), (dict(tb=True), True), (dict(cross_eyed=True), True),
+    (dict(max_output_width=4096, max_output_height=4096), True),       # caps that do not bite
+    (dict(max_output_width=100), False), (dict(max_output_height=40), False),
+    (dict(half_sbs=True), False), (dict(half_tb=True), False), (dict(half_rgbd=True), False), (dict(vr180=True), False),
+    (dict(pad=0.1), False), (dict(pad_mode="16:9"), False), (dict(anaglyph="dubois"), False), (dict(ipd_offset=3), False),
+])
+def test_fused_leave_path_is_taken_exactly_for_the_plain_formats(kw, fused, monkeypatch):
+    """Host logic only (no GPU): ``postprocess_to_frame`` may skip ``postprocess_image`` only where that function would do nothing
+    but compose — every padding, projection, half-size, anaglyph or biting output cap must go the two-step way."""
+    from nunif_amd.iw3 import utils as U
+    calls = []
+    monkeypatch.setattr(U._ops, "stereo_to_frame", lambda le, re, layout, bits: calls.append(("fused", layout, bits)) or "F")
+    monkeypatch.setattr(U, "postprocess_image", lambda le, re, args: calls.append(("post",)) or "P")
+    monkeypatch.setattr(U, "to_frame_tensor", lambda x, use_16bit=False: calls.append(("frame", x, use_16bit)) or "T")
+    left, right = torch.zeros(3, 54, 96), torch.zeros(3, 54, 96)
+    out = U.postprocess_to_frame(left, right, _args(**kw), use_16bit=True)
+    if fused:
+        layout = "tb" if kw.get("tb") else ("cross_eyed" if kw.get("cross_eyed") else "sbs")
+        assert out == "F" and calls == [("fused", layout, 16)]
+    else:
+        assert out == "T" and calls == [("post",), ("frame", "P", True)]
