@@ -73,6 +73,7 @@ needs_hf = pytest.mark.skipif(hf_pin is None, reason="HuggingFace transformers i
     ("vits", 8, (1, 3, 70, 98), (8, 9, 10, 11), 0.0),        # Depth-Anything V1: the last four blocks
     ("vits", 8, (1, 3, 70, 98), None, 20.0),                 # V2 metric head (hypersim)
     ("vitb", 8, (1, 3, 70, 98), None, 0.0),                  # embed 768, DPT 96-192-384-768 / 128
+    ("vitl", 8, (1, 3, 70, 98), None, 0.0),                  # embed 1024, 24 blocks (taps 4-11-17-23), DPT 256-512-1024-1024 / 256
 ])
 def test_restatement_equals_huggingface_live(encoder, grid, shape, taps, max_depth):
     sd = ODA.random_state_dict(640, grid=grid, encoder=encoder)
