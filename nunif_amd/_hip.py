@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnunif_hip.so")
+# NUNIF_HIP_LIB: another build of the same ABI (same-box A/B runs of two kernel versions, tools/ab_lib.sh); never a fallback
+LIB_PATH = os.environ.get("NUNIF_HIP_LIB") or os.path.join(_HERE, "libnunif_hip.so")
 
 c_void_p, c_int32, c_int64, c_float, c_char_p, c_double = (
     ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_char_p, ctypes.c_double)

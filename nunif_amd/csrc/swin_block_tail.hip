@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "swin_gelu.h"
 #include "swin_kernels.h"
@@ -83,27 +84,31 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
     // (bytes in flight per CU ~ 20 KB; Little's law wants >= 40 KB for 5 TB/s).
     auto gmap = [&](long g) { return rev ? n_groups - 1 - g : g; };          // snake order between kernels
     // pixn[f]: row of x (and of the image head) that token f*16 + r16 of the group lives at.  Plain map: the token index.
-    // Window map (wm.on): token n = window * 36 + t of the SHIFTED 6x6 windows, t row-major in the window — the order
-    // qkv_attn_r_kernel writes its window-major att map in; att is then [window][head 6][36][16].
-    const int nwx = WM ? wm.W / 6 : 1, nwy = WM ? wm.H / 6 : 1;
-    auto load_group = [&](long g, f16x8 (&of)[MF][KS], f16x8 (&xr)[MF][KS], long (&pixn)[MF]) {
+    // Window map (WM): token n = window * 36 + t of the SHIFTED 6x6 windows, t row-major in the window — the order
+    // qkv_attn_r_kernel writes its window-major att map in; att is then [window][head 6][36][16].  The token -> pixel map
+    // is a TABLE (wm.pixmap, one int per token, built once per geometry by winmap_build_kernel): round 3 recomputed it per
+    // lane and group with five integer divisions, ~150 of the 1 380 issue slots of a group in a kernel that is issue-bound
+    // (profiles/r04_isa_counts.txt).  A group's table entries are requested one group EARLIER than its att / x tiles
+    // (pm_next), so the dependent loads never wait on each other.
+    auto token_of = [&](long g, int f) -> long {
+        const long m = gmap(g) * (MF * 16) + f * 16 + r16;
+        return m < M ? m : M - 1;
+    };
+    auto load_pixmap = [&](long g, int (&pm)[MF]) {
+#pragma unroll
+        for (int f = 0; f < MF; ++f) pm[f] = wm.pixmap[(int)token_of(g, f)];
+    };
+    auto load_group = [&](long g, const int (&pm)[MF], f16x8 (&of)[MF][KS], f16x8 (&xr)[MF][KS], long (&pixn)[MF]) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            const long m = gmap(g) * (MF * 16) + f * 16 + r16;
-            const long r = m < M ? m : M - 1;
+            const long r = token_of(g, f);
             const f16 *p;
             if constexpr (WM) {
-                const int ri = (int)r;                                   // M < 2^31 in this mode (checked by the launcher): 32-bit divides
-                const int w = ri / 36, t = ri - 36 * w;
-                const int wx = w % nwx, t2 = w / nwx;
-                const int wy = t2 % nwy, b = t2 / nwy;
-                const int iy = t / 6, ix = t - 6 * iy;
-                int yy = wy * 6 + iy + wm.shift, xx = wx * 6 + ix + wm.shift;
-                if (yy >= wm.H) yy -= wm.H;
-                if (xx >= wm.W) xx -= wm.W;
-                pixn[f] = (b * wm.H + yy) * wm.W + xx;
-                // lane group g holds channels 32 ks + 8 g .. + 7 = head 2 ks + (g >> 1), dims 8 (g & 1) ..
-                p = att + (((long)w * 6 + (grp >> 1)) * 36 + t) * 16 + 8 * (grp & 1);
+                // lane group g holds channels 32 ks + 8 g .. + 7 = head 2 ks + (g >> 1), dims 8 (g & 1) ..:
+                // ((w 6 + head) 36 + t) 16 = 16 r + 2880 w + 576 head   (r = 36 w + t; M < 2^31 checked by the launcher)
+                const int ri = (int)r, w = ri / 36;
+                pixn[f] = pm[f];
+                p = att + (ri * 16 + w * 2880 + (grp >> 1) * 576 + 8 * (grp & 1));
             } else {
                 pixn[f] = r;
                 p = att + r * C + grp * 8;
@@ -120,15 +125,25 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
     f16x8 xrn[PF ? MF : 1][PF ? KS : 1];
     long pixnn[MF];
     const long g_first = (long)blockIdx.x * WAVES + wave;
+    int pm_next[MF] = {};
+    auto g_clamp = [&](long g) { return g < n_groups ? g : n_groups - 1; };
     if constexpr (PF) {
-        if (g_first < n_groups) load_group(g_first, ofn, xrn, pixnn);
+        if (g_first < n_groups) {
+            if constexpr (WM) load_pixmap(g_first, pm_next);
+            load_group(g_first, pm_next, ofn, xrn, pixnn);
+            if constexpr (WM) load_pixmap(g_clamp(g_first + gstride), pm_next);
+        }
     }
 #pragma unroll 1
     for (long g = g_first; g < n_groups; g += gstride) {
         const long m_base = gmap(g) * (MF * 16);
-        // opaque per-iteration copies: keeps LICM from hoisting 48 registers of (loop-invariant) LDS bias reads
-        const float *lbp = bl, *lb0 = bl + C, *lb3 = bl + 3 * C;
-        asm volatile("" : "+v"(lbp), "+v"(lb0), "+v"(lb3));
+        // an opaque per-iteration OFFSET keeps LICM from hoisting 48 registers of (loop-invariant) LDS bias reads.  (Rounds 1-3
+        // laundered the POINTERS: hipcc then no longer knows they are LDS addresses and reads the biases with flat_load,
+        // which counts on vmcnt — every `s_waitcnt vmcnt(0)` in front of a bias use, i.e. the top of each hidden-slice trip,
+        // also drained the next group's att / x prefetch issued just before the loop: one HBM latency exposed per group.)
+        int lofs = 0;
+        asm volatile("" : "+v"(lofs));
+        const float *lbp = bl + lofs, *lb0 = bl + C + lofs, *lb3 = bl + 3 * C + lofs;
         long row[MF];
         bool valid[MF];
         f16x8 yf[MF][KS];
@@ -147,9 +162,11 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) { of[f][ks] = ofn[f][ks]; xr[f][ks] = xrn[f][ks]; }
                 }
-                load_group(g + gstride < n_groups ? g + gstride : g, ofn, xrn, pixnn);
+                load_group(g_clamp(g + gstride), pm_next, ofn, xrn, pixnn);
+                if constexpr (WM) load_pixmap(g_clamp(g + 2 * gstride), pm_next);
             } else {
-                load_group(g, of, xr, row);
+                if constexpr (WM) load_pixmap(g, pm_next);
+                load_group(g, pm_next, of, xr, row);
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -216,7 +233,7 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
             f16x8 hf[MF];
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
-                hf[f] = gelu8(h0[f], h1[f]);
+                hf[f] = gelu8t(h0[f], h1[f]);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -241,10 +258,12 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
                     img = MFMA_16x16x32(wlane[(NF + ks) * 64], bfrag, img);
                 }
                 if (!valid[f]) continue;
-                const long m = row[f];
-                const int px = (int)(m % ti.W);
-                const long t2 = m / ti.W;
-                const int py = (int)(t2 % ti.H), pb = (int)(t2 / ti.H);
+                // window-map launches address < 2^31 pixels (checked by the launcher): 32-bit divisions
+                using pix_t = std::conditional_t<WM, unsigned, long>;
+                const pix_t m = (pix_t)row[f];
+                const int px = (int)(m % (pix_t)ti.W);
+                const pix_t t2 = m / (pix_t)ti.W;
+                const int py = (int)(t2 % (pix_t)ti.H), pb = (int)(t2 / (pix_t)ti.H);
                 const int OC = ti.n_real / s2;
                 const long OH = (long)ti.H * ti.ps, OW = (long)ti.W * ti.ps;
 #pragma unroll
@@ -273,6 +292,31 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
     }
 }
 
+// pixmap[n] = pixel (b H + y) W + x of token n = window * 36 + t in the order of the SHIFTED 6x6 windows (torchvision rolls the
+// map by -shift, partitions, and rolls back: window (wy, wx) token (iy, ix) is pixel ((6 wy + iy + shift) mod H, ...)).
+__global__ void winmap_build_kernel(int *__restrict__ pixmap, int B, int H, int W, int shift) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nwx = W / 6, nwy = H / 6;
+    if (n >= B * H * W) return;
+    const int w = n / 36, t = n - 36 * w;
+    const int wx = w % nwx, t2 = w / nwx;
+    const int wy = t2 % nwy, b = t2 / nwy;
+    const int iy = t / 6, ix = t - 6 * iy;
+    int yy = wy * 6 + iy + shift, xx = wx * 6 + ix + shift;
+    if (yy >= H) yy -= H;
+    if (xx >= W) xx -= W;
+    pixmap[n] = (b * H + yy) * W + xx;
+}
+
+int launch_winmap_build(int *pixmap, int B, int H, int W, int shift, hipStream_t s) {
+    NUNIF_REQUIRE(H % 6 == 0 && W % 6 == 0 && (long)B * H * W < (1L << 31), "winmap: geometry %d x %d x %d", B, H, W);
+    const long n = (long)B * H * W;
+    if (n == 0) return NUNIF_HIP_OK;
+    winmap_build_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(pixmap, B, H, W, shift);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
 constexpr int proj_mlp_stream_frags_c(int C) { return 2 * (C / 32) * (C / 32) + (2 * C / 32) * (2 * (C / 32) + C / 16); }
 
 int proj_mlp_stream_frags(int C) {
@@ -294,8 +338,8 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
     WinMap wm;
     memset(&wm, 0, sizeof(wm));
     if (wmap) wm = *wmap;
-    NUNIF_REQUIRE(!wm.on || (wm.H % 6 == 0 && wm.W % 6 == 0 && M % ((long)wm.H * wm.W) == 0 && M < (1L << 31)),
-                  "proj_mlp: window map geometry");
+    NUNIF_REQUIRE(!wm.on || (wm.pixmap && wm.H % 6 == 0 && wm.W % 6 == 0 && M % ((long)wm.H * wm.W) == 0 && M < (1L << 27)),
+                  "proj_mlp: window map geometry");        // 16 M + 2880 (M / 36) att elements are indexed in 32 bits
     constexpr int MF = 2, WAVES = 8;
     static bool configured = false;
     if (!configured) {

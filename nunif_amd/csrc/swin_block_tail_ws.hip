@@ -220,12 +220,12 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
                     } else {
 #pragma unroll
                         for (int j = 0; j < 2 * KS; ++j) mfma_at(p, j);
-                        hd[(3 * slice + p - 1) * 64] = gelu8(acc[2 * p - 2], acc[2 * p - 1]);
+                        hd[(3 * slice + p - 1) * 64] = gelu8t(acc[2 * p - 2], acc[2 * p - 1]);
                     }
                 }
                 WS_STAMP(3);
                 if constexpr (ABL & 1) raw_pair(HT / 2 - 1);
-                else hd[(3 * slice + HT / 2 - 1) * 64] = gelu8(acc[HT - 2], acc[HT - 1]);
+                else hd[(3 * slice + HT / 2 - 1) * 64] = gelu8t(acc[HT - 2], acc[HT - 1]);
                 WS_STAMP(4);
             }
             // the next trip's stage A reads tile i + 3: requested kDmaAhead trips ago

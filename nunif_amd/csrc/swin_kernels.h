@@ -96,7 +96,8 @@ struct TailToImage { const f16 *w; const float *bias; float *out; int H, W, ps, 
 // WinMap (C = 96 resident kernel only): tokens are walked in WINDOW order (n = window * 36 + t, the shifted 6x6 windows of
 // launch_qkv_attn_r) and att is the window-major map that kernel writes with window_major = 1; x rows / image pixels are
 // addressed through the same window -> pixel map.  The per-token arithmetic is unchanged (bit-identical results).
-struct WinMap { int on, H, W, shift; };
+struct WinMap { int on, H, W, shift; const int *pixmap; };     // pixmap: token -> pixel table of launch_winmap_build (B H W ints)
+int launch_winmap_build(int *pixmap, int B, int H, int W, int shift, hipStream_t s);
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
                     long M, int C, hipStream_t s, const TailToImage *to_image = nullptr, int rev = 0,
                     const WinMap *wm = nullptr);

@@ -14,7 +14,7 @@
 //     softmax = exp2(s - max) with a bare v_exp_f32, no multiply;
 //   * the qkv biases initialise the accumulators (no epilogue add);
 //   * the window-invariant one-hot key fragments are built once per wave;
-//   * C = 96 prefetches the next window's x while the current one is computed.
+//   * the next window's x is requested at the end of a window's trip (four waves per SIMD hide the rest).
 #include <algorithm>
 #include <cstdlib>
 
@@ -32,7 +32,7 @@ struct QkvAttnRArgs {
     f16 *att;                // [B,H,W,C]
     const f16 *wres;         // per head: Wq tiles, Wk tiles, Wv tiles, each (nt, ks) fragment-major; q pre-scaled
     const float *bqkv;       // [3C], q part pre-scaled
-    const float *btab32;     // [heads][36][52] fp32: log2e * bias, cols 36..47 = -1000 (padded keys), 48..51 unused
+    const float *btab32;     // [heads][36][52] fp32: log2e * bias, key columns in win_token order (col 32 + 4 g = key 32 + g), 48..51 unused
     int B, H, W, shift, n_windows;
     int rev;                 // 1: walk the windows from the last to the first (snake order, see launch_qkv_attn_r)
 };
@@ -43,12 +43,31 @@ __device__ __forceinline__ f16x8 cat8r(f16x4 lo, f16x4 hi) {
 
 constexpr int kBiasStride = 52;        // fp32 row stride of the CBIAS table: 16 lanes x 16 B land in 16 distinct bank quads
 
+
+// Column r16 of token tile mt holds window token win_token(mt, r16): tiles 0 / 1 the tokens 0..31 in order, tile 2 the
+// tokens 32..35 at columns 0, 4, 8, 12 (every other column of tile 2 repeats token 35 and is never stored).  The host packs
+// the bias table's key columns in the same order (swin_unet.cpp: column 32 + 4 g = key 32 + g).
+__device__ __host__ inline int win_token(int mt, int r16) { return mt < 2 ? 16 * mt + r16 : ((r16 & 3) == 0 ? 32 + (r16 >> 2) : 35); }
+
 // The score accumulators are INITIALISED from an fp32 bias table in LDS (relative-position bias and
 // the padded-key mask are the MFMA C operand), the softmax denominator comes from one MFMA against a ones fragment, and
 // the shift-region term rides in the unused half of the K = 32 step (head_dim 16) or in one extra MFMA that only the
 // windows of the last row / column issue (head_dim 32).  Per head this removes 9 (hd 16) / 18 (hd 32) one-hot MFMAs and
-// ~45 VALU instructions; MFMA and VALU do not overlap on a SIMD, so both count.
-template <int C, int HD, int HPP, bool PREFETCH, int WAVES = 8, bool WM = false>
+// ~45 VALU instructions.
+//
+// Round 4 — the instruction diet (the kernel is VALU-issue bound: 245 issue slots per head + 360 per window of address
+// arithmetic against 45 MFMAs per head, profiles/r04_isa_counts.txt):
+//   * the 36 tokens of a window sit in the three 16-column tiles as 16 + 16 + 4, and the 4 sit at COLUMNS 0, 4, 8, 12 of
+//     tile 2 (win_token).  As KEYS they are then row 4 g of the score tile = accumulator register 0 of every lane
+//     group g, and registers 1-3 of key tile 2 are padding in ALL lanes: their 3 subtractions, 3 exponentials and half of
+//     the converts are not issued at all (the contiguous placement kept 4 real + 12 padded keys in one lane group, so
+//     every VALU instruction still had to run).  25 % of the softmax;
+//   * the window index is wave-uniform: (batch, window row, window column) live in SGPRs and advance by the decomposition
+//     of the stride (add + carry), a lane's pixel offset inside a window is a constant (two divisions per lane per
+//     LAUNCH instead of ~360 VALU instructions of index arithmetic per window), loads / stores are `base SGPR + 32-bit
+//     lane offset`; only the windows of the last row / column of a shifted map (which wrap around) compute offsets;
+//   * the region one-hot fragments are constants outside those windows.
+template <int C, int HD, int HPP, int WAVES = 8, bool WM = false>
 __global__ void __launch_bounds__(WAVES * 64)
 qkv_attn_r_kernel(QkvAttnRArgs a) {
     constexpr int kWavesR = WAVES;
@@ -66,7 +85,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15;
     const int grp = lane >> 4;
     const int nwx = a.W / 6, nwy = a.H / 6;
@@ -75,25 +94,22 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     for (int i = tid; i < 3 * C; i += NTHR) bl[i] = a.bqkv[i];
     const f16x8 ones8 = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
 
-    auto pix_of = [&](int wi, int t) -> long {       // window-local token -> pixel of the un-rolled map
-        const int wx = wi % nwx, t2 = wi / nwx;
-        const int wy = t2 % nwy, b = t2 / nwy;
-        t = min(t, 35);
-        const int iy = t / 6, ix = t - 6 * iy;
-        int yy = wy * 6 + iy + a.shift, xx = wx * 6 + ix + a.shift;
-        if (yy >= a.H) yy -= a.H;
-        if (xx >= a.W) xx -= a.W;
-        return ((long)b * a.H + yy) * a.W + xx;
-    };
-    auto load_x = [&](int wi, f16x8 (&xf)[3][KS], long (&pix)[3]) {
+    // ---- per-lane constants of the launch: the window token of column r16 of tile mt, its pixel offset ----------------------
+    int tokc[3], iyc[3], ixc[3];
+    unsigned xoff[3];                       // byte offset of (token, channel 8 grp) from the window's first pixel, no wrap-around
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) {
-            pix[mt] = pix_of(wi, 16 * mt + r16);
-            const f16 *p = a.x + pix[mt] * C + 8 * grp;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = *reinterpret_cast<const f16x8 *>(p + 32 * ks);
-        }
-    };
+    for (int mt = 0; mt < 3; ++mt) {
+        tokc[mt] = win_token(mt, r16);
+        iyc[mt] = tokc[mt] / 6;
+        ixc[mt] = tokc[mt] - 6 * iyc[mt];
+        xoff[mt] = (unsigned)(((iyc[mt] * a.W + ixc[mt]) * C + 8 * grp) * 2);
+    }
+    const bool store2 = (r16 & 3) == 0;                                              // tile 2: columns 0, 4, 8, 12 are real
+    // store offset of a lane relative to its load offset (non-WM): channel run of the 16-byte epilogue instead of 8 grp
+    const int st_delta = (NTH == 2 ? pair_run_channel(grp) : 4 * grp) * 2 - 16 * grp;
+    // shift-region one-hots of a window that does not touch the last row / column: every token is in region 0
+    f16x4 rk0 = zero4, rq0 = zero4;
+    if (a.shift > 0 && grp == 2) { rk0[0] = (f16)1.f; rq0[0] = (f16)kRegionR; }
 
     // Head passes are spread over WORKGROUPS, not run back to back inside one: workgroup i serves pass i % PASSES for the
     // windows (i / PASSES) + k * gridDim.x / PASSES.  Every workgroup loads its weight slice exactly once, there is no
@@ -107,178 +123,202 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     // windows = one contiguous stretch of the window-major att map).
     const bool spread = a.n_windows < 8 * wstride;
     const int w0 = spread ? wave * n_wg + (int)(blockIdx.x / PASSES) : (int)(blockIdx.x / PASSES) * kWavesR + wave;
+    const int pass = blockIdx.x % PASSES;
     {
-        const int pass = blockIdx.x % PASSES;
-        {
-            const f16x8 *src = reinterpret_cast<const f16x8 *>(a.wres) + (long)pass * HPP * FPH * 64;
-            for (int i = tid; i < HPP * FPH * 64; i += NTHR) wl[i] = src[i];
-            const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.btab32 + (long)pass * HPP * 36 * kBiasStride);
-            for (int i = tid; i < HPP * 36 * kBiasStride / 4; i += NTHR) reinterpret_cast<f32x4 *>(bt32)[i] = bsrc[i];
+        const f16x8 *src = reinterpret_cast<const f16x8 *>(a.wres) + (long)pass * HPP * FPH * 64;
+        for (int i = tid; i < HPP * FPH * 64; i += NTHR) wl[i] = src[i];
+        const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.btab32 + (long)pass * HPP * 36 * kBiasStride);
+        for (int i = tid; i < HPP * 36 * kBiasStride / 4; i += NTHR) reinterpret_cast<f32x4 *>(bt32)[i] = bsrc[i];
+    }
+    __syncthreads();
+
+    // (cb, cy, cx): batch / window row / window column of window wi — all wave-uniform; (db, dy, dx): of the stride
+    int cx = w0 % nwx, cy = (w0 / nwx) % nwy, cb = w0 / (nwx * nwy);
+    const int dx = wstride % nwx, dy = (wstride / nwx) % nwy, db = wstride / (nwx * nwy);
+    const long img_bytes = (long)a.H * a.W * C * 2;
+
+    // x of window (wb, wy, wx) -> B fragments; vo[mt]: byte offset of this lane's 16 bytes from the image of batch wb
+    auto load_x = [&](int wb, int wy, int wx, bool special, f16x8 (&xf)[3][KS], unsigned (&vo)[3]) {
+        const int y0 = wy * 6 + a.shift, x0 = wx * 6 + a.shift;
+        const char *xb = reinterpret_cast<const char *>(a.x) + (long)wb * img_bytes;
+        if (special) {
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                int yy = y0 + iyc[mt], xx = x0 + ixc[mt];
+                if (yy >= a.H) yy -= a.H;
+                if (xx >= a.W) xx -= a.W;
+                vo[mt] = (unsigned)(((yy * a.W + xx) * C + 8 * grp) * 2);
+            }
+        } else {
+            const unsigned org = (unsigned)((y0 * a.W + x0) * C * 2);
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) vo[mt] = org + xoff[mt];
         }
-        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = *reinterpret_cast<const f16x8 *>(xb + vo[mt] + 64 * ks);
+        }
+    };
+    auto decode = [&](int &wb, int &wy, int &wx, bool &special) {          // snake order: digit-wise complement of the index
+        wb = a.rev ? a.B - 1 - cb : cb;
+        wy = a.rev ? nwy - 1 - cy : cy;
+        wx = a.rev ? nwx - 1 - cx : cx;
+        special = a.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
+    };
+    auto advance = [&]() {
+        cx += dx;
+        if (cx >= nwx) { cx -= nwx; ++cy; }
+        cy += dy;
+        if (cy >= nwy) { cy -= nwy; ++cb; }
+        cb += db;
+    };
 
-        f16x8 xf[3][KS];
-        long pix[3];
-        auto wmap = [&](int wi) { return a.rev ? a.n_windows - 1 - wi : wi; };
-        if (w0 < a.n_windows) load_x(wmap(w0), xf, pix);
+    f16x8 xf[3][KS];
+    unsigned vo[3];
+    int wb, wy, wx;
+    bool special;
+    decode(wb, wy, wx, special);
+    if (w0 < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
 
 #pragma unroll 1
-        for (int wi = w0; wi < a.n_windows; wi += wstride) {
-            f16x8 xn[PREFETCH ? 3 : 1][PREFETCH ? KS : 1];
-            long pixn[3];
-            if constexpr (PREFETCH) {
-                const int wnext = wi + wstride < a.n_windows ? wi + wstride : wi;
-                load_x(wmap(wnext), xn, pixn);
+    for (int wi = w0; wi < a.n_windows; wi += wstride) {
+        // shift regions of this window (only the last window row / column straddles two regions)
+        f16x4 rkr[3], rqr[3];
+        if (special) {
+            const bool last_y = wy == nwy - 1, last_x = wx == nwx - 1;
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                const int reg = ((last_y && iyc[mt] >= 3) ? 2 : 0) + ((last_x && ixc[mt] >= 3) ? 1 : 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool on = grp == 2 && reg == j;                  // cols 40..43 live in lane group 2
+                    rkr[mt][j] = (f16)(on ? 1.f : 0.f);
+                    rqr[mt][j] = (f16)(on ? kRegionR : 0.f);
+                }
             }
-            // shift regions of this window (only the last window row / column straddles two regions)
-            f16x4 rkr[3], rqr[3];
-            bool special;
-            {
-                const int wq = wmap(wi);
-                const int wx = wq % nwx, wy = (wq / nwx) % nwy;
-                const bool last_y = a.shift > 0 && wy == nwy - 1, last_x = a.shift > 0 && wx == nwx - 1;
-                special = __builtin_amdgcn_readfirstlane((int)(last_y || last_x)) != 0;   // one window per wave: uniform
+        } else {
 #pragma unroll
-                for (int mt = 0; mt < 3; ++mt) {
-                    const int t = min(16 * mt + r16, 35);
-                    const int iy = t / 6, ix = t - 6 * iy;
-                    const int reg = ((last_y && iy >= 3) ? 2 : 0) + ((last_x && ix >= 3) ? 1 : 0);
+            for (int mt = 0; mt < 3; ++mt) { rkr[mt] = rk0; rqr[mt] = rq0; }
+        }
+        const int wq = (wb * nwy + wy) * nwx + wx;                         // index of this window in the window-major att map
+        char *ab = reinterpret_cast<char *>(a.att) + (WM ? (long)wq * (HEADS * 36 * HD * 2) : (long)wb * img_bytes);
+
+#pragma unroll 1
+        for (int hl = 0; hl < HPP; ++hl) {
+            const int head = pass * HPP + hl;
+            const f16x8 *wh = wl + (hl * FPH) * 64 + lane;
+            // ---- q, k (channels x tokens) and v (tokens x channels: operands swapped) of this head ----------------
+            f16x4 qt4[NTH][3], kt4[NTH][3], vt4[NTH][3];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool on = a.shift > 0 && grp == 2 && reg == j;       // cols 40..43 live in lane group 2
-                        rkr[mt][j] = (f16)(on ? 1.f : 0.f);
-                        rqr[mt][j] = (f16)(on ? kRegionR : 0.f);
+            for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                for (int nt = 0; nt < NTH; ++nt) {
+                    const int ch0 = part * C + head * HD + nt * 16;
+                    f32x4 acc[3];
+                    if (part == 2) {
+                        const float bv = bl[ch0 + r16];
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){bv, bv, bv, bv};
+                    } else {
+                        const f32x4 bb = *reinterpret_cast<const f32x4 *>(bl + ch0 + 4 * grp);
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt) acc[mt] = bb;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const f16x8 w = wh[((part * NTH + nt) * KS + ks) * 64];
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt)
+                            acc[mt] = part == 2 ? MFMA_16x16x32(xf[mt][ks], w, acc[mt]) : MFMA_16x16x32(w, xf[mt][ks], acc[mt]);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt) {
+                        const f16x4 v = {(f16)acc[mt][0], (f16)acc[mt][1], (f16)acc[mt][2], (f16)acc[mt][3]};
+                        if (part == 0) qt4[nt][mt] = v; else if (part == 1) kt4[nt][mt] = v; else vt4[nt][mt] = v;
                     }
                 }
             }
 
-#pragma unroll 1
-            for (int hl = 0; hl < HPP; ++hl) {
-                const int head = pass * HPP + hl;
-                const f16x8 *wh = wl + (hl * FPH) * 64 + lane;
-                // ---- q, k (channels x tokens) and v (tokens x channels: operands swapped) of this head ----------------
-                f16x4 qt4[NTH][3], kt4[NTH][3], vt4[NTH][3];
+            // ---- attention of this head: 3 q tiles x 3 key tiles ---------------------------------------------------
 #pragma unroll
-                for (int part = 0; part < 3; ++part) {
-#pragma unroll
-                    for (int nt = 0; nt < NTH; ++nt) {
-                        const int ch0 = part * C + head * HD + nt * 16;
-                        f32x4 acc[3];
-                        if (part == 2) {
-                            const float bv = bl[ch0 + r16];
-#pragma unroll
-                            for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){bv, bv, bv, bv};
-                        } else {
-                            const f32x4 bb = *reinterpret_cast<const f32x4 *>(bl + ch0 + 4 * grp);
-#pragma unroll
-                            for (int mt = 0; mt < 3; ++mt) acc[mt] = bb;
-                        }
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) {
-                            const f16x8 w = wh[((part * NTH + nt) * KS + ks) * 64];
-#pragma unroll
-                            for (int mt = 0; mt < 3; ++mt)
-                                acc[mt] = part == 2 ? MFMA_16x16x32(xf[mt][ks], w, acc[mt]) : MFMA_16x16x32(w, xf[mt][ks], acc[mt]);
-                        }
-#pragma unroll
-                        for (int mt = 0; mt < 3; ++mt) {
-                            const f16x4 v = {(f16)acc[mt][0], (f16)acc[mt][1], (f16)acc[mt][2], (f16)acc[mt][3]};
-                            if (part == 0) qt4[nt][mt] = v; else if (part == 1) kt4[nt][mt] = v; else vt4[nt][mt] = v;
-                        }
-                    }
-                }
-
-                // ---- attention of this head: 3 q tiles x 3 key tiles ---------------------------------------------------
-#pragma unroll
-                for (int qt = 0; qt < 3; ++qt) {
-                    const int tokq = min(16 * qt + r16, 35);
-                    f32x4 s[3];
-                    float mx = -3.0e38f;
-                    {
-                        const float *brow = bt32 + (hl * 36 + tokq) * kBiasStride + 4 * grp;
-#pragma unroll
-                        for (int kt = 0; kt < 3; ++kt) {
-                            f32x4 acc = *reinterpret_cast<const f32x4 *>(brow + 16 * kt);
-                            if constexpr (HD == 16) {
-                                acc = MFMA_16x16x32(cat8r(kt4[0][kt], rkr[kt]), cat8r(qt4[0][qt], rqr[qt]), acc);
-                            } else {
-                                acc = MFMA_16x16x32(cat8r(kt4[0][kt], kt4[1][kt]), cat8r(qt4[0][qt], qt4[1][qt]), acc);
-                                if (special) acc = MFMA_16x16x32(cat8r(rkr[kt], zero4), cat8r(rqr[qt], zero4), acc);
-                            }
-                            s[kt] = acc;
-                        }
-                        mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
-                                   fmaxf(fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])),
-                                         fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3]))));
-                    }
-                    mx = row_group_max(mx);
-                    float sum = 0.f;
-                    f16x4 pf[3];
+            for (int qt = 0; qt < 3; ++qt) {
+                f32x4 s[3];
+                {
+                    const float *brow = bt32 + (hl * 36 + tokc[qt]) * kBiasStride + 4 * grp;
 #pragma unroll
                     for (int kt = 0; kt < 3; ++kt) {
-                        const float p0 = __builtin_amdgcn_exp2f(s[kt][0] - mx), p1 = __builtin_amdgcn_exp2f(s[kt][1] - mx);
-                        const float p2 = __builtin_amdgcn_exp2f(s[kt][2] - mx), p3 = __builtin_amdgcn_exp2f(s[kt][3] - mx);
-                        pf[kt] = (f16x4){(f16)p0, (f16)p1, (f16)p2, (f16)p3};
-                    }
-                    {
-                        // denominator = sum of the fp16 probabilities the PV product actually uses: ones x P on the MFMA
-                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                        const f32x4 sm = MFMA_16x16x32(ones8, cat8r(pf[0] + pf[1], pf[2]), z4);
-                        sum = sm[0];
-                    }
-                    const float inv = __builtin_amdgcn_rcpf(sum);
-                    const bool store = (16 * qt + r16) < 36;
-                    // 16-byte stores: two adjacent 16-channel tiles -> one 8-channel run per lane (common.h pair_to_run).
-                    // head_dim 32: the two tiles of this head.
-                    f16x4 ov[NTH];
-#pragma unroll
-                    for (int dt = 0; dt < NTH; ++dt) {
-                        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                        o = MFMA_16x16x32(cat8r(vt4[dt][0], vt4[dt][1]), cat8r(pf[0], pf[1]), o);
-                        o = MFMA_16x16x32(cat8r(vt4[dt][2], zero4), cat8r(pf[2], zero4), o);
-                        ov[dt] = (f16x4){(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
-                    }
-                    if constexpr (NTH == 2) {
-                        const f16x8 run = pair_to_run(ov[0], ov[1]);
-                        if (store) *reinterpret_cast<f16x8 *>(a.att + pix[qt] * C + head * HD + pair_run_channel(grp)) = run;
-                    } else {
-                        // head_dim 16: pairing with the neighbouring head's tile (held across one trip of the head loop)
-                        // was measured slower (504 vs 457 us): plain 8-byte stores
-                        // window-major map (WM: att is [window][head][36 tokens][HD], the C = 96 tail reads it so): the 64 lanes of this store cover ONE contiguous 512-byte run (16 tokens x 32 B)
-                        // instead of sixteen 8-byte pieces 192 B apart (1.48x write amplification in the r02 counters)
-                        f16 *dst = WM ? a.att + ((long)(wmap(wi) * HEADS + head) * 36 + 16 * qt + r16) * HD + 4 * grp
-                                      : a.att + pix[qt] * C + head * HD + 4 * grp;
-                        if (store) *reinterpret_cast<f16x4 *>(dst) = ov[0];
+                        f32x4 acc = *reinterpret_cast<const f32x4 *>(brow + 16 * kt);
+                        if constexpr (HD == 16) {
+                            acc = MFMA_16x16x32(cat8r(kt4[0][kt], rkr[kt]), cat8r(qt4[0][qt], rqr[qt]), acc);
+                        } else {
+                            acc = MFMA_16x16x32(cat8r(kt4[0][kt], kt4[1][kt]), cat8r(qt4[0][qt], qt4[1][qt]), acc);
+                            if (special) acc = MFMA_16x16x32(cat8r(rkr[kt], zero4), cat8r(rqr[qt], zero4), acc);
+                        }
+                        s[kt] = acc;
                     }
                 }
-            }
-
-            if constexpr (PREFETCH) {
+                // 9 real keys per lane: tiles 0 and 1 whole, register 0 of tile 2 (key 32 + grp); registers 1-3 of tile 2 are padding
+                float mx = fmaxf(fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]), fmaxf(fmaxf(s[0][3], s[1][0]), s[1][1])),
+                                 fmaxf(fmaxf(s[1][2], s[1][3]), s[2][0]));
+                mx = row_group_max(mx);
+                f16x4 pf[3];
 #pragma unroll
-                for (int mt = 0; mt < 3; ++mt) {
-                    pix[mt] = pixn[mt];
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = xn[mt][ks];
+                for (int kt = 0; kt < 2; ++kt) {
+                    const float p0 = __builtin_amdgcn_exp2f(s[kt][0] - mx), p1 = __builtin_amdgcn_exp2f(s[kt][1] - mx);
+                    const float p2 = __builtin_amdgcn_exp2f(s[kt][2] - mx), p3 = __builtin_amdgcn_exp2f(s[kt][3] - mx);
+                    pf[kt] = (f16x4){(f16)p0, (f16)p1, (f16)p2, (f16)p3};
                 }
-            } else {
-                if (wi + wstride < a.n_windows) load_x(wmap(wi + wstride), xf, pix);
+                pf[2] = (f16x4){(f16)__builtin_amdgcn_exp2f(s[2][0] - mx), (f16)0.f, (f16)0.f, (f16)0.f};
+                // ONE fragment [p0 + p1 | p2] serves the denominator (ones x it = the sum of the fp16 probabilities the PV
+                // product actually uses) AND the key-tile-2 part of PV (V of tile 2 sits in the HIGH k-slots of vz, zeros below)
+                const f16x8 psum = cat8r(pf[0] + pf[1], pf[2]);
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 sm = MFMA_16x16x32(ones8, psum, z4);
+                const float inv = __builtin_amdgcn_rcpf(sm[0]);
+                const bool store = qt < 2 || store2;
+                // 16-byte stores: two adjacent 16-channel tiles -> one 8-channel run per lane (common.h pair_to_run).
+                // head_dim 32: the two tiles of this head.
+                f16x4 ov[NTH];
+#pragma unroll
+                for (int dt = 0; dt < NTH; ++dt) {
+                    f32x4 o = MFMA_16x16x32(cat8r(vt4[dt][0], vt4[dt][1]), cat8r(pf[0], pf[1]), z4);
+                    o = MFMA_16x16x32(cat8r(zero4, vt4[dt][2]), psum, o);
+                    ov[dt] = (f16x4){(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
+                }
+                if constexpr (NTH == 2) {
+                    const f16x8 run = pair_to_run(ov[0], ov[1]);
+                    if (store) *reinterpret_cast<f16x8 *>(ab + (vo[qt] + (unsigned)st_delta) + head * (HD * 2)) = run;
+                } else if constexpr (WM) {
+                    // head_dim 16, window-major map (att is [window][head][36 tokens][HD], the C = 96 tail reads it so): the 64 lanes
+                    // of this store cover ONE contiguous 512-byte run (16 tokens x 32 B) instead of sixteen 8-byte pieces 192 B
+                    // apart (1.48x write amplification in the r02 counters).  Pairing with the neighbouring head's tile (held
+                    // across one trip of the head loop) was measured slower (504 vs 457 us): plain 8-byte stores
+                    if (store) *reinterpret_cast<f16x4 *>(ab + ((head * 36 + tokc[qt]) * HD + 4 * grp) * 2) = ov[0];
+                } else {
+                    if (store) *reinterpret_cast<f16x4 *>(ab + (vo[qt] + (unsigned)st_delta) + head * (HD * 2)) = ov[0];
+                }
             }
         }
+
+        advance();
+        decode(wb, wy, wx, special);
+        if (wi + wstride < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
     }
 }
 
 int qkv_attn_r_frags(int C) { return 3 * (C / 16) * (C / 32); }
 
-template <int C, int HD, int HPP, bool PREFETCH, int WAVES = 8, bool WM = false>
+template <int C, int HD, int HPP, int WAVES = 8, bool WM = false>
 static int launch_r(const QkvAttnRArgs &a, int grid, hipStream_t s) {
     constexpr size_t smem = (size_t)HPP * 3 * (HD / 16) * (C / 32) * 1024 + HPP * 36 * kBiasStride * 4 + 3 * C * 4;
     static bool configured = false;
     if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)qkv_attn_r_kernel<C, HD, HPP, PREFETCH, WAVES, WM>,
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)qkv_attn_r_kernel<C, HD, HPP, WAVES, WM>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = true;
     }
-    qkv_attn_r_kernel<C, HD, HPP, PREFETCH, WAVES, WM><<<grid, WAVES * 64, smem, s>>>(a);
+    qkv_attn_r_kernel<C, HD, HPP, WAVES, WM><<<grid, WAVES * 64, smem, s>>>(a);
     return NUNIF_HIP_OK;
 }
 
@@ -303,10 +343,10 @@ int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv
     int rc;
     if (C == 96) {
         ProfScope ps("qkv_attn_r_kernel<96,16>", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 4.0);
-        rc = window_major ? launch_r<96, 16, 6, false, 16, true>(a, grid, s) : launch_r<96, 16, 6, false, 16, false>(a, grid, s);
+        rc = window_major ? launch_r<96, 16, 6, 16, true>(a, grid, s) : launch_r<96, 16, 6, 16, false>(a, grid, s);
     } else {
         ProfScope ps("qkv_attn_r_kernel<192,32>", s, 2.0 * tok * C * 3.0 * C + 4.0 * tok * 36.0 * C, tok * C * 4.0);
-        rc = launch_r<192, 32, 3, false>(a, grid, s);
+        rc = launch_r<192, 32, 3>(a, grid, s);
     }
     if (rc) return rc;
     NUNIF_LAUNCH_CHECK();

@@ -87,6 +87,9 @@ struct nunif_swin_unet {
     std::vector<Block> swin[5];
     std::vector<void *> owned;        // every device allocation made at create time
     DeviceBuf s1, f1, f2, f3, g1, qkv, att, hid, tile_out;
+    // token -> pixel tables of the window-major C = 96 tail (launch_winmap_build), one per shift, for the geometry last seen
+    DeviceBuf winmap[2];
+    int winmap_B = 0, winmap_S = 0;
     int device = 0;
     // debug taps (tests only): when on, every stage's fp16 output is snapshotted device-side
     struct Tap { std::string name; void *dev; size_t bytes; };
@@ -319,13 +322,18 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
                     bias[((size_t)hh * 36 + q) * 48 + k] = v;
                 }
         if ((rc = upload(h, bias, &bl.attn_bias))) return rc;
-        // fp32 table read as the MFMA C operand: [heads][36][52], log2(e) * bias, padded keys 1000 log2-units down
+        // fp32 table read as the MFMA C operand: [heads][36 queries][52], log2(e) * bias.  Key COLUMNS follow the token
+        // placement of qkv_attn_r_kernel (win_token, swin_qkv_attn_r.hip): columns 0..31 = keys 0..31, column 32 + 4 g =
+        // key 32 + g (register 0 of lane group g in key tile 2); the other columns of tile 2 are padding the kernel never
+        // exponentiates (-1000 all the same)
         std::vector<float> btab32((size_t)heads * 36 * 52, 0.0f);
         for (int hh = 0; hh < heads; ++hh)
             for (int q = 0; q < 36; ++q)
-                for (int k = 0; k < 48; ++k)
+                for (int k = 0; k < 48; ++k) {
+                    const int key = k < 32 ? k : (((k - 32) & 3) == 0 ? 32 + ((k - 32) >> 2) : -1);
                     btab32[((size_t)hh * 36 + q) * 52 + k] =
-                        k < 36 ? bias[((size_t)hh * 36 + q) * 48 + k] * 1.4426950408889634f : -1000.0f;
+                        key >= 0 ? bias[((size_t)hh * 36 + q) * 48 + key] * 1.4426950408889634f : -1000.0f;
+                }
         if ((rc = upload(h, btab32, &bl.attn_btab32))) return rc;
     }
     return NUNIF_HIP_OK;
@@ -424,7 +432,20 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
             if ((rc = launch_proj_mlp_ws(att, x, bl.tail_ws, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, s, next_dir(h))))
                 return rc;
         } else {
-            const WinMap wmap = {att_wm ? 1 : 0, S, S, S <= 6 ? 0 : shift};
+            const int eff_shift = S <= 6 ? 0 : shift;
+            WinMap wmap = {att_wm ? 1 : 0, S, S, eff_shift, nullptr};
+            if (att_wm) {
+                if (h->winmap_S != S || B > h->winmap_B) {
+                    // (re)build both tables on this stream: every launch that reads them is ordered behind it.  The table of a
+                    // larger batch contains the smaller one's as its prefix (token n -> batch n / (36 windows per image))
+                    for (int k = 0; k < 2; ++k) {
+                        if ((rc = h->winmap[k].ensure(tok * sizeof(int)))) return rc;
+                        if ((rc = launch_winmap_build((int *)h->winmap[k].p, B, S, S, k ? 3 : 0, s))) return rc;
+                    }
+                    h->winmap_B = B; h->winmap_S = S;
+                }
+                wmap.pixmap = (const int *)h->winmap[eff_shift ? 1 : 0].p;
+            }
             if ((rc = launch_proj_mlp(att, x, bl.tail_stream, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, dim, s,
                                       last ? to_image : nullptr, next_dir(h), &wmap)))
                 return rc;
@@ -716,7 +737,7 @@ extern "C" void nunif_hip_swin_unet_destroy(nunif_swin_unet *h) {
     if (!h) return;
     h->clear_taps();
     for (void *p : h->owned) (void)hipFree(p);
-    for (DeviceBuf *b : {&h->s1, &h->f1, &h->f2, &h->f3, &h->g1, &h->qkv, &h->att, &h->hid, &h->tile_out}) b->release();
+    for (DeviceBuf *b : {&h->s1, &h->f1, &h->f2, &h->f3, &h->g1, &h->qkv, &h->att, &h->hid, &h->tile_out, &h->winmap[0], &h->winmap[1]}) b->release();
     delete h;
 }
 
