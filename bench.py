@@ -73,6 +73,14 @@ def parse_args():
     return ap.parse_args()
 
 
+def emit(result):
+    """Print THE line.  ``ok`` is false whenever a leg recorded an error (``errors``); the return value is the exit code rank 0
+    leaves with after the line is out — a failed leg must not look like a clean run to a driver that only checks rc."""
+    result["ok"] = not result.get("errors")
+    print(json.dumps(result), flush=True)
+    return 0 if result["ok"] else 3
+
+
 def relaunch_as_ranks(args):
     """``python bench.py --gpus N`` without a rendezvous: become ``torch.distributed.run`` with N local ranks."""
     with socket.socket() as s:
@@ -384,24 +392,27 @@ def cunet_record(dev, with_cpu):
     m = create_model("waifu2x.cunet").eval()
     m.load_state_dict(sd)
     m = m.to(dev)
-    rec = {"config": "BASELINE configs[0] geometry on the GPU: waifu2x cunet (noise geometry, random-init), tile 256, batch 16: "
+    # tile minibatch = the whole frame (66 tiles), as the swin_unet leg does with its 45: five launches of 16 + 16 + 16 + 16 + 2 tiles
+    # per layer cost 225 vs 298 MPix/s on the same build (tools/cunet_probe.py, CUNET_BATCH); results do not depend on it
+    CB = 66
+    rec = {"config": f"BASELINE configs[0] geometry on the GPU: waifu2x cunet (noise geometry, random-init), tile 256, tile batch {CB}: "
                      "one 512 x 512 image (9 tiles) and a 1080p frame (66 tiles)", "unit": "input MPix/s"}
     img = synth_frame(31, 512, 512).to(dev)
     frame = synth_frame(32, FRAME_H, FRAME_W).to(dev)
     for key, x, n in (("image_512", img, 60), ("frame_1080p", frame, 30)):
         for _ in range(3):
-            tiled_render(x, m, tile_size=TILE, batch_size=16)
+            tiled_render(x, m, tile_size=TILE, batch_size=CB)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(n):
-            y = tiled_render(x, m, tile_size=TILE, batch_size=16)
+            y = tiled_render(x, m, tile_size=TILE, batch_size=CB)
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / n
         rec[key] = {"ms": round(dt * 1e3, 3), "value": round(x.shape[1] * x.shape[2] / dt / 1e6, 1)}
     _hip.profile_read(reset=True)
     _hip.profile_enable(True)
     for _ in range(3):
-        tiled_render(frame, m, tile_size=TILE, batch_size=16)
+        tiled_render(frame, m, tile_size=TILE, batch_size=CB)
     torch.cuda.synchronize(dev)
     recs = _hip.profile_read(reset=True)
     _hip.profile_enable(False)
@@ -421,7 +432,7 @@ def cunet_record(dev, with_cpu):
         t0 = time.perf_counter()
         ref = OS.tiled_render(img.cpu(), lambda mb: OC.model_forward(sd, mb), 1, 28, 0, TILE, 4)
         dt = time.perf_counter() - t0
-        got = tiled_render(img, m, tile_size=TILE, batch_size=16).cpu()
+        got = tiled_render(img, m, tile_size=TILE, batch_size=CB).cpu()
         mse = torch.mean((got.double() - ref.double()) ** 2).item()
         rec["psnr_vs_oracle_db"] = round(10 * math.log10(1.0 / (mse + 1e-6)), 2)
         rec["cpu_baseline"] = {"value": round(512 * 512 / 1e6 / dt, 4), "unit": "MPix/s", "cores": min(32, physical_cores()),
@@ -682,17 +693,22 @@ def main():
                 hf["ms_per_frame" if mode == "view" else "ms_per_frame_copying_every_frame"] = round(1e3 * dt / n_host, 3)
                 del ring
             result["host_frames"] = hf
-        if not args.no_4k and world == 1:
-            result["scale4x_4k"] = scale4x_record(dev)
-        if not args.no_cunet and world == 1:
-            result["cunet"] = cunet_record(dev, with_cpu=not args.no_cpu_baseline)
-        if not args.no_iw3 and world == 1:
-            result["iw3"] = iw3_record(dev, with_cpu=not args.no_cpu_baseline)
-        if not args.no_config5 and world == 1:
+        def sub_record(key, fn):
+            # a sub-record must never cost the headline line — but a failed one is an error of the run (``ok`` false, rc 3)
             try:
-                result["config5"] = config5_record(dev)
-            except Exception as e:                       # a sub-record must never cost the headline line
-                result["config5"] = {"error": repr(e)}
+                result[key] = fn()
+            except Exception as e:
+                result[key] = {"error": repr(e)}
+                result.setdefault("errors", []).append(f"sub-record {key} raised")
+
+        if not args.no_4k and world == 1:
+            sub_record("scale4x_4k", lambda: scale4x_record(dev))
+        if not args.no_cunet and world == 1:
+            sub_record("cunet", lambda: cunet_record(dev, with_cpu=not args.no_cpu_baseline))
+        if not args.no_iw3 and world == 1:
+            sub_record("iw3", lambda: iw3_record(dev, with_cpu=not args.no_cpu_baseline))
+        if not args.no_config5 and world == 1:
+            sub_record("config5", lambda: config5_record(dev))
         if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
             base, crop, ref = cpu_baseline(sd, frames[0].cpu())
             got = tiled_render(crop.to(dev), model, tile_size=TILE, batch_size=args.batch_size).cpu()
@@ -710,7 +726,7 @@ def main():
                 result["gathered"] = {"error": f"the delivery leg did not finish within {GATHER_TIMEOUT_S} s; value / roofline "
                                                "above are unaffected (they contain no collective)"}
                 result.setdefault("errors", []).append("delivery leg hung (watchdog)")
-                print(json.dumps(result), flush=True)
+                os._exit(emit(result))           # rank 0: the line first, then a non-zero exit code
             os._exit(0)
 
         def gather_leg():
@@ -752,14 +768,14 @@ def main():
             if rank == 0:
                 result["gathered"] = {"error": repr(e)}
                 result.setdefault("errors", []).append("delivery leg raised")
-                print(json.dumps(result), flush=True)
-                os._exit(0)
+                os._exit(emit(result))
             threading.Event().wait()            # the watchdog ends this rank with exit code 0
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    rc = emit(result) if rank == 0 else 0
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)                # only rank 0, only AFTER its line is out and the process group is down
 
 
 if __name__ == "__main__":

@@ -713,10 +713,18 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     int rc;
     if ((rc = h->a_col.ensure((size_t)B * N * kKp * e2)) || (rc = h->pe.ensure((size_t)B * N * kD * e2)) ||
         (rc = h->t.ensure(T * kD * e2)) || (rc = h->y.ensure(T * kD * e2)) || (rc = h->qkv.ensure(T * 3 * kD * e2)) ||
-        (rc = h->att.ensure(T * kD * e2)) || (rc = h->lnstats.ensure((size_t)((T + 31) / 32) * 32 * 12 * sizeof(float2))) ||
+        (rc = h->att.ensure(T * kD * e2)) ||
         (rc = h->hid.ensure(T * 4 * kD * e2)) || (rc = h->m1.ensure(big * e2)) || (rc = h->m2.ensure(big * e2)) ||
         (rc = h->m3.ensure(big * e2)) || (rc = h->m4.ensure(big * e2)) || (rc = h->m5.ensure(big * e2)))
         return rc;
+    {
+        // LayerNorm partial sums: producers write live rows only, the consumer's last 32-token tile reads its pad rows as well
+        // (results discarded by the m < M store guard): zeroed once per allocation so that nothing uninitialised is ever read
+        const size_t ln_bytes = (size_t)((T + 31) / 32) * 32 * 12 * sizeof(float2);
+        const bool fresh = ln_bytes > h->lnstats.cap;
+        if ((rc = h->lnstats.ensure(ln_bytes))) return rc;
+        if (fresh) NUNIF_HIP_CHECK(hipMemsetAsync(h->lnstats.p, 0, h->lnstats.cap, s));
+    }
     for (int i = 0; i < 4; ++i)
         if ((rc = h->feat[i].ensure(T * kD * e2)) || (rc = h->rnb[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2))) return rc;
     f16 *a_col = (f16 *)h->a_col.p, *pe = (f16 *)h->pe.p, *t = (f16 *)h->t.p, *y = (f16 *)h->y.p, *qkv = (f16 *)h->qkv.p;

@@ -130,15 +130,25 @@ def install(registry=True, strict=True):
                     importlib.import_module(m)
             ref_reg = importlib.import_module("nunif.models.register")._models
             our_reg = importlib.import_module("nunif_amd.nunif.models.register")._models
+            new_entries = {}
             for name, factory in our_reg.items():
-                if name in ref_reg:                      # only names the reference itself knows: a drop-in, not an extension
-                    reg_saved[name] = ref_reg[name]
-                    ref_reg[name] = factory
-                    report["models"].append(name)
+                if name not in ref_reg:                  # only names the reference itself knows: a drop-in, not an extension
+                    continue
+                if getattr(factory, "_nunif_amd_unsupported", False):
+                    # a name the engine only knows in order to refuse it: the reference's own torch factory stays reachable
+                    report["skipped"].append((name, "engine factory is an 'unsupported' stub; reference factory kept"))
+                    continue
+                new_entries[name] = factory
+            # built first, applied in one step: nothing between here and `_state` can fail half-way through the registry
+            reg_saved = {name: ref_reg[name] for name in new_entries}
+            ref_reg.update(new_entries)
+            report["models"].extend(new_entries)
         _state = {"bindings": bindings, "registry": reg_saved}
     except Exception:
         for mod, key, orig in reversed(bindings):
             setattr(mod, key, orig)
+        if reg_saved:
+            importlib.import_module("nunif.models.register")._models.update(reg_saved)
         raise
     return report
 

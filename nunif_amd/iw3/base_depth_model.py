@@ -4,8 +4,9 @@ Mirrors ``iw3/base_depth_model.py`` ``BaseDepthModel`` :30-238 — ``load``, abs
 plumbing (``enable_ema`` / ``disable_ema`` / ``reset`` / ``minmax_normalize`` / ``flush_minmax_normalize``), 16-bit
 depth PNG I/O — and provides ``CallableDepthModel``: the ``DepthAnythingModel.infer`` pipeline
 (``iw3/depth_anything_model.py:241-253`` → ``batch_infer`` :123-182) around an arbitrary backbone callable.  The
-reference's backbones live in external ``torch.hub`` repositories (:200-230) that cannot be fetched here; wiring a
-HIP ViT/DPT behind this class is the "next" row f2 of SURVEY.md §8f.
+reference's backbones live in external ``torch.hub`` repositories (:200-230) that cannot be fetched here; the in-tree HIP
+ViT / DPT (``nunif_amd/iw3/depth_anything_v2.py``, SURVEY.md §8f row f2, pinned against HuggingFace since round 3) is the
+backbone ``DepthAnythingModel`` puts behind this class.
 
 Multi-GPU: the reference swaps in ``DeviceSwitchInference`` replicas for a thread pool (:129-133).  Here a model is
 bound to ONE device; frames are sharded across ranks by ``nunif_amd.parallel`` instead.

@@ -4,7 +4,10 @@ The reference obtains this network with ``torch.hub.load("nagadomi/Depth-Anythin
 (``iw3/depth_anything_model.py:200-230``) and calls it as ``model(x)`` on the ImageNet-normalised, /14-aligned batch from
 ``batch_preprocess`` (``_forward`` :113-119).  Neither that repository nor its weights are reachable offline, so this
 class follows the PUBLISHED architecture and checkpoint key layout (``pretrained.*`` DINOv2 ViT-S/14, ``depth_head.*``
-DPT) — see ``oracle/depth_anything_v2.py``; parity against the real hub model is unpinned.
+DPT) — see ``oracle/depth_anything_v2.py``.  Since round 3 that restatement is pinned against HuggingFace ``transformers``
+(``tests/test_depth_anything_vs_hf.py``, <= 5e-5 for ViT-S / B / L, V1 taps, the metric head) and this engine against
+HuggingFace-produced fixtures (``tests/golden/depth_anything_hf.npz``); what nobody can check offline is the hub FORK itself —
+first of all its position-embedding resize (upstream ``scale_factor=(g + 0.1) / 37``, restated from memory).
 
 The geometry (embed 384 / 768 / 1024, 12 / 24 blocks, DPT widths) is read from the checkpoint; ``taps`` (the four encoder blocks
 that feed the head: V2 default, V1 = the last four) and ``max_depth`` (> 0: the V2 metric head, Sigmoid x max_depth) are what

@@ -158,6 +158,7 @@ class VideoDepthAnythingModel(BaseDepthModel):
         return [d for d in done if d is not None]
 
     def _aa(self, flag):
+        """``flush_with_normalize`` (reference :223-225): a bool selects the model's own DepthAA, anything else passes through."""
         return flag if not isinstance(flag, bool) and flag is not None else (self.depth_aa if flag else None)
 
     @torch.inference_mode()
@@ -177,7 +178,7 @@ class VideoDepthAnythingModel(BaseDepthModel):
     @torch.inference_mode()
     def infer_with_normalize(self, x, pts, reset_pts, enable_amp=True, edge_dilation=0, depth_aa=None, **kwargs):
         assert x.ndim == 4
-        aa = self._aa(depth_aa)
+        aa = self.depth_aa if depth_aa else None          # reference :195: ANY truthy value selects the model's own DepthAA here
         book, out = self._book(), []
         for frame, t in zip(self._prepare(x), pts):
             out += self._normalised(book.feed(frame, enable_amp), edge_dilation, aa, enable_amp)

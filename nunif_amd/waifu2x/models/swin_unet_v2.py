@@ -206,6 +206,7 @@ def _swin_unet_v2_1xs(**kwargs):
                               "registered 1x / 2x / 4x geometries (base_dim 64 / 96 / 128, lv1_mlp_ratio 2)")
 
 
+_swin_unet_v2_1xs._nunif_amd_unsupported = True          # nunif_amd.install() leaves the reference's own factory for this name in place
 register_model_factory("waifu2x.swin_unet_v2_1xs", _swin_unet_v2_1xs)
 
 
