@@ -47,13 +47,28 @@ def window_score_bias_input(window):
     return index, ud / ud.abs().max()
 
 
-def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_channels=3, layer_norm=False):
+# regime="hot": the numeric regime of a TRAINED net that the benign conditioning above deliberately avoids:
+# relative-position tables N(0, HOT_TABLE_STD) (trained swin tables reach several units: the bias decides the winner), residual
+# branches NOT damped (stream rms grows 7-30x over the 14 blocks, |stream| reaches 50-160, logits tens of units), and HOT_OUTLIERS
+# channels of the stem output scaled by HOT_OUTLIER_GAIN (the "massive activation" channels every trained transformer carries).  No fp16 engine is
+# within 50 dB of fp32 here — the reference's own autocast mode is not — so these weights are used with the relative criterion
+# of tests/test_gpu_hot_regime.py (no worse than the emulated fp16 reference), never with the absolute one.
+HOT_TABLE_STD = 1.5
+HOT_OUTLIERS = (5, 37, 70)
+HOT_OUTLIER_GAIN = 6.0          # x 20 .. x 50 on a RANDOM net saturates the whole picture (the outliers feed every later weight at full
+                                # strength, which a trained net's weights do not): 47-95 % of the output clamped, nothing left to compare
+HOT_HEAD_GAIN = 0.02            # the undamped stream ends at rms 7-30 instead of 1.3: the head is scaled so that the output stays a picture
+
+
+def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_channels=3, layer_norm=False, regime="benign"):
     """Seeded random weights in the reference's key layout and shapes.
 
     Magnitudes follow the reference initialisers (kaiming/xavier) but every bias and relative-position
     table is drawn N(0, 0.02) instead of zero so that bias handling is exercised.
-    Deterministic for a given torch build (CPU generator).
+    Deterministic for a given torch build (CPU generator).  ``regime="hot"``: see HOT_TABLE_STD above.
     """
+    assert regime in ("benign", "hot")
+    hot = regime == "hot"
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
@@ -75,11 +90,11 @@ def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_c
         for i in range(layers):
             p = f"{key}.block.{i}."
             lin(p + "attn.qkv", dim, dim * 3)
-            lin(p + "attn.proj", dim, dim, BRANCH_GAIN)
-            sd[p + "attn.relative_position_bias_table"] = normal((121, heads), 0.02)
+            lin(p + "attn.proj", dim, dim, 1.0 if hot else BRANCH_GAIN)
+            sd[p + "attn.relative_position_bias_table"] = normal((121, heads), HOT_TABLE_STD if hot else 0.02)
             sd[p + "attn.relative_position_index"] = relative_position_index(*WINDOW)
             lin(p + "mlp.0", dim, dim * 2)
-            lin(p + "mlp.3", dim * 2, dim, BRANCH_GAIN)
+            lin(p + "mlp.3", dim * 2, dim, 1.0 if hot else BRANCH_GAIN)
             if layer_norm:      # LayerNormNoBias (swin_unet_4xl): weight only, drawn around 1 so that it is exercised
                 sd[p + "norm1.weight"] = 1.0 + normal((dim,), 0.1)
                 sd[p + "norm2.weight"] = 1.0 + normal((dim,), 0.1)
@@ -88,6 +103,10 @@ def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_c
     P = "unet."
     conv(P + "patch.0", in_channels, c // 2, 3)
     conv(P + "patch.2", c // 2, c, 3)
+    if hot:
+        for ch in HOT_OUTLIERS:
+            sd[P + "patch.2.weight"][ch] *= HOT_OUTLIER_GAIN
+            sd[P + "patch.2.bias"][ch] *= HOT_OUTLIER_GAIN
     stage(P + "swin1", c, h, 2)
     conv(P + "down1.conv", c, c * 2, 2)
     stage(P + "swin2", c * 2, h, 2)
@@ -98,16 +117,16 @@ def swin_unet_state_dict(seed, scale_factor=2, base_dim=96, in_channels=3, out_c
     if scale_factor in (1, 2):
         lin(P + "up1.proj", c * 2, c * 4)
         stage(P + "swin5", c, h, 2)
-        lin(P + "to_image.proj", c, out_channels * scale_factor ** 2, HEAD_GAIN, 0.5)
+        lin(P + "to_image.proj", c, out_channels * scale_factor ** 2, HOT_HEAD_GAIN if hot else HEAD_GAIN, 0.5)
     else:
         lin(P + "proj2", c, c * 2)
         lin(P + "up1.proj", c * 2, c * 2 * 4)
         stage(P + "swin5", c * 2, h, 2)
         if scale_factor == 8:        # ToImage :96-101: Linear, LeakyReLU(0.2), Linear
             lin(P + "to_image.proj.0", c * 2, out_channels * 64)
-            lin(P + "to_image.proj.2", out_channels * 64, out_channels * 64, HEAD_GAIN, 0.5)
+            lin(P + "to_image.proj.2", out_channels * 64, out_channels * 64, HOT_HEAD_GAIN if hot else HEAD_GAIN, 0.5)
         else:
-            lin(P + "to_image.proj", c * 2, out_channels * scale_factor ** 2, HEAD_GAIN, 0.5)
+            lin(P + "to_image.proj", c * 2, out_channels * scale_factor ** 2, HOT_HEAD_GAIN if hot else HEAD_GAIN, 0.5)
     return sd
 
 
@@ -177,9 +196,13 @@ def swin_unet_v2_state_dict(seed, scale_factor=2, base_dim=None, lv1_mlp_ratio=2
     return sd
 
 
-def cunet_state_dict(seed, up=False, in_channels=3, out_channels=3):
+def cunet_state_dict(seed, up=False, in_channels=3, out_channels=3, regime="benign"):
     """Seeded weights in the reference's key layout; biases non-zero; the two image heads are scaled so that z1 and
-    the final image sit inside [0,1] like a trained net's (same reasoning as oracle.swin_unet.random_state_dict)."""
+    the final image sit inside [0,1] like a trained net's (same reasoning as oracle.swin_unet.random_state_dict).
+    ``regime="hot"`` (tests/test_gpu_hot_regime.py): every 3x3 conv 1.6x wider than kaiming (activations grow ~25x over the
+    cascade), three output channels of each unet's first UNetConv x 8, SE gates driven into saturation (conv2 x 6)."""
+    assert regime in ("benign", "hot")
+    hot = regime == "hot"
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
@@ -219,6 +242,19 @@ def cunet_state_dict(seed, up=False, in_channels=3, out_channels=3):
     conv(p + "conv4_up", 64, 64, 2, transposed=True)
     conv(p + "conv5", 64, 64, 3)
     conv(p + "conv_bottom", 64, out_channels, 3, gain=0.12, bias_mean=0.0)
+    if hot:
+        for k in list(sd):
+            if k.endswith(".weight") and sd[k].ndim == 4 and sd[k].shape[-1] == 3 and "conv_bottom" not in k:
+                sd[k] = sd[k] * 1.6
+            if k.endswith("seblock.conv2.weight"):
+                sd[k] = sd[k] * 6.0
+        for u in ("unet1.", "unet2."):
+            for ch in HOT_OUTLIERS[:3]:
+                sd[u + "conv1.conv.2.weight"][ch % 64] *= 8.0
+                sd[u + "conv1.conv.2.bias"][ch % 64] *= 8.0
+        # the heads see ~25x larger maps: keep z1 and the image pictures
+        sd["unet1.conv_bottom.weight"] = sd["unet1.conv_bottom.weight"] * 0.04
+        sd["unet2.conv_bottom.weight"] = sd["unet2.conv_bottom.weight"] * 0.02
     return sd
 
 
@@ -422,10 +458,16 @@ DEPTH_ANYTHING_ENCODERS = {      # published geometries (Depth-Anything-V2 dpt.p
 }
 
 
-def depth_anything_v2_state_dict(seed, grid=37, encoder="vits"):
+def depth_anything_v2_state_dict(seed, grid=37, encoder="vits", regime="benign"):
     """Seeded weights in the public checkpoint's key layout (``encoder``: vits / vitb / vitl).  LayerScale gammas are
     O(1) * 0.3 (0.2 for the 24 blocks of vitl) and the residual branches are damped so that the blocks keep the token rms O(1)
-    (a trained ViT's regime), every bias is non-zero."""
+    (a trained ViT's regime), every bias is non-zero.
+    ``regime="hot"`` (tests/test_gpu_hot_regime.py): DINOv2-style MASSIVE ACTIVATIONS — block 1's MLP writes +-45 into two
+    embedding channels of every token (fc2 bias; the rest of the token has rms ~1, so LayerNorm statistics are dominated by two
+    of 384 values), a common offset of +12 on every channel from block 3 on (mean >> spread: the E[x^2] - mean^2 form of the
+    folded LayerNorm is at its worst), and qkv weights 2x wider (logits tens of units)."""
+    assert regime in ("benign", "hot")
+    hot = regime == "hot"
     g = torch.Generator().manual_seed(seed)
     sd = {}
     cfg = DEPTH_ANYTHING_ENCODERS[encoder]
@@ -453,7 +495,7 @@ def depth_anything_v2_state_dict(seed, grid=37, encoder="vits"):
         for n in ("norm1", "norm2"):
             sd[b + n + ".weight"] = 1.0 + rnd(EMBED, std=0.1)
             sd[b + n + ".bias"] = rnd(EMBED, std=0.05)
-        lin(b + "attn.qkv", 3 * EMBED, EMBED, std=1.5 * math.sqrt(1.0 / EMBED))
+        lin(b + "attn.qkv", 3 * EMBED, EMBED, std=(3.0 if hot else 1.5) * math.sqrt(1.0 / EMBED))
         lin(b + "attn.proj", EMBED, EMBED)
         lin(b + "mlp.fc1", MLP, EMBED)
         lin(b + "mlp.fc2", EMBED, MLP)
@@ -461,6 +503,11 @@ def depth_anything_v2_state_dict(seed, grid=37, encoder="vits"):
         sd[b + "ls2.gamma"] = ls + rnd(EMBED, std=0.05)
     sd[p + "norm.weight"] = 1.0 + rnd(EMBED, std=0.1)
     sd[p + "norm.bias"] = rnd(EMBED, std=0.05)
+    if hot:
+        b1 = sd[p + "blocks.1.mlp.fc2.bias"]
+        b1[7] += 45.0 / float(sd[p + "blocks.1.ls2.gamma"][7])
+        b1[200] -= 45.0 / float(sd[p + "blocks.1.ls2.gamma"][200])
+        sd[p + "blocks.3.mlp.fc2.bias"] += 12.0 / sd[p + "blocks.3.ls2.gamma"]
     h = "depth_head."
     for i, oc in enumerate(OUT_CH):
         lin(f"{h}projects.{i}", oc, EMBED, 1, 1)

@@ -32,6 +32,15 @@ def synth_image(seed, c, h, w):
     return torch.clamp(up * 0.8 + 0.2 * torch.rand(c, h, w, generator=g), 0, 1)
 
 
+def hot_image(seed, h, w):
+    """synth_image with saturated flats (blocks of exact 0 / 1); must stay identical to tests/golden/make_golden.py::hot_image."""
+    x = synth_image(seed, 3, h, w)
+    x[:, : h // 3, : w // 2] = 1.0
+    x[:, h // 2:, w // 3: 2 * w // 3] = 0.0
+    x[1, h // 4: h // 2, w // 2:] = 1.0
+    return x
+
+
 def sd_checksum(sd):
     return float(sum(v.double().sum().item() for v in sd.values() if v.is_floating_point()))
 

@@ -851,7 +851,65 @@ def gen_depth_aa():
     save("depth_aa", **out)
 
 
-GROUPS = {"seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
+def hot_image(seed, h, w):
+    """synth_image with SATURATED FLATS: blocks of exact 0 / 1 (clipped highlights, crushed blacks of real pictures).
+    Must stay identical to tests/conftest.py::hot_image."""
+    x = synth_image(seed, 3, h, w)
+    x[:, : h // 3, : w // 2] = 1.0
+    x[:, h // 2:, w // 3: 2 * w // 3] = 0.0
+    x[1, h // 4: h // 2, w // 2:] = 1.0
+    return x
+
+
+# (tag, class name, scale factor, seed): seeds picked so that the emulated-fp16 reference sits between 45 and 50 dB (a hard but
+# meaningful regime) plus one chaotic case (2x, seed 422: 29 dB, 37 % of the picture clamped)
+HOT_SWIN = (("2x", "SwinUNet2x", 2, 432), ("2x_chaos", "SwinUNet2x", 2, 422), ("4x", "SwinUNet4x", 4, 404), ("1x", "SwinUNet", 1, 411))
+
+
+def gen_hot():
+    """Trained-regime stress: ``regime="hot"`` weights (nunif_amd/synthetic.py), inputs with saturated flats.
+    Per case the fixture holds the REFERENCE's fp32 output (``y_ref``; for the external depth net: the HuggingFace-pinned
+    restatement's) and the output of the same arithmetic under ``oracle.fp16_emulation`` (``y_emu``: every op result rounded to
+    fp16 = the reference's own CUDA autocast mode, emulated).  tests/test_gpu_hot_regime.py holds the HIP engine to
+    PSNR(hip, y_ref) >= PSNR(y_emu, y_ref) - 1 dB."""
+    import waifu2x.models.swin_unet as RS
+    from waifu2x.models.cunet import CUNet
+    from oracle import swin_unet as O, cunet as OC, depth_anything_v2 as OD
+    from oracle.fp16_emulation import fp16_autocast_emulation, half_weights
+    out = {}
+    x = torch.stack([hot_image(21, 64, 64), hot_image(22, 64, 64)])
+    out["swin_x"] = x
+    for tag, cls, sf, seed in HOT_SWIN:
+        sd = O.random_state_dict(seed, sf, regime="hot")
+        m = getattr(RS, cls)().eval()
+        m.load_state_dict(sd, strict=True)
+        y_ref = m(x)
+        y_or = torch.clamp(O.unet_forward(sd, x, sf), 0, 1)
+        # the oracle IS the reference here too (fp32 op order differs; the chaotic case amplifies that to 7e-3 max-abs)
+        assert torch.mean((y_ref - y_or) ** 2).item() < 1e-7 and (y_ref - y_or).abs().max() < 2e-2, (tag, (y_ref - y_or).abs().max())
+        with fp16_autocast_emulation():
+            y_emu = torch.clamp(O.unet_forward(half_weights(sd), x, sf), 0, 1)
+        out[f"swin_{tag}_ref"], out[f"swin_{tag}_emu"], out[f"swin_{tag}_sdsum"] = y_ref, y_emu, sd_checksum(sd)
+        mse = torch.mean((y_emu.double() - y_ref.double()) ** 2).item()
+        print(f"swin {tag}: emulated fp16 vs fp32 {10 * np.log10(1 / (mse + 1e-6)):.2f} dB, clamped {float(((y_ref == 0) | (y_ref == 1)).float().mean()):.3f}")
+    xc = torch.stack([hot_image(51, 96, 96), hot_image(52, 96, 96)])
+    sd = OC.random_state_dict(601, up=False, regime="hot")
+    m = CUNet().eval()
+    m.load_state_dict(sd, strict=True)
+    with fp16_autocast_emulation():
+        y_emu = OC.model_forward(half_weights(sd), xc)
+    out["cunet_x"], out["cunet_ref"], out["cunet_emu"], out["cunet_sdsum"] = xc, m(xc), y_emu, sd_checksum(sd)
+    g = torch.Generator().manual_seed(5)
+    xd = torch.randn(2, 3, 56, 70, generator=g)
+    sd = OD.random_state_dict(301, grid=37, regime="hot")
+    with fp16_autocast_emulation():
+        y_emu = OD.model_forward(half_weights(sd), xd)
+    out["depth_x"], out["depth_ref"], out["depth_emu"] = xd, OD.model_forward(sd, xd), y_emu
+    out["depth_sdsum"] = sd_checksum(sd)
+    save("hot_regime", **out)
+
+
+GROUPS = {"hot": gen_hot, "seam": gen_seam, "swin": gen_swin, "iw3": gen_iw3, "cunet": gen_cunet, "row_flow": gen_row_flow,
           "mlbw": gen_mlbw, "depth_aa": gen_depth_aa, "hole_mask": gen_hole_mask, "formats": gen_formats, "convstack": gen_convstack, "row_flow_sym": gen_row_flow_sym, "row_flow_steps": gen_row_flow_steps, "swin8x": gen_swin8x, "swin4xl": gen_swin4xl, "morph": gen_morph, "vda": gen_vda, "vda_online": gen_vda_online, "light_inpaint": gen_light_inpaint, "light_video_inpaint": gen_light_video_inpaint, "light_video_inpaint_ml": gen_light_video_inpaint_ml,
           "frame_pool": gen_frame_pool, "forward_inpaint": gen_forward_inpaint, "swin_v2": gen_swin_v2}
 
