@@ -1,0 +1,232 @@
+"""``python -m nunif_amd.launch {waifu2x|iw3} <the reference CLI's own arguments>`` — the reference command line, unchanged, on
+the HIP engine, and its ``--gpu 0 1 2 3`` list turned into ONE PROCESS PER GPU.
+
+The reference handles ``--gpu 0 1 ...`` inside one process: ``nn.DataParallel`` over the tile minibatch
+(``nunif/models/register.py:44-61``, ``nunif/models/data_parallel.py:8-68``) and one worker thread per device in
+``FrameCallbackPool`` (``nunif/utils/video.py:1622-1757``, ``iw3/utils.py:709-831``).  On MI355X the unit is one process per GPU
+(DESIGN.md §7), so this launcher
+
+* with one GPU (or none named): calls ``nunif_amd.install()`` and the reference's ``<tool>.cli.main()`` in this process;
+* with N GPUs: re-launches itself as N ranks through ``torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+  127.0.0.1`` (the same launcher ``bench.py --gpus N`` uses); rank r binds ``--gpu <r-th id of the list>``, installs the engine
+  and runs the SAME reference ``main()`` over its share of the input FILES: every directory listing the CLI makes under ``-i``
+  (``ImageLoader.listdir`` ``nunif/utils/image_loader.py:40-51``, ``VU.list_videos`` ``nunif/utils/video.py:44-49``) returns
+  files ``r, r + N, r + 2N, ...`` of the sorted listing, a text-list input (``waifu2x/ui_utils.py:406-409``,
+  ``iw3/utils.py:2425-2437``) is cut the same way.  Output names and directory layout are the CLI's own, so the N ranks together
+  write exactly what one process would have; there is no collective on this path (frames / files are independent units —
+  north_star) and no rank waits for another.
+
+What it refuses, with the reason: ONE video (or one ``.yml`` export config) with several GPUs.  Splitting a single stream needs
+its frames dealt to the ranks and the EMA depth normalisation replayed across them — ``nunif_amd.iw3.frame_pipeline
+.stereo_frames_sharded`` / ``nunif_amd.parallel.render_sharded`` do that behind an API (2- and 3-rank tests), but the
+reference's decode loop (PyAV) cannot be exercised in the build container, so the CLI is not wired to it blind.  A single image
+runs on the first GPU of the list.
+
+The reference checkout must be importable (``PYTHONPATH=/path/to/nunif``): this is a launcher FOR it, it carries no CLI of its own.
+"""
+import mimetypes
+import os
+import socket
+import subprocess
+import sys
+
+TOOLS = ("waifu2x", "iw3")
+_RANK_FLAG = "--nunif-amd-rank-entry"
+
+
+def split_gpu_args(argv):
+    """-> (gpu id list, argv without the ``--gpu`` / ``-g`` option).  The reference declares ``--gpu/-g type=int nargs="+"``
+    (``waifu2x/ui_utils.py:231``, ``iw3/utils.py:1957``)."""
+    gpus, rest, i = [], [], 0
+    while i < len(argv):
+        a = argv[i]
+        if a in ("--gpu", "-g"):
+            i += 1
+            while i < len(argv) and argv[i].lstrip("-").isdigit():
+                gpus.append(int(argv[i]))
+                i += 1
+            continue
+        if a.startswith("--gpu="):
+            gpus += [int(v) for v in a.split("=", 1)[1].split()]
+            i += 1
+            continue
+        rest.append(a)
+        i += 1
+    seen, uniq = set(), []
+    for g in gpus:
+        if g not in seen:
+            seen.add(g)
+            uniq.append(g)
+    return uniq, rest
+
+
+def option_value(argv, *names):
+    for i, a in enumerate(argv):
+        if a in names and i + 1 < len(argv):
+            return argv[i + 1]
+        for n in names:
+            if n.startswith("--") and a.startswith(n + "="):
+                return a.split("=", 1)[1]
+    return None
+
+
+def _mime(path, kind):
+    m = mimetypes.guess_type(path)[0]               # the reference's own test: nunif/utils/ui.py:46-58
+    return bool(m and m.startswith(kind))
+
+
+def classify_input(path):
+    if path is None:
+        return "none"
+    if os.path.isdir(path):
+        return "dir"
+    if _mime(path, "text"):
+        return "list"
+    if _mime(path, "image"):
+        return "image"
+    if _mime(path, "video"):
+        return "video"
+    if path.endswith((".yml", ".yaml")):
+        return "config"
+    return "other"
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def shard(seq, rank, world):
+    return list(seq)[rank::world]
+
+
+def install_listing_shards(rank, world, input_root):
+    """Every directory listing under ``input_root`` that the reference CLI makes returns this rank's share.  Listings elsewhere
+    (model directories, an ``--import`` rgb / depth pair outside the input) are left alone."""
+    import importlib
+    root = os.path.realpath(input_root)
+
+    def under_root(directory):
+        d = os.path.realpath(directory)
+        return d == root or d.startswith(root + os.sep)
+
+    il = importlib.import_module("nunif.utils.image_loader")
+    orig_list_images = il.list_images
+
+    def list_images(directory, *a, **kw):
+        files = orig_list_images(directory, *a, **kw)
+        return shard(files, rank, world) if under_root(directory) else files
+
+    il.list_images = list_images                     # ImageLoader.listdir resolves the module global at call time
+    try:
+        vu = importlib.import_module("nunif.utils.video")
+    except Exception:                                # PyAV missing: the CLI cannot list videos either
+        vu = None
+    if vu is not None and hasattr(vu, "list_videos"):
+        orig_list_videos = vu.list_videos
+
+        def list_videos(directory, *a, **kw):
+            files = orig_list_videos(directory, *a, **kw)
+            return shard(files, rank, world) if under_root(directory) else files
+
+        vu.list_videos = list_videos
+
+
+def shard_text_list(path, rank, world, tmp_dir):
+    """The reference reads one path per line, ``#`` starts a comment (``iw3/utils.py:2431-2436``, ``waifu2x/ui_utils.py:208``)."""
+    with open(path, mode="r", encoding="utf-8") as f:
+        files = [ln.strip() for ln in f.readlines()]
+    files = [ln for ln in files if ln and not ln.startswith("#")]
+    out = os.path.join(tmp_dir, f"nunif_amd_shard_{rank}_of_{world}.txt")
+    with open(out, mode="w", encoding="utf-8") as f:
+        f.write("\n".join(shard(files, rank, world)) + "\n")
+    return out
+
+
+def replace_option(argv, names, value):
+    out, i, done = [], 0, False
+    while i < len(argv):
+        a = argv[i]
+        if a in names and i + 1 < len(argv):
+            out += [a, value]
+            i += 2
+            done = True
+            continue
+        out.append(a)
+        i += 1
+    if not done:
+        out += [names[0], value]
+    return out
+
+
+def tool_main(tool):
+    import importlib
+    mod = os.environ.get("NUNIF_AMD_LAUNCH_CLI_MODULE") or f"{tool}.cli"       # the override exists for the launcher's own test
+    return importlib.import_module(mod).main
+
+
+def run_in_process(tool, argv, gpu, rank=0, world=1):
+    """install() + the reference's ``<tool>.cli.main()`` with ``--gpu <gpu>`` and, for world > 1, this rank's share of the files."""
+    import tempfile
+    argv = list(argv)
+    if gpu is not None:
+        argv += ["--gpu", str(gpu)]
+    src = option_value(argv, "--input", "-i")
+    kind = classify_input(src)
+    from nunif_amd import install as engine_install
+    # load the CLI layer BEFORE install() so that its ``from x import y`` copies exist and get rebound (nunif_amd/install.py)
+    main = tool_main(tool)
+    if not engine_install.is_installed():
+        engine_install.install(strict=False)
+    if world > 1:
+        if kind == "dir":
+            install_listing_shards(rank, world, src)
+        elif kind == "list":
+            argv = replace_option(argv, ("--input", "-i"), shard_text_list(src, rank, world, tempfile.gettempdir()))
+        elif rank > 0:
+            return 0                                  # a single image: the first GPU of the list renders it
+    old = sys.argv
+    sys.argv = [f"{tool}.cli"] + argv
+    try:
+        main()
+    finally:
+        sys.argv = old
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    as_rank = False
+    if argv and argv[0] == _RANK_FLAG:
+        as_rank, argv = True, argv[1:]
+    if not argv or argv[0] not in TOOLS:
+        sys.stderr.write(f"usage: python -m nunif_amd.launch {{{'|'.join(TOOLS)}}} <arguments of the reference's <tool>.cli>\n")
+        return 2
+    tool, argv = argv[0], argv[1:]
+    gpus, rest = split_gpu_args(argv)
+    if as_rank:
+        rank, world = int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+        gpus = gpus or list(range(world))
+        assert len(gpus) == world, (gpus, world)
+        return run_in_process(tool, rest, gpus[rank], rank, world)
+    if len(gpus) <= 1:
+        return run_in_process(tool, rest, gpus[0] if gpus else None)
+    kind = classify_input(option_value(rest, "--input", "-i"))
+    if kind in ("video", "config", "other", "none"):
+        sys.stderr.write(
+            f"nunif_amd.launch: --gpu {' '.join(map(str, gpus))} with a single {kind} input.  One process per GPU shards FILES "
+            "(a directory or a text list); the frames of one stream are sharded by nunif_amd.iw3.frame_pipeline."
+            "stereo_frames_sharded / nunif_amd.parallel.render_sharded (API), which the reference's decode loop is not wired to. "
+            "Run it with one GPU, or pass a directory / list of files.\n")
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={len(gpus)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "-m", "nunif_amd.launch", _RANK_FLAG, tool,
+           "--gpu", *map(str, gpus), *rest]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

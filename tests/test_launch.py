@@ -1,0 +1,78 @@
+"""``python -m nunif_amd.launch``: the reference's ``--gpu 0 1 ...`` list becomes one process per GPU, each
+running the reference's OWN ``cli.main()`` on the installed engine over its share of the input files.  CPU only: the ranks are
+real processes started through ``torch.distributed.run`` on 127.0.0.1, the CLI is a stand-in that makes the reference's listing
+calls and records what it was given (``tests/fake_cli/cli.py``) — nothing is rendered.
+
+Reference: ``waifu2x/ui_utils.py:231,385-409`` / ``iw3/utils.py:1957,2254-2437`` (``--gpu``, input kinds),
+``nunif/utils/image_loader.py:40-51`` (listing), ``nunif/utils/video.py:1622-1757`` (the in-process multi-device pool this replaces).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from oracle import refstub
+from nunif_amd import launch as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not refstub.reference_available(), reason="/root/reference is not mounted here")
+
+
+def test_gpu_list_parsing_and_input_kinds(tmp_path):
+    assert L.split_gpu_args(["-i", "a", "--gpu", "0", "1", "3", "-o", "b"]) == ([0, 1, 3], ["-i", "a", "-o", "b"])
+    assert L.split_gpu_args(["-g", "2", "-m", "scale"]) == ([2], ["-m", "scale"])
+    assert L.split_gpu_args(["--gpu", "1", "1", "0", "--tta"]) == ([1, 0], ["--tta"])
+    assert L.split_gpu_args(["-i", "x"]) == ([], ["-i", "x"])
+    (tmp_path / "d").mkdir()
+    (tmp_path / "l.txt").write_text("a.png\n")
+    assert [L.classify_input(str(p)) for p in (tmp_path / "d", tmp_path / "l.txt", "x.png", "y.mp4", "z.yml")] == \
+        ["dir", "list", "image", "video", "config"]
+    assert L.shard(range(7), 1, 3) == [1, 4]
+    # one stream on several GPUs is refused with the reason, not silently run on one
+    assert L.main(["iw3", "-i", "movie.mp4", "-o", "out", "--gpu", "0", "1"]) == 2
+
+
+def _run(args, tmp_path):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), refstub.REFERENCE_ROOT,
+                                                       os.environ.get("PYTHONPATH", "")]),
+               NUNIF_AMD_LAUNCH_CLI_MODULE="fake_cli.cli")
+    r = subprocess.run([sys.executable, "-m", "nunif_amd.launch"] + args, env=env, cwd=str(tmp_path), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r
+
+
+def _make_images(d, names):
+    d.mkdir(parents=True, exist_ok=True)
+    for n in names:
+        (d / n).write_bytes(b"")
+    return sorted(str(d / n) for n in names if n.endswith(".png"))
+
+
+def test_two_ranks_split_a_directory_and_a_list_between_them(tmp_path):
+    imgs = _make_images(tmp_path / "in", [f"f{i:02d}.png" for i in range(7)] + ["notes.md"])
+    sub = _make_images(tmp_path / "in" / "sub", ["a.png", "b.png", "c.png"])
+    out = tmp_path / "out"
+    _run(["waifu2x", "-m", "noise", "-i", str(tmp_path / "in"), "-o", str(out), "--gpu", "2", "5", "-r"], tmp_path)
+    recs = [json.load(open(out / f"rank{r}.json")) for r in range(2)]
+    assert [r["gpu"] for r in recs] == [[2], [5]] and all(r["world"] == 2 and r["method"] == "noise" for r in recs)
+    # every listing is cut r, r + 2, ...: together the ranks cover each directory exactly once, in the CLI's own order
+    assert recs[0]["files"] == imgs[0::2] + sub[0::2] and recs[1]["files"] == imgs[1::2] + sub[1::2]
+    # the ranks run on the installed engine: the reference's name now resolves to ours
+    assert all(r["tiled_render_module"].startswith("nunif_amd.") for r in recs)
+    lst = tmp_path / "files.txt"
+    lst.write_text("# picked by hand\n" + "\n".join(imgs[:5]) + "\n")
+    out2 = tmp_path / "out2"
+    _run(["waifu2x", "-i", str(lst), "-o", str(out2), "--gpu", "0", "1"], tmp_path)
+    recs = [json.load(open(out2 / f"rank{r}.json")) for r in range(2)]
+    assert recs[0]["files"] == imgs[0:5:2] and recs[1]["files"] == imgs[1:5:2]
+
+
+def test_one_gpu_runs_in_process_on_the_whole_input(tmp_path):
+    imgs = _make_images(tmp_path / "in", ["a.png", "b.png", "c.png"])
+    out = tmp_path / "out"
+    _run(["waifu2x", "-i", str(tmp_path / "in"), "-o", str(out), "--gpu", "3"], tmp_path)
+    rec = json.load(open(out / "rank0.json"))
+    assert rec["files"] == imgs and rec["gpu"] == [3] and rec["world"] == 1 and rec["tiled_render_module"].startswith("nunif_amd.")
