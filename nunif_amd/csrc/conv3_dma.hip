@@ -1,0 +1,270 @@
+// 3x3 stride-1 conv for gfx950, PERSISTENT, with input halo AND weights moved into LDS by LDS-DMA (global_load_lds_dwordx4).
+//
+// Same contract and the same accumulation order over k as conv3_lds_kernel (conv3_lds.hip) for the shapes it takes — results are
+// bit-identical — and the same callers: the VALID 3x3 convs of waifu2x cunet / upcunet / vgg_7 / upconv_7
+// (waifu2x/models/cunet.py:10-28 UNetConv, :31-121), the padded 3x3 convs of the side nets.
+//
+// Why (profiles/r04c_sq.txt, cunet 1080p, 66 tiles per launch).  conv3_lds_kernel<4> ran at 10 % of the matrix pipe: a wave lived
+// 17 us for 2.1 us of MFMAs, 52 % of its cycles in s_waitcnt / s_barrier, and issued 2 100 VALU instructions next to 255 MFMAs —
+//   * every workgroup staged its halo through registers (11 loads + 11 ds_write_b128 per thread, ~60 VALU of index arithmetic
+//     per item), and nothing else happened in that workgroup until the last store had landed;
+//   * the weight ring went through registers too (a copy chain in rounds 1-3 that forced `vmcnt(0)` at every chunk boundary);
+//   * one patch per workgroup: launch, weight-pipe fill, halo round trip and epilogue of a patch never overlapped with its own
+//     MFMAs, only with the one other workgroup an LDS-limited CU holds.
+// Here a workgroup is persistent and owns a sequence of 8 x 32 patches:
+//   * HALO: (8+2) x (32+2) pixels x Cin channels go global -> LDS by DMA, no registers, no ds_write.  The LDS image is LINEAR in
+//     (pixel, 16-byte segment) with the segment index XOR-swizzled by the pixel index (seg ^ ((pixel / PPR) % SEG), PPR = pixels
+//     per 256 B): any 16 consecutive pixels then read their fragment from 64 distinct banks — conflict free for every tap shift,
+//     with no padding (the round-3 kernel padded each pixel by 16 B, which a DMA cannot).  A lane's 36 fragment addresses
+//     (4 token tiles x 9 taps) are constants of the launch; the second 32-channel part of a tap is `address ^ 64`.
+//     The next patch's halo is requested as soon as the last k-step has read the current one, i.e. it travels under the epilogue;
+//   * WEIGHTS: 8-KiB chunks through a 3-slot LDS ring, also by DMA, two chunks ahead.  The chunk sequence simply wraps from one
+//     patch to the next (the trip count per patch is rounded up to a multiple of three so that slot = chunk % 3 holds across
+//     patches), so the ring never drains;
+//   * zero padding (Conv2d(padding=1)) = the lanes of out-of-map pixels fetch from the zero padding behind the weight stream;
+//     replicate padding / VALID edges = clamped coordinates.
+// LDS: 24 KiB ring + 340 x Cin x 2 B halo = 67 KiB at Cin = 64: two workgroups per CU, as before.
+//
+// vmcnt is counted by hand (the DMAs are inline asm, hipcc never sees a vector-memory instruction inside the k loop): loads return
+// in order, a wave issues 2 DMA instructions per weight chunk, so `vmcnt(2)` at a chunk boundary = "my part of this chunk has
+// landed, the next one may still be in flight"; the workgroup barrier behind it publishes all four waves' parts.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "swin_kernels.h"
+
+namespace nunif {
+
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+namespace {
+constexpr int kTH = 8, kTW = 32;                        // output patch of a workgroup (4 waves x 2 rows x 32 columns)
+constexpr int kHH = kTH + 2, kHW = kTW + 2;             // halo
+constexpr int kHaloPix = kHH * kHW;                     // 340
+constexpr int kCH = 8;                                  // fragments (KiB) per weight chunk
+constexpr int kSlots = 3;
+
+__device__ __forceinline__ void dma16(const void *src, unsigned lds_byte_addr) {
+    // each lane moves 16 B to LDS[m0 + 16 * lane]; m0 is wave-uniform
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
+}
+}  // namespace
+
+template <int NT, int CIN, bool RELU_IN>
+__global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_patches) {
+    constexpr int MF = 4;
+    constexpr int SEG = CIN / 8;                         // 16-byte segments per pixel
+    constexpr int PB = CIN * 2;                          // bytes per pixel
+    constexpr int PPR = 256 / PB;                        // pixels per 256-byte LDS row
+    constexpr int CPT = CIN / 32;                        // 32-channel parts per tap
+    constexpr int KSTEPS = 9 * CPT;
+    constexpr int KPC = kCH / NT;                        // k-steps per chunk
+    constexpr int NCH = (KSTEPS * NT + kCH - 1) / kCH;   // chunks that carry data
+    constexpr int NCH3 = (NCH + 2) / 3 * 3;              // trip count per patch: a multiple of the slot count
+    constexpr int HITEMS = kHaloPix * SEG;               // 16-byte items of a halo
+    constexpr int HDMA = (HITEMS + 255) / 256;           // DMA instructions per wave... per THREAD ROW: items tid + 256 u
+    static_assert(CIN == 32 || CIN == 64, "segment swizzle / part addressing below are written for 32 and 64 input channels");
+    static_assert(kCH % NT == 0, "a chunk holds whole k-steps");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_d[];
+    f16x8 *ring = reinterpret_cast<f16x8 *>(smem_d);                      // [kSlots][kCH * 64]
+    unsigned char *halo = smem_d + kSlots * kCH * 1024;                   // [340 px][SEG] 16-byte items, swizzled
+    const unsigned ring_lds = (unsigned)reinterpret_cast<size_t>(ring);
+    const unsigned halo_lds = (unsigned)reinterpret_cast<size_t>(halo);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, r16 = lane & 15, grp = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pad = (g.zpad || g.rpad) ? 1 : 0;                           // 0: VALID 3x3 (Ho = Hi - 2)
+    const int tiles_x = (g.Wo + kTW - 1) / kTW, tiles_y = (g.Ho + kTH - 1) / kTH;
+    const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.wstream);       // zero-padded by 16 KiB on the host
+    const f16x8 *zero16 = gsrc + (long)KSTEPS * NT * 64;                  // first 16 bytes of that padding: the "zero pixel"
+
+    // ---- per-lane constants --------------------------------------------------------------------------------------------
+    // halo item q = tid + 256 u lives at LDS byte 16 q = pixel (q / SEG), slot (q % SEG); it holds segment slot ^ swz(pixel)
+    int hq[HDMA];                                                         // (y << 16) | (x << 8) | segment
+#pragma unroll
+    for (int u = 0; u < HDMA; ++u) {
+        const int q = min(tid + 256 * u, HITEMS - 1);
+        const int p = q / SEG, slot = q - p * SEG;
+        const int hy = p / kHW, hx = p - hy * kHW;
+        hq[u] = (hy << 16) | (hx << 8) | (slot ^ ((p / PPR) % SEG));
+    }
+    // B fragment of token tile f (row 2 wave + (f >> 1), columns 16 (f & 1) + r16) at tap (dy, dx), part 0: segment grp
+    unsigned faddr[MF][9];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            const int p = (2 * wave + (f >> 1) + dy) * kHW + 16 * (f & 1) + r16 + dx;
+            faddr[f][tap] = (unsigned)(p * PB + ((grp ^ ((p / PPR) % SEG)) * 16));
+        }
+
+    auto patch_of = [&](int i, int &b, int &ty0, int &tx0) {
+        tx0 = (i % tiles_x) * kTW;
+        ty0 = ((i / tiles_x) % tiles_y) * kTH;
+        b = i / (tiles_x * tiles_y);
+    };
+    auto halo_dma = [&](int b, int ty0, int tx0) {
+        const long img = (long)b * g.Hi * g.Wi;
+#pragma unroll
+        for (int u = 0; u < HDMA; ++u) {
+            if (256 * u + 64 * wave < HITEMS) {                           // wave-uniform: the last row of instructions is partial
+                const int yy = ty0 + (hq[u] >> 16) - pad, xx = tx0 + ((hq[u] >> 8) & 255) - pad;
+                const int yc = min(max(yy, 0), g.Hi - 1), xc = min(max(xx, 0), g.Wi - 1);
+                const f16 *src = g.a + ((img + (long)yc * g.Wi + xc) * CIN + (hq[u] & 255) * 8);
+                if (g.zpad && (yy != yc || xx != xc)) src = reinterpret_cast<const f16 *>(zero16);
+                dma16(src, halo_lds + (unsigned)(256 * u + 64 * wave) * 16);
+            }
+        }
+    };
+    // weight chunk c of the stream (c >= NCH: zero padding) -> ring slot: 2 DMA instructions per wave
+    auto chunk_dma = [&](int c, int slot) {
+        const f16x8 *src = gsrc + (long)min(c, NCH + 1) * (kCH * 64) + 64 * wave + lane;
+        dma16(src, ring_lds + (unsigned)(slot * kCH * 64 + 64 * wave) * 16);
+        dma16(src + 256, ring_lds + (unsigned)(slot * kCH * 64 + 256 + 64 * wave) * 16);
+    };
+
+    int pi = blockIdx.x;
+    int b, ty0, tx0;
+    if (pi < n_patches) {
+        patch_of(pi, b, ty0, tx0);
+        chunk_dma(0, 0);
+        chunk_dma(1, 1);
+        halo_dma(b, ty0, tx0);
+    }
+#pragma unroll 1
+    for (; pi < n_patches; pi += gridDim.x) {
+        f32x4 acc[NT][MF];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc[nt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // halo + chunks 0, 1 of this patch (and the previous patch's stores) have landed; the barrier publishes all waves' parts
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // the chunk loop is fully unrolled: chunk index, ring slot, tap and 32-channel part of every k-step are compile-time
+#pragma unroll
+        for (int c = 0; c < NCH3; ++c) {
+            // chunk boundary.  My DMAs in flight: chunk c + 1 (2 instructions) at most -> chunk c has landed at vmcnt(2).
+            // Behind the barrier every wave has finished reading chunk c - 1, whose slot chunk c + 2 now takes.
+            if (c > 0) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            chunk_dma(c + 2 < NCH3 ? c + 2 : c + 2 - NCH3, (c + 2) % kSlots);      // wraps into the next patch: the same stream again
+#pragma unroll
+            for (int q = 0; q < KPC; ++q) {
+                const int ks = c * KPC + q;
+                if (ks < KSTEPS) {
+                    const int tap = ks / CPT, cc = ks % CPT;
+                    const f16x8 *wsrc = ring + ((c % kSlots) * kCH + q * NT) * 64 + lane;
+                    f16x8 xq[MF];
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+                        // part cc of the tap: segment 4 cc + grp; the swizzle is an XOR, so part 1 = address ^ 64
+                        xq[f] = *reinterpret_cast<const f16x8 *>(halo + (faddr[f][tap] ^ (unsigned)(cc * 64)));
+                        if constexpr (RELU_IN) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) xq[f][e] = xq[f][e] > (f16)0.f ? xq[f][e] : (f16)0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const f16x8 w = wsrc[nt * 64];
+#pragma unroll
+                        for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(w, xq[f], acc[nt][f]);
+                    }
+                }
+            }
+        }
+        // every wave is done with the halo: the next patch's may overwrite it while this one's epilogue runs
+        const int cb = b, cty0 = ty0, ctx0 = tx0;
+        asm volatile("s_barrier" ::: "memory");
+        if (pi + (int)gridDim.x < n_patches) {
+            patch_of(pi + gridDim.x, b, ty0, tx0);
+            halo_dma(b, ty0, tx0);
+        }
+
+        // ---- epilogue (as conv3_lds_kernel): bias, activation, residuals / image head ---------------------------------------
+        const int ldo = g.ldo > 0 ? g.ldo : g.n_real;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n0 = nt * 16 + grp * 4;
+            const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const int oy = cty0 + 2 * wave + (f >> 1), ox = ctx0 + 16 * (f & 1) + r16;
+                if (oy >= g.Ho || ox >= g.Wo || n0 >= g.n_real) continue;
+                float v[4] = {acc[nt][f][0] + bv.x, acc[nt][f][1] + bv.y, acc[nt][f][2] + bv.z, acc[nt][f][3] + bv.w};
+                if (g.act == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * g.slope;
+                } else if (g.act == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                const long off = (((long)cb * g.Ho + oy) * g.Wo + ox) * ldo + n0;
+                if (g.res) {
+                    const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
+                if (g.res2) {
+                    const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res2 + off);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
+                *reinterpret_cast<f16x4 *>(g.out + off) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            }
+        }
+    }
+    // drain the two weight chunks the last trip requested for a patch that does not exist (LDS must not be written after exit)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static inline int conv3_dma_enabled() { const char *e = getenv("NUNIF_CONV3_DMA"); return e ? atoi(e) : 1; }
+
+bool conv3_dma_applies(const ConvArgs &g) {
+    const int pad = (g.zpad || g.rpad) ? 1 : 0;
+    const int nt = g.N / 16;
+    if (!conv3_dma_enabled()) return false;
+    if (!(g.kh == 3 && g.kw == 3 && g.stride == 1) || g.a2 || g.cmaj || g.out32 || g.N % 16 != 0) return false;
+    if (g.Ho != g.Hi + 2 * pad - 2 || g.Wo != g.Wi + 2 * pad - 2 || g.zpad > 1 || g.rpad > 1 || (g.zpad && g.rpad)) return false;
+    if (!(g.Cin == 32 || g.Cin == 64) || !(nt == 2 || nt == 4)) return false;
+    const long n_patches = (long)g.B * ((g.Ho + kTH - 1) / kTH) * ((g.Wo + kTW - 1) / kTW);
+    // small launches (at most one patch per workgroup slot) keep the resident-weight form of conv3_lds_kernel
+    return n_patches > 512 && n_patches < (1L << 30) && (long)g.B * g.Hi * g.Wi * g.Cin < (1L << 40);
+}
+
+template <int NT, int CIN, bool RELU_IN>
+static int launch_c3d(const ConvArgs &g, hipStream_t s, const char *name) {
+    // the last DMA instruction of a halo is a full 1 KiB whatever the item count: round the halo up to a multiple of 64 items
+    const size_t smem = (size_t)kSlots * kCH * 1024 + (size_t)((kHaloPix * (CIN / 8) + 63) / 64) * 1024;
+    const long M = (long)g.B * g.Ho * g.Wo;
+    ProfScope ps(name, s, 2.0 * (double)M * 9.0 * g.Cin * g.n_real, (double)M * (g.Cin + g.n_real) * 2.0);
+    static bool configured = false;
+    if (!configured) {
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_dma_kernel<NT, CIN, RELU_IN>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        configured = true;
+    }
+    const long n_patches = (long)g.B * ((g.Ho + kTH - 1) / kTH) * ((g.Wo + kTW - 1) / kTW);
+    const unsigned grid = (unsigned)std::min<long>(n_patches, 512);         // two persistent workgroups per CU
+    conv3_dma_kernel<NT, CIN, RELU_IN><<<grid, 256, smem, s>>>(g, (int)n_patches);
+    NUNIF_LAUNCH_CHECK();
+    return NUNIF_HIP_OK;
+}
+
+int launch_conv3_dma(const ConvArgs &g, hipStream_t s) {
+    const int nt = g.N / 16;
+    if (g.Cin == 64) {
+        if (nt == 4) return g.relu_in ? launch_c3d<4, 64, true>(g, s, "conv3_dma_kernel<4,64>") : launch_c3d<4, 64, false>(g, s, "conv3_dma_kernel<4,64>");
+        if (nt == 2) return g.relu_in ? launch_c3d<2, 64, true>(g, s, "conv3_dma_kernel<2,64>") : launch_c3d<2, 64, false>(g, s, "conv3_dma_kernel<2,64>");
+    } else if (g.Cin == 32) {
+        if (nt == 4) return g.relu_in ? launch_c3d<4, 32, true>(g, s, "conv3_dma_kernel<4,32>") : launch_c3d<4, 32, false>(g, s, "conv3_dma_kernel<4,32>");
+        if (nt == 2) return g.relu_in ? launch_c3d<2, 32, true>(g, s, "conv3_dma_kernel<2,32>") : launch_c3d<2, 32, false>(g, s, "conv3_dma_kernel<2,32>");
+    }
+    set_error("conv3_dma: Cin=%d Cout=%d unsupported", g.Cin, g.N);
+    return NUNIF_HIP_EUNSUPPORTED;
+}
+
+}  // namespace nunif

@@ -12,6 +12,7 @@
 // output with bias, LeakyReLU / ReLU, up to two residuals, ldo), same accumulation order over k — results are identical.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "swin_kernels.h"
 
@@ -45,7 +46,10 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
                         (g.cmaj ? (long)blockIdx.y * 9 * cpt * NT * 64 : 0);
     const int ksteps = 9 * cpt;
     const int n_chunks = (ksteps * NT + CH - 1) / CH;
-    constexpr int UW = 4, UH = 4;                                        // loads in flight per thread and batch: weights, halo
+    // loads in flight per thread and batch: weights, halo.  UH = 11 covers the whole 10 x 34 x 64-channel halo (2 720 16-byte
+    // items) in ONE batch: round 3 staged it in three batches of four, three dependent memory round trips before the first MFMA
+    // of a workgroup that then computes for 2 us (only two workgroups per CU overlap each other)
+    constexpr int UW = 4, UH1 = 11, UH2 = 6;                             // UH2: the two-input form (twice the registers per item)
     const int w_total = ksteps * NT * 64;                                // 16-byte items of the weight stream
     const int segs = cin >> 3;                                           // 16-byte segments per pixel
     const int h_items = kC3HH * kC3HW * segs;
@@ -60,7 +64,9 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
     };
     // halo: (pixel, 16-byte segment) = work item; zero / replicate padding and the pre-activation ReLU are applied while it is
     // written to LDS, once per element
-    auto h_load = [&](int i0, int b, int ty0, int tx0, f16x8 (&v)[UH], f16x8 (&v2)[UH], unsigned &inb) {
+    auto h_load = [&](auto a2_tag, int i0, int b, int ty0, int tx0, auto &v, auto &v2, unsigned &inb) {
+        constexpr bool A2 = decltype(a2_tag)::value;
+        constexpr int UH = std::extent_v<std::remove_reference_t<decltype(v)>>;
         inb = 0u;
 #pragma unroll
         for (int u = 0; u < UH; ++u) {
@@ -71,11 +77,13 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
             const int yc = min(max(yy, 0), g.Hi - 1), xc = min(max(xx, 0), g.Wi - 1);
             inb |= ((!g.zpad || (yy == yc && xx == xc)) ? 1u : 0u) << u;
             v[u] = *reinterpret_cast<const f16x8 *>(a_in + (((long)b * g.Hi + yc) * g.Wi + xc) * lda + sg * 8);
-            if (g.a2)               // second input (cropped U-Net skip, VALID convs only): added while staging
+            if constexpr (A2)       // second input (cropped U-Net skip, VALID convs only): added while staging
                 v2[u] = *reinterpret_cast<const f16x8 *>(g.a2 + (((long)b * g.H2 + yc + g.crop2) * g.W2 + xc + g.crop2) * lda + sg * 8);
         }
     };
-    auto h_store = [&](int i0, const f16x8 (&v)[UH], const f16x8 (&v2)[UH], unsigned inb) {
+    auto h_store = [&](auto a2_tag, int i0, const auto &v, const auto &v2, unsigned inb) {
+        constexpr bool A2 = decltype(a2_tag)::value;
+        constexpr int UH = std::extent_v<std::remove_reference_t<decltype(v)>>;
         const f16x8 z8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
 #pragma unroll
         for (int u = 0; u < UH; ++u) {
@@ -83,7 +91,7 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
             if (i >= h_items) continue;
             const int p = i / segs, sg = i - p * segs;
             f16x8 w = ((inb >> u) & 1u) ? v[u] : z8;
-            if (g.a2) w += v2[u];
+            if constexpr (A2) w += v2[u];
             if (g.relu_in) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) w[j] = w[j] > (f16)0.f ? w[j] : (f16)0.f;
@@ -97,45 +105,45 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
     const int tx0 = (tile % tiles_x) * kC3TW;
     const int ty0 = ((tile / tiles_x) % tiles_y) * kC3TH;
     const int b = tile / (tiles_x * tiles_y);
-    f16x8 st0, st1, sq0, sq1, sr0, sr1;
-    {
-        f16x8 hv[UH], hv2[UH];
+    // ring staging: chunk c travels HBM / L2 -> stage[c % 3] (requested three chunks ahead) -> LDS slot c & 1.  The stage index is
+    // STATIC (the chunk loop is unrolled by three): rounds 1-3 rotated three named registers with copies (st = sq; sq = sr; ...),
+    // and a copy of a register whose load is still in flight has to wait for it — hipcc put `s_waitcnt vmcnt(0)` right behind the
+    // two loads it had just issued, so every chunk boundary (9 per 64 -> 64 patch) exposed a full L2 round trip
+    // (profiles/r04_conv3_ring.txt: 12 us per workgroup for 2.1 us of MFMAs).
+    f16x8 stage[3][2];
+    // the second-input form is its own instantiation of the staging code: its eleven extra registers per load batch would
+    // otherwise be reserved in every launch (the staging arrays are the kernel's register high-water mark)
+    auto stage_in = [&](auto a2_tag) {
+        constexpr int UH = decltype(a2_tag)::value ? UH2 : UH1;
+        f16x8 hv[UH], hv2[decltype(a2_tag)::value ? UH : 1];
         unsigned hin;
         if (RESW) {
             // the first batches of BOTH streams are requested before anything is waited for: one round trip
             f16x8 wv[UW];
             w_load(0, wv);
-            h_load(0, b, ty0, tx0, hv, hv2, hin);
+            h_load(a2_tag, 0, b, ty0, tx0, hv, hv2, hin);
             w_store(0, wv);
-            h_store(0, hv, hv2, hin);
+            h_store(a2_tag, 0, hv, hv2, hin);
             for (int i0 = 256 * UW; i0 < w_total; i0 += 256 * UW) { w_load(i0, wv); w_store(i0, wv); }
         } else {
-            h_load(0, b, ty0, tx0, hv, hv2, hin);
-            h_store(0, hv, hv2, hin);
+            // the first three weight chunks travel together with the halo
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int cj = min(j, n_chunks);                         // (the stream is zero-padded by 16 KiB on the host)
+                stage[j][0] = gsrc[cj * (CH * 64) + tid];
+                stage[j][1] = gsrc[cj * (CH * 64) + tid + 256];
+            }
+            h_load(a2_tag, 0, b, ty0, tx0, hv, hv2, hin);
+            h_store(a2_tag, 0, hv, hv2, hin);
         }
-        for (int i0 = 256 * UH; i0 < h_items; i0 += 256 * UH) { h_load(i0, b, ty0, tx0, hv, hv2, hin); h_store(i0, hv, hv2, hin); }
-    }
-    if constexpr (!RESW) {
-        const int c1 = min(1, n_chunks), c2 = min(2, n_chunks);
-        st0 = gsrc[tid]; st1 = gsrc[tid + 256];
-        sq0 = gsrc[c1 * CH * 64 + tid]; sq1 = gsrc[c1 * CH * 64 + tid + 256];
-        sr0 = gsrc[c2 * CH * 64 + tid]; sr1 = gsrc[c2 * CH * 64 + tid + 256];
-    }
-    if constexpr (RESW) __syncthreads();
-    auto wfrag = [&](int fi) -> f16x8 {
-        if constexpr (RESW) return ring[fi * 64 + lane];
-        const int c = fi / CH;
-        if (fi % CH == 0) {
-            ring[(c & 1) * (CH * 64) + tid] = st0;
-            ring[(c & 1) * (CH * 64) + tid + 256] = st1;
-            __syncthreads();                                             // (the first one also publishes the halo)
-            st0 = sq0; st1 = sq1; sq0 = sr0; sq1 = sr1;
-            const int cn = min(c + 3, n_chunks);
-            sr0 = gsrc[cn * (CH * 64) + tid];
-            sr1 = gsrc[cn * (CH * 64) + tid + 256];
+        for (int i0 = 256 * UH; i0 < h_items; i0 += 256 * UH) {
+            h_load(a2_tag, i0, b, ty0, tx0, hv, hv2, hin);
+            h_store(a2_tag, i0, hv, hv2, hin);
         }
-        return ring[(c & 1) * (CH * 64) + (fi % CH) * 64 + lane];
     };
+    if (g.a2) stage_in(std::true_type{});
+    else stage_in(std::false_type{});
+    if constexpr (RESW) __syncthreads();
     // token tile f of wave w: output row ty0 + 2w + (f >> 1), columns tx0 + 16 (f & 1) + r16
     int hoff[MF];                                                        // byte offsets into the halo (tap (0, 0), channel 8 grp)
 #pragma unroll
@@ -146,22 +154,51 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int f = 0; f < MF; ++f) acc[nt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
+    // one k-step = tap (dy, dx), 32-channel part c: four B fragments from the halo against the NT weight fragments `wsrc[nt * 64]`
+    auto kstep = [&](int tap, int c, const f16x8 *wsrc) {
         const int dy = tap / 3, dx = tap - 3 * dy;
         const int toff = (dy * kC3HW + dx) * pstride;
+        f16x8 xq[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) xq[f] = *reinterpret_cast<const f16x8 *>(halo + hoff[f] + toff + c * 64);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f16x8 w = wsrc[nt * 64];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(w, xq[f], acc[nt][f]);
+        }
+    };
+    if constexpr (RESW) {
 #pragma unroll 1
-        for (int c = 0; c < cpt; ++c) {
-            const int ks = tap * cpt + c;
-            f16x8 xq[MF];
-            f16x8 w0 = wfrag(ks * NT);                                   // (its barrier, if any, comes before the halo reads)
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll 1
+            for (int c = 0; c < cpt; ++c) kstep(tap, c, ring + (tap * cpt + c) * NT * 64 + lane);
+        }
+    } else {
+        constexpr int KPC = CH / NT;                                     // k-steps per 8-KiB chunk
+        int tap = 0, cc = 0;                                             // (tap, part) of the next k-step, advanced incrementally
+        // The trip count is rounded up to a multiple of three and NOTHING that touches vmcnt sits under a branch (stores to the
+        // ring, barrier and refill are unconditional; past the end they move zero padding): with a conditional boundary hipcc
+        // no longer knows how many loads are pending at the next one and waits for all of them again.
+#pragma unroll 1
+        for (int c0 = 0; c0 < n_chunks; c0 += 3) {
 #pragma unroll
-            for (int f = 0; f < MF; ++f) xq[f] = *reinterpret_cast<const f16x8 *>(halo + hoff[f] + toff + c * 64);
+            for (int j = 0; j < 3; ++j) {
+                const int c = c0 + j;
+                // chunk boundary: stage j (requested three chunks ago) -> LDS slot c & 1, then refill the stage
+                ring[(c & 1) * (CH * 64) + tid] = stage[j][0];
+                ring[(c & 1) * (CH * 64) + tid + 256] = stage[j][1];
+                __syncthreads();                                         // (the first one also publishes the halo)
+                const int cn = min(c + 3, n_chunks);                     // <= n_chunks: inside the host's 16-KiB zero padding
+                stage[j][0] = gsrc[cn * (CH * 64) + tid];
+                stage[j][1] = gsrc[cn * (CH * 64) + tid + 256];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f16x8 w = nt == 0 ? w0 : wfrag(ks * NT + nt);
-#pragma unroll
-                for (int f = 0; f < MF; ++f) acc[nt][f] = MFMA_16x16x32(w, xq[f], acc[nt][f]);
+                for (int q = 0; q < KPC; ++q) {
+                    if (c * KPC + q < ksteps) {
+                        kstep(tap, cc, ring + (c & 1) * (CH * 64) + q * NT * 64 + lane);
+                        if (++cc == cpt) { cc = 0; ++tap; }
+                    }
+                }
             }
         }
     }
@@ -179,6 +216,44 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
         return;
     }
     const int ldo = g.ldo > 0 ? g.ldo : g.n_real;
+    if constexpr (NT == 1) {
+        if (g.out32) {
+            // Image head (planar fp32, `+ crop(add32)`, clamp; cunet.py:183-196).  All `add32` reads of a lane are requested
+            // BEFORE any of them is used — unconditionally, from clamped addresses: as a load under `if` next to its use every
+            // one of the 12 was followed by `s_waitcnt vmcnt(0)`, twelve dependent memory round trips per workgroup in a
+            // kernel that otherwise moves 130 B per pixel (conv3_lds_kernel<1>: 340 us per launch at 1.1 TB/s).
+            const int n0 = grp * 4;
+            const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+            const float bvr[4] = {bv.x, bv.y, bv.z, bv.w};
+            float addv[MF][4];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const int oy = min(ty0 + 2 * wave + (f >> 1), g.Ho - 1), ox = min(tx0 + 16 * (f & 1) + r16, g.Wo - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = min(n0 + r, g.n_real - 1);
+                    addv[f][r] = g.add32 ? g.add32[(((long)b * g.n_real + n) * g.addH + oy + g.add_crop) * g.addW + ox + g.add_crop] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const int oy = ty0 + 2 * wave + (f >> 1), ox = tx0 + 16 * (f & 1) + r16;
+                if (oy >= g.Ho || ox >= g.Wo) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + r;
+                    if (n >= g.n_real) continue;
+                    float o = acc[0][f][r] + bvr[r];
+                    if (g.act == 2) o = o >= 0.f ? o : o * g.slope;
+                    else if (g.act == 3) o = fmaxf(o, 0.f);
+                    o += addv[f][r];
+                    if (g.clamp01) o = fminf(fmaxf(o, 0.f), 1.f);
+                    g.out32[(((long)b * g.n_real + n) * g.Ho + oy) * g.Wo + ox] = o;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n0 = nt * 16 + grp * 4;

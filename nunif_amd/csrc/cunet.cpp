@@ -213,12 +213,17 @@ int run_conv(const ConvW &c, const f16 *a, const f16 *a2, int H2, int crop2, int
     return launch_conv(g, s);
 }
 
-int run_up(const UpW &u, const f16 *a, int B, int Hi, f16 *out, hipStream_t s) {
+// ConvTranspose2d(k = stride = 2) + LeakyReLU as a pixel-shuffle GEMM; with `skip`: + crop(skip, crop) in the epilogue, so that
+// the next conv reads ONE input (`conv3(crop(x1) + x2)`, cunet.py:58-60,111-118 — the add used to ride in that conv's staging,
+// which a DMA-staged conv cannot do)
+int run_up(const UpW &u, const f16 *a, int B, int Hi, f16 *out, hipStream_t s, const f16 *skip = nullptr, int skip_side = 0,
+           int crop = 0) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.B = B; g.Hi = Hi; g.Wi = Hi; g.Cin = u.K; g.Ho = Hi; g.Wo = Hi; g.stride = 1; g.kw = 1;
     g.K = u.K; g.w = u.w; g.bias = u.bias; g.N = u.N; g.mode = 1; g.act = 2; g.slope = 0.1f;
     g.out = out; g.ldo = u.cq; g.n_real = u.N; g.ps = 1;
+    if (skip) { g.res = skip; g.res_H = skip_side; g.res_W = skip_side; g.res_crop = crop; }
     return launch_gemm(g, s, "cunet_up");
 }
 
@@ -310,9 +315,9 @@ int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif
     if ((rc = run_conv(h->u1c2a, tD, nullptr, 0, 0, B, d1, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u1c2b, tE, nullptr, 0, 0, B, e1, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = launch_se(tF, sums, scale, h->u1se2.w1, h->u1se2.b1, h->u1se2.w2, h->u1se2.b2, B, (long)f1 * f1, 64, s))) return rc;
-    if ((rc = run_up(h->u1up, tF, B, f1, tG, s))) return rc;
-    // conv3(crop(x1, 4) + x2)
-    if ((rc = run_conv(h->u1c3, tG, tX1, x1, 4, B, g1, tH, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    // conv3(crop(x1, 4) + x2): the add happens in the up-GEMM's epilogue
+    if ((rc = run_up(h->u1up, tF, B, f1, tG, s, tX1, x1, 4))) return rc;
+    if ((rc = run_conv(h->u1c3, tG, nullptr, 0, 0, B, g1, tH, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     // conv_bottom -> z1 (clamped unless no_clip, cunet.py:185-186)
     if (h->up) {
         if ((rc = run_deconv4(h->u1bottom_up, tH, B, h1, z1, h->no_clip ? 1 : 0, s))) return rc;
@@ -332,14 +337,14 @@ int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif
     if ((rc = run_conv(h->u2c3a, tD, nullptr, 0, 0, B, d3, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u2c3b, tE, nullptr, 0, 0, B, e3, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = launch_se(tF, sums, scale, h->u2se3.w1, h->u2se3.b1, h->u2se3.w2, h->u2se3.b2, B, (long)f3 * f3, 128, s))) return rc;
-    if ((rc = run_up(h->u2up3, tF, B, f3, tG, s))) return rc;
     // conv4(crop(x2, 4) + x3)
-    if ((rc = run_conv(h->u2c4a, tG, tX2, y2, 4, B, g3, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_up(h->u2up3, tF, B, f3, tG, s, tX2, y2, 4))) return rc;
+    if ((rc = run_conv(h->u2c4a, tG, nullptr, 0, 0, B, g3, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u2c4b, tE, nullptr, 0, 0, B, e4, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = launch_se(tF, sums, scale, h->u2se4.w1, h->u2se4.b1, h->u2se4.w2, h->u2se4.b2, B, (long)f4 * f4, 64, s))) return rc;
-    if ((rc = run_up(h->u2up4, tF, B, f4, tG, s))) return rc;
     // conv5(crop(x1, 16) + x4)
-    if ((rc = run_conv(h->u2c5, tG, tY1, y1, 16, B, g4, tH, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_up(h->u2up4, tF, B, f4, tG, s, tY1, y1, 16))) return rc;
+    if ((rc = run_conv(h->u2c5, tG, nullptr, 0, 0, B, g4, tH, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     // z = clamp(crop(z1, 20) + conv_bottom(x5), 0, 1)
     if ((rc = run_conv(h->u2bottom, tH, nullptr, 0, 0, B, h5, nullptr, z, z1, T2, 20, 1, 0, s))) return rc;
     return NUNIF_HIP_OK;

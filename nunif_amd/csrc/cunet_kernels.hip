@@ -257,6 +257,7 @@ int launch_conv(const ConvArgs &g, hipStream_t s) {
     NUNIF_REQUIRE(!(g.zpad || g.relu_in) || (!g.a2 && !g.rpad), "conv: zero padding / relu_in need a single input");
     const long M = (long)g.B * g.Ho * g.Wo;
     if (M == 0) return NUNIF_HIP_OK;
+    if (conv3_dma_applies(g)) return launch_conv3_dma(g, s);          // large grids: persistent, halo + weights by LDS-DMA
     if (conv3_lds_applies(g)) return launch_conv3_lds(g, s);
     NUNIF_REQUIRE(!g.cmaj, "conv: a chunk-major weight stream needs the 3x3 stride-1 LDS kernel (NUNIF_CONV3_LDS=0 set?)");
     const double K = (double)g.kh * g.kw * g.Cin;

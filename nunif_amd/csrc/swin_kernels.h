@@ -17,7 +17,8 @@ struct GemmArgs {
     int mode;                 // 0: NHWC fp16 [M][ldo]   1: 2x2 pixel-shuffle NHWC fp16   2: to_image NCHW f32 clamp
     int act;                  // 0 none, 1 GELU(erf), 2 LeakyReLU(slope)
     float slope;
-    const f16 *res;           // optional residual, indexed like out (modes 0,1)
+    const f16 *res;           // optional residual, indexed like out (modes 0,1) — or, with res_W > 0, pixel (y + res_crop, x + res_crop)
+                              // of a LARGER map [B, res_H, res_W, ldo] (the cropped U-Net skip of cunet: cunet.py:58-60,111-118)
     void *out;
     int ldo;                  // channels per output pixel (mode 0: N_real, mode 1: N/4)
     int n_real;               // number of valid output columns
@@ -28,6 +29,7 @@ struct GemmArgs {
     int lda;                  // element stride between input pixels (0: Cin) — lets a GEMM read a K-slice of wider rows
     int rev;                  // 1: walk the token groups downwards (snake order, swin_unet.cpp next_dir)
     int nt_chunk;             // set by the launcher: output tiles per workgroup column (blockIdx.y) for small-M GEMMs
+    int res_H = 0, res_W = 0, res_crop = 0;
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag);
 
@@ -169,6 +171,10 @@ int launch_conv(const ConvArgs &g, hipStream_t s);
 // 3x3 stride-1 same conv with the input tile staged in LDS (conv3_lds.hip); launch_conv takes it when it applies
 bool conv3_lds_applies(const ConvArgs &g);
 int launch_conv3_lds(const ConvArgs &g, hipStream_t s);
+// the same conv, persistent, with halo and weights moved into LDS by LDS-DMA (conv3_dma.hip): launches of more than 512 patches,
+// Cin 32 / 64, Cout 32 / 64, one input, NHWC fp16 output
+bool conv3_dma_applies(const ConvArgs &g);
+int launch_conv3_dma(const ConvArgs &g, hipStream_t s);
 
 struct C3ConvArgs {
     const float *x; int frame_mode, H, W, wb, istep, pad_t, pad_l, tile_begin;

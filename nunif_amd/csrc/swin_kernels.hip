@@ -145,6 +145,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         }
         return off + pair_run_channel(grp);
     };
+    // residual position: out_off, or (res_W > 0, mode 1) the same output pixel shifted by res_crop inside a larger map
+    auto res_off = [&](int f, int np) -> long {
+        if (g.res_W == 0) return out_off(f, np);
+        const int q = np / g.ldo, c = np - q * g.ldo;
+        const int sf = g.ps > 1 ? g.ps : 2;
+        const int qi = q / sf, qj = q - qi * sf;
+        return (((long)tb[f] * g.res_H + sf * ty[f] + qi + g.res_crop) * g.res_W + sf * tx[f] + qj + g.res_crop) * g.ldo + c +
+               pair_run_channel(grp);
+    };
     // The residual of a tile pair is requested at the TOP of its trip, in front of the trip's MFMAs: the chunk barriers of the
     // weight ring otherwise pin the load right in front of its use in the epilogue, and with the U-Net skip as residual (PatchUp)
     // every trip then exposed one HBM latency.  (Requesting it a whole trip ahead costs 16 more registers and the third resident
@@ -158,7 +167,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
             for (int f = 0; f < MF; ++f) {
                 const int npn = (nt_lo + nt) * 16;
                 const bool live = valid[f] && npn < g.n_real;
-                rcur[f] = *reinterpret_cast<const f16x8 *>(g.res + (live ? out_off(f, npn) : 0));
+                rcur[f] = *reinterpret_cast<const f16x8 *>(g.res + (live ? res_off(f, npn) : 0));
             }
         }
 #pragma unroll
@@ -401,7 +410,7 @@ static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym,
     // slower for the MF = 4 shapes (K = 96, 192), which keep the ring (re-checked at the end of round 2: PatchDown through the
     // ring 134 us, resident 112 us).
     const bool fits = wbytes <= 144 * 1024 && M >= 8 * MF * 16 * 64;
-    const bool res = fits && !ring_only && MF == 2;
+    const bool res = fits && !ring_only && MF == 2 && g.res_W == 0;     // (the cropped residual exists in the ring form only)
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
     // (NUNIF_PROF_TAGS=1 names the class after the call site instead: separates e.g. the two gemm_kernel<6,4> users)
     ProfScope ps(g_prof_tag ? g_prof_tag : res ? res_sym : ring_sym, s, flops, bytes);

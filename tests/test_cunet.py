@@ -111,3 +111,31 @@ def test_hip_config1_512_tile256(hiplib):
     assert psnr(out[:, 200:400, 200:400].cpu(), z) >= 50.0
     with pytest.raises(Exception):
         m(torch.rand(1, 3, 62, 62).to("cuda:0"))                     # not a multiple of 4
+
+
+@pytest.mark.gpu
+def test_dma_staged_conv_is_bit_identical_to_the_register_staged_one(hiplib, monkeypatch):
+    """conv3_dma_kernel (persistent, halo + weights by LDS-DMA; launches of more than 512 patches) against conv3_lds_kernel on the
+    same engines: same MFMA order over k, so the outputs must be EQUAL — cunet / upcunet on a 12-tile minibatch of 256 x 256
+    (VALID convs, Cin 32 / 64, LeakyReLU) and the depth net's DPT head on a 4 x 392 x 686 batch (zero padding, pre-activation
+    ReLU, two residuals)."""
+    from nunif_amd.waifu2x.models.cunet import CUNet, UpCUNet
+    from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+    from oracle import depth_anything_v2 as ODA
+    x = torch.stack([synth_image(70 + i, 3, 256, 256) for i in range(12)]).to("cuda:0")
+    for cls, up in ((CUNet, False), (UpCUNet, True)):
+        m = cls().eval()
+        m.load_state_dict(OC.random_state_dict(205, up=up), strict=True)
+        m = m.to("cuda:0")
+        monkeypatch.setenv("NUNIF_CONV3_DMA", "0")
+        a = m(x).clone()
+        monkeypatch.setenv("NUNIF_CONV3_DMA", "1")
+        b = m(x).clone()
+        assert torch.isfinite(b).all() and torch.equal(a, b), float((a - b).abs().max())
+    net = HipDepthAnythingV2(ODA.random_state_dict(601), "cuda:0")
+    xd = torch.stack([synth_image(90 + i, 3, 392, 686) for i in range(4)]).to("cuda:0") * 2 - 1
+    monkeypatch.setenv("NUNIF_CONV3_DMA", "0")
+    a = net(xd).clone()
+    monkeypatch.setenv("NUNIF_CONV3_DMA", "1")
+    b = net(xd).clone()
+    assert torch.isfinite(b).all() and torch.equal(a, b), float((a - b).abs().max())

@@ -15,8 +15,12 @@ from nunif_amd.synthetic import cunet_state_dict  # noqa: E402
 torch.set_grad_enabled(False)
 BATCH = int(os.environ.get("CUNET_BATCH", "16"))
 TAGS = os.environ.get("NUNIF_PROF_TAGS")
+ONLY = os.environ.get("CUNET_ONLY")
+ITERS = int(os.environ.get("CUNET_ITERS", "20"))
 x = torch.rand(3, 1080, 1920, device="cuda:0")
 for name, up in (("waifu2x.cunet", False), ("waifu2x.upcunet", True)):
+    if ONLY and not name.endswith("." + ONLY):
+        continue
     m = create_model(name).eval()
     m.load_state_dict(cunet_state_dict(7, up=up))
     m = m.to("cuda:0")
@@ -24,10 +28,10 @@ for name, up in (("waifu2x.cunet", False), ("waifu2x.upcunet", True)):
         tiled_render(x, m, tile_size=256, batch_size=BATCH)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(ITERS):
         tiled_render(x, m, tile_size=256, batch_size=BATCH)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 20
+    dt = (time.perf_counter() - t0) / ITERS
     print(f"{name} batch {BATCH}: {dt * 1e3:.3f} ms per 1080p frame = {1080 * 1920 / dt / 1e6:.1f} MPix/s")
     if os.environ.get("CUNET_PROF"):
         from nunif_amd import _hip
