@@ -51,9 +51,12 @@ __device__ __forceinline__ void dma16(const void *src, unsigned lds_byte_addr) {
 }
 }  // namespace
 
-template <int NT, int CIN, bool RELU_IN>
+// NTT output tiles in NPASS passes of NT = NTT / NPASS over the SAME halo (64 -> 128: two passes of four tiles; eight tiles x four
+// token tiles of accumulators do not fit 256 registers)
+template <int NTT, int CIN, bool RELU_IN, int NPASS = 1>
 __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_patches) {
     constexpr int MF = 4;
+    constexpr int NT = NTT / NPASS;
     constexpr int SEG = CIN / 8;                         // 16-byte segments per pixel
     constexpr int PB = CIN * 2;                          // bytes per pixel
     constexpr int PPR = 256 / PB;                        // pixels per 256-byte LDS row
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
     const int pad = (g.zpad || g.rpad) ? 1 : 0;                           // 0: VALID 3x3 (Ho = Hi - 2)
     const int tiles_x = (g.Wo + kTW - 1) / kTW, tiles_y = (g.Ho + kTH - 1) / kTH;
     const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.wstream);       // zero-padded by 16 KiB on the host
-    const f16x8 *zero16 = gsrc + (long)KSTEPS * NT * 64;                  // first 16 bytes of that padding: the "zero pixel"
+    const f16x8 *zero16 = gsrc + (long)KSTEPS * NTT * 64;                 // first 16 bytes of that padding: the "zero pixel"
 
     // ---- per-lane constants --------------------------------------------------------------------------------------------
     // halo item q = tid + 256 u lives at LDS byte 16 q = pixel (q / SEG), slot (q % SEG); it holds segment slot ^ swz(pixel)
@@ -120,37 +123,53 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
             }
         }
     };
-    // weight chunk c of the stream (c >= NCH: zero padding) -> ring slot: 2 DMA instructions per wave
-    auto chunk_dma = [&](int c, int slot) {
-        const f16x8 *src = gsrc + (long)min(c, NCH + 1) * (kCH * 64) + 64 * wave + lane;
-        dma16(src, ring_lds + (unsigned)(slot * kCH * 64 + 64 * wave) * 16);
-        dma16(src + 256, ring_lds + (unsigned)(slot * kCH * 64 + 256 + 64 * wave) * 16);
+    // weight chunk c of pass p -> ring slot: 2 DMA instructions per wave.  A chunk = KPC k-steps x the NT fragments of the
+    // pass; the stream is [k-step][NTT fragments], so fragment i of the chunk is k-step c KPC + i / NT, tile p NT + i % NT
+    // (contiguous when NPASS == 1).  Fragments past the last k-step come from the zero padding behind the stream.
+    auto chunk_dma = [&](int c, int p, int slot) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = wave + 4 * h;                                   // fragment of the chunk this wave moves
+            const int ks = min(c * KPC + i / NT, KSTEPS);                 // KSTEPS: first k-step of the zero padding
+            const f16x8 *src = gsrc + ((long)ks * NTT + (ks < KSTEPS ? p * NT + i % NT : i % NT)) * 64 + lane;
+            dma16(src, ring_lds + (unsigned)(slot * kCH * 64 + i * 64) * 16);
+        }
     };
 
     int pi = blockIdx.x;
     int b, ty0, tx0;
     if (pi < n_patches) {
         patch_of(pi, b, ty0, tx0);
-        chunk_dma(0, 0);
-        chunk_dma(1, 1);
+        chunk_dma(0, 0, 0);
+        chunk_dma(1, 0, 1);
         halo_dma(b, ty0, tx0);
     }
 #pragma unroll 1
     for (; pi < n_patches; pi += gridDim.x) {
+        // halo + chunks 0, 1 of this patch (and the previous patch's stores) have landed; the barrier publishes all waves' parts
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const int cb = b, cty0 = ty0, ctx0 = tx0;
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {                        // (a real loop: unrolled, hipcc keeps two accumulator sets alive)
         f32x4 acc[NT][MF];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int f = 0; f < MF; ++f) acc[nt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // halo + chunks 0, 1 of this patch (and the previous patch's stores) have landed; the barrier publishes all waves' parts
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         // the chunk loop is fully unrolled: chunk index, ring slot, tap and 32-channel part of every k-step are compile-time
 #pragma unroll
         for (int c = 0; c < NCH3; ++c) {
             // chunk boundary.  My DMAs in flight: chunk c + 1 (2 instructions) at most -> chunk c has landed at vmcnt(2).
             // Behind the barrier every wave has finished reading chunk c - 1, whose slot chunk c + 2 now takes.
-            if (c > 0) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-            chunk_dma(c + 2 < NCH3 ? c + 2 : c + 2 - NCH3, (c + 2) % kSlots);      // wraps into the next patch: the same stream again
+            // (The first chunk of a later pass is a boundary like any other; an earlier pass's stores also count in vmcnt, they
+            // are older than the chunk and only make the wait longer.)
+            if (c > 0 || pass > 0) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            {
+                // two chunks ahead; wraps into the next pass / the next patch (the same stream again)
+                const int cn = c + 2 < NCH3 ? c + 2 : c + 2 - NCH3;
+                const int pn = c + 2 < NCH3 ? pass : (pass + 1 < NPASS ? pass + 1 : 0);
+                chunk_dma(cn, pn, (c + 2) % kSlots);
+            }
 #pragma unroll
             for (int q = 0; q < KPC; ++q) {
                 const int ks = c * KPC + q;
@@ -176,19 +195,56 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
                 }
             }
         }
-        // every wave is done with the halo: the next patch's may overwrite it while this one's epilogue runs
-        const int cb = b, cty0 = ty0, ctx0 = tx0;
-        asm volatile("s_barrier" ::: "memory");
-        if (pi + (int)gridDim.x < n_patches) {
-            patch_of(pi + gridDim.x, b, ty0, tx0);
-            halo_dma(b, ty0, tx0);
+        if (pass == NPASS - 1) {
+            // every wave is done with the halo: the next patch's may overwrite it while this one's epilogue runs
+            asm volatile("s_barrier" ::: "memory");
+            if (pi + (int)gridDim.x < n_patches) {
+                patch_of(pi + gridDim.x, b, ty0, tx0);
+                halo_dma(b, ty0, tx0);
+            }
         }
 
         // ---- epilogue (as conv3_lds_kernel): bias, activation, residuals / image head ---------------------------------------
         const int ldo = g.ldo > 0 ? g.ldo : g.n_real;
+        if constexpr (NT == 1) {
+            if (g.out32) {
+                // image head (planar fp32, `+ crop(add32)`, clamp; cunet.py:183-196): every add32 value is requested before any
+                // is used (conv3_lds.hip)
+                const int n0 = grp * 4;
+                const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+                const float bvr[4] = {bv.x, bv.y, bv.z, bv.w};
+                float addv[MF][4];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    const int oy = min(cty0 + 2 * wave + (f >> 1), g.Ho - 1), ox = min(ctx0 + 16 * (f & 1) + r16, g.Wo - 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = min(n0 + r, g.n_real - 1);
+                        addv[f][r] = g.add32 ? g.add32[(((long)cb * g.n_real + n) * g.addH + oy + g.add_crop) * g.addW + ox + g.add_crop] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    const int oy = cty0 + 2 * wave + (f >> 1), ox = ctx0 + 16 * (f & 1) + r16;
+                    if (oy >= g.Ho || ox >= g.Wo) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + r;
+                        if (n >= g.n_real) continue;
+                        float o = acc[0][f][r] + bvr[r];
+                        if (g.act == 2) o = o >= 0.f ? o : o * g.slope;
+                        else if (g.act == 3) o = fmaxf(o, 0.f);
+                        o += addv[f][r];
+                        if (g.clamp01) o = fminf(fmaxf(o, 0.f), 1.f);
+                        g.out32[(((long)cb * g.n_real + n) * g.Ho + oy) * g.Wo + ox] = o;
+                    }
+                }
+                continue;
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int n0 = nt * 16 + grp * 4;
+            const int n0 = (pass * NT + nt) * 16 + grp * 4;
             const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
@@ -216,6 +272,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
                 *reinterpret_cast<f16x4 *>(g.out + off) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
             }
         }
+        }   // pass
     }
     // drain the two weight chunks the last trip requested for a patch that does not exist (LDS must not be written after exit)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -227,15 +284,15 @@ bool conv3_dma_applies(const ConvArgs &g) {
     const int pad = (g.zpad || g.rpad) ? 1 : 0;
     const int nt = g.N / 16;
     if (!conv3_dma_enabled()) return false;
-    if (!(g.kh == 3 && g.kw == 3 && g.stride == 1) || g.a2 || g.cmaj || g.out32 || g.N % 16 != 0) return false;
+    if (!(g.kh == 3 && g.kw == 3 && g.stride == 1) || g.a2 || g.cmaj || (g.out32 && nt != 1) || g.N % 16 != 0) return false;
     if (g.Ho != g.Hi + 2 * pad - 2 || g.Wo != g.Wi + 2 * pad - 2 || g.zpad > 1 || g.rpad > 1 || (g.zpad && g.rpad)) return false;
-    if (!(g.Cin == 32 || g.Cin == 64) || !(nt == 2 || nt == 4)) return false;
+    if (!(g.Cin == 32 || g.Cin == 64) || !(nt == 1 || nt == 2 || nt == 4 || (nt == 8 && g.Cin == 64))) return false;
     const long n_patches = (long)g.B * ((g.Ho + kTH - 1) / kTH) * ((g.Wo + kTW - 1) / kTW);
     // small launches (at most one patch per workgroup slot) keep the resident-weight form of conv3_lds_kernel
     return n_patches > 512 && n_patches < (1L << 30) && (long)g.B * g.Hi * g.Wi * g.Cin < (1L << 40);
 }
 
-template <int NT, int CIN, bool RELU_IN>
+template <int NT, int CIN, bool RELU_IN, int NPASS = 1>
 static int launch_c3d(const ConvArgs &g, hipStream_t s, const char *name) {
     // the last DMA instruction of a halo is a full 1 KiB whatever the item count: round the halo up to a multiple of 64 items
     const size_t smem = (size_t)kSlots * kCH * 1024 + (size_t)((kHaloPix * (CIN / 8) + 63) / 64) * 1024;
@@ -243,13 +300,13 @@ static int launch_c3d(const ConvArgs &g, hipStream_t s, const char *name) {
     ProfScope ps(name, s, 2.0 * (double)M * 9.0 * g.Cin * g.n_real, (double)M * (g.Cin + g.n_real) * 2.0);
     static bool configured = false;
     if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_dma_kernel<NT, CIN, RELU_IN>,
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_dma_kernel<NT, CIN, RELU_IN, NPASS>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = true;
     }
     const long n_patches = (long)g.B * ((g.Ho + kTH - 1) / kTH) * ((g.Wo + kTW - 1) / kTW);
     const unsigned grid = (unsigned)std::min<long>(n_patches, 512);         // two persistent workgroups per CU
-    conv3_dma_kernel<NT, CIN, RELU_IN><<<grid, 256, smem, s>>>(g, (int)n_patches);
+    conv3_dma_kernel<NT, CIN, RELU_IN, NPASS><<<grid, 256, smem, s>>>(g, (int)n_patches);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
@@ -257,9 +314,12 @@ static int launch_c3d(const ConvArgs &g, hipStream_t s, const char *name) {
 int launch_conv3_dma(const ConvArgs &g, hipStream_t s) {
     const int nt = g.N / 16;
     if (g.Cin == 64) {
+        if (nt == 8) return g.relu_in ? launch_c3d<8, 64, true, 2>(g, s, "conv3_dma_kernel<8,64>") : launch_c3d<8, 64, false, 2>(g, s, "conv3_dma_kernel<8,64>");
+        if (nt == 1) return g.relu_in ? launch_c3d<1, 64, true>(g, s, "conv3_dma_kernel<1,64>") : launch_c3d<1, 64, false>(g, s, "conv3_dma_kernel<1,64>");
         if (nt == 4) return g.relu_in ? launch_c3d<4, 64, true>(g, s, "conv3_dma_kernel<4,64>") : launch_c3d<4, 64, false>(g, s, "conv3_dma_kernel<4,64>");
         if (nt == 2) return g.relu_in ? launch_c3d<2, 64, true>(g, s, "conv3_dma_kernel<2,64>") : launch_c3d<2, 64, false>(g, s, "conv3_dma_kernel<2,64>");
     } else if (g.Cin == 32) {
+        if (nt == 1) return g.relu_in ? launch_c3d<1, 32, true>(g, s, "conv3_dma_kernel<1,32>") : launch_c3d<1, 32, false>(g, s, "conv3_dma_kernel<1,32>");
         if (nt == 4) return g.relu_in ? launch_c3d<4, 32, true>(g, s, "conv3_dma_kernel<4,32>") : launch_c3d<4, 32, false>(g, s, "conv3_dma_kernel<4,32>");
         if (nt == 2) return g.relu_in ? launch_c3d<2, 32, true>(g, s, "conv3_dma_kernel<2,32>") : launch_c3d<2, 32, false>(g, s, "conv3_dma_kernel<2,32>");
     }

@@ -39,7 +39,7 @@ struct Buf {
 struct ConvW { f16 *stream = nullptr; float *bias = nullptr; int N = 0, n_real = 0, Cin = 0, k = 3, stride = 1; };
 struct UpW { f16 *w = nullptr; float *bias = nullptr; int N = 0, K = 0, cq = 0; };       // ConvTranspose2d 2x2 s2
 struct SEW { float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr; int C = 0; };
-struct C3W { float *w = nullptr, *b = nullptr; int C = 0; };
+struct C3W { float *w = nullptr, *b = nullptr; int C = 0; f16 *frag = nullptr; };   // frag: MFMA A fragments of the fused stem (K = 27 taps + bias)
 
 }  // namespace
 
@@ -174,6 +174,18 @@ int make_c3(nunif_cunet *h, const TMap &m, const std::string &key, int cout, C3W
     NUNIF_REQUIRE(w->numel == (int64_t)cout * 27 && b->numel == cout, "%s: unexpected shape (3 input channels)", key.c_str());
     if (cout_pad <= cout) {
         c->C = cout;
+        if (cout % 16 == 0) {
+            // the same conv as cout / 16 MFMA A fragments for stem_fused_kernel (swin_stem.hip): row n, k = ci*9 + ky*3 + kx
+            // (the weight's own layout), k = 27: the bias (the B operand carries a constant one there), k > 27: zero
+            std::vector<f16> fr((size_t)cout / 16 * 512);
+            for (int nt = 0; nt < cout / 16; ++nt)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = nt * 16 + (l & 15), k = (l >> 4) * 8 + j;
+                        fr[((size_t)nt * 64 + l) * 8 + j] = (f16)(k < 27 ? w->data[(size_t)n * 27 + k] : (k == 27 ? b->data[n] : 0.0f));
+                    }
+            if ((rc = upload(h, fr, &c->frag))) return rc;
+        }
         if ((rc = upload_f32(h, w, &c->w))) return rc;
         return upload_f32(h, b, &c->b);
     }
@@ -234,6 +246,20 @@ int run_deconv4(const UpW &u, const f16 *a, int B, int Hi, float *out, int no_cl
     g.K = u.K; g.w = u.w; g.bias = u.bias; g.N = u.N; g.mode = 2; g.act = 0;
     g.out = out; g.n_real = 4 * u.cq; g.ps = 2; g.oshift = -1; g.OH = 2 * Hi - 4; g.OW = 2 * Hi - 4; g.no_clamp = no_clamp;
     return launch_gemm(g, s, "upcunet_bottom");
+}
+
+static inline bool stem_fused_enabled() { const char *e = getenv("NUNIF_CUNET_STEM"); return e ? atoi(e) != 0 : true; }
+
+// first UNetConv of a U-Net through stem_fused_kernel<32, 64, 0>: c3 carries the input geometry (tile / frame mode), c2.stream is
+// already in the kernel's [k-step][n-tile] order with k = tap * 32 + ci (make_conv)
+int run_stem(const C3ConvArgs &c3, const C3W &c1, const ConvW &c2, f16 *out, hipStream_t s) {
+    StemFusedArgs sf;
+    memset(&sf, 0, sizeof(sf));
+    sf.x = c3.x; sf.frame_mode = c3.frame_mode; sf.H = c3.H; sf.W = c3.W; sf.wb = c3.wb; sf.istep = c3.istep;
+    sf.pad_t = c3.pad_t; sf.pad_l = c3.pad_l; sf.tile_begin = c3.tile_begin;
+    sf.B = c3.B; sf.T = c3.T; sf.w1 = c1.frag; sf.w2 = c2.stream; sf.b2 = c2.bias; sf.out = out; sf.slope = c3.slope;
+    sf.C1 = 32; sf.C = 64; sf.crop = 0;
+    return launch_stem_fused(sf, s);
 }
 
 // waifu2x.vgg_7 / waifu2x.upconv_7: first conv on the VALU (3 input channels), the 3x3 VALID convs on conv_kernel with
@@ -309,8 +335,15 @@ int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif
         c3.x = x;
     }
     c3.B = B; c3.T = T; c3.w = h->u1c1a.w; c3.bias = h->u1c1a.b; c3.C = h->u1c1a.C; c3.out = tA; c3.slope = 0.1f;
-    if ((rc = launch_c3_conv(c3, s))) return rc;
-    if ((rc = run_conv(h->u1c1b, tA, nullptr, 0, 0, B, a1, tX1, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;       // x1
+    // UNetConv(3, 32, 64) as ONE kernel (conv + LeakyReLU + conv + LeakyReLU, the 32-channel map never leaves LDS): the VALU
+    // first conv (0.2 ms per launch at 1.3 TB/s, 27 FMAs per output) and the 32 -> 64 conv's read of its 0.27-GB output are gone
+    const bool fused_stem = stem_fused_enabled() && h->u1c1a.frag && h->u2c1a.frag && h->u1c1b.Cin == 32 && h->u1c1b.N == 64;
+    if (fused_stem) {
+        if ((rc = run_stem(c3, h->u1c1a, h->u1c1b, tX1, s))) return rc;                                                // x1
+    } else {
+        if ((rc = launch_c3_conv(c3, s))) return rc;
+        if ((rc = run_conv(h->u1c1b, tA, nullptr, 0, 0, B, a1, tX1, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;   // x1
+    }
     if ((rc = run_conv(h->u1down, tX1, nullptr, 0, 0, B, x1, tD, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u1c2a, tD, nullptr, 0, 0, B, d1, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u1c2b, tE, nullptr, 0, 0, B, e1, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
@@ -327,8 +360,12 @@ int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif
     // ---------------- unet2 (cunet.py:99-121) ----------------
     memset(&c3, 0, sizeof(c3));
     c3.x = z1; c3.B = B; c3.T = T2; c3.w = h->u2c1a.w; c3.bias = h->u2c1a.b; c3.C = h->u2c1a.C; c3.out = tA; c3.slope = 0.1f;
-    if ((rc = launch_c3_conv(c3, s))) return rc;
-    if ((rc = run_conv(h->u2c1b, tA, nullptr, 0, 0, B, a2, tY1, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;       // x1
+    if (fused_stem) {
+        if ((rc = run_stem(c3, h->u2c1a, h->u2c1b, tY1, s))) return rc;                                                // x1
+    } else {
+        if ((rc = launch_c3_conv(c3, s))) return rc;
+        if ((rc = run_conv(h->u2c1b, tA, nullptr, 0, 0, B, a2, tY1, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;   // x1
+    }
     if ((rc = run_conv(h->u2down1, tY1, nullptr, 0, 0, B, y1, tD, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u2c2a, tD, nullptr, 0, 0, B, d2, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u2c2b, tE, nullptr, 0, 0, B, e2, tX2, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;       // x2

@@ -83,6 +83,7 @@ struct StemFusedArgs {
     f16 *out;                 // [B, T-16, T-16, 96]
     float slope;
     int rev;                  // snake order flag
+    int C1, C, crop;          // 0 / 0 / 0 = the swin_unet stem (48, 96, crop 6); 32 / 64 / 0 = cunet's UNetConv(3, 32, 64)
 };
 bool stem_fused_supported(int C1, int C);
 int launch_stem_fused(const StemFusedArgs &a, hipStream_t s);

@@ -25,21 +25,31 @@ namespace nunif {
 #define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 namespace {
-constexpr int kC1 = 48, kC = 96;
 constexpr int kTile = 16;                 // output tile side
 constexpr int kS1 = kTile + 2;            // conv1 tile side
 constexpr int kIn = kTile + 4;            // input patch side
-constexpr int kPix = 112;                 // bytes per conv1 pixel in LDS (48 ch x 2 B = 96, padded)
-constexpr int kKS2 = 14;                  // ceil(9 * 48 / 32)
-constexpr int kNT2 = kC / 16;
 constexpr int kWaves = 8;
-constexpr int kW2Bytes = kKS2 * kNT2 * 1024, kW1Bytes = 3 * 1024, kS1Bytes = kS1 * kS1 * kPix;
 constexpr int kInElems = 3 * kIn * kIn;   // + [kInElems] = 1.0, [kInElems + 1] = 0.0
 constexpr int kInBytes = (kInElems + 8) * 2;
-constexpr int kSmem = kW2Bytes + kW1Bytes + kS1Bytes + kInBytes + kC * 4;
+
+// Geometry of one instantiation.  <48, 96, 6>: the swin_unet stem (crop 6 = F.pad(x, [-6] * 4), swin_unet.py:182).
+// <32, 64, 0>: UNetConv(3, 32, 64) at the head of both cunet U-Nets (waifu2x/models/cunet.py:10-28,36,77), no crop.
+template <int C1, int C, int CROP>
+struct StemGeom {
+    static constexpr int kPix = C1 * 2 + 16;                 // bytes per conv1 pixel in LDS: an odd multiple of 16 B
+    static constexpr int kKS2 = (9 * C1 + 31) / 32;
+    static constexpr int kNT1 = C1 / 16, kNT2 = C / 16;
+    static constexpr int kW2Bytes = kKS2 * kNT2 * 1024, kW1Bytes = kNT1 * 1024, kS1Bytes = kS1 * kS1 * kPix;
+    static constexpr int kSmem = kW2Bytes + kW1Bytes + kS1Bytes + kInBytes + C * 4;
+    static_assert(C1 % 16 == 0 && C % 32 == 0 && (kPix / 16) % 2 == 1 && C1 % 8 == 0, "stem geometry");
+};
 }  // namespace
 
+template <int C1, int C, int CROP>
 __global__ void __launch_bounds__(kWaves * 64) stem_fused_kernel(StemFusedArgs a) {
+    typedef StemGeom<C1, C, CROP> G;
+    constexpr int kC1 = C1, kC = C, kPix = G::kPix, kKS2 = G::kKS2, kNT1 = G::kNT1, kNT2 = G::kNT2;
+    constexpr int kW2Bytes = G::kW2Bytes, kW1Bytes = G::kW1Bytes, kS1Bytes = G::kS1Bytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
     const f16x8 *w2l = reinterpret_cast<const f16x8 *>(smem_s);
     unsigned char *s1l = smem_s + kW2Bytes + kW1Bytes;
@@ -80,9 +90,11 @@ __global__ void __launch_bounds__(kWaves * 64) stem_fused_kernel(StemFusedArgs a
         koff[ks] = ((tap / 3) * kS1 + tap % 3) * kPix + c * 2;
     }
     const f16x8 *w1g = reinterpret_cast<const f16x8 *>(a.w1);
-    const f16x8 w1f[3] = {w1g[lane], w1g[64 + lane], w1g[128 + lane]};
+    f16x8 w1f[kNT1];
+#pragma unroll
+    for (int nt = 0; nt < kNT1; ++nt) w1f[nt] = w1g[nt * 64 + lane];
 
-    const int S = a.T - 16;
+    const int S = a.T - 4 - 2 * CROP;
     const int ntx = (S + kTile - 1) / kTile;
     const int n_tiles = a.B * ntx * ntx;
 
@@ -104,7 +116,7 @@ __global__ void __launch_bounds__(kWaves * 64) stem_fused_kernel(StemFusedArgs a
             if (e < kInElems) {
                 const int ci = e / (kIn * kIn), r = e - ci * (kIn * kIn);
                 const int iy = r / kIn, ix = r - iy * kIn;
-                const int yy = min(kTile * tyt + 6 + iy, a.T - 1), xx = min(kTile * txt + 6 + ix, a.T - 1);
+                const int yy = min(kTile * tyt + CROP + iy, a.T - 1), xx = min(kTile * txt + CROP + ix, a.T - 1);
                 if (a.frame_mode) {
                     const int sy = min(max(fy + yy, 0), a.H - 1), sx = min(max(fx + xx, 0), a.W - 1);
                     v[i] = a.x[((long)ci * a.H + sy) * a.W + sx];
@@ -145,7 +157,7 @@ __global__ void __launch_bounds__(kWaves * 64) stem_fused_kernel(StemFusedArgs a
                 for (int j = 0; j < 8; ++j) bfrag[j] = inl[ioff[j] + imul[j] * pb];
                 const bool wr = mt * 16 + r16 < kS1 * kS1;
 #pragma unroll
-                for (int nt = 0; nt < 3; ++nt) {
+                for (int nt = 0; nt < kNT1; ++nt) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                     acc = MFMA_16x16x32(w1f[nt], bfrag, acc);
                     f16x4 o;
@@ -202,25 +214,35 @@ __global__ void __launch_bounds__(kWaves * 64) stem_fused_kernel(StemFusedArgs a
     }
 }
 
-bool stem_fused_supported(int C1, int C) { return C1 == kC1 && C == kC; }
+bool stem_fused_supported(int C1, int C) { return (C1 == 48 && C == 96) || (C1 == 32 && C == 64); }
 
-int launch_stem_fused(const StemFusedArgs &a, hipStream_t s) {
-    NUNIF_REQUIRE(a.T > 16, "stem: tile size %d too small", a.T);
-    const int S = a.T - 16;
+template <int C1, int C, int CROP>
+static int launch_stem_t(const StemFusedArgs &a, hipStream_t s, const char *name) {
+    typedef StemGeom<C1, C, CROP> G;
+    const int S = a.T - 4 - 2 * CROP;
+    NUNIF_REQUIRE(S > 0, "stem: tile size %d too small", a.T);
     const int ntx = (S + kTile - 1) / kTile;
     const long n_tiles = (long)a.B * ntx * ntx;
     if (n_tiles == 0) return NUNIF_HIP_OK;
     const double px = (double)a.B * S * S;
-    ProfScope ps("stem_fused_kernel", s, 2.0 * px * (27.0 * kC1 + 9.0 * kC1 * kC), px * (12.0 + kC * 2.0));
+    ProfScope ps(name, s, 2.0 * px * (27.0 * C1 + 9.0 * C1 * C), px * (12.0 + C * 2.0));
     static bool configured = false;
     if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)stem_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)stem_fused_kernel<C1, C, CROP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            G::kSmem));
         configured = true;
     }
-    const unsigned grid = (unsigned)std::min<long>(n_tiles, 256);
-    stem_fused_kernel<<<grid, kWaves * 64, kSmem, s>>>(a);
+    // persistent: one workgroup per CU, two where the LDS image allows it (the <32, 64> form is 67 KiB)
+    const unsigned grid = (unsigned)std::min<long>(n_tiles, G::kSmem <= 80 * 1024 ? 512 : 256);
+    stem_fused_kernel<C1, C, CROP><<<grid, kWaves * 64, G::kSmem, s>>>(a);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
+}
+
+int launch_stem_fused(const StemFusedArgs &a, hipStream_t s) {
+    if (a.C1 == 32 && a.C == 64 && a.crop == 0) return launch_stem_t<32, 64, 0>(a, s, "stem_fused_kernel<32,64>");
+    NUNIF_REQUIRE((a.C1 == 48 || a.C1 == 0) && (a.C == 96 || a.C == 0), "stem: C1=%d C=%d unsupported", a.C1, a.C);
+    return launch_stem_t<48, 96, 6>(a, s, "stem_fused_kernel");
 }
 
 }  // namespace nunif

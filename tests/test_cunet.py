@@ -132,6 +132,11 @@ def test_dma_staged_conv_is_bit_identical_to_the_register_staged_one(hiplib, mon
         monkeypatch.setenv("NUNIF_CONV3_DMA", "1")
         b = m(x).clone()
         assert torch.isfinite(b).all() and torch.equal(a, b), float((a - b).abs().max())
+        # the fused UNetConv(3, 32, 64) stem (conv1 on the MFMA with fp16 weights) against the VALU first conv + separate 32 -> 64 conv
+        monkeypatch.setenv("NUNIF_CUNET_STEM", "0")
+        c = m(x).clone()
+        monkeypatch.setenv("NUNIF_CUNET_STEM", "1")
+        assert psnr(b, c) >= 57.0, psnr(b, c)
     net = HipDepthAnythingV2(ODA.random_state_dict(601), "cuda:0")
     xd = torch.stack([synth_image(90 + i, 3, 392, 686) for i in range(4)]).to("cuda:0") * 2 - 1
     monkeypatch.setenv("NUNIF_CONV3_DMA", "0")
