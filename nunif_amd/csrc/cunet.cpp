@@ -36,7 +36,8 @@ struct Buf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct ConvW { f16 *stream = nullptr; float *bias = nullptr; int N = 0, n_real = 0, Cin = 0, k = 3, stride = 1; };
+struct ConvW { f16 *stream = nullptr; float *bias = nullptr; int N = 0, n_real = 0, Cin = 0, k = 3, stride = 1;
+               f16 *gemm_w = nullptr; };        // 2x2 stride-2 convs: the same weights in gemm_kernel's [n-tile][k-step] order
 struct UpW { f16 *w = nullptr; float *bias = nullptr; int N = 0, K = 0, cq = 0; };       // ConvTranspose2d 2x2 s2
 struct SEW { float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr; int C = 0; };
 struct C3W { float *w = nullptr, *b = nullptr; int C = 0; f16 *frag = nullptr; };   // frag: MFMA A fragments of the fused stem (K = 27 taps + bias)
@@ -109,6 +110,16 @@ int make_conv(nunif_cunet *h, const TMap &m, const std::string &key, int cin, in
     for (int n = 0; n < cout; ++n) bias[n] = b->data[n];
     c->N = N; c->n_real = cout; c->Cin = cin; c->k = k; c->stride = stride;
     if ((rc = upload(h, stream, &c->stream))) return rc;
+    if (k == 2 && stride == 2 && cin_real == cin && N == cout && N % 32 == 0) {
+        // k = stride: a 2 x 2 gather GEMM (the PatchDown form of gemm_kernel: every input pixel is read exactly once, the token
+        // tile's whole K extent sits in registers) instead of the K-looped conv_kernel with its nine-tap machinery
+        std::vector<f16> packed((size_t)N * k * k * cin + 8192, (f16)0.0f);
+        for (int nt = 0; nt < NT; ++nt)
+            for (int ks = 0; ks < KS; ++ks)
+                std::copy(stream.begin() + ((size_t)ks * NT + nt) * 512, stream.begin() + ((size_t)ks * NT + nt + 1) * 512,
+                          packed.begin() + ((size_t)nt * KS + ks) * 512);
+        if ((rc = upload(h, packed, &c->gemm_w))) return rc;
+    }
     return upload(h, bias, &c->bias);
 }
 
@@ -223,6 +234,19 @@ int run_conv(const ConvW &c, const f16 *a, const f16 *a2, int H2, int crop2, int
     g.out = out; g.out32 = out32; g.add32 = add32; g.addH = addH; g.addW = addH; g.add_crop = add_crop;
     g.clamp01 = clamp01;
     return launch_conv(g, s);
+}
+
+static inline bool down_gemm_enabled() { const char *e = getenv("NUNIF_CUNET_DOWN_GEMM"); return e ? atoi(e) != 0 : true; }
+
+// Conv2d(k = stride = 2) + LeakyReLU (cunet.py:37,78,81) as a gather GEMM
+int run_down(const ConvW &c, const f16 *a, int B, int Hi, f16 *out, hipStream_t s) {
+    if (!c.gemm_w || !down_gemm_enabled()) return run_conv(c, a, nullptr, 0, 0, B, Hi, out, nullptr, nullptr, 0, 0, 0, 2, s);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = a; g.B = B; g.Hi = Hi; g.Wi = Hi; g.Cin = c.Cin; g.Ho = Hi / 2; g.Wo = Hi / 2; g.stride = 2; g.kw = 2;
+    g.K = 4 * c.Cin; g.w = c.gemm_w; g.bias = c.bias; g.N = c.N; g.mode = 0; g.act = 2; g.slope = 0.1f;
+    g.out = out; g.ldo = c.N; g.n_real = c.N; g.ps = 1;
+    return launch_gemm(g, s, "cunet_down");
 }
 
 // ConvTranspose2d(k = stride = 2) + LeakyReLU as a pixel-shuffle GEMM; with `skip`: + crop(skip, crop) in the epilogue, so that
@@ -344,7 +368,7 @@ int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif
         if ((rc = launch_c3_conv(c3, s))) return rc;
         if ((rc = run_conv(h->u1c1b, tA, nullptr, 0, 0, B, a1, tX1, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;   // x1
     }
-    if ((rc = run_conv(h->u1down, tX1, nullptr, 0, 0, B, x1, tD, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_down(h->u1down, tX1, B, x1, tD, s))) return rc;
     if ((rc = run_conv(h->u1c2a, tD, nullptr, 0, 0, B, d1, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u1c2b, tE, nullptr, 0, 0, B, e1, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = launch_se(tF, sums, scale, h->u1se2.w1, h->u1se2.b1, h->u1se2.w2, h->u1se2.b2, B, (long)f1 * f1, 64, s))) return rc;
@@ -366,11 +390,11 @@ int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif
         if ((rc = launch_c3_conv(c3, s))) return rc;
         if ((rc = run_conv(h->u2c1b, tA, nullptr, 0, 0, B, a2, tY1, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;   // x1
     }
-    if ((rc = run_conv(h->u2down1, tY1, nullptr, 0, 0, B, y1, tD, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_down(h->u2down1, tY1, B, y1, tD, s))) return rc;
     if ((rc = run_conv(h->u2c2a, tD, nullptr, 0, 0, B, d2, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u2c2b, tE, nullptr, 0, 0, B, e2, tX2, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;       // x2
     if ((rc = launch_se(tX2, sums, scale, h->u2se2.w1, h->u2se2.b1, h->u2se2.w2, h->u2se2.b2, B, (long)y2 * y2, 128, s))) return rc;
-    if ((rc = run_conv(h->u2down2, tX2, nullptr, 0, 0, B, y2, tD, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
+    if ((rc = run_down(h->u2down2, tX2, B, y2, tD, s))) return rc;
     if ((rc = run_conv(h->u2c3a, tD, nullptr, 0, 0, B, d3, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u2c3b, tE, nullptr, 0, 0, B, e3, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = launch_se(tF, sums, scale, h->u2se3.w1, h->u2se3.b1, h->u2se3.w2, h->u2se3.b2, B, (long)f3 * f3, 128, s))) return rc;

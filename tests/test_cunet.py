@@ -137,6 +137,11 @@ def test_dma_staged_conv_is_bit_identical_to_the_register_staged_one(hiplib, mon
         c = m(x).clone()
         monkeypatch.setenv("NUNIF_CUNET_STEM", "1")
         assert psnr(b, c) >= 57.0, psnr(b, c)
+        # the 2 x 2 stride-2 convs as gather GEMMs against conv_kernel: same products, another summation order
+        monkeypatch.setenv("NUNIF_CUNET_DOWN_GEMM", "0")
+        d = m(x).clone()
+        monkeypatch.setenv("NUNIF_CUNET_DOWN_GEMM", "1")
+        assert psnr(b, d) >= 57.0, psnr(b, d)
     net = HipDepthAnythingV2(ODA.random_state_dict(601), "cuda:0")
     xd = torch.stack([synth_image(90 + i, 3, 392, 686) for i in range(4)]).to("cuda:0") * 2 - 1
     monkeypatch.setenv("NUNIF_CONV3_DMA", "0")
