@@ -288,8 +288,10 @@ bool conv3_dma_applies(const ConvArgs &g) {
     if (g.Ho != g.Hi + 2 * pad - 2 || g.Wo != g.Wi + 2 * pad - 2 || g.zpad > 1 || g.rpad > 1 || (g.zpad && g.rpad)) return false;
     if (!(g.Cin == 32 || g.Cin == 64) || !(nt == 1 || nt == 2 || nt == 4 || (nt == 8 && g.Cin == 64))) return false;
     const long n_patches = (long)g.B * ((g.Ho + kTH - 1) / kTH) * ((g.Wo + kTW - 1) / kTW);
-    // small launches (at most one patch per workgroup slot) keep the resident-weight form of conv3_lds_kernel
-    return n_patches > 512 && n_patches < (1L << 30) && (long)g.B * g.Hi * g.Wi * g.Cin < (1L << 40);
+    // tiny launches keep the resident-weight form of conv3_lds_kernel.  Threshold sweep on the depth net (4 x 1080p, ViT-S):
+    // 512 -> 2 033 fps, 256 -> 2 031, 96 -> 2 049, 24 -> 2 070 (one patch per workgroup from 24 to 512 patches)
+    static const long min_patches = getenv("NUNIF_CONV3_DMA_MIN") ? atol(getenv("NUNIF_CONV3_DMA_MIN")) : 24;
+    return n_patches > min_patches && n_patches < (1L << 30) && (long)g.B * g.Hi * g.Wi * g.Cin < (1L << 40);
 }
 
 template <int NT, int CIN, bool RELU_IN, int NPASS = 1>

@@ -338,7 +338,7 @@ struct Buf {
 };
 struct Lin { f16 *w = nullptr; float *b = nullptr; int N = 0, K = 0; float *ws = nullptr; };     // gemm_kernel packing [nt][ks]; ws: row sums (LayerNorm-folded Linears)
 struct Cnv { f16 *w = nullptr; float *b = nullptr; int N = 0, Cin = 0, k = 3, cmaj = 0; };     // conv_kernel stream [ks][nt]
-struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2[4], fc2_full, qkv_ln, fc1_ln; int n_fc2; };   // *_ln: norm1 / norm2 folded in (ViT-S)   // fc2 (K = 4 D) = 2 or 4 GEMMs of K = 768 / 1024
+struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2[4], fc2_full, qkv_ln, fc1_ln; int n_fc2; f16 *fc2c = nullptr; };   // fc2c: fc2_full in the chained k order (depth_mlp.hip)   // *_ln: norm1 / norm2 folded in (ViT-S)   // fc2 (K = 4 D) = 2 or 4 GEMMs of K = 768 / 1024
 struct Rcu { Cnv c1, c2; };
 struct Fus { Rcu r1, r2; Lin out; };
 }  // namespace
@@ -351,7 +351,8 @@ struct nunif_depth_anything {
     Lin patch; float *cls = nullptr, *norm_g = nullptr, *norm_b = nullptr;
     std::vector<Blk> blk;
     Lin proj[4], rs0, rs1, rs3g; std::vector<Cnv> rs3; Cnv rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
-    Buf a_col, pe, t, y, qkv, att, hid, lnstats, feat[4], rnb[4], m1, m2, m3, m4, m5, part, col;
+    Buf a_col, pe, t, y, qkv, att, hid, lnstats, mlp_flags, feat[4], rnb[4], m1, m2, m3, m4, m5, part, col;
+    unsigned mlp_epoch = 0;
 };
 
 namespace {
@@ -580,6 +581,23 @@ extern "C" int nunif_hip_depth_anything_create_ex(const nunif_tensor_desc *tenso
                     bk.n_fc2 = 0;
                     rc = make_lin(h, kD, 4 * kD, [=](int n, int k) { return wd[(size_t)n * 4 * kD + k] * ls[n]; },
                                   [=](int n) { return bd[n] * ls[n]; }, &bk.fc2_full);
+                    if (!rc && da_mlp_supported(kD, 4 * kD) && bk.fc1_ln.w) {
+                        // the same matrix for the fused MLP kernel: its B operand is the hidden tile PAIR taken straight from
+                        // fc1's accumulators, so the 8 k-slots of lane group g in k-chunk ks are the channels 32 ks + 4 g + 0..3
+                        // (tile 2 ks) and 32 ks + 16 + 4 g + 0..3 (tile 2 ks + 1).  Fragment order [ks / 4][tile][ks % 4]: the
+                        // kernel's 24 concurrent streams then sit on different L2 channels (depth_mlp.hip)
+                        const int NT = kD / 16, KS = 4 * kD / 32;
+                        std::vector<f16> pc((size_t)NT * KS * 512 + 8192, (f16)0.f);
+                        for (int nt = 0; nt < NT; ++nt)
+                            for (int ks = 0; ks < KS; ++ks)
+                                for (int l = 0; l < 64; ++l)
+                                    for (int j = 0; j < 8; ++j) {
+                                        const int g = l >> 4, n = nt * 16 + (l & 15);
+                                        const int k = ks * 32 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+                                        pc[((((size_t)(ks >> 2) * NT + nt) * 4 + (ks & 3)) * 64 + l) * 8 + j] = (f16)(wd[(size_t)n * 4 * kD + k] * ls[n]);
+                                    }
+                        rc = upload(h, pc, &bk.fc2c);
+                    }
                 }
                 for (int q = 0; q < bk.n_fc2 && !rc; ++q)
                     rc = make_lin(h, kD, kpiece, [=](int n, int k) { return wd[(size_t)n * 4 * kD + (size_t)q * kpiece + k] * ls[n]; },
@@ -684,7 +702,7 @@ extern "C" int nunif_hip_depth_anything_create(const nunif_tensor_desc *tensors,
 extern "C" void nunif_hip_depth_anything_destroy(nunif_depth_anything *h) {
     if (!h) return;
     for (void *p : h->owned) (void)hipFree(p);
-    Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->att, &h->hid, &h->lnstats, &h->feat[0], &h->feat[1], &h->feat[2],
+    Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->att, &h->hid, &h->lnstats, &h->mlp_flags, &h->feat[0], &h->feat[1], &h->feat[2],
                    &h->feat[3], &h->rnb[0], &h->rnb[1], &h->rnb[2], &h->rnb[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5, &h->part, &h->col};
     for (Buf *b : bufs) b->release();
     delete h;
@@ -724,6 +742,11 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         const bool fresh = ln_bytes > h->lnstats.cap;
         if ((rc = h->lnstats.ensure(ln_bytes))) return rc;
         if (fresh) NUNIF_HIP_CHECK(hipMemsetAsync(h->lnstats.p, 0, h->lnstats.cap, s));
+        // the hidden-split MLP kernel's hand-off flags (one per 64 tokens, compared with a launch counter: zeroed once)
+        const size_t fl_bytes = (size_t)da_mlp_flag_count(T) * sizeof(unsigned);
+        const bool fresh_fl = fl_bytes > h->mlp_flags.cap;
+        if ((rc = h->mlp_flags.ensure(fl_bytes))) return rc;
+        if (fresh_fl) { NUNIF_HIP_CHECK(hipMemsetAsync(h->mlp_flags.p, 0, h->mlp_flags.cap, s)); h->mlp_epoch = 0; }
     }
     for (int i = 0; i < 4; ++i)
         if ((rc = h->feat[i].ensure(T * kD * e2)) || (rc = h->rnb[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2))) return rc;
@@ -732,6 +755,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     float2 *lnstats = (float2 *)h->lnstats.p;
     bool fuse_ln = kD / 32 == 12 && gemm_os_consumes_stats(T, 3 * kD, kD) && gemm_os_supported(T, kD, kD) && gemm_os_supported(T, kD, 4 * kD);
     for (const Blk &bk : h->blk) fuse_ln = fuse_ln && bk.qkv_ln.w && bk.fc1_ln.w && bk.n_fc2 == 0;
+    const bool use_mlp = !(getenv("NUNIF_DA_MLP") && atoi(getenv("NUNIF_DA_MLP")) == 0);      // read per call (tests A/B it)
     auto blocks = [](long n) { return (unsigned)((n + 255) / 256); };
 
     {   // patch embedding
@@ -777,6 +801,22 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             NUNIF_LAUNCH_CHECK();
         }
         if ((rc = run_tok(bk.proj, att, T, 0, t, t, s, "da_proj", ln2 ? lnstats : nullptr))) return rc;        // t += ls1 * proj(att)
+        if (ln2 && bk.fc2c && use_mlp) {
+            // fc1 + GELU + fc2 + residual (+ the next norm1's statistics) in one kernel: the hidden rows never leave the CU
+            DaMlpArgs ma;
+            memset(&ma, 0, sizeof(ma));
+            ma.t = t; ma.M = T; ma.w1 = bk.fc1_ln.w; ma.b1 = bk.fc1_ln.b; ma.ws1 = bk.fc1_ln.ws; ma.w2c = bk.fc2c; ma.b2 = bk.fc2_full.b;
+            ma.stats_in = lnstats; ma.stats_out = ln1_next ? lnstats : nullptr; ma.ln_eps = 1e-6f;
+            if (h->mlp_flags.p && (size_t)da_mlp_partial_bytes(T) <= h->hid.cap) {   // the hidden rows' buffer is free on this path
+                ma.partial = hid; ma.flags = (unsigned *)h->mlp_flags.p; ma.epoch = ++h->mlp_epoch;
+            }
+            if ((rc = launch_da_mlp(ma, s))) return rc;
+            if (tap < 4 && i == h->taps[tap]) {
+                if ((rc = launch_da_layernorm(t, h->norm_g, h->norm_b, (f16 *)h->feat[tap].p, T, kD, s))) return rc;
+                ++tap;
+            }
+            continue;
+        }
         if (ln2) {
             if ((rc = run_tok(bk.fc1_ln, t, T, 1, nullptr, hid, s, "da_fc1", nullptr, lnstats))) return rc;
         } else {

@@ -233,41 +233,52 @@ __global__ void __launch_bounds__(256) li_ln2_t_kernel(const f16 *__restrict__ a
     }
 }
 
-// temporal block (light_video_inpaint_v1.py GMLP3DBlock, window (12,1,1)): LayerNorm over the gate half, token-major
+// temporal block (light_video_inpaint_v1.py GMLP3DBlock, window (12,1,1)): LayerNorm over the gate half, token-major.
+// 32 lanes per token, 16 bytes per lane: a token's V channels are one contiguous run of the row, so a wave's load / store
+// instruction covers two whole runs.  (Rounds 1-3 gave every THREAD a token: the 64 lanes of a load touched 64 rows 4 V bytes
+// apart — 0.55 TB/s = 7 % of the HBM peak, 4.5 ms per launch in the config-5 leg.)  Two-pass statistics in fp32 as before; the
+// sums are now reduced across lanes, i.e. in another order.
 template <int V>
 __global__ void __launch_bounds__(256) li_ln2_kernel(const f16 *__restrict__ a, const float *__restrict__ w, f16 *__restrict__ vn,
                                                       long tokens) {
-    const long id = (long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= tokens) return;
+    constexpr int LPT = 32, SEGS = V / 8, PER = (SEGS + LPT - 1) / LPT;
+    const long id = (long)blockIdx.x * (256 / LPT) + (threadIdx.x / LPT);
+    const int l = threadIdx.x % LPT;
+    if (id >= tokens) return;                                   // (a 32-lane group leaves together)
     const f16x8 *p = reinterpret_cast<const f16x8 *>(a + id * (2 * V) + V);
-    constexpr bool HOLD = V <= 256;
-    constexpr int UNR = HOLD ? V / 8 : 8;
-    f16x8 v[HOLD ? V / 8 : 1];
+    f16x8 v[PER];
     float sum = 0.f;
-#pragma unroll UNR
-    for (int i = 0; i < V / 8; ++i) {
-        const f16x8 t = p[i];
-        if constexpr (HOLD) v[i] = t;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += (float)t[j];
+    for (int i = 0; i < PER; ++i) {
+        const int sg = l + LPT * i;
+        v[i] = sg < SEGS ? p[sg] : (f16x8){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
     }
+#pragma unroll
+    for (int m = LPT / 2; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
     const float mean = sum / (float)V;
     float var = 0.f;
-#pragma unroll UNR
-    for (int i = 0; i < V / 8; ++i) {
-        const f16x8 t = HOLD ? v[HOLD ? i : 0] : p[i];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = (float)t[j] - mean; var += d * d; }
+    for (int i = 0; i < PER; ++i) {
+        if (l + LPT * i < SEGS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = (float)v[i][j] - mean; var += d * d; }
+        }
     }
+#pragma unroll
+    for (int m = LPT / 2; m >= 1; m >>= 1) var += __shfl_xor(var, m);
     const float rs = rsqrtf(var / (float)V + 1e-5f);
     f16x8 *o = reinterpret_cast<f16x8 *>(vn + id * V);
-#pragma unroll UNR
-    for (int i = 0; i < V / 8; ++i) {
-        const f16x8 t = HOLD ? v[HOLD ? i : 0] : p[i];
-        f16x8 r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (f16)(((float)t[j] - mean) * rs * w[8 * i + j]);
-        o[i] = r;
+    for (int i = 0; i < PER; ++i) {
+        const int sg = l + LPT * i;
+        if (sg < SEGS) {
+            f16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (f16)(((float)v[i][j] - mean) * rs * w[8 * sg + j]);
+            o[sg] = r;
+        }
     }
 }
 
@@ -571,7 +582,7 @@ int run_gblock(nunif_light_inpaint *h, const GBlock &g, f16 *x, int B, int hh, i
         const long pixels = (long)hh * ww;
         {
             ProfScope ps("li_ln2_kernel", s, 0.0, (double)tok * V * 4.0);
-            li_ln2_kernel<V><<<bp, 256, 0, s>>>(pi, g.ln2, vt, tok);
+            li_ln2_kernel<V><<<(unsigned)((tok + 7) / 8), 256, 0, s>>>(pi, g.ln2, vt, tok);
         }
         const long n = pixels * (V / 8);
         ProfScope ps("li_tmix_gate_kernel", s, 2.0 * 144.0 * pixels * V, (double)tok * V * 6.0);

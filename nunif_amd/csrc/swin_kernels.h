@@ -59,6 +59,23 @@ bool gemm_os_supported(long M, int N, int K);
 bool gemm_os_consumes_stats(long M, int N, int K);
 int launch_gemm_os(const GemmOsArgs &g, hipStream_t s, const char *tag);
 
+// ---- the MLP of a ViT-S block in one kernel (depth_mlp.hip): t += fc2'(gelu(fc1'(norm2(t)))), embed 384, hidden 1536 ---------
+// w1 / b1 / ws1: fc1 with norm2 folded in (gemm_kernel packing [n-tile 96][k-step 12], bias, row sums — the GemmOsArgs::stats_in
+// convention); w2c: fc2 with LayerScale folded in, CHAINED k order, [n-tile 24][k-step 48]; b2: its bias.  stats_in: the 12
+// (sum, sum of squares) partials per token that the producer of t wrote; stats_out (optional): the same for the rows stored here.
+struct DaMlpArgs {
+    f16 *t; long M;
+    const f16 *w1; const float *b1, *ws1;
+    const f16 *w2c; const float *b2;
+    const float2 *stats_in; float2 *stats_out; float ln_eps;
+    // hidden-split form (optional): scratch of da_mlp_partial_bytes(M), da_mlp_flag_count(M) flags zeroed once, a launch counter
+    void *partial; unsigned *flags; unsigned epoch;
+};
+bool da_mlp_supported(int D, int hidden);
+long da_mlp_partial_bytes(long M);
+long da_mlp_flag_count(long M);
+int launch_da_mlp(const DaMlpArgs &a, hipStream_t s);
+
 // ---- first conv of the stem (3 -> C1 real channels, stored padded to C1P), VALU ----------------------------------
 struct Stem1Args {
     const float *x;           // tile mode: [B,3,T,T]; frame mode: [3,H,W]

@@ -3,6 +3,8 @@
 The real network lives in an external hub repository that is not available offline.  The restatement is
 pinned against HuggingFace's independent ``DepthAnythingForDepthEstimation`` (tests/test_depth_anything_vs_hf.py), and
 ``test_hip_backbone_vs_huggingface_fixture`` compares the engine with HF-produced outputs directly."""
+import os
+
 import pytest
 import torch
 
@@ -169,3 +171,39 @@ def test_lds_staged_conv_is_bit_identical_to_the_gather_form(hiplib, monkeypatch
         c = HipDepthAnythingV2(sd, "cuda:0")(x).cpu()       # chunk-major layer{3,4}_rn
         span = float(a.max() - a.min())
         assert float((c - a).abs().max()) < 2e-3 * span, (enc, shape, float((c - a).abs().max()), span)
+
+
+@pytest.mark.gpu
+def test_fused_mlp_kernel_matches_the_two_linear_launches(hiplib):
+    """ViT-S: fc1 + GELU + fc2 + residual in one kernel (depth_mlp.hip) against the two gemm launches it replaces, in both forms:
+    the hidden-split pair of workgroups (the default while the grid fits the chip) and the one-workgroup form behind it.  Same
+    fp16 operands and fp32 accumulation; the contraction order of fc2 differs (chained k order, two halves), so not bit-identical.
+    The split form hands fp32 partials from one workgroup to another: every launch is repeated and must reproduce itself."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from conftest import psnr, synth_image
+from oracle import depth_anything_v2 as ODA
+from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1); std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+net = HipDepthAnythingV2(ODA.random_state_dict(601), "cuda:0")
+for shape in ((4, 392, 686), (2, 56, 70), (1, 28, 42), (3, 266, 490)):
+    x = ((torch.stack([synth_image(120 + i, 3, shape[1], shape[2]) for i in range(shape[0])]) - mean) / std).to("cuda:0")
+    os.environ["NUNIF_DA_MLP"] = "0"
+    a = net(x).clone()
+    os.environ["NUNIF_DA_MLP"] = "1"
+    outs = [net(x).clone() for _ in range(4)]
+    span = float(a.max() - a.min())
+    for b in outs:
+        rel = ((a - b).pow(2).mean().sqrt() / a.std()).item()
+        assert torch.isfinite(b).all() and psnr(a / span, b / span) >= 55.0 and rel < 3e-3, (shape, rel)
+        assert torch.equal(b, outs[0]), shape
+print("OK")
+"""
+    for split in ("1", "0"):
+        env = dict(os.environ, NUNIF_DA_MLP_SPLIT=split)        # read once per process by the launcher
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "OK" in r.stdout, (split, r.stdout[-2000:], r.stderr[-2000:])
