@@ -352,7 +352,6 @@ struct nunif_depth_anything {
     std::vector<Blk> blk;
     Lin proj[4], rs0, rs1, rs3g; std::vector<Cnv> rs3; Cnv rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
     Buf a_col, pe, t, y, qkv, att, hid, lnstats, mlp_flags, feat[4], rnb[4], m1, m2, m3, m4, m5, part, col;
-    unsigned mlp_epoch = 0;
 };
 
 namespace {
@@ -742,11 +741,11 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         const bool fresh = ln_bytes > h->lnstats.cap;
         if ((rc = h->lnstats.ensure(ln_bytes))) return rc;
         if (fresh) NUNIF_HIP_CHECK(hipMemsetAsync(h->lnstats.p, 0, h->lnstats.cap, s));
-        // the hidden-split MLP kernel's hand-off flags (one per 64 tokens, compared with a launch counter: zeroed once)
+        // the hidden-split MLP kernel's hand-off flags (one per workgroup, raised by the sender and lowered by the receiver: zeroed once)
         const size_t fl_bytes = (size_t)da_mlp_flag_count(T) * sizeof(unsigned);
         const bool fresh_fl = fl_bytes > h->mlp_flags.cap;
         if ((rc = h->mlp_flags.ensure(fl_bytes))) return rc;
-        if (fresh_fl) { NUNIF_HIP_CHECK(hipMemsetAsync(h->mlp_flags.p, 0, h->mlp_flags.cap, s)); h->mlp_epoch = 0; }
+        if (fresh_fl) NUNIF_HIP_CHECK(hipMemsetAsync(h->mlp_flags.p, 0, h->mlp_flags.cap, s));
     }
     for (int i = 0; i < 4; ++i)
         if ((rc = h->feat[i].ensure(T * kD * e2)) || (rc = h->rnb[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2))) return rc;
@@ -808,7 +807,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             ma.t = t; ma.M = T; ma.w1 = bk.fc1_ln.w; ma.b1 = bk.fc1_ln.b; ma.ws1 = bk.fc1_ln.ws; ma.w2c = bk.fc2c; ma.b2 = bk.fc2_full.b;
             ma.stats_in = lnstats; ma.stats_out = ln1_next ? lnstats : nullptr; ma.ln_eps = 1e-6f;
             if (h->mlp_flags.p && (size_t)da_mlp_partial_bytes(T) <= h->hid.cap) {   // the hidden rows' buffer is free on this path
-                ma.partial = hid; ma.flags = (unsigned *)h->mlp_flags.p; ma.epoch = ++h->mlp_epoch;
+                ma.partial = hid; ma.flags = (unsigned *)h->mlp_flags.p;
             }
             if ((rc = launch_da_mlp(ma, s))) return rc;
             if (tap < 4 && i == h->taps[tap]) {

@@ -6,17 +6,19 @@
 // of it launch ramp, operand latency and the round trip of the 1536-wide hidden rows through HBM (2 x 16.9 MB per layer).
 // Here ONE workgroup owns 32 tokens from their 384-wide rows to their updated 384-wide rows:
 //   * 8 waves split the OUTPUT channels, so every weight fragment is private to one wave and goes straight from L2 into its
-//     registers (no LDS, no barrier for weights): 24 fragments (96 registers) per wave, each reloaded with the fragment the wave
-//     needs 24 fragments later right after its MFMAs — a full 48-MFMA distance, with hipcc's own in-order vmcnt accounting (the
-//     code is straight line);
-//   * phase B (fc1): the 32 rows sit in LDS as B fragments (LDS-DMA'd from HBM), wave w computes hidden tiles 12 w .. 12 w + 11;
+//     registers (no LDS, no barrier for weights): a ring of 24 fragments (96 registers) per wave, each slot reloaded right after
+//     its MFMAs with the fragment the wave needs 24 fragments later, as inline asm with hand-counted s_waitcnt vmcnt(22 / 21)
+//     (left to hipcc, the reloads sink to within two loads of their use);
+//   * phase B (fc1): the 32 rows sit in LDS as B fragments (LDS-DMA'd from HBM), wave w computes hidden pairs w, w + 8, ...;
 //     norm2 is folded into fc1 as in gemm_ws_kernel<LNF>: raw rows, then r (W x) - r mu wsum + b with mu / r from
 //     the 12 partial sums per token that attn.proj wrote; GELU; the hidden tile pair (32 channels) is written to LDS as ONE
 //     chained-order B fragment of fc2 (accumulator tiles ARE k-slots of the next contraction, swin_block_tail.hip);
-//   * phase C (fc2): wave w computes output tiles 3 w .. 3 w + 2 over all 48 hidden fragments, adds the residual rows, stores, and
-//     writes the per-token partial sums of what it stored for the NEXT block's norm1 (12 per token, the format qkv consumes).
-// The hidden activation never leaves the CU.  LDS: 24 (rows) + 96 (hidden) + 9 (statistics) KiB, one workgroup per CU; 172
-// workgroups for 4 x 1080p, one pass.  What bounds it: each CU pulls all 2.36 MB of weights through its own L2 port.
+//   * phase C (fc2): wave w computes output tiles 3 w .. 3 w + 2 over all 48 hidden fragments on top of bias + residual rows
+//     (still in LDS), stores, and writes the per-token partial sums of what it stored for the NEXT block's norm1 (12 per token,
+//     the format qkv consumes).
+// The hidden activation never leaves the CU.  LDS: 24 (rows) + 14 (biases) + 96 (hidden) + 9 (statistics) KiB, one workgroup per
+// CU; 172 workgroups for 4 x 1080p, one pass.  This form is the fallback; the hidden-split pair below is what runs while its grid
+// fits the chip.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -50,7 +52,7 @@ constexpr int kOpOff = kMurOff + kTok * 8;                               // [32]
 constexpr int kSmemM = kOpOff + kTok * kNT2 * 8;
 
 // A weight fragment goes L2 -> registers with no compiler bookkeeping: hipcc sinks its own loads to within two loads of their use
-// (profiles/r04_isa_notes.md), which leaves ~2 KiB in flight per wave.  These are counted by hand instead; every other vector
+// (s_waitcnt vmcnt(1..2) before every MFMA pair, profiles/r04_isa_notes.md), which leaves ~2 KiB in flight per wave.  These are counted by hand instead; every other vector
 // memory operation of the kernel is issued before the first one or after the last.
 __device__ __forceinline__ void wload(f16x8 &dst, unsigned voff, const void *sbase) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_kernel(DaMlpArgs a) {
                     acc[e][mt][2] = fmaf(r, acc[e][mt][2], fmaf(-rm, wv[e].z, bv[e].z));
                     acc[e][mt][3] = fmaf(r, acc[e][mt][3], fmaf(-rm, wv[e].w, bv[e].w));
                 }
-                hl[((T0 >> 1) * 2 + mt) * 64 + lane] = gelu8(acc[0][mt], acc[1][mt]);
+                hl[((T0 >> 1) * 2 + mt) * 64 + lane] = gelu8t(acc[0][mt], acc[1][mt]);
             }
         }
     }
@@ -257,49 +259,57 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_kernel(DaMlpArgs a) {
 }
 
 // ---- the same MLP with the HIDDEN dimension split over a pair of workgroups ---------------------------------------------------
-// What bounds da_mlp_kernel is that every CU pulls all 2.36 MB of weights through its own L1 fill path (~46 B/clk/CU at best,
-// MI355X_MICROARCH "22 cycles per extra L2-hit load": >= 23 us; measured 38).  Here a workgroup owns 64 tokens and ONE HALF of the
-// 1536 hidden channels: half of fc1's rows and half of fc2's contraction = 1.18 MB per CU for the same 576 MFMAs per wave.  The
-// two halves of a token group are blocks 2 g (half 0) and 2 g + 1 (half 1).  Block 2 g writes its fp32 partial output (96 KiB, in
-// accumulator layout) to scratch with write-through stores and raises flag[g] = epoch; block 2 g + 1, whose accumulators started
-// from bias + residual, polls the flag, adds the partial and stores the rows and their statistics.  Both blocks are resident at
-// once (the launcher takes this kernel only while the grid fits the chip: HIP promises no dispatch order), the hand-off is the
-// {sc0 sc1 stores, relaxed agent flag, sc0 sc1 loads} form (MI355X_MICROARCH, inter-workgroup visibility).
+// What bounds da_mlp_kernel: every CU pulls all 2.36 MB of weights through its own L1 at 30-50 B/clk (172 CUs re-reading the same
+// lines from 8 L2s), behind a prologue in which all CUs burst at once — and the chip holds one such workgroup per CU, so the
+// kernel's time is ONE workgroup's chain (38 us at 4 x 1080p; the two GEMM launches it replaces: 49).
+// Here a workgroup owns 64 tokens and ONE HALF of the 1536 hidden channels: half of fc1's rows, half of fc2's contraction, 1.18 MB
+// per CU for the same 576 MFMAs per wave.  Blocks 2 g and 2 g + 1 are the halves of token group g.  In fc2 a block's waves 0-3
+// compute the partial sums of the PARTNER's 192 output channels (they are the older waves of their SIMDs and win its arbitration:
+// they finish first, s_setprio changes nothing), store them fp32 in accumulator layout to scratch with write-through stores and
+// raise flag[block] (the last of the four does); waves 4-7 compute the block's own 192 channels on top of bias + residual, poll
+// the partner's flag, add its partial, and the finished rows go through LDS so that all 8 waves store whole 384-byte runs.  The
+// receiver lowers the flag again: nothing depends on a launch counter, a replayed graph would behave the same.  Both blocks must
+// be resident at once: the launcher takes this kernel only while the grid fits the chip (HIP promises no dispatch order).  The
+// hand-off is the {sc0 sc1 stores, relaxed agent flag, sc0 sc1 loads} form (MI355X_MICROARCH, inter-workgroup visibility).
+// Every vector memory operation is inline asm and counted by hand: the prologue is LDS-DMA (rows, biases, statistics: 62 KiB) with
+// the first 24 weight fragments issued behind it, so that s_waitcnt vmcnt(24) releases the rows while the weights are in flight.
+// Phases of one workgroup (s_memtime, -DNUNIF_MLP_TRACE, profiles/r04_mlp_trace.txt), 49.5 k ticks = 29 us per launch:
+//   prologue 8.4 k | statistics 0.8 | fc1 + GELU 17.6 | barrier 2.3 | fc2 15.1 (senders 8.5) | flag 0.8 | partial in 2.2 | rows out 2.5
+// SQ counters (profiles/r04_mlp_sq.txt): MFMA busy 18.4 k cycles per SIMD of ~64 k; 66 % of wave-cycles in s_waitcnt — on the
+// weight ring: 64 tokens per fragment want 64 B/clk/CU at full MFMA rate, the L2s deliver about 40 with every CU asking.
 namespace {
 constexpr int kTok2 = 64, kMT2 = 4, kPairsHalf = kKS2 / 2;                // 24 hidden pairs (= fc2 k-steps) per half
 constexpr int kY2Bytes = kKS1 * kMT2 * 1024;                             // 48 KiB of rows
-constexpr int kB1Off2 = kY2Bytes, kWsOff2 = kB1Off2 + 3072, kB2Off2 = kWsOff2 + 3072;
-constexpr int kDmaItems2 = (kB2Off2 + 2048) / 1024;                      // 56 items of 1 KiB
-constexpr int kH2Off = kB2Off2 + 2048, kH2Bytes = kPairsHalf * kMT2 * 1024;   // 96 KiB of hidden fragments
+constexpr int kB1Off2 = kY2Bytes, kWsOff2 = kB1Off2 + 3072, kB2Off2 = kWsOff2 + 3072, kSt2Off = kB2Off2 + 2048;
+constexpr int kDmaItems2 = (kSt2Off + kTok2 * kParts * 8) / 1024;        // 62 items of 1 KiB
+constexpr int kH2Off = kDmaItems2 * 1024, kH2Bytes = kPairsHalf * kMT2 * 1024;   // 96 KiB of hidden fragments
 constexpr int kMur2Off = kH2Off + kH2Bytes;
-constexpr int kSmemM2 = kMur2Off + kTok2 * 8;
-constexpr int kSt2Off = kH2Off;                                          // statistics in: dead before the first hidden write
-constexpr int kOp2Off = 0;                                               // partials of the stored rows: over the rows, dead by then
-constexpr int kPartialBytes = kNT2 * kMT2 * 1024;                        // 96 KiB per token group
+constexpr int kSentOff = kMur2Off + kTok2 * 8;                               // count of sending waves that have stored
+constexpr int kSmemM2 = kSentOff + 16;
+constexpr int kOwnTiles = kNT2 / 2;                                      // 12 output tiles per half
+constexpr int kORowBytes = kD + 16;                                      // finished rows in LDS: 192 fp16 + a 16-byte pad (banks)
+constexpr int kPartialBytes = 2 * kOwnTiles * kMT2 * 1024;               // per token group: 48 KiB from each half
+static_assert(kSmemM2 <= 160 * 1024, "LDS");
 }  // namespace
 
-
-// Phase timestamps of the split kernel (-DNUNIF_MLP_TRACE builds only): wave 0 of every workgroup stamps s_memtime at 8 points.
+// Phase timestamps of the split kernel (-DNUNIF_MLP_TRACE builds only): waves 0 and 4 of every workgroup stamp s_memtime.
 #ifdef NUNIF_MLP_TRACE
-__device__ unsigned long long g_mlp_trace[512 * 8];
-#define NUNIF_MLP_STAMP_INIT() const bool stamp_lane_ = threadIdx.x == 0
-#define NUNIF_MLP_STAMP(i) do { if (stamp_lane_ && blockIdx.x < 512) g_mlp_trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long g_mlp_trace[512 * 32];
+#define NUNIF_MLP_STAMP(i) do { if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 512) g_mlp_trace[blockIdx.x * 32 + (wave >> 2) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
-#define NUNIF_MLP_STAMP_INIT()
 #define NUNIF_MLP_STAMP(i)
 #endif
 
 __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a) {
-    NUNIF_MLP_STAMP_INIT();
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_m[];
     const f16x8 *yl = reinterpret_cast<const f16x8 *>(smem_m);
     const float *b1l = reinterpret_cast<const float *>(smem_m + kB1Off2);
     const float *wsl = reinterpret_cast<const float *>(smem_m + kWsOff2);
     const float *b2l = reinterpret_cast<const float *>(smem_m + kB2Off2);
     f16x8 *hl = reinterpret_cast<f16x8 *>(smem_m + kH2Off);
-    float2 *stl = reinterpret_cast<float2 *>(smem_m + kSt2Off);
+    const float2 *stl = reinterpret_cast<const float2 *>(smem_m + kSt2Off);
     float2 *mur = reinterpret_cast<float2 *>(smem_m + kMur2Off);
-    float2 *opl = reinterpret_cast<float2 *>(smem_m + kOp2Off);
+    int *sent = reinterpret_cast<int *>(smem_m + kSentOff);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, r16 = lane & 15, grp = lane >> 4;
@@ -309,21 +319,21 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
     const unsigned voff = (unsigned)lane * 16u;
     NUNIF_MLP_STAMP(0);
 
-    // fc1: this half's tiles are 48 half .. 48 half + 47; wave w owns the local pairs w, w + 8, w + 16 (L2 channels: as above)
-    // fc2: this half's k-steps are 24 half .. + 23 = blocks 6 half .. 6 half + 5 of the packed [ks / 4][tile][ks % 4] order
+    // fc1: this half's tiles are 48 half .. 48 half + 47; wave w owns the local pairs w, w + 8, w + 16 (L2 channels: as above).
+    // fc2: this half's k-steps are 24 half .. + 23 = blocks 6 half .. 6 half + 5 of the packed [ks / 4][tile][ks % 4] order; waves
+    // 0-3 take the partner's tiles, waves 4-7 this block's own, three each.
+    const int role = wave >> 2, wl = wave & 3;                                // role 0: send, role 1: finish
+    const int tile0 = kOwnTiles * (role ? half : 1 - half) + 3 * wl;          // first of the wave's three output tiles
     const unsigned char *w1w = reinterpret_cast<const unsigned char *>(a.w1) + (long)(48 * half + 2 * wave) * kKS1 * 1024;
-    const unsigned char *w2w = reinterpret_cast<const unsigned char *>(a.w2c) + (long)(6 * half * kNT2 + 3 * wave) * 4096;
+    const unsigned char *w2w = reinterpret_cast<const unsigned char *>(a.w2c) + (long)(6 * half * kNT2 + tile0) * 4096;
     auto w1_at = [&](int pair, int e, int ks) { return w1w + ((2 * kWavesM * pair + e) * kKS1 + ks) * 1024; };
     auto w2_at = [&](int n, int k) { return w2w + (((k >> 2) * kNT2 + n) * 4 + (k & 3)) * 1024; };
 
-    f16x8 wq[kRing];
-#pragma unroll
-    for (int j = 0; j < kRing; ++j) wload(wq[j], voff, w1_at(0, j & 1, j >> 1));
-
+    // ---- prologue: rows, bias vectors, statistics -> LDS by DMA (62 items over 8 waves), then the ring's first tenants -----------
     {
         const unsigned lds0 = (unsigned)reinterpret_cast<size_t>(smem_m);
 #pragma unroll
-        for (int u = 0; u < kDmaItems2 / kWavesM; ++u) {
+        for (int u = 0; u < (kDmaItems2 + kWavesM - 1) / kWavesM; ++u) {
             const int i = wave + kWavesM * u;
             const void *src;
             if (i < kKS1 * kMT2) {
@@ -335,20 +345,25 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
                 src = a.b1 + half * (kH / 2) + (i - kKS1 * kMT2) * 256 + lane * 4;
             } else if (i < kKS1 * kMT2 + 6) {
                 src = a.ws1 + half * (kH / 2) + (i - kKS1 * kMT2 - 3) * 256 + lane * 4;
-            } else {
+            } else if (i < kKS1 * kMT2 + 8) {
                 const int q = (i - kKS1 * kMT2 - 6) * 256 + lane * 4;
                 src = a.b2 + (q < kD ? q : kD - 4);
+            } else {
+                const int e = (i - kKS1 * kMT2 - 8) * 128 + 2 * lane;           // two of a token's 12 (sum, sum of squares) pairs
+                long m = m0 + e / kParts;
+                m = m < a.M ? m : a.M - 1;
+                src = a.stats_in + m * kParts + e % kParts;
             }
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds0 + (unsigned)i * 1024)
-                         : "memory");
-        }
-        for (int idx = tid; idx < kTok2 * kParts; idx += kWavesM * 64) {
-            long m = m0 + idx / kParts;
-            m = m < a.M ? m : a.M - 1;
-            stl[idx] = a.stats_in[m * kParts + idx % kParts];
+            // waves 6, 7 have one item less; their counted wait below still covers what they issued
+            if (i < kDmaItems2)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds0 + (unsigned)i * 1024)
+                             : "memory");
         }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    f16x8 wq[kRing];
+#pragma unroll
+    for (int j = 0; j < kRing; ++j) wload(wq[j], voff, w1_at(0, j & 1, j >> 1));
+    asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
     NUNIF_MLP_STAMP(1);
     if (tid < kTok2) {
         float su = 0.f, sq = 0.f;
@@ -357,6 +372,7 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
         const float mu = su * (1.0f / kD);
         const float var = fmaxf(sq * (1.0f / kD) - mu * mu, 0.f);
         mur[tid] = make_float2(mu, rsqrtf(var + a.ln_eps));
+        if (tid == 0) *sent = 0;
     }
     __syncthreads();
     NUNIF_MLP_STAMP(2);
@@ -366,6 +382,9 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
         float2 mr[kMT2];
 #pragma unroll
         for (int mt = 0; mt < kMT2; ++mt) mr[mt] = mur[16 * mt + r16];
+        f16x8 yb[2][kMT2];
+#pragma unroll
+        for (int mt = 0; mt < kMT2; ++mt) yb[0][mt] = yl[mt * 64 + lane];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int Pl = wave + kWavesM * p;                                  // local pair = local k-step of fc2
@@ -376,14 +395,16 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
                 for (int mt = 0; mt < kMT2; ++mt) acc[e][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < kKS1; ++ks) {
-                f16x8 y[kMT2];
+                // the NEXT k-step's rows are read before this one's MFMAs; the rows are the same for every pair.  (Same-box A/B
+                // against reading and waiting at once: no difference — the waves wait on the weight ring, not on LDS.)
+                f16x8 *yc = yb[ks & 1], *yn = yb[(ks & 1) ^ 1];
 #pragma unroll
-                for (int mt = 0; mt < kMT2; ++mt) y[mt] = yl[(ks * kMT2 + mt) * 64 + lane];
+                for (int mt = 0; mt < kMT2; ++mt) yn[mt] = yl[(((ks + 1) % kKS1) * kMT2 + mt) * 64 + lane];
                 vm_wait2(22, wq[2 * ks], wq[2 * ks + 1]);
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int mt = 0; mt < kMT2; ++mt) acc[e][mt] = MFMA_16x16x32(wq[2 * ks + e], y[mt], acc[e][mt]);
+                    for (int mt = 0; mt < kMT2; ++mt) acc[e][mt] = MFMA_16x16x32(wq[2 * ks + e], yc[mt], acc[e][mt]);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int j = 2 * ks + e;
@@ -407,24 +428,21 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
                     acc[e][mt][2] = fmaf(r, acc[e][mt][2], fmaf(-rm, wv[e].z, bv[e].z));
                     acc[e][mt][3] = fmaf(r, acc[e][mt][3], fmaf(-rm, wv[e].w, bv[e].w));
                 }
-                hl[(Pl * kMT2 + mt) * 64 + lane] = gelu8(acc[0][mt], acc[1][mt]);
+                hl[(Pl * kMT2 + mt) * 64 + lane] = gelu8t(acc[0][mt], acc[1][mt]);
             }
         }
     }
     NUNIF_MLP_STAMP(3);
-    __syncthreads();
-    NUNIF_MLP_STAMP(4);
-
-    // ---- phase C: output tiles 3 w .. 3 w + 2 over this half's 24 hidden fragments -----------------------------------------------
+    // ---- phase C: three output tiles per wave over this half's 24 hidden fragments ------------------------------------------------
     constexpr int NW = 3, GK = 8;
     f32x4 acc[NW][kMT2];
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
-        const int N = NW * wave + n;
+        const int N = tile0 + n;
         const float4 bb = *reinterpret_cast<const float4 *>(b2l + N * 16 + 4 * grp);
 #pragma unroll
         for (int mt = 0; mt < kMT2; ++mt) {
-            if (half) {     // bias + residual row (still in LDS) ride on the half that finishes
+            if (role) {     // bias + residual row ride on the waves that finish; read BEFORE the barrier: the rows' LDS is free after it
                 const f16x4 rv = *reinterpret_cast<const f16x4 *>(
                     reinterpret_cast<const f16 *>(yl + ((N >> 1) * kMT2 + mt) * 64 + (2 * (N & 1) + (grp >> 1)) * 16 + r16) + 4 * (grp & 1));
                 acc[n][mt] = (f32x4){bb.x + (float)rv[0], bb.y + (float)rv[1], bb.z + (float)rv[2], bb.w + (float)rv[3]};
@@ -433,12 +451,19 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
             }
         }
     }
+    __syncthreads();
+    NUNIF_MLP_STAMP(4);
+    f16x8 hb[2][kMT2];
+#pragma unroll
+    for (int mt = 0; mt < kMT2; ++mt) hb[0][mt] = hl[mt * 64 + lane];
 #pragma unroll
     for (int k = 0; k < kPairsHalf; ++k) {
         const int sl = k % GK;
-        f16x8 hf[kMT2];
+        f16x8 *hf = hb[k & 1], *hn = hb[(k & 1) ^ 1];
+        if (k + 1 < kPairsHalf) {
 #pragma unroll
-        for (int mt = 0; mt < kMT2; ++mt) hf[mt] = hl[(k * kMT2 + mt) * 64 + lane];
+            for (int mt = 0; mt < kMT2; ++mt) hn[mt] = hl[((k + 1) * kMT2 + mt) * 64 + lane];
+        }
         vm_wait3(k + GK < kPairsHalf ? 21 : 21 - 3 * (k + GK - kPairsHalf), wq[3 * sl], wq[3 * sl + 1], wq[3 * sl + 2]);
 #pragma unroll
         for (int n = 0; n < NW; ++n)
@@ -449,11 +474,13 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
             for (int n = 0; n < NW; ++n) wload(wq[3 * sl + n], voff, w2_at(n, k + GK));
         }
     }
-
     NUNIF_MLP_STAMP(5);
-    unsigned char *part = reinterpret_cast<unsigned char *>(a.partial) + (long)g * kPartialBytes + (long)(NW * wave) * kMT2 * 1024;
-    if (!half) {
-        // the partial, in accumulator layout: [tile][mt][lane] x 16 bytes, write-through
+
+    // scratch: [token group][sending half][local tile 12][mt 4][lane] x 16 bytes
+    unsigned char *pbase = reinterpret_cast<unsigned char *>(a.partial) + (long)g * kPartialBytes;
+    unsigned char *orow = smem_m;                                               // [64 tokens][192 channels] fp16, rows kORowBytes apart
+    if (!role) {
+        unsigned char *part = pbase + (long)(half * kOwnTiles + 3 * wl) * kMT2 * 1024;
 #pragma unroll
         for (int n = 0; n < NW; ++n)
 #pragma unroll
@@ -461,17 +488,17 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
                 asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(acc[n][mt]), "s"(part + (n * kMT2 + mt) * 1024)
                              : "memory");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.flags + g, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        NUNIF_MLP_STAMP(7);
-        return;
-    }
-    if (tid == 0) {
-        while (__hip_atomic_load(a.flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();                                                            // also: every wave is past its reads of the rows
-    NUNIF_MLP_STAMP(6);
-    {
+        // the last of the four sending waves (its own stores and, by the LDS counter's order, the others' are complete) raises the flag
+        if (lane == 0 && atomicAdd(sent, 1) == 3) __hip_atomic_store(a.flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        NUNIF_MLP_STAMP(8);
+    } else {
+        if (lane == 0) {
+            while (__hip_atomic_load(a.flags + (blockIdx.x ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_wave_barrier();
+        NUNIF_MLP_STAMP(6);
+        const unsigned char *part = pbase + (long)((1 - half) * kOwnTiles + 3 * wl) * kMT2 * 1024;
         f32x4 pv[NW][kMT2];
 #pragma unroll
         for (int n = 0; n < NW; ++n)
@@ -481,30 +508,38 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
 #pragma unroll
         for (int n = 0; n < NW; ++n)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[n][0]), "+v"(pv[n][1]), "+v"(pv[n][2]), "+v"(pv[n][3]));
+        NUNIF_MLP_STAMP(9);
+        // the finished rows go through LDS (the input rows' space) so that the global stores are whole 384-byte runs
 #pragma unroll
         for (int n = 0; n < NW; ++n)
 #pragma unroll
             for (int mt = 0; mt < kMT2; ++mt) {
-                const long m = m0 + 16 * mt + r16;
                 const f32x4 v = acc[n][mt] + pv[n][mt];
                 const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                if (m < a.M) *reinterpret_cast<f16x4 *>(a.t + m * kD + (NW * wave + n) * 16 + 4 * grp) = o;
-                if (a.stats_out) {
-                    const float v0 = (float)o[0], v1 = (float)o[1], v2 = (float)o[2], v3 = (float)o[3];
-                    float su = (v0 + v1) + (v2 + v3), sq = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-                    su += __shfl_xor(su, 16); sq += __shfl_xor(sq, 16);
-                    su += __shfl_xor(su, 32); sq += __shfl_xor(sq, 32);
-                    if (grp == 0) opl[(16 * mt + r16) * kNT2 + NW * wave + n] = make_float2(su, sq);
-                }
+                *reinterpret_cast<f16x4 *>(orow + (16 * mt + r16) * kORowBytes + ((3 * wl + n) * 16 + 4 * grp) * 2) = o;
             }
     }
-    if (a.stats_out) {
-        __syncthreads();
-        for (int idx = tid; idx < kTok2 * kParts; idx += kWavesM * 64) {
-            const int tok = idx / kParts, q = idx % kParts;
-            const float2 u = opl[tok * kNT2 + 2 * q], v = opl[tok * kNT2 + 2 * q + 1];
-            if (m0 + tok < a.M) a.stats_out[(m0 + tok) * kParts + q] = make_float2(u.x + v.x, u.y + v.y);
+    NUNIF_MLP_STAMP(10);
+    __syncthreads();
+    // all four finishing waves have seen the partner's flag: lower it for the next launch (stream order makes that visible)
+    if (tid == 0) __hip_atomic_store(a.flags + (blockIdx.x ^ 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int j = 0; j < kTok2 * 24 / (kWavesM * 64); ++j) {
+        const int c = tid + kWavesM * 64 * j, tok = c / 24, ch = c % 24;            // 16-byte chunk ch of this half's 192 channels
+        const f16x8 v = *reinterpret_cast<const f16x8 *>(orow + tok * kORowBytes + ch * 16);
+        if (m0 + tok < a.M) *reinterpret_cast<f16x8 *>(a.t + (m0 + tok) * kD + half * (kD / 2) + ch * 8) = v;
+    }
+    if (a.stats_out && tid < kTok2 * (kParts / 2)) {
+        // this block's six of a token's twelve partials (32-channel pairs of its own 192 channels), from the fp16 values as stored
+        const int tok = tid / (kParts / 2), q = tid % (kParts / 2);
+        float su = 0.f, sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f16x8 v = *reinterpret_cast<const f16x8 *>(orow + tok * kORowBytes + q * 64 + u * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float x = (float)v[e]; su += x; sq = fmaf(x, x, sq); }
         }
+        if (m0 + tok < a.M) a.stats_out[(m0 + tok) * kParts + half * (kParts / 2) + q] = make_float2(su, sq);
     }
     NUNIF_MLP_STAMP(7);
 }
@@ -512,7 +547,7 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
 bool da_mlp_supported(int D, int hidden) { return D == kD && hidden == kH; }
 
 long da_mlp_partial_bytes(long M) { return ((M + kTok2 - 1) / kTok2) * (long)kPartialBytes; }
-long da_mlp_flag_count(long M) { return (M + kTok2 - 1) / kTok2; }
+long da_mlp_flag_count(long M) { return 2 * ((M + kTok2 - 1) / kTok2); }   // one per block, zero between launches
 
 int launch_da_mlp(const DaMlpArgs &a, hipStream_t s) {
     NUNIF_REQUIRE(a.t && a.w1 && a.b1 && a.ws1 && a.w2c && a.b2 && a.stats_in && a.M > 0, "da_mlp: bad argument");
@@ -540,24 +575,23 @@ int launch_da_mlp(const DaMlpArgs &a, hipStream_t s) {
     {
         static int dumped = 0;
         if (a.partial && dumped < 40 && ++dumped >= 38) {
-            static unsigned long long host[512 * 8];
+            static unsigned long long host[512 * 32];
             NUNIF_HIP_CHECK(hipStreamSynchronize(s));
             NUNIF_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mlp_trace), sizeof(host)));
             const int nb = (int)std::min<long>(2 * groups, 512);
-            unsigned long long t0 = ~0ull;
-            for (int b = 0; b < nb; ++b) t0 = std::min(t0, host[b * 8]);
-            double avg[8] = {0}, mx[8] = {0};
-            for (int b = 0; b < nb; ++b)
-                for (int i = 0; i < 8; ++i) { const double v = (double)(host[b * 8 + i] - t0); avg[i] += v / nb; mx[i] = std::max(mx[i], v); }
-            fprintf(stderr, "[mlp trace] blocks %d  avg:", nb);
-            for (int i = 0; i < 8; ++i) fprintf(stderr, " %.0f", avg[i]);
-            fprintf(stderr, "  max:");
-            for (int i = 0; i < 8; ++i) fprintf(stderr, " %.0f", mx[i]);
-            fprintf(stderr, "\n  even(avg 5,7):");
-            double e5 = 0, e7 = 0, o5 = 0, o6 = 0, o7 = 0;
-            for (int b = 0; b < nb; b += 2) { e5 += (double)(host[b * 8 + 5] - t0); e7 += (double)(host[b * 8 + 7] - t0); }
-            for (int b = 1; b < nb; b += 2) { o5 += (double)(host[b * 8 + 5] - t0); o6 += (double)(host[b * 8 + 6] - t0); o7 += (double)(host[b * 8 + 7] - t0); }
-            fprintf(stderr, " %.0f %.0f  odd(avg 5,6,7): %.0f %.0f %.0f\n", e5 / (nb / 2), e7 / (nb / 2), o5 / (nb / 2), o6 / (nb / 2), o7 / (nb / 2));
+            for (int role = 0; role < 2; ++role) {
+                double avg[12] = {0}, mx[12] = {0};
+                for (int b = 0; b < nb; ++b)
+                    for (int i = 0; i < 12; ++i) {
+                        const double v = (double)(long long)(host[b * 32 + role * 16 + i] - host[b * 32]);
+                        avg[i] += v / nb; mx[i] = std::max(mx[i], v);
+                    }
+                fprintf(stderr, "[mlp trace] role %d blocks %d  avg:", role, nb);
+                for (int i = 0; i < 12; ++i) fprintf(stderr, " %.0f", avg[i]);
+                fprintf(stderr, "  max:");
+                for (int i = 0; i < 12; ++i) fprintf(stderr, " %.0f", mx[i]);
+                fprintf(stderr, "\n");
+            }
         }
     }
 #endif

@@ -68,8 +68,8 @@ struct DaMlpArgs {
     const f16 *w1; const float *b1, *ws1;
     const f16 *w2c; const float *b2;
     const float2 *stats_in; float2 *stats_out; float ln_eps;
-    // hidden-split form (optional): scratch of da_mlp_partial_bytes(M), da_mlp_flag_count(M) flags zeroed once, a launch counter
-    void *partial; unsigned *flags; unsigned epoch;
+    // hidden-split form (optional): scratch of da_mlp_partial_bytes(M) and da_mlp_flag_count(M) flags, zeroed once
+    void *partial; unsigned *flags;
 };
 bool da_mlp_supported(int D, int hidden);
 long da_mlp_partial_bytes(long M);

@@ -204,6 +204,6 @@ print("OK")
 """
     for split in ("1", "0"):
         env = dict(os.environ, NUNIF_DA_MLP_SPLIT=split)        # read once per process by the launcher
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "OK" in r.stdout, (split, r.stdout[-2000:], r.stderr[-2000:])
