@@ -170,8 +170,14 @@ def cpu_baseline(sd, frame):
             "sample": sample + "; tools/cpu_ref_vs_port.py gives the reference / port ratio measured in the build container"}, crop, out
 
 
-def pmc_traffic_bytes(symbol):
-    """HBM bytes per launch of ``symbol`` from the newest committed PMC summaries (profiles/rNN_pmc_*.txt) that list it."""
+# PMC summaries of workloads other than the headline bench: the same kernel symbol runs other shapes there, so they are looked up
+# by name only (profiles/<tag>_pmc_{FETCH,WRITE}_SIZE.txt, written by tools/profile_cunet.sh / tools/profile_config5.sh)
+WORKLOAD_PMC = {"cunet": "r04c", "config5": "r04f"}
+
+
+def pmc_traffic_bytes(symbol, only=None):
+    """HBM bytes per launch of ``symbol`` from the newest committed PMC summaries (profiles/rNN_pmc_*.txt) that list it; ``only``
+    names the one summary set to read (a workload of its own, WORKLOAD_PMC)."""
     def per_launch(path):
         key = re.sub(r"[^A-Za-z0-9]", "", symbol.split("<")[0])
         args = re.findall(r"\d+", symbol.split("<", 1)[1]) if "<" in symbol else []
@@ -189,6 +195,7 @@ def pmc_traffic_bytes(symbol):
     pdir = os.path.join(ROOT, "profiles")
     rounds = sorted({re.match(r"(r\d\d[a-z]{0,2})_pmc_FETCH_SIZE", f).group(1) for f in os.listdir(pdir)
                      if re.match(r"r\d\d[a-z]{0,2}_pmc_FETCH_SIZE", f)}) if os.path.isdir(pdir) else []
+    rounds = [only] if only else [r for r in rounds if r not in WORKLOAD_PMC.values()]
     for r in reversed(rounds):
         fetch = per_launch(os.path.join(pdir, f"{r}_pmc_FETCH_SIZE.txt"))
         write = per_launch(os.path.join(pdir, f"{r}_pmc_WRITE_SIZE.txt"))
@@ -210,13 +217,13 @@ def kernel_table(recs, n_frames):
     return classes
 
 
-def roofline_of(rec, with_pmc=True):
+def roofline_of(rec, with_pmc=True, pmc_set=None):
     n = max(1, rec["launches"])
     avg_s = rec["total_ms"] * 1e-3 / n
     flops_l, bytes_l = rec["flops"] / n, rec["bytes"] / n
     intensity = flops_l / bytes_l if bytes_l else float("inf")
     ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-    traffic, src = pmc_traffic_bytes(rec["name"]) if with_pmc else (None, None)
+    traffic, src = pmc_traffic_bytes(rec["name"], pmc_set) if with_pmc else (None, None)
     if intensity >= ridge:
         ach = flops_l / avg_s / 1e12
         roof = {"kernel": rec["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
@@ -419,7 +426,7 @@ def cunet_record(dev, with_cpu):
     if recs:
         rec["kernel_classes"] = kernel_table(recs, 3)[:6]
         dom = max(recs, key=lambda r: r["total_ms"])
-        rec["roofline"] = roofline_of(dom, with_pmc=False)
+        rec["roofline"] = roofline_of(dom, pmc_set=WORKLOAD_PMC["cunet"])
         conv_ms = sum(r["total_ms"] for r in recs if r["flops"] > 0) / 3
         tiles = 66
         rec["model_tflops"] = round(tiles * 28e9 / (rec["frame_1080p"]["ms"] * 1e-3) / 1e12, 1)
@@ -510,7 +517,7 @@ def config5_record(dev):
     if recs:
         rec["kernel_classes"] = kernel_table(recs, 4 * batch)[:8]
         dom = max(recs, key=lambda r: r["total_ms"])
-        rec["roofline"] = roofline_of(dom, with_pmc=False)
+        rec["roofline"] = roofline_of(dom, pmc_set=WORKLOAD_PMC["config5"])
     side.reset()
     return rec
 
