@@ -321,26 +321,26 @@ __global__ void __launch_bounds__(256) li_tmix_gate_kernel(const f16 *__restrict
 template <int C2>
 __global__ void __launch_bounds__(256) li_gate_kernel(const f16 *__restrict__ a, const f16 *__restrict__ st, f16 *__restrict__ g,
                                                        int B, int hp, int wp, int ws) {
+    // one thread = one 16-byte run of a token: neighbouring lanes read and write neighbouring runs (a thread per token stored
+    // 16 bytes into 64 different lines per instruction: WRITE_SIZE 3.2x the output, profiles/r04f_pmc_*)
+    constexpr int R = C2 / 8;
     const int N = ws * ws, nwx = wp / ws, nwy = hp / ws;
-    const long n = (long)B * hp * wp, id = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)B * hp * wp * R, id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= n) return;
-    const long win = id / N;
-    const int tn = (int)(id - win * N);
+    const long tw = id / R;                       // token in window order
+    const int i = (int)(id - tw * R);
+    const long win = tw / N;
+    const int tn = (int)(tw - win * N);
     const int wx = (int)(win % nwx);
     const long t2 = win / nwx;
     const int wy = (int)(t2 % nwy), b = (int)(t2 / nwy);
     const long tok = ((long)b * hp + wy * ws + tn / ws) * wp + wx * ws + tn % ws;
-    const f16x8 *u = reinterpret_cast<const f16x8 *>(a + tok * (2 * C2));
-    const f16 *s = st + (win * C2) * N + tn;
-    f16x8 *o = reinterpret_cast<f16x8 *>(g + tok * C2);
+    const f16x8 uv = reinterpret_cast<const f16x8 *>(a + tok * (2 * C2))[i];
+    const f16 *s = st + (win * C2 + 8 * i) * N + tn;
+    f16x8 r;
 #pragma unroll
-    for (int i = 0; i < C2 / 8; ++i) {
-        const f16x8 uv = u[i];
-        f16x8 r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (f16)((float)uv[j] * (float)s[(long)(8 * i + j) * N]);
-        o[i] = r;
-    }
+    for (int j = 0; j < 8; ++j) r[j] = (f16)((float)uv[j] * (float)s[(long)j * N]);
+    reinterpret_cast<f16x8 *>(g + tok * C2)[i] = r;
 }
 
 // x = x + crop(proj_out(...) + shortcut) with shortcut = the (padded) block input: x <- 2 x + crop(po)
@@ -595,7 +595,7 @@ int run_gblock(nunif_light_inpaint *h, const GBlock &g, f16 *x, int B, int hh, i
         // token mixing: rows = (window, channel), K = tokens of the window
         if ((rc = lin(g.spatial, vt, wins * V, N, 0, 0.f, nullptr, st, s, "li_spatial"))) return rc;
         ProfScope ps("li_gate_kernel", s, 0.0, (double)tokp * V * 6.0);
-        li_gate_kernel<V><<<bp, 256, 0, s>>>(pi, st, gg, B, hp, wp, g.ws);
+        li_gate_kernel<V><<<(unsigned)((tokp * (V / 8) + 255) / 256), 256, 0, s>>>(pi, st, gg, B, hp, wp, g.ws);
     }
     if ((rc = lin(g.proj_out, gg, tokp, C, 0, 0.f, nullptr, po, s, "li_proj_out"))) return rc;
     {
