@@ -321,26 +321,39 @@ __global__ void __launch_bounds__(256) li_tmix_gate_kernel(const f16 *__restrict
 template <int C2>
 __global__ void __launch_bounds__(256) li_gate_kernel(const f16 *__restrict__ a, const f16 *__restrict__ st, f16 *__restrict__ g,
                                                        int B, int hp, int wp, int ws) {
-    // one thread = one 16-byte run of a token: neighbouring lanes read and write neighbouring runs (a thread per token stored
-    // 16 bytes into 64 different lines per instruction: WRITE_SIZE 3.2x the output, profiles/r04f_pmc_*)
-    constexpr int R = C2 / 8;
-    const int N = ws * ws, nwx = wp / ws, nwy = hp / ws;
-    const long n = (long)B * hp * wp * R, id = (long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= n) return;
-    const long tw = id / R;                       // token in window order
-    const int i = (int)(id - tw * R);
-    const long win = tw / N;
-    const int tn = (int)(tw - win * N);
+    // g[token][c] = u[token][c] * s[window][c][token in window]: the gate s comes out of the token-mixing GEMM channel-major, the
+    // tokens are channel-minor.  A workgroup owns (window, 64 channels): the 64 x N gate tile goes through LDS (coalesced in, read
+    // transposed), so that u is read and g written as whole 128-byte runs per token.  A thread per token moved 16 bytes into 64
+    // different lines per instruction (WRITE_SIZE 3.2x the output, 2 006 us); a thread per 16-byte run with the gate gathered
+    // straight from L2 1 845 us (profiles/r04f_pmc_*).
+    constexpr int CB = 64, NCB = C2 / CB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char li_gate_smem[];
+    f16 *sl = reinterpret_cast<f16 *>(li_gate_smem);                       // [64][N + 2]: the + 2 spreads the transposed reads over banks
+    const int N = ws * ws, nwx = wp / ws, nwy = hp / ws, ld = N + 2;
+    const long win = blockIdx.x / NCB;
+    const int cb = blockIdx.x % NCB;
     const int wx = (int)(win % nwx);
     const long t2 = win / nwx;
     const int wy = (int)(t2 % nwy), b = (int)(t2 / nwy);
-    const long tok = ((long)b * hp + wy * ws + tn / ws) * wp + wx * ws + tn % ws;
-    const f16x8 uv = reinterpret_cast<const f16x8 *>(a + tok * (2 * C2))[i];
-    const f16 *s = st + (win * C2 + 8 * i) * N + tn;
-    f16x8 r;
+    const int tid = threadIdx.x;
+    const f16 *sg = st + (win * C2 + cb * CB) * N;
+    for (int p = tid; p < CB * N / 8; p += 256) {                           // 16-byte pieces: channel p / (N / 8), tokens 8 (p % (N / 8)) ..
+        const int c = p / (N / 8), off = p % (N / 8);
+        const f16x8 v = *reinterpret_cast<const f16x8 *>(sg + (long)c * N + 8 * off);
+        unsigned int *d = reinterpret_cast<unsigned int *>(sl + c * ld + 8 * off);     // ld is even: 4-byte aligned
+        const unsigned int *w = reinterpret_cast<const unsigned int *>(&v);
+        d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+    }
+    __syncthreads();
+    for (int it = tid; it < N * (CB / 8); it += 256) {
+        const int ch = it & 7, tn = it >> 3;                                // 8 lanes = the 128 bytes of one token's 64 channels
+        const long tok = ((long)b * hp + wy * ws + tn / ws) * wp + wx * ws + tn % ws;
+        const f16x8 uv = *reinterpret_cast<const f16x8 *>(a + tok * (2 * C2) + cb * CB + 8 * ch);
+        f16x8 r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (f16)((float)uv[j] * (float)s[(long)j * N]);
-    reinterpret_cast<f16x8 *>(g + tok * C2)[i] = r;
+        for (int j = 0; j < 8; ++j) r[j] = (f16)((float)uv[j] * (float)sl[(8 * ch + j) * ld + tn]);
+        *reinterpret_cast<f16x8 *>(g + tok * C2 + cb * CB + 8 * ch) = r;
+    }
 }
 
 // x = x + crop(proj_out(...) + shortcut) with shortcut = the (padded) block input: x <- 2 x + crop(po)
@@ -595,7 +608,7 @@ int run_gblock(nunif_light_inpaint *h, const GBlock &g, f16 *x, int B, int hh, i
         // token mixing: rows = (window, channel), K = tokens of the window
         if ((rc = lin(g.spatial, vt, wins * V, N, 0, 0.f, nullptr, st, s, "li_spatial"))) return rc;
         ProfScope ps("li_gate_kernel", s, 0.0, (double)tokp * V * 6.0);
-        li_gate_kernel<V><<<(unsigned)((tokp * (V / 8) + 255) / 256), 256, 0, s>>>(pi, st, gg, B, hp, wp, g.ws);
+        li_gate_kernel<V><<<(unsigned)(wins * (V / 64)), 256, (size_t)64 * (N + 2) * sizeof(f16), s>>>(pi, st, gg, B, hp, wp, g.ws);
     }
     if ((rc = lin(g.proj_out, gg, tokp, C, 0, 0.f, nullptr, po, s, "li_proj_out"))) return rc;
     {

@@ -410,7 +410,11 @@ static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym,
     // slower for the MF = 4 shapes (K = 96, 192), which keep the ring (re-checked at the end of round 2: PatchDown through the
     // ring 134 us, resident 112 us).
     const bool fits = wbytes <= 144 * 1024 && M >= 8 * MF * 16 * 64;
-    const bool res = fits && !ring_only && MF == 2 && g.res_W == 0;     // (the cropped residual exists in the ring form only)
+    // ... and for the plain K = 192 Linears over millions of tokens (the inpaint net's proj_out at 4K, config 5: 3.4 M tokens x
+    // (384 B in + 192 B out)): the ring form is one 256-token tile per workgroup and all prologue, 1 040 us = 1.9 TB/s; resident
+    // 543 us = 3.2 TB/s.  K = 96 measured equal (stays on the ring).
+    const bool big_plain = MF == 4 && KS == 6 && g.mode == 0 && M >= (1L << 20);
+    const bool res = fits && !ring_only && (MF == 2 || big_plain) && g.res_W == 0;     // (the cropped residual exists in the ring form only)
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
     // (NUNIF_PROF_TAGS=1 names the class after the call site instead: separates e.g. the two gemm_kernel<6,4> users)
     ProfScope ps(g_prof_tag ? g_prof_tag : res ? res_sym : ring_sym, s, flops, bytes);
