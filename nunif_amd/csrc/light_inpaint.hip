@@ -444,7 +444,13 @@ struct Buf {
 };
 
 struct Lin { f16 *w = nullptr; float *bias = nullptr; int N = 0, K = 0; };                 // gemm_kernel packing [nt][ks]
-struct Conv3 { f16 *stream = nullptr; float *bias = nullptr; int N = 0, n_real = 0, Cin = 0; };   // conv_kernel stream [ks][nt]
+struct Conv3 {                                                  // conv_kernel stream [ks][nt]
+    f16 *stream = nullptr; float *bias = nullptr; int N = 0, n_real = 0, Cin = 0;
+    // the same weights as streams of OUTPUT-CHANNEL SLICES whose tile counts the LDS-staged convs take (conv3_dma: Cin 32 / 64,
+    // 1 / 2 / 4 / 8 tiles; conv3_lds: Cin <= 128, the same counts): 96 = 64 + 32, 192 = 128 + 64.  A slice writes its channels
+    // of the NHWC map through ConvArgs::ldo; the input patch is staged once per slice.
+    f16 *slice_stream[2] = {nullptr, nullptr}; int slice_nt[2] = {0, 0}, n_slices = 0;
+};
 struct GBlock {
     int C = 0, V = 0, ws = 0, shift = 0, temporal = 0;      // V = gate / value width (mlp_ratio * C); temporal: window (12,1,1)
     TMix tmix;
@@ -522,6 +528,22 @@ int make_conv3(nunif_light_inpaint *h, const TMap &m, const std::string &key, in
     std::copy(b->data, b->data + cout, bias.begin());
     c->N = N; c->n_real = cout; c->Cin = cin;
     if ((rc = upload(h, stream, &c->stream))) return rc;
+    if ((NT == 6 || NT == 12) && cout == N && cin <= 128) {
+        const int parts[2] = {NT == 6 ? 4 : 8, NT == 6 ? 2 : 4};
+        int nt0 = 0;
+        for (int q = 0; q < 2; ++q) {
+            const int nts = parts[q];
+            std::vector<f16> sl((size_t)KS * nts * 512 + 8192, (f16)0.f);
+            for (int ks = 0; ks < KS; ++ks)
+                for (int nt = 0; nt < nts; ++nt)
+                    std::copy(stream.begin() + ((size_t)ks * NT + nt0 + nt) * 512, stream.begin() + ((size_t)ks * NT + nt0 + nt + 1) * 512,
+                              sl.begin() + ((size_t)ks * nts + nt) * 512);
+            if ((rc = upload(h, sl, &c->slice_stream[q]))) return rc;
+            c->slice_nt[q] = nts;
+            nt0 += nts;
+        }
+        c->n_slices = 2;
+    }
     return upload(h, bias, &c->bias);
 }
 
@@ -567,6 +589,27 @@ int make_gblock(nunif_light_inpaint *h, const TMap &m, const std::string &p, int
     return make_conv3(h, m, p + "glu_conv.w2", C / 2, (C / 2 + 31) / 32 * 32, C, &g->w2);
 }
 
+// A 3x3 conv whose output width is not a tile count the LDS-staged convs take, as two launches over channel slices (Conv3).
+static inline int li_conv_slices() { const char *e = getenv("NUNIF_LI_CONV_SLICES"); return e ? atoi(e) : 1; }
+int launch_conv3_sliced(const Conv3 &c, const ConvArgs &cv, hipStream_t s) {
+    if (!c.n_slices || !li_conv_slices() || cv.n_real != c.N) return launch_conv(cv, s);
+    ConvArgs t = cv;
+    t.N = c.slice_nt[0] * 16; t.n_real = t.N; t.wstream = c.slice_stream[0];
+    if (!conv3_dma_applies(t) && !conv3_lds_applies(t)) return launch_conv(cv, s);
+    int n0 = 0, rc;
+    for (int q = 0; q < c.n_slices; ++q) {
+        t = cv;
+        t.N = c.slice_nt[q] * 16; t.n_real = t.N; t.wstream = c.slice_stream[q]; t.bias = cv.bias + n0;
+        t.ldo = cv.ldo > 0 ? cv.ldo : cv.n_real;
+        t.out = cv.out + n0;
+        if (cv.res) t.res = cv.res + n0;
+        if (cv.res2) t.res2 = cv.res2 + n0;
+        if ((rc = launch_conv(t, s))) return rc;
+        n0 += t.N;
+    }
+    return NUNIF_HIP_OK;
+}
+
 int lin(const Lin &L, const f16 *a, long rows, int n_real, int act, float slope, const f16 *res, f16 *out, hipStream_t s,
         const char *tag) {
     GemmArgs g;
@@ -574,6 +617,18 @@ int lin(const Lin &L, const f16 *a, long rows, int n_real, int act, float slope,
     g.a = a; g.B = 1; g.Hi = 1; g.Wi = (int)rows; g.Cin = L.K; g.Ho = 1; g.Wo = (int)rows; g.stride = 1; g.kw = 1;
     g.K = L.K; g.w = L.w; g.bias = L.bias; g.N = L.N; g.mode = 0; g.act = act; g.slope = slope; g.res = res; g.out = out;
     g.ldo = n_real; g.n_real = n_real; g.ps = 1;
+    // K = 192 -> 768 over millions of tokens (proj_in of the 1/8-resolution blocks at 4K): 288 KiB of weights do not fit the
+    // resident-weight GEMM's LDS, and the ring form runs it at 1.1 TB/s (2.8 ms).  Two launches over the output halves (the packed
+    // weights are n-tile major: the second half is an offset) read the rows twice and still finish in less than half the time.
+    const size_t wbytes = (size_t)(L.N / 16) * (L.K / 32) * 1024;
+    if (L.K == 192 && rows >= (1L << 20) && wbytes > 144 * 1024 && wbytes <= 288 * 1024 && L.N % 64 == 0 && n_real == L.N) {
+        int rc;
+        g.N = L.N / 2; g.n_real = L.N / 2;
+        if ((rc = launch_gemm(g, s, tag))) return rc;
+        g.w = L.w + (size_t)(L.N / 32) * (L.K / 32) * 512; g.bias = L.bias + L.N / 2; g.out = out + L.N / 2;
+        if (res) g.res = res + L.N / 2;
+        return launch_gemm(g, s, tag);
+    }
     return launch_gemm(g, s, tag);
 }
 
@@ -627,7 +682,7 @@ int run_gblock(nunif_light_inpaint *h, const GBlock &g, f16 *x, int B, int hh, i
     memset(&cv, 0, sizeof(cv));
     cv.a = z; cv.B = B; cv.Hi = hh; cv.Wi = ww; cv.Cin = g.w2.Cin; cv.Ho = hh; cv.Wo = ww; cv.stride = 1; cv.kh = 3; cv.kw = 3;
     cv.wstream = g.w2.stream; cv.bias = g.w2.bias; cv.N = g.w2.N; cv.n_real = C; cv.act = 0; cv.out = x; cv.rpad = 1; cv.res = x;
-    if ((rc = launch_conv(cv, s))) return rc;
+    if ((rc = launch_conv3_sliced(g.w2, cv, s))) return rc;
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
