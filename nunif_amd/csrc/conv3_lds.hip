@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
     // STATIC (the chunk loop is unrolled by three): rounds 1-3 rotated three named registers with copies (st = sq; sq = sr; ...),
     // and a copy of a register whose load is still in flight has to wait for it — hipcc put `s_waitcnt vmcnt(0)` right behind the
     // two loads it had just issued, so every chunk boundary (9 per 64 -> 64 patch) exposed a full L2 round trip
-    // (profiles/r04_conv3_ring.txt: 12 us per workgroup for 2.1 us of MFMAs).
+    // (tools/ring_trace.py on the 64 -> 64 layer: 12 us per workgroup for 2.1 us of MFMAs; profiles/r04_isa_notes.md item 3).
     f16x8 stage[3][2];
     // the second-input form is its own instantiation of the staging code: its eleven extra registers per load batch would
     // otherwise be reserved in every launch (the staging arrays are the kernel's register high-water mark)
