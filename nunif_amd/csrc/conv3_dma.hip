@@ -32,6 +32,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <cstdio>
+
 #include "swin_kernels.h"
 
 namespace nunif {
@@ -43,7 +45,6 @@ constexpr int kTH = 8, kTW = 32;                        // output patch of a wor
 constexpr int kHH = kTH + 2, kHW = kTW + 2;             // halo
 constexpr int kHaloPix = kHH * kHW;                     // 340
 constexpr int kCH = 8;                                  // fragments (KiB) per weight chunk
-constexpr int kSlots = 3;
 
 __device__ __forceinline__ void dma16(const void *src, unsigned lds_byte_addr) {
     // each lane moves 16 B to LDS[m0 + 16 * lane]; m0 is wave-uniform
@@ -53,8 +54,21 @@ __device__ __forceinline__ void dma16(const void *src, unsigned lds_byte_addr) {
 
 // NTT output tiles in NPASS passes of NT = NTT / NPASS over the SAME halo (64 -> 128: two passes of four tiles; eight tiles x four
 // token tiles of accumulators do not fit 256 registers)
-template <int NTT, int CIN, bool RELU_IN, int NPASS = 1>
+#ifdef NUNIF_C3D_TRACE
+__device__ unsigned long long g_c3d_trace[1024 * 8];
+#define NUNIF_C3D_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_c3d_trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NUNIF_C3D_STAMP(i)
+#endif
+
+// D = how many weight chunks ahead of the MFMAs the DMAs run (ring of D + 1 slots; 2: 67 KiB of LDS, two workgroups per CU).
+// A deeper ring for the launches of one patch per workgroup (the DPT head's 64 -> 64 layers: 32 / 112 / 392 patches) was measured
+// and is NOT dispatched: D = 8 (the whole 72 KiB stream in flight) 0.274 vs 0.258 ms per 13 launches — phase stamps show the chunk
+// loop at 8.6 k ticks either way (it is not waiting for weights), the halo wait 6-9 k and the EPILOGUE 11-21 k
+// (profiles/r04_c3d_trace.txt), which is what the 16-byte-run epilogue below addresses.
+template <int NTT, int CIN, bool RELU_IN, int NPASS = 1, int D = 2>
 __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_patches) {
+    constexpr int kSlots = D + 1;
     constexpr int MF = 4;
     constexpr int NT = NTT / NPASS;
     constexpr int SEG = CIN / 8;                         // 16-byte segments per pixel
@@ -64,7 +78,8 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
     constexpr int KSTEPS = 9 * CPT;
     constexpr int KPC = kCH / NT;                        // k-steps per chunk
     constexpr int NCH = (KSTEPS * NT + kCH - 1) / kCH;   // chunks that carry data
-    constexpr int NCH3 = (NCH + 2) / 3 * 3;              // trip count per patch: a multiple of the slot count
+    constexpr int NCH3 = (NCH + kSlots - 1) / kSlots * kSlots;   // trip count per patch: a multiple of the slot count
+    static_assert(D >= 2 && D <= NCH3, "the prologue requests D distinct chunks of the first pass");
     constexpr int HITEMS = kHaloPix * SEG;               // 16-byte items of a halo
     constexpr int HDMA = (HITEMS + 255) / 256;           // DMA instructions per wave... per THREAD ROW: items tid + 256 u
     static_assert(CIN == 32 || CIN == 64, "segment swizzle / part addressing below are written for 32 and 64 input channels");
@@ -138,16 +153,23 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
 
     int pi = blockIdx.x;
     int b, ty0, tx0;
+    NUNIF_C3D_STAMP(0);
     if (pi < n_patches) {
         patch_of(pi, b, ty0, tx0);
-        chunk_dma(0, 0, 0);
-        chunk_dma(1, 0, 1);
-        halo_dma(b, ty0, tx0);
+        halo_dma(b, ty0, tx0);                                            // first: the top wait below releases it with chunk 0
+#pragma unroll
+        for (int c = 0; c < D; ++c) chunk_dma(c, 0, c);
     }
+    bool first = true;
 #pragma unroll 1
     for (; pi < n_patches; pi += gridDim.x) {
-        // halo + chunks 0, 1 of this patch (and the previous patch's stores) have landed; the barrier publishes all waves' parts
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // first patch: the halo and chunk 0 have landed once at most my 2 (D - 1) newest DMAs are in flight; later patches: their
+        // halo was requested AFTER their first chunks (and the previous patch's stores are in the count): everything.
+        // The barrier publishes all waves' parts.
+        if (first) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (D - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        first = false;
+        NUNIF_C3D_STAMP(1);
         const int cb = b, cty0 = ty0, ctx0 = tx0;
 #pragma unroll 1
         for (int pass = 0; pass < NPASS; ++pass) {                        // (a real loop: unrolled, hipcc keeps two accumulator sets alive)
@@ -159,16 +181,16 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
         // the chunk loop is fully unrolled: chunk index, ring slot, tap and 32-channel part of every k-step are compile-time
 #pragma unroll
         for (int c = 0; c < NCH3; ++c) {
-            // chunk boundary.  My DMAs in flight: chunk c + 1 (2 instructions) at most -> chunk c has landed at vmcnt(2).
-            // Behind the barrier every wave has finished reading chunk c - 1, whose slot chunk c + 2 now takes.
+            // chunk boundary.  My DMAs in flight: chunks c + 1 .. c + D - 1 (2 instructions each) at most -> chunk c has landed at
+            // vmcnt(2 (D - 1)).  Behind the barrier every wave has finished reading chunk c - 1, whose slot chunk c + D now takes.
             // (The first chunk of a later pass is a boundary like any other; an earlier pass's stores also count in vmcnt, they
             // are older than the chunk and only make the wait longer.)
-            if (c > 0 || pass > 0) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            if (c > 0 || pass > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (D - 1)) : "memory");
             {
-                // two chunks ahead; wraps into the next pass / the next patch (the same stream again)
-                const int cn = c + 2 < NCH3 ? c + 2 : c + 2 - NCH3;
-                const int pn = c + 2 < NCH3 ? pass : (pass + 1 < NPASS ? pass + 1 : 0);
-                chunk_dma(cn, pn, (c + 2) % kSlots);
+                // D chunks ahead; wraps into the next pass / the next patch (the same stream again)
+                const int cn = c + D < NCH3 ? c + D : c + D - NCH3;
+                const int pn = c + D < NCH3 ? pass : (pass + 1 < NPASS ? pass + 1 : 0);
+                chunk_dma(cn, pn, (c + D) % kSlots);
             }
 #pragma unroll
             for (int q = 0; q < KPC; ++q) {
@@ -195,6 +217,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
                 }
             }
         }
+        NUNIF_C3D_STAMP(2);
         if (pass == NPASS - 1) {
             // every wave is done with the halo: the next patch's may overwrite it while this one's epilogue runs
             asm volatile("s_barrier" ::: "memory");
@@ -242,40 +265,118 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
                 continue;
             }
         }
+        // NHWC fp16.  An accumulator lane holds 4 channels of a tile = 8 bytes, and a wave-wide store of those touches 16 pixels x 32
+        // bytes; this epilogue (residual loads + stores) measured 14-21 k of a single-patch workgroup's ~30-50 k ticks
+        // (profiles/r04_c3d_trace.txt).  Two adjacent tiles are turned into one run of 8 consecutive channels per lane (common.h
+        // pair_to_run, here on the fp32 values so that `fp16(conv + res)` rounds exactly as before): 16-byte loads and stores,
+        // 64 bytes per pixel, half the instructions.
+        // (the two-pass instantiation has no registers to spare for it: 11 spills)
+        const bool runs = (NT % 2 == 0) && NPASS == 1 && g.n_real % 32 == 0 && ldo % 8 == 0;
+        if (runs) {
+            if constexpr (NT % 2 == 0 && NPASS == 1) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n0 = (pass * NT + nt) * 16 + grp * 4;
-            const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+                for (int np = 0; np < NT / 2; ++np) {
+                    const int nb = (pass * NT + 2 * np) * 16;                       // first channel of the 32-channel pair
+                    const float4 b0 = *reinterpret_cast<const float4 *>(g.bias + nb + grp * 4);
+                    const float4 b1 = *reinterpret_cast<const float4 *>(g.bias + nb + 16 + grp * 4);
+                    const float bb[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+                    // residual values are requested for two fragments at a time BEFORE the swaps that use them (a load behind a
+                    // run-time `if` is waited for at once: 71 x vmcnt(0) in the first form of this epilogue)
 #pragma unroll
-            for (int f = 0; f < MF; ++f) {
-                const int oy = cty0 + 2 * wave + (f >> 1), ox = ctx0 + 16 * (f & 1) + r16;
-                if (oy >= g.Ho || ox >= g.Wo || n0 >= g.n_real) continue;
-                float v[4] = {acc[nt][f][0] + bv.x, acc[nt][f][1] + bv.y, acc[nt][f][2] + bv.z, acc[nt][f][3] + bv.w};
-                if (g.act == 2) {
+                    for (int f0 = 0; f0 < MF; f0 += 2) {
+                        long off[2];
+                        bool live[2];
+                        f16x8 rv1[2], rv2[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * g.slope;
-                } else if (g.act == 3) {
+                        for (int u = 0; u < 2; ++u) {
+                            const int f = f0 + u;
+                            const int oy = cty0 + 2 * wave + (f >> 1), ox = ctx0 + 16 * (f & 1) + r16;
+                            live[u] = oy < g.Ho && ox < g.Wo && nb < g.n_real;
+                            off[u] = (((long)cb * g.Ho + min(oy, g.Ho - 1)) * g.Wo + min(ox, g.Wo - 1)) * ldo + nb + pair_run_channel(grp);
+                        }
+                        if (g.res) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                            for (int u = 0; u < 2; ++u) rv1[u] = *reinterpret_cast<const f16x8 *>(g.res + off[u]);
+                        }
+                        if (g.res2) {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) rv2[u] = *reinterpret_cast<const f16x8 *>(g.res2 + off[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int f = f0 + u;
+                            float v[2][4];
+#pragma unroll
+                            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    float x = acc[2 * np + t][f][r] + bb[t][r];
+                                    if (g.act == 2) x = x >= 0.f ? x : x * g.slope;
+                                    else if (g.act == 3) x = fmaxf(x, 0.f);
+                                    v[t][r] = x;
+                                }
+                            float run[8];                                           // channels nb + pair_run_channel(grp) + 0..7
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const u32x2 sw = lane16_swap(__builtin_bit_cast(unsigned, v[0][r]), __builtin_bit_cast(unsigned, v[1][r]));
+                                const unsigned lo = sw[0], hi = sw[1];
+                                run[r] = __builtin_bit_cast(float, lo);
+                                run[4 + r] = __builtin_bit_cast(float, hi);
+                            }
+                            if (g.res) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) run[e] += (float)rv1[u][e];
+                            }
+                            if (g.res2) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) run[e] += (float)rv2[u][e];
+                            }
+                            f16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (f16)run[e];
+                            if (live[u]) *reinterpret_cast<f16x8 *>(g.out + off[u]) = o;   // (after the swap: it needs every lane)
+                        }
+                    }
                 }
-                const long off = (((long)cb * g.Ho + oy) * g.Wo + ox) * ldo + n0;
-                if (g.res) {
-                    const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
+            }
+        } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n0 = (pass * NT + nt) * 16 + grp * 4;
+                const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n0);
+    #pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    const int oy = cty0 + 2 * wave + (f >> 1), ox = ctx0 + 16 * (f & 1) + r16;
+                    if (oy >= g.Ho || ox >= g.Wo || n0 >= g.n_real) continue;
+                    float v[4] = {acc[nt][f][0] + bv.x, acc[nt][f][1] + bv.y, acc[nt][f][2] + bv.z, acc[nt][f][3] + bv.w};
+                    if (g.act == 2) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * g.slope;
+                    } else if (g.act == 3) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    const long off = (((long)cb * g.Ho + oy) * g.Wo + ox) * ldo + n0;
+                    if (g.res) {
+                        const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res + off);
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                    }
+                    if (g.res2) {
+                        const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res2 + off);
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                    }
+                    *reinterpret_cast<f16x4 *>(g.out + off) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                 }
-                if (g.res2) {
-                    const f16x4 rv = *reinterpret_cast<const f16x4 *>(g.res2 + off);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-                }
-                *reinterpret_cast<f16x4 *>(g.out + off) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
             }
         }
+        NUNIF_C3D_STAMP(3);
         }   // pass
     }
     // drain the two weight chunks the last trip requested for a patch that does not exist (LDS must not be written after exit)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NUNIF_C3D_STAMP(4);
 }
 
 static inline int conv3_dma_enabled() { const char *e = getenv("NUNIF_CONV3_DMA"); return e ? atoi(e) : 1; }
@@ -294,22 +395,38 @@ bool conv3_dma_applies(const ConvArgs &g) {
     return n_patches > min_patches && n_patches < (1L << 30) && (long)g.B * g.Hi * g.Wi * g.Cin < (1L << 40);
 }
 
-template <int NT, int CIN, bool RELU_IN, int NPASS = 1>
+template <int NT, int CIN, bool RELU_IN, int NPASS = 1, int D = 2>
 static int launch_c3d(const ConvArgs &g, hipStream_t s, const char *name) {
     // the last DMA instruction of a halo is a full 1 KiB whatever the item count: round the halo up to a multiple of 64 items
-    const size_t smem = (size_t)kSlots * kCH * 1024 + (size_t)((kHaloPix * (CIN / 8) + 63) / 64) * 1024;
+    const size_t smem = (size_t)(D + 1) * kCH * 1024 + (size_t)((kHaloPix * (CIN / 8) + 63) / 64) * 1024;
     const long M = (long)g.B * g.Ho * g.Wo;
     ProfScope ps(name, s, 2.0 * (double)M * 9.0 * g.Cin * g.n_real, (double)M * (g.Cin + g.n_real) * 2.0);
     static bool configured = false;
     if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_dma_kernel<NT, CIN, RELU_IN, NPASS>,
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_dma_kernel<NT, CIN, RELU_IN, NPASS, D>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = true;
     }
     const long n_patches = (long)g.B * ((g.Ho + kTH - 1) / kTH) * ((g.Wo + kTW - 1) / kTW);
     const unsigned grid = (unsigned)std::min<long>(n_patches, 512);         // two persistent workgroups per CU
-    conv3_dma_kernel<NT, CIN, RELU_IN, NPASS><<<grid, 256, smem, s>>>(g, (int)n_patches);
+    conv3_dma_kernel<NT, CIN, RELU_IN, NPASS, D><<<grid, 256, smem, s>>>(g, (int)n_patches);
     NUNIF_LAUNCH_CHECK();
+#ifdef NUNIF_C3D_TRACE
+    if (NT == 4 && CIN == 64 && n_patches <= 512) {
+        static int n = 0;
+        if (++n > 60 && n <= 73) {
+            static unsigned long long host[1024 * 8];
+            NUNIF_HIP_CHECK(hipStreamSynchronize(s));
+            NUNIF_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c3d_trace), sizeof(host)));
+            const int nb = (int)std::min<long>(grid, 1024);
+            double avg[5] = {0};
+            for (int b = 0; b < nb; ++b)
+                for (int i = 0; i < 5; ++i) avg[i] += (double)(long long)(host[b * 8 + i] - host[b * 8]) / nb;
+            fprintf(stderr, "[c3d trace] D %d patches %ld relu %d res %d res2 %d: %.0f %.0f %.0f %.0f %.0f\n", D, n_patches, (int)RELU_IN, g.res != nullptr,
+                    g.res2 != nullptr, avg[0], avg[1], avg[2], avg[3], avg[4]);
+        }
+    }
+#endif
     return NUNIF_HIP_OK;
 }
 
