@@ -254,6 +254,76 @@ __global__ void __launch_bounds__(256) conv3_lds_kernel(ConvArgs g) {
             return;
         }
     }
+    if constexpr (NT % 2 == 0) {
+        // NHWC fp16 in 16-byte runs: two adjacent tiles -> 8 consecutive channels per lane (fp32 permlane swap, so that
+        // `fp16(conv + res)` rounds exactly as in the 8-byte form below), residual values requested two fragments at a time
+        // before the swaps that use them.  As in conv3_dma_kernel (profiles/r04_c3d_trace.txt).
+        if (!g.out32 && g.n_real % 32 == 0 && ldo % 8 == 0) {
+#pragma unroll
+            for (int np = 0; np < NT / 2; ++np) {
+                const int nb = 2 * np * 16;
+                const float4 b0 = *reinterpret_cast<const float4 *>(g.bias + nb + grp * 4);
+                const float4 b1 = *reinterpret_cast<const float4 *>(g.bias + nb + 16 + grp * 4);
+                const float bb[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+                for (int f0 = 0; f0 < MF; f0 += 2) {
+                    long off[2];
+                    bool live[2];
+                    f16x8 rv1[2], rv2[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int f = f0 + u;
+                        const int oy = ty0 + 2 * wave + (f >> 1), ox = tx0 + 16 * (f & 1) + r16;
+                        live[u] = oy < g.Ho && ox < g.Wo && nb < g.n_real;
+                        off[u] = (((long)b * g.Ho + min(oy, g.Ho - 1)) * g.Wo + min(ox, g.Wo - 1)) * ldo + nb + pair_run_channel(grp);
+                    }
+                    if (g.res) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) rv1[u] = *reinterpret_cast<const f16x8 *>(g.res + off[u]);
+                    }
+                    if (g.res2) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) rv2[u] = *reinterpret_cast<const f16x8 *>(g.res2 + off[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int f = f0 + u;
+                        float v[2][4];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float x = acc[2 * np + t][f][r] + bb[t][r];
+                                if (g.act == 2) x = x >= 0.f ? x : x * g.slope;
+                                else if (g.act == 3) x = fmaxf(x, 0.f);
+                                v[t][r] = x;
+                            }
+                        float run[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const u32x2 sw = lane16_swap(__builtin_bit_cast(unsigned, v[0][r]), __builtin_bit_cast(unsigned, v[1][r]));
+                            const unsigned lo = sw[0], hi = sw[1];
+                            run[r] = __builtin_bit_cast(float, lo);
+                            run[4 + r] = __builtin_bit_cast(float, hi);
+                        }
+                        if (g.res) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) run[e] += (float)rv1[u][e];
+                        }
+                        if (g.res2) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) run[e] += (float)rv2[u][e];
+                        }
+                        f16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (f16)run[e];
+                        if (live[u]) *reinterpret_cast<f16x8 *>(g.out + off[u]) = o;      // (after the swap: it needs every lane)
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n0 = nt * 16 + grp * 4;
