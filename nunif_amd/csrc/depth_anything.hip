@@ -880,8 +880,19 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     };
     // path4
     if ((rc = rcu(h->fus[3].r2, rn[3], H4, W4, nullptr, m1, m2))) return rc;
-    if ((rc = upsample(m2, H4, W4, H3, W3, F, m3))) return rc;
-    if ((rc = run_lin(h->fus[3].out, m3, B, W3, W3, 0, 0, nullptr, m4, s, "da_out_conv", 0, 0, 1, H3))) return rc;      // path4 in m4
+    // A refinenet ends with `interpolate(x, bilinear, align_corners=True)` then the 1x1 `out_conv` (DPT FeatureFusionBlock).  Both
+    // are linear and the interpolation weights of a pixel sum to 1, so the 1x1 conv (with its bias) commutes with the resize: it
+    // runs on the map BEFORE the resize, a quarter of the pixels (the largest of the four was a 351 k-pixel GEMM).  Same result
+    // in real arithmetic; the fp16 rounding of the intermediate map moves (tests: unchanged PSNR against the oracle and the
+    // HuggingFace fixture).  NUNIF_DA_OUTCONV_FIRST=0 keeps the reference's order.
+    static const bool conv_first = !(getenv("NUNIF_DA_OUTCONV_FIRST") && atoi(getenv("NUNIF_DA_OUTCONV_FIRST")) == 0);
+    if (conv_first) {
+        if ((rc = run_lin(h->fus[3].out, m2, B, W4, W4, 0, 0, nullptr, m3, s, "da_out_conv", 0, 0, 1, H4))) return rc;
+        if ((rc = upsample(m3, H4, W4, H3, W3, F, m4))) return rc;                                                          // path4 in m4
+    } else {
+        if ((rc = upsample(m2, H4, W4, H3, W3, F, m3))) return rc;
+        if ((rc = run_lin(h->fus[3].out, m3, B, W3, W3, 0, 0, nullptr, m4, s, "da_out_conv", 0, 0, 1, H3))) return rc;      // path4 in m4
+    }
     // path3 .. path1
     const f16 *path = m4;
     f16 *pout = m5;
@@ -890,8 +901,13 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         const int Hn = k > 0 ? Hs[k - 1] : HF, Wn = k > 0 ? Ws[k - 1] : WF;
         if ((rc = rcu(h->fus[k].r1, rn[k], Hc, Wc, path, m1, m2))) return rc;        // m2 = path + RCU1(skip)
         if ((rc = rcu(h->fus[k].r2, m2, Hc, Wc, nullptr, m1, m3))) return rc;        // m3 = RCU2(m2)
-        if ((rc = upsample(m3, Hc, Wc, Hn, Wn, F, m2))) return rc;
-        if ((rc = run_lin(h->fus[k].out, m2, B, Wn, Wn, 0, 0, nullptr, pout, s, "da_out_conv", 0, 0, 1, Hn))) return rc;
+        if (conv_first) {
+            if ((rc = run_lin(h->fus[k].out, m3, B, Wc, Wc, 0, 0, nullptr, m1, s, "da_out_conv", 0, 0, 1, Hc))) return rc;
+            if ((rc = upsample(m1, Hc, Wc, Hn, Wn, F, pout))) return rc;
+        } else {
+            if ((rc = upsample(m3, Hc, Wc, Hn, Wn, F, m2))) return rc;
+            if ((rc = run_lin(h->fus[k].out, m2, B, Wn, Wn, 0, 0, nullptr, pout, s, "da_out_conv", 0, 0, 1, Hn))) return rc;
+        }
         path = pout;
         pout = (pout == m5) ? m4 : m5;
     }

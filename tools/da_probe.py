@@ -36,7 +36,7 @@ for enc in (sys.argv[1:] or ["vits", "vitb", "vitl"]):
         torch.cuda.synchronize()
         recs = sorted(_hip.profile_read(reset=True), key=lambda r: -r["total_ms"])
         _hip.profile_enable(False)
-        for r in recs[:10]:
+        for r in recs[:int(os.environ.get("DA_TOP", "10"))]:
             sec = r["total_ms"] * 1e-3
             print(f"    {r['name'][:34]:34s} {r['total_ms'] / 3:8.3f} ms/batch  {r['launches'] // 3:4d} launches  "
                   f"{r['flops'] / sec / 1e12 if sec else 0:7.1f} TF/s")
