@@ -66,8 +66,13 @@ __device__ unsigned long long g_c3d_trace[1024 * 8];
 // and is NOT dispatched: D = 8 (the whole 72 KiB stream in flight) 0.274 vs 0.258 ms per 13 launches — phase stamps show the chunk
 // loop at 8.6 k ticks either way (it is not waiting for weights), the halo wait 6-9 k and the EPILOGUE 11-21 k
 // (profiles/r04_c3d_trace.txt), which is what the 16-byte-run epilogue below addresses.
-template <int NTT, int CIN, bool RELU_IN, int NPASS = 1, int D = 2>
+// KS > 1: the input has KS x CIN channels and the contraction runs in KS halves over the SAME LDS halo space (Cin = 128 as 2 x 64:
+// a 128-channel halo would be 87 KiB, one workgroup per CU).  Half kh stages channels CIN kh .. of the patch, walks the k-steps
+// tap-major inside the half (global k-step = tap (CPT KS) + kh CPT + part) into the same accumulators; the epilogue follows the
+// last half.  Between halves the halo is re-staged behind a barrier (nothing to overlap it with but the ring's two chunks).
+template <int NTT, int CIN, bool RELU_IN, int NPASS = 1, int D = 2, int KS = 1>
 __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_patches) {
+    static_assert(KS == 1 || NPASS == 1, "K halves and N passes are not combined");
     constexpr int kSlots = D + 1;
     constexpr int MF = 4;
     constexpr int NT = NTT / NPASS;
@@ -97,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
     const int pad = (g.zpad || g.rpad) ? 1 : 0;                           // 0: VALID 3x3 (Ho = Hi - 2)
     const int tiles_x = (g.Wo + kTW - 1) / kTW, tiles_y = (g.Ho + kTH - 1) / kTH;
     const f16x8 *gsrc = reinterpret_cast<const f16x8 *>(g.wstream);       // zero-padded by 16 KiB on the host
-    const f16x8 *zero16 = gsrc + (long)KSTEPS * NTT * 64;                 // first 16 bytes of that padding: the "zero pixel"
+    const f16x8 *zero16 = gsrc + (long)KSTEPS * KS * NTT * 64;            // first 16 bytes of that padding: the "zero pixel"
 
     // ---- per-lane constants --------------------------------------------------------------------------------------------
     // halo item q = tid + 256 u lives at LDS byte 16 q = pixel (q / SEG), slot (q % SEG); it holds segment slot ^ swz(pixel)
@@ -125,14 +130,14 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
         ty0 = ((i / tiles_x) % tiles_y) * kTH;
         b = i / (tiles_x * tiles_y);
     };
-    auto halo_dma = [&](int b, int ty0, int tx0) {
+    auto halo_dma = [&](int b, int ty0, int tx0, int kh) {
         const long img = (long)b * g.Hi * g.Wi;
 #pragma unroll
         for (int u = 0; u < HDMA; ++u) {
             if (256 * u + 64 * wave < HITEMS) {                           // wave-uniform: the last row of instructions is partial
                 const int yy = ty0 + (hq[u] >> 16) - pad, xx = tx0 + ((hq[u] >> 8) & 255) - pad;
                 const int yc = min(max(yy, 0), g.Hi - 1), xc = min(max(xx, 0), g.Wi - 1);
-                const f16 *src = g.a + ((img + (long)yc * g.Wi + xc) * CIN + (hq[u] & 255) * 8);
+                const f16 *src = g.a + ((img + (long)yc * g.Wi + xc) * (CIN * KS) + kh * CIN + (hq[u] & 255) * 8);
                 if (g.zpad && (yy != yc || xx != xc)) src = reinterpret_cast<const f16 *>(zero16);
                 dma16(src, halo_lds + (unsigned)(256 * u + 64 * wave) * 16);
             }
@@ -141,12 +146,13 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
     // weight chunk c of pass p -> ring slot: 2 DMA instructions per wave.  A chunk = KPC k-steps x the NT fragments of the
     // pass; the stream is [k-step][NTT fragments], so fragment i of the chunk is k-step c KPC + i / NT, tile p NT + i % NT
     // (contiguous when NPASS == 1).  Fragments past the last k-step come from the zero padding behind the stream.
-    auto chunk_dma = [&](int c, int p, int slot) {
+    auto chunk_dma = [&](int c, int p, int slot, int kh) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int i = wave + 4 * h;                                   // fragment of the chunk this wave moves
-            const int ks = min(c * KPC + i / NT, KSTEPS);                 // KSTEPS: first k-step of the zero padding
-            const f16x8 *src = gsrc + ((long)ks * NTT + (ks < KSTEPS ? p * NT + i % NT : i % NT)) * 64 + lane;
+            const int kl = min(c * KPC + i / NT, KSTEPS);                 // k-step inside the half; KSTEPS: the zero padding
+            const int ks = kl < KSTEPS ? (kl / CPT) * (CPT * KS) + kh * CPT + kl % CPT : KSTEPS * KS;
+            const f16x8 *src = gsrc + ((long)ks * NTT + (kl < KSTEPS ? p * NT + i % NT : i % NT)) * 64 + lane;
             dma16(src, ring_lds + (unsigned)(slot * kCH * 64 + i * 64) * 16);
         }
     };
@@ -156,9 +162,9 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
     NUNIF_C3D_STAMP(0);
     if (pi < n_patches) {
         patch_of(pi, b, ty0, tx0);
-        halo_dma(b, ty0, tx0);                                            // first: the top wait below releases it with chunk 0
+        halo_dma(b, ty0, tx0, 0);                                         // first: the top wait below releases it with chunk 0
 #pragma unroll
-        for (int c = 0; c < D; ++c) chunk_dma(c, 0, c);
+        for (int c = 0; c < D; ++c) chunk_dma(c, 0, c, 0);
     }
     bool first = true;
 #pragma unroll 1
@@ -171,13 +177,16 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
         first = false;
         NUNIF_C3D_STAMP(1);
         const int cb = b, cty0 = ty0, ctx0 = tx0;
-#pragma unroll 1
-        for (int pass = 0; pass < NPASS; ++pass) {                        // (a real loop: unrolled, hipcc keeps two accumulator sets alive)
         f32x4 acc[NT][MF];
+#pragma unroll 1
+        for (int ph = 0; ph < NPASS * KS; ++ph) {                         // (a real loop: unrolled, hipcc keeps two accumulator sets alive)
+        const int pass = KS > 1 ? 0 : ph, kh = KS > 1 ? ph : 0;
+        if (KS == 1 || kh == 0) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int f = 0; f < MF; ++f) acc[nt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int f = 0; f < MF; ++f) acc[nt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         // the chunk loop is fully unrolled: chunk index, ring slot, tap and 32-channel part of every k-step are compile-time
 #pragma unroll
         for (int c = 0; c < NCH3; ++c) {
@@ -185,12 +194,13 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
             // vmcnt(2 (D - 1)).  Behind the barrier every wave has finished reading chunk c - 1, whose slot chunk c + D now takes.
             // (The first chunk of a later pass is a boundary like any other; an earlier pass's stores also count in vmcnt, they
             // are older than the chunk and only make the wait longer.)
-            if (c > 0 || pass > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (D - 1)) : "memory");
+            if (KS > 1 && c == 0 && ph > 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // this half's halo (requested last)
+            else if (c > 0 || ph > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (D - 1)) : "memory");
             {
-                // D chunks ahead; wraps into the next pass / the next patch (the same stream again)
+                // D chunks ahead; wraps into the next pass / half / patch (the stream again, or its other half)
                 const int cn = c + D < NCH3 ? c + D : c + D - NCH3;
-                const int pn = c + D < NCH3 ? pass : (pass + 1 < NPASS ? pass + 1 : 0);
-                chunk_dma(cn, pn, (c + D) % kSlots);
+                const int phn = c + D < NCH3 ? ph : (ph + 1 < NPASS * KS ? ph + 1 : 0);
+                chunk_dma(cn, KS > 1 ? 0 : phn, (c + D) % kSlots, KS > 1 ? phn : 0);
             }
 #pragma unroll
             for (int q = 0; q < KPC; ++q) {
@@ -218,13 +228,17 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
             }
         }
         NUNIF_C3D_STAMP(2);
-        if (pass == NPASS - 1) {
+        if (ph == NPASS * KS - 1) {
             // every wave is done with the halo: the next patch's may overwrite it while this one's epilogue runs
             asm volatile("s_barrier" ::: "memory");
             if (pi + (int)gridDim.x < n_patches) {
                 patch_of(pi + gridDim.x, b, ty0, tx0);
-                halo_dma(b, ty0, tx0);
+                halo_dma(b, ty0, tx0, 0);
             }
+        } else if (KS > 1) {
+            asm volatile("s_barrier" ::: "memory");                      // the next half of the same patch, no epilogue yet
+            halo_dma(cb, cty0, ctx0, kh + 1);
+            continue;
         }
 
         // ---- epilogue (as conv3_lds_kernel): bias, activation, residuals / image head ---------------------------------------
@@ -270,10 +284,10 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
         // (profiles/r04_c3d_trace.txt).  Two adjacent tiles are turned into one run of 8 consecutive channels per lane (common.h
         // pair_to_run, here on the fp32 values so that `fp16(conv + res)` rounds exactly as before): 16-byte loads and stores,
         // 64 bytes per pixel, half the instructions.
-        // (the two-pass instantiation has no registers to spare for it: 11 spills)
-        const bool runs = (NT % 2 == 0) && NPASS == 1 && g.n_real % 32 == 0 && ldo % 8 == 0;
+        // (the two-pass and the two-half instantiations have no registers to spare for it: 11 / 26 spills)
+        const bool runs = (NT % 2 == 0) && NPASS == 1 && KS == 1 && g.n_real % 32 == 0 && ldo % 8 == 0;
         if (runs) {
-            if constexpr (NT % 2 == 0 && NPASS == 1) {
+            if constexpr (NT % 2 == 0 && NPASS == 1 && KS == 1) {
 #pragma unroll
                 for (int np = 0; np < NT / 2; ++np) {
                     const int nb = (pass * NT + 2 * np) * 16;                       // first channel of the 32-channel pair
@@ -387,15 +401,19 @@ bool conv3_dma_applies(const ConvArgs &g) {
     if (!conv3_dma_enabled()) return false;
     if (!(g.kh == 3 && g.kw == 3 && g.stride == 1) || g.a2 || g.cmaj || (g.out32 && nt != 1) || g.N % 16 != 0) return false;
     if (g.Ho != g.Hi + 2 * pad - 2 || g.Wo != g.Wi + 2 * pad - 2 || g.zpad > 1 || g.rpad > 1 || (g.zpad && g.rpad)) return false;
-    if (!(g.Cin == 32 || g.Cin == 64) || !(nt == 1 || nt == 2 || nt == 4 || (nt == 8 && g.Cin == 64))) return false;
+    // Cin = 128 with 64 outputs: two K halves over one halo space (NUNIF_CONV3_DMA_KSPLIT=0: conv3_lds_kernel as before)
+    const bool ksplit = g.Cin == 128 && nt == 4 && !(getenv("NUNIF_CONV3_DMA_KSPLIT") && atoi(getenv("NUNIF_CONV3_DMA_KSPLIT")) == 0);
+    if (!ksplit && (!(g.Cin == 32 || g.Cin == 64) || !(nt == 1 || nt == 2 || nt == 4 || (nt == 8 && g.Cin == 64)))) return false;
     const long n_patches = (long)g.B * ((g.Ho + kTH - 1) / kTH) * ((g.Wo + kTW - 1) / kTW);
     // tiny launches keep the resident-weight form of conv3_lds_kernel.  Threshold sweep on the depth net (4 x 1080p, ViT-S):
     // 512 -> 2 033 fps, 256 -> 2 031, 96 -> 2 049, 24 -> 2 070 (one patch per workgroup from 24 to 512 patches)
     static const long min_patches = getenv("NUNIF_CONV3_DMA_MIN") ? atol(getenv("NUNIF_CONV3_DMA_MIN")) : 24;
-    return n_patches > min_patches && n_patches < (1L << 30) && (long)g.B * g.Hi * g.Wi * g.Cin < (1L << 40);
+    // (the two-half form sums in another order than conv3_lds_kernel: it takes EVERY launch of its shape, so that a result does not
+    //  depend on how many tiles share a launch — tests/test_cunet.py renders with minibatches of 4 and 9 and compares bits)
+    return (ksplit || n_patches > min_patches) && n_patches < (1L << 30) && (long)g.B * g.Hi * g.Wi * g.Cin < (1L << 40);
 }
 
-template <int NT, int CIN, bool RELU_IN, int NPASS = 1, int D = 2>
+template <int NT, int CIN, bool RELU_IN, int NPASS = 1, int D = 2, int KS = 1>
 static int launch_c3d(const ConvArgs &g, hipStream_t s, const char *name) {
     // the last DMA instruction of a halo is a full 1 KiB whatever the item count: round the halo up to a multiple of 64 items
     const size_t smem = (size_t)(D + 1) * kCH * 1024 + (size_t)((kHaloPix * (CIN / 8) + 63) / 64) * 1024;
@@ -403,13 +421,13 @@ static int launch_c3d(const ConvArgs &g, hipStream_t s, const char *name) {
     ProfScope ps(name, s, 2.0 * (double)M * 9.0 * g.Cin * g.n_real, (double)M * (g.Cin + g.n_real) * 2.0);
     static bool configured = false;
     if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_dma_kernel<NT, CIN, RELU_IN, NPASS, D>,
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)conv3_dma_kernel<NT, CIN, RELU_IN, NPASS, D, KS>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         configured = true;
     }
     const long n_patches = (long)g.B * ((g.Ho + kTH - 1) / kTH) * ((g.Wo + kTW - 1) / kTW);
     const unsigned grid = (unsigned)std::min<long>(n_patches, 512);         // two persistent workgroups per CU
-    conv3_dma_kernel<NT, CIN, RELU_IN, NPASS, D><<<grid, 256, smem, s>>>(g, (int)n_patches);
+    conv3_dma_kernel<NT, CIN, RELU_IN, NPASS, D, KS><<<grid, 256, smem, s>>>(g, (int)n_patches);
     NUNIF_LAUNCH_CHECK();
 #ifdef NUNIF_C3D_TRACE
     if (NT == 4 && CIN == 64 && n_patches <= 512) {
@@ -437,6 +455,8 @@ int launch_conv3_dma(const ConvArgs &g, hipStream_t s) {
         if (nt == 1) return g.relu_in ? launch_c3d<1, 64, true>(g, s, "conv3_dma_kernel<1,64>") : launch_c3d<1, 64, false>(g, s, "conv3_dma_kernel<1,64>");
         if (nt == 4) return g.relu_in ? launch_c3d<4, 64, true>(g, s, "conv3_dma_kernel<4,64>") : launch_c3d<4, 64, false>(g, s, "conv3_dma_kernel<4,64>");
         if (nt == 2) return g.relu_in ? launch_c3d<2, 64, true>(g, s, "conv3_dma_kernel<2,64>") : launch_c3d<2, 64, false>(g, s, "conv3_dma_kernel<2,64>");
+    } else if (g.Cin == 128) {
+        if (nt == 4) return g.relu_in ? launch_c3d<4, 64, true, 1, 2, 2>(g, s, "conv3_dma_kernel<4,128>") : launch_c3d<4, 64, false, 1, 2, 2>(g, s, "conv3_dma_kernel<4,128>");
     } else if (g.Cin == 32) {
         if (nt == 1) return g.relu_in ? launch_c3d<1, 32, true>(g, s, "conv3_dma_kernel<1,32>") : launch_c3d<1, 32, false>(g, s, "conv3_dma_kernel<1,32>");
         if (nt == 4) return g.relu_in ? launch_c3d<4, 32, true>(g, s, "conv3_dma_kernel<4,32>") : launch_c3d<4, 32, false>(g, s, "conv3_dma_kernel<4,32>");

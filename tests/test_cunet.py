@@ -130,8 +130,13 @@ def test_dma_staged_conv_is_bit_identical_to_the_register_staged_one(hiplib, mon
         monkeypatch.setenv("NUNIF_CONV3_DMA", "0")
         a = m(x).clone()
         monkeypatch.setenv("NUNIF_CONV3_DMA", "1")
+        monkeypatch.setenv("NUNIF_CONV3_DMA_KSPLIT", "0")
         b = m(x).clone()
         assert torch.isfinite(b).all() and torch.equal(a, b), float((a - b).abs().max())
+        # the 128 -> 64 convs in two K halves on the DMA conv: same products, the halves summed one after the other
+        monkeypatch.setenv("NUNIF_CONV3_DMA_KSPLIT", "1")
+        bk = m(x).clone()
+        assert torch.isfinite(bk).all() and psnr(b, bk) >= 57.0, psnr(b, bk)
         # the fused UNetConv(3, 32, 64) stem (conv1 on the MFMA with fp16 weights) against the VALU first conv + separate 32 -> 64 conv
         monkeypatch.setenv("NUNIF_CUNET_STEM", "0")
         c = m(x).clone()
