@@ -176,6 +176,22 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         first = false;
         NUNIF_C3D_STAMP(1);
+        if constexpr (RELU_IN && KS == 1) {
+            // the pre-activation ReLU once, in place, on the landed halo (11 items per thread) instead of on every B fragment of
+            // every k-step (288 packed max per thread and patch: the chunk loop of the relu_in launches was 13.4 k ticks against
+            // 8.6 k, profiles/r04_c3d_trace.txt)
+#pragma unroll 1
+            for (int u = 0; u < HDMA; ++u) {
+                const int q = tid + 256 * u;
+                if (q < HITEMS) {
+                    f16x8 v = *reinterpret_cast<f16x8 *>(halo + 16 * q);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > (f16)0.f ? v[e] : (f16)0.f;
+                    *reinterpret_cast<f16x8 *>(halo + 16 * q) = v;
+                }
+            }
+            __syncthreads();
+        }
         const int cb = b, cty0 = ty0, ctx0 = tx0;
         f32x4 acc[NT][MF];
 #pragma unroll 1
@@ -213,7 +229,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(ConvArgs g, int n_pat
                     for (int f = 0; f < MF; ++f) {
                         // part cc of the tap: segment 4 cc + grp; the swizzle is an XOR, so part 1 = address ^ 64
                         xq[f] = *reinterpret_cast<const f16x8 *>(halo + (faddr[f][tap] ^ (unsigned)(cc * 64)));
-                        if constexpr (RELU_IN) {
+                        if constexpr (RELU_IN && KS > 1) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) xq[f][e] = xq[f][e] > (f16)0.f ? xq[f][e] : (f16)0.f;
                         }
