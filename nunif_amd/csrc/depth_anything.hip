@@ -352,6 +352,11 @@ struct nunif_depth_anything {
     std::vector<Blk> blk;
     Lin proj[4], rs0, rs1, rs3g; std::vector<Cnv> rs3; Cnv rn[4]; Fus fus[4]; Cnv oc1, oc2; float *w_final = nullptr;
     Buf a_col, pe, t, y, qkv, att, hid, lnstats, mlp_flags, feat[4], rnb[4], m1, m2, m3, m4, m5, part, col;
+    // the reassemble branch of tap k (project -> resize -> layer_rn conv) on a stream of its own, beside the encoder layers that
+    // follow the tap: per-branch temporaries, fork / join events (forward())
+    Buf bm1[4], bm2[4], bpart[4];
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -704,6 +709,12 @@ extern "C" void nunif_hip_depth_anything_destroy(nunif_depth_anything *h) {
     Buf *bufs[] = {&h->a_col, &h->pe, &h->t, &h->y, &h->qkv, &h->att, &h->hid, &h->lnstats, &h->mlp_flags, &h->feat[0], &h->feat[1], &h->feat[2],
                    &h->feat[3], &h->rnb[0], &h->rnb[1], &h->rnb[2], &h->rnb[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5, &h->part, &h->col};
     for (Buf *b : bufs) b->release();
+    for (int i = 0; i < 4; ++i) { h->bm1[i].release(); h->bm2[i].release(); h->bpart[i].release(); }
+    for (int i = 0; i < 3; ++i) {
+        if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+        if (h->ev_fork[i]) (void)hipEventDestroy(h->ev_fork[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
     delete h;
 }
 
@@ -749,6 +760,23 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     }
     for (int i = 0; i < 4; ++i)
         if ((rc = h->feat[i].ensure(T * kD * e2)) || (rc = h->rnb[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2))) return rc;
+    // Reassemble branches beside the encoder.  Tap k (after layers 2 / 5 / 8 of ViT-S) feeds project -> resize -> layer_rn conv,
+    // three small launches (43 / 22 / up to 392 workgroups) that nothing needs before the refinenets: they run on side streams
+    // while the encoder goes on (its launches leave a quarter to a third of the CUs idle).  Everything is allocated here, before
+    // the first fork (hipMalloc synchronises the device).  NUNIF_DA_BRANCH_STREAMS=0: everything on the caller's stream.
+    const bool side_streams = !(getenv("NUNIF_DA_BRANCH_STREAMS") && atoi(getenv("NUNIF_DA_BRANCH_STREAMS")) == 0);
+    for (int i = 0; i < 4; ++i) {
+        if ((rc = h->bm1[i].ensure((size_t)B * N * h->OCP[i] * e2)) || (rc = h->bm2[i].ensure((size_t)B * Hs[i] * Ws[i] * h->OCP[i] * e2))) return rc;
+        if (h->rn[i].cmaj && (rc = h->bpart[i].ensure((size_t)(h->rn[i].Cin / h->rn[i].cmaj) * B * Hs[i] * Ws[i] * h->rn[i].N * sizeof(float)))) return rc;
+    }
+    if (h->rs3g.w && (rc = h->col.ensure((size_t)B * H4 * W4 * 9 * h->OCP[3] * e2))) return rc;
+    if (side_streams && !h->side[0]) {
+        for (int i = 0; i < 3; ++i) {
+            NUNIF_HIP_CHECK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+            NUNIF_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming));
+            NUNIF_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
+    }
     f16 *a_col = (f16 *)h->a_col.p, *pe = (f16 *)h->pe.p, *t = (f16 *)h->t.p, *y = (f16 *)h->y.p, *qkv = (f16 *)h->qkv.p;
     f16 *att = (f16 *)h->att.p, *hid = (f16 *)h->hid.p;
     float2 *lnstats = (float2 *)h->lnstats.p;
@@ -765,6 +793,47 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     if ((rc = run_lin(h->patch, a_col, 1, B * N, B * N, 0, 0, nullptr, pe, s, "da_patch"))) return rc;
     da_assemble_kernel<<<blocks(T * kD), 256, 0, s>>>(pe, h->cls, pos, t, B, Np, kD);
     NUNIF_LAUNCH_CHECK();
+
+    f16 *rn[4];
+    for (int i = 0; i < 4; ++i) rn[i] = (f16 *)h->rnb[i].p;
+    // reassemble branch i: projects[i] (1x1 on the patch tokens) -> resize_layers[i] -> layer{i+1}_rn, on stream st
+    auto branch = [&](int i, hipStream_t st) -> int {
+        int rc;
+        f16 *m1 = (f16 *)h->bm1[i].p, *m2 = (f16 *)h->bm2[i].p;
+        const f16 *feat = (const f16 *)h->feat[i].p;
+        // projects[i]: 1x1 on the patch tokens (row 0 of every image = class token is skipped: Wi = Np, ox = 1)
+        if ((rc = run_lin(h->proj[i], feat, B, Np, N, 1, 0, nullptr, m1, st, "da_project"))) return rc;
+        const f16 *src = m1;
+        if (i == 0) { if ((rc = run_lin(h->rs0, m1, B, gw, gw, 0, 0, nullptr, m2, st, "da_resize0", 1, h->OCP[0], 4, gh))) return rc; src = m2; }
+        else if (i == 1) { if ((rc = run_lin(h->rs1, m1, B, gw, gw, 0, 0, nullptr, m2, st, "da_resize1", 1, h->OCP[1], 2, gh))) return rc; src = m2; }
+        else if (i == 3) {
+            if (h->rs3g.w) {
+                const int C3 = h->OCP[3];
+                const long M4 = (long)B * H4 * W4;
+                da_im2col_s2_kernel<<<blocks(M4 * 9 * (C3 / 8)), 256, 0, st>>>(m1, (f16 *)h->col.p, B, gh, gw, C3, H4, W4);
+                NUNIF_LAUNCH_CHECK();
+                if ((rc = run_tok(h->rs3g, (const f16 *)h->col.p, M4, 0, nullptr, m2, st, "da_resize3"))) return rc;
+            } else {
+                const int chunk = h->rs3[0].N;
+                for (size_t c = 0; c < h->rs3.size(); ++c)
+                    if ((rc = run_cnv(h->rs3[c], m1, B, gh, gw, 2, 1, 0, 0, nullptr, nullptr, m2 + c * chunk, st, h->OCP[3]))) return rc;
+            }
+            src = m2;
+        }
+        float *part = h->rn[i].cmaj ? (float *)h->bpart[i].p : nullptr;
+        return run_cnv(h->rn[i], src, B, Hs[i], Ws[i], 1, 1, 0, 0, nullptr, nullptr, rn[i], st, 0, part);
+    };
+    bool forked[4] = {false, false, false, false};
+    auto fork = [&](int k) -> int {              // tap k's map is complete on s: its branch starts now, on its own stream
+        if (!side_streams || k >= 3) return NUNIF_HIP_OK;
+        NUNIF_HIP_CHECK(hipEventRecord(h->ev_fork[k], s));
+        NUNIF_HIP_CHECK(hipStreamWaitEvent(h->side[k], h->ev_fork[k], 0));
+        int rc = branch(k, h->side[k]);
+        if (rc) return rc;
+        NUNIF_HIP_CHECK(hipEventRecord(h->ev_join[k], h->side[k]));
+        forked[k] = true;
+        return NUNIF_HIP_OK;
+    };
 
     int tap = 0;
     for (int i = 0; i < h->depth; ++i) {
@@ -812,6 +881,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             if ((rc = launch_da_mlp(ma, s))) return rc;
             if (tap < 4 && i == h->taps[tap]) {
                 if ((rc = launch_da_layernorm(t, h->norm_g, h->norm_b, (f16 *)h->feat[tap].p, T, kD, s))) return rc;
+                if ((rc = fork(tap))) return rc;
                 ++tap;
             }
             continue;
@@ -829,43 +899,19 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
                 return rc;
         if (tap < 4 && i == h->taps[tap]) {
             if ((rc = launch_da_layernorm(t, h->norm_g, h->norm_b, (f16 *)h->feat[tap].p, T, kD, s))) return rc;
+            if ((rc = fork(tap))) return rc;
             ++tap;
         }
     }
 
     // ---- DPT head ----------------------------------------------------------------------------------------------------
     f16 *m1 = (f16 *)h->m1.p, *m2 = (f16 *)h->m2.p, *m3 = (f16 *)h->m3.p, *m4 = (f16 *)h->m4.p, *m5 = (f16 *)h->m5.p;
-    f16 *rn[4];
-    for (int i = 0; i < 4; ++i) rn[i] = (f16 *)h->rnb[i].p;
-    for (int i = 0; i < 4; ++i) {
-        const f16 *feat = (const f16 *)h->feat[i].p;
-        // projects[i]: 1x1 on the patch tokens (row 0 of every image = class token is skipped: Wi = Np, ox = 1)
-        if ((rc = run_lin(h->proj[i], feat, B, Np, N, 1, 0, nullptr, m1, s, "da_project"))) return rc;
-        const f16 *src = m1;
-        if (i == 0) { if ((rc = run_lin(h->rs0, m1, B, gw, gw, 0, 0, nullptr, m2, s, "da_resize0", 1, h->OCP[0], 4, gh))) return rc; src = m2; }
-        else if (i == 1) { if ((rc = run_lin(h->rs1, m1, B, gw, gw, 0, 0, nullptr, m2, s, "da_resize1", 1, h->OCP[1], 2, gh))) return rc; src = m2; }
-        else if (i == 3) {
-            if (h->rs3g.w) {
-                const int C3 = h->OCP[3];
-                const long M4 = (long)B * H4 * W4;
-                if ((rc = h->col.ensure((size_t)M4 * 9 * C3 * e2))) return rc;
-                da_im2col_s2_kernel<<<blocks(M4 * 9 * (C3 / 8)), 256, 0, s>>>(m1, (f16 *)h->col.p, B, gh, gw, C3, H4, W4);
-                NUNIF_LAUNCH_CHECK();
-                if ((rc = run_tok(h->rs3g, (const f16 *)h->col.p, M4, 0, nullptr, m2, s, "da_resize3"))) return rc;
-            } else {
-                const int chunk = h->rs3[0].N;
-                for (size_t c = 0; c < h->rs3.size(); ++c)
-                    if ((rc = run_cnv(h->rs3[c], m1, B, gh, gw, 2, 1, 0, 0, nullptr, nullptr, m2 + c * chunk, s, h->OCP[3]))) return rc;
-            }
-            src = m2;
-        }
-        float *part = nullptr;
-        if (h->rn[i].cmaj) {
-            if ((rc = h->part.ensure((size_t)(h->rn[i].Cin / h->rn[i].cmaj) * B * Hs[i] * Ws[i] * h->rn[i].N * sizeof(float)))) return rc;
-            part = (float *)h->part.p;
-        }
-        if ((rc = run_cnv(h->rn[i], src, B, Hs[i], Ws[i], 1, 1, 0, 0, nullptr, nullptr, rn[i], s, 0, part))) return rc;
-    }
+    // branches that were not forked beside the encoder (the last tap's always) run here; the others are joined where their map is
+    // first needed
+    for (int i = 0; i < 4; ++i)
+        if (!forked[i] && (rc = branch(i, s))) return rc;
+    for (int i = 0; i < 3; ++i)
+        if (forked[i]) NUNIF_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
     // refinenet k: x = path (+ RCU1(skip)); x = RCU2(x); upsample; out_conv
     auto rcu = [&](const Rcu &r, const f16 *in, int Hc, int Wc, const f16 *extra, f16 *tmp, f16 *out) -> int {
         // out = conv2(relu(conv1(relu(in)))) + in (+ extra)

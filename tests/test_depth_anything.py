@@ -207,3 +207,26 @@ print("OK")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "OK" in r.stdout, (split, r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_reassemble_branches_on_side_streams_change_nothing(hiplib, monkeypatch):
+    """The project -> resize -> layer_rn branch of a tap runs on a stream of its own beside the encoder layers that follow the tap
+    (depth_anything.hip forward()): same kernels, same operands — the depth map must be EQUAL to the single-stream one, also when
+    calls follow each other without a synchronisation in between (the branches of call n + 1 reuse the buffers of call n)."""
+    from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+    net = HipDepthAnythingV2(ODA.random_state_dict(601), "cuda:0")
+    xs = [_norm(torch.stack([synth_image(140 + 7 * j + i, 3, 392, 686) for i in range(4)])).to("cuda:0") for j in range(3)]
+    monkeypatch.setenv("NUNIF_DA_BRANCH_STREAMS", "0")
+    ref = [net(x).clone() for x in xs]
+    monkeypatch.setenv("NUNIF_DA_BRANCH_STREAMS", "1")
+    for _ in range(3):
+        outs = [net(x) .clone() for x in xs]                 # back to back, no synchronisation between the calls
+        torch.cuda.synchronize()
+        for a, b in zip(ref, outs):
+            assert torch.equal(a, b), float((a - b).abs().max())
+    small = _norm(torch.stack([synth_image(170, 3, 56, 70)])).to("cuda:0")
+    monkeypatch.setenv("NUNIF_DA_BRANCH_STREAMS", "0")
+    a = net(small).clone()
+    monkeypatch.setenv("NUNIF_DA_BRANCH_STREAMS", "1")
+    assert torch.equal(a, net(small))
