@@ -13,6 +13,10 @@
 // ReLU and up to two residuals fused).  LayerScale is folded into proj / fc2 on the host, the softmax scale * log2(e) into Wq.
 // ViT-S: norm1 (from the second block on) and norm2 have no kernel — proj / fc2 write per-token partial sums of what they
 // store, qkv / fc1 multiply the raw rows and finish with r (W x - mu wsum) + b (GemmOsArgs::stats_out / stats_in).
+// Round 4: the ViT-S MLP (fc1 + GELU + fc2 + residual + the next norm1's statistics) is ONE kernel over a pair of workgroups per
+// 64 tokens (depth_mlp.hip); the 3x3 convs of the head with 32 / 64 / 128 input channels run on conv3_dma_kernel (persistent,
+// halo + weights by LDS-DMA, 16-byte-run epilogue); a fusion block's 1x1 out_conv runs before the resize it commutes with; the
+// reassemble branch of every tap but the last runs on a side stream beside the encoder (forward()).
 // New kernels here:
 //   da_layernorm_kernel   one wave per token, fp32 statistics (the first norm1, the four tap norms; every norm of ViT-B / L)
 //   da_attn_kernel<WAVES> global softmax attention over 1 + gh*gw tokens, heads of 64: one wave per 16 queries, 8 or 12 query tiles

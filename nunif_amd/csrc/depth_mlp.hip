@@ -269,7 +269,11 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_kernel(DaMlpArgs a) {
 // raise flag[block] (the last of the four does); waves 4-7 compute the block's own 192 channels on top of bias + residual, poll
 // the partner's flag, add its partial, and the finished rows go through LDS so that all 8 waves store whole 384-byte runs.  The
 // receiver lowers the flag again: nothing depends on a launch counter, a replayed graph would behave the same.  Both blocks must
-// be resident at once: the launcher takes this kernel only while the grid fits the chip (HIP promises no dispatch order).  The
+// be resident at once: the launcher takes this kernel only while the grid fits the chip (HIP promises no dispatch order).  With
+// other kernels on the device at the same time (the depth net's own side streams, the stereo stream of the frame pipeline) the grid
+// may be admitted piecemeal: what keeps it live then is that a kernel's workgroups are dispatched in index order (observed, not
+// promised), so at most ONE pair straddles the dispatch frontier and every other waiting block's partner is running — none of the
+// co-running kernels waits for anything.  The
 // hand-off is the {sc0 sc1 stores, relaxed agent flag, sc0 sc1 loads} form (MI355X_MICROARCH, inter-workgroup visibility).
 // Every vector memory operation is inline asm and counted by hand: the prologue is LDS-DMA (rows, biases, statistics: 62 KiB) with
 // the first 24 weight fragments issued behind it, so that s_waitcnt vmcnt(24) releases the rows while the weights are in flight.
