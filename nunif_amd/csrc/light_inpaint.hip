@@ -621,7 +621,7 @@ int lin(const Lin &L, const f16 *a, long rows, int n_real, int act, float slope,
     // resident-weight GEMM's LDS, and the ring form runs it at 1.1 TB/s (2.8 ms).  Two launches over the output halves (the packed
     // weights are n-tile major: the second half is an offset) read the rows twice and still finish in less than half the time.
     const size_t wbytes = (size_t)(L.N / 16) * (L.K / 32) * 1024;
-    if (L.K == 192 && rows >= (1L << 20) && wbytes > 144 * 1024 && wbytes <= 288 * 1024 && L.N % 64 == 0 && n_real == L.N) {
+    if (L.K == 192 && rows >= gemm_big_m() && wbytes > 144 * 1024 && wbytes <= 288 * 1024 && L.N % 64 == 0 && n_real == L.N) {
         int rc;
         g.N = L.N / 2; g.n_real = L.N / 2;
         if ((rc = launch_gemm(g, s, tag))) return rc;

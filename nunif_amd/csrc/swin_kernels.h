@@ -185,6 +185,7 @@ struct ConvArgs {
                               //     0: tap-major (k = tap * Cin + ci)
     float *part32;            // cmaj: scratch for the fp32 partials, (Cin / cmaj) * B * Ho * Wo * N floats
 };
+long gemm_big_m();          // swin_kernels.hip: M from which plain K = 192 Linears run on the resident-weight GEMM
 int launch_conv(const ConvArgs &g, hipStream_t s);
 // 3x3 stride-1 same conv with the input tile staged in LDS (conv3_lds.hip); launch_conv takes it when it applies
 bool conv3_lds_applies(const ConvArgs &g);

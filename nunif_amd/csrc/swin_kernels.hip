@@ -401,6 +401,10 @@ __global__ void __launch_bounds__(512) gemm_res_kernel(GemmArgs g) {
 
 static thread_local const char *g_prof_tag = nullptr;
 
+// token count from which the plain K = 192 Linears take the resident-weight form (NUNIF_GEMM_BIG_M: tests lower it to cover that
+// path at small sizes; read per launch)
+long gemm_big_m() { const char *e = getenv("NUNIF_GEMM_BIG_M"); return e ? atol(e) : (1L << 20); }
+
 template <int KS, int MF>
 static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym, const char *res_sym, double flops,
                          double bytes, bool ring_only = false) {
@@ -413,7 +417,7 @@ static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym,
     // ... and for the plain K = 192 Linears over millions of tokens (the inpaint net's proj_out at 4K, config 5: 3.4 M tokens x
     // (384 B in + 192 B out)): the ring form is one 256-token tile per workgroup and all prologue, 1 040 us = 1.9 TB/s; resident
     // 543 us = 3.2 TB/s.  K = 96 measured equal (stays on the ring).
-    const bool big_plain = MF == 4 && KS == 6 && g.mode == 0 && M >= (1L << 20);
+    const bool big_plain = MF == 4 && KS == 6 && g.mode == 0 && M >= gemm_big_m();
     const bool res = fits && !ring_only && (MF == 2 || big_plain) && g.res_W == 0;     // (the cropped residual exists in the ring form only)
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
     // (NUNIF_PROF_TAGS=1 names the class after the call site instead: separates e.g. the two gemm_kernel<6,4> users)
