@@ -1,0 +1,85 @@
+"""Static checks on the gfx950 ISA of the hot kernels (hipcc cross-compiles without a GPU): the properties below were each lost at
+least once while a kernel was being changed, silently, and each costs tens of per cent — a register count that halves the resident
+workgroups, a spill, a `flat_load` whose `s_waitcnt vmcnt(0)` drains a prefetch, a hand-counted wait the compiler no longer emits
+(profiles/r04_isa_notes.md).  The numbers are occupancy limits of the launch shape, not tuning targets."""
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nunif_amd import build  # noqa: E402
+
+FILES = ["swin_qkv_attn_r.hip", "swin_block_tail.hip", "swin_block_tail_ws.hip", "conv3_dma.hip", "depth_mlp.hip", "iw3_warp.hip"]
+
+
+def _asm(fname):
+    src = os.path.join(build.CSRC, fname)
+    out = os.path.join("/tmp", f"nunif_isa_{fname}.s")
+    newest = max(os.path.getmtime(p) for p in [src] + build.headers())
+    if not (os.path.exists(out) and os.path.getmtime(out) >= newest):
+        flags = [x for x in build.FLAGS if x != "-fPIC"] + build.EXTRA_FLAGS.get(fname, [])
+        subprocess.run([build.hipcc()] + flags + ["-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", out, src],
+                       check=True, capture_output=True)
+    return open(out).read()
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    """{mangled kernel name: (body, sgprs, vgprs, spills)} over FILES"""
+    try:
+        build.hipcc()
+    except RuntimeError:
+        pytest.skip("hipcc not available")
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        texts = list(ex.map(_asm, FILES))
+    found = {}
+    for text in texts:
+        meta = {m.group(1): (int(m.group(2)), int(m.group(3)), int(m.group(4))) for m in re.finditer(
+            r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.sgpr_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)}
+        for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)s_endpgm", text, re.S | re.M):
+            if m.group(1) in meta:
+                found[m.group(1)] = (m.group(2),) + meta[m.group(1)]
+    return found
+
+
+def _pick(kernels, *needles):
+    hits = [(k, v) for k, v in kernels.items() if all(n in k for n in needles)]
+    assert hits, (needles, sorted(kernels)[:5])
+    return hits
+
+
+def test_no_spills_no_scratch_in_the_dispatched_kernels(kernels):
+    for name, (body, sg, vg, sp) in kernels.items():
+        assert sp == 0 and "scratch_" not in body, (name, sp)
+        assert vg <= 256, (name, vg)
+
+
+def test_forward_warp_keeps_two_rows_per_cu(kernels):
+    # 1024 threads x 2 workgroups per CU = 8 waves per SIMD: <= 64 VGPRs, and <= 80 SGPRs (above 96 the hardware admits 6 waves per
+    # SIMD whatever the occupancy API says: measured 129 vs 87 us, profiles/r04_fw_trace.txt)
+    for name, (body, sg, vg, sp) in _pick(kernels, "forward_warp_kernel"):
+        assert vg <= 64 and sg <= 80, (name, vg, sg)
+
+
+def test_level1_swin_kernels_hold_their_occupancy_and_address_spaces(kernels):
+    for name, (body, sg, vg, sp) in _pick(kernels, "qkv_attn_r_kernel", "ILi96ELi16E"):
+        assert vg <= 128, (name, vg)                          # 16 waves per workgroup: four per SIMD
+    for name, (body, sg, vg, sp) in _pick(kernels, "proj_mlp_r_kernel"):
+        assert "flat_load" not in body and "flat_store" not in body, name      # a laundered LDS pointer drains the weight prefetch
+    for name, (body, sg, vg, sp) in _pick(kernels, "proj_mlp_ws_kernel"):
+        assert "flat_load" not in body, name
+
+
+def test_hand_counted_waits_are_what_was_written(kernels):
+    # depth MLP: the weight ring is inline asm; every fc1 k-step waits vmcnt(22), every fc2 k-step vmcnt(21) (tail: 18 .. 0)
+    (name, (body, sg, vg, sp)), = _pick(kernels, "da_mlp_split_kernel")
+    assert body.count("s_waitcnt vmcnt(22)") == 36 and body.count("s_waitcnt vmcnt(21)") >= 16, name
+    assert body.count("v_mfma_f32_16x16x32") == 576
+    # conv3_dma: 2 DMA instructions per wave and chunk, two chunks ahead -> vmcnt(2) at every chunk boundary but the first
+    for name, (body, sg, vg, sp) in _pick(kernels, "conv3_dma_kernel", "ILi4ELi64ELb0ELi1ELi2ELi1E"):
+        assert body.count("s_waitcnt vmcnt(2)") >= 8 and "global_load_lds_dwordx4" in body, name
