@@ -149,14 +149,14 @@ def cpu_baseline(sd, frame):
     torch.set_num_threads(threads)
     dt, out = median_time(lambda: OS.tiled_render(crop, fn, 2, 16, 8, TILE, mb), repeats=3)
     frame_s = dt / 4 * 45
-    value, whole = crop.shape[1] * crop.shape[2] / 1e6 / dt, None
+    value, whole, whole_out = crop.shape[1] * crop.shape[2] / 1e6 / dt, None, None
     sample = (f"oracle tiled_render of a 476x476 crop of the bench frame (4 tiles of 256, minibatch {mb}), best of a threads x "
               f"minibatch sweep ({threads} threads), 1 warm-up + median of 3 passes, {dt:.2f} s per pass "
               f"(= {frame_s:.0f} s per 1080p frame of 45 tiles")
     if frame_s <= CPU_WHOLE_FRAME_BUDGET_S:
         # BASELINE.md section 4 asks for ONE WHOLE FRAME when it fits: a single timed pass (everything is warm after the sweep)
         t0 = time.perf_counter()
-        OS.tiled_render(frame, fn, 2, 16, 8, TILE, mb)
+        whole_out = OS.tiled_render(frame, fn, 2, 16, 8, TILE, mb)        # kept: the GPU frame at the timed configuration is compared with it
         whole = time.perf_counter() - t0
         value = frame.shape[1] * frame.shape[2] / 1e6 / whole
         sample += f"); `value` is the WHOLE 1080p frame (45 tiles) timed once with that setting: {whole:.1f} s"
@@ -167,7 +167,7 @@ def cpu_baseline(sd, frame):
             "sweep_s_per_pass": {f"{t}thr_mb{b}": round(v, 2) for (t, b), v in sorted(sweep.items())},
             "whole_1080p_frame_estimate_s": round(frame_s, 1),
             "whole_1080p_frame_s": round(whole, 2) if whole is not None else None,
-            "sample": sample + "; tools/cpu_ref_vs_port.py gives the reference / port ratio measured in the build container"}, crop, out
+            "sample": sample + "; tools/cpu_ref_vs_port.py gives the reference / port ratio measured in the build container"}, crop, out, whole_out
 
 
 # PMC summaries of workloads other than the headline bench: the same kernel symbol runs other shapes there, so they are looked up
@@ -399,23 +399,29 @@ def cunet_record(dev, with_cpu):
     m = create_model("waifu2x.cunet").eval()
     m.load_state_dict(sd)
     m = m.to(dev)
-    # tile minibatch = the whole frame (66 tiles), as the swin_unet leg does with its 45: five launches of 16 + 16 + 16 + 16 + 2 tiles
-    # per layer cost 225 vs 298 MPix/s on the same build (tools/cunet_probe.py, CUNET_BATCH); results do not depend on it
+    # tile minibatch = the whole frame, as the swin_unet leg does with its 45 (CB >= the frame's tile count); the reference's own
+    # default minibatch for this net is 16, and that figure is reported next to it (`*_batch16`): round 3's 225 vs 298 MPix/s on
+    # the same build was this batching alone (tools/cunet_probe.py, CUNET_BATCH); results do not depend on it (test_cunet.py)
+    from nunif_amd.nunif.utils.seam_blending import SeamBlending
     CB = 66
-    rec = {"config": f"BASELINE configs[0] geometry on the GPU: waifu2x cunet (noise geometry, random-init), tile 256, tile batch {CB}: "
-                     "one 512 x 512 image (9 tiles) and a 1080p frame (66 tiles)", "unit": "input MPix/s"}
+    grid = SeamBlending.create_config((FRAME_H, FRAME_W), m.i2i_scale, m.i2i_offset, TILE, m.i2i_blend_size)
+    tiles = int(grid["h_blocks"]) * int(grid["w_blocks"])
+    rec = {"config": f"BASELINE configs[0] geometry on the GPU: waifu2x cunet (noise geometry, random-init), tile 256, tile batch {CB} "
+                     f"(= whole frame in one minibatch): one 512 x 512 image (9 tiles) and a 1080p frame ({tiles} tiles); "
+                     "`*_batch16` = the same renders at the reference's default tile minibatch of 16", "unit": "input MPix/s",
+           "tiles_per_1080p_frame": tiles}
     img = synth_frame(31, 512, 512).to(dev)
     frame = synth_frame(32, FRAME_H, FRAME_W).to(dev)
-    for key, x, n in (("image_512", img, 60), ("frame_1080p", frame, 30)):
+    for key, x, n, cb in (("image_512", img, 60, CB), ("frame_1080p", frame, 30, CB), ("frame_1080p_batch16", frame, 30, 16)):
         for _ in range(3):
-            tiled_render(x, m, tile_size=TILE, batch_size=CB)
+            tiled_render(x, m, tile_size=TILE, batch_size=cb)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(n):
-            y = tiled_render(x, m, tile_size=TILE, batch_size=CB)
+            y = tiled_render(x, m, tile_size=TILE, batch_size=cb)
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / n
-        rec[key] = {"ms": round(dt * 1e3, 3), "value": round(x.shape[1] * x.shape[2] / dt / 1e6, 1)}
+        rec[key] = {"ms": round(dt * 1e3, 3), "value": round(x.shape[1] * x.shape[2] / dt / 1e6, 1), "tile_batch": cb}
     _hip.profile_read(reset=True)
     _hip.profile_enable(True)
     for _ in range(3):
@@ -428,7 +434,6 @@ def cunet_record(dev, with_cpu):
         dom = max(recs, key=lambda r: r["total_ms"])
         rec["roofline"] = roofline_of(dom, pmc_set=WORKLOAD_PMC["cunet"])
         conv_ms = sum(r["total_ms"] for r in recs if r["flops"] > 0) / 3
-        tiles = 66
         rec["model_tflops"] = round(tiles * 28e9 / (rec["frame_1080p"]["ms"] * 1e-3) / 1e12, 1)
         rec["model_mfma_frac"] = round(rec["model_tflops"] / MFMA_PEAK_TFLOPS, 4)
         rec["conv_kernel_ms_per_frame"] = round(conv_ms, 3)
@@ -717,11 +722,23 @@ def main():
         if not args.no_config5 and world == 1:
             sub_record("config5", lambda: config5_record(dev))
         if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
-            base, crop, ref = cpu_baseline(sd, frames[0].cpu())
+            base, crop, ref, ref_whole = cpu_baseline(sd, frames[0].cpu())
             got = tiled_render(crop.to(dev), model, tile_size=TILE, batch_size=args.batch_size).cpu()
             mse = torch.mean((got.double() - ref.double()) ** 2).item()
             result["cpu_baseline"] = base
             result["psnr_vs_oracle_db"] = round(10 * math.log10(1.0 / (mse + 1e-6)), 2)
+            if ref_whole is not None:
+                # the GPU frame against the CPU frame, at the TIMED configuration — the whole 1080p frame,
+                # tile batch args.batch_size, every stream of the timed step busy with a frame of its own
+                hs = [pool.submit(render, frames[k % len(frames)]) for k in range(n_streams)]
+                outs = [pool.result(h).float().cpu() for h in hs]
+                torch.cuda.synchronize(dev)
+                mse_w = torch.mean((outs[0].double() - ref_whole.double()) ** 2).item()
+                result["psnr_whole_frame_db"] = round(10 * math.log10(1.0 / (mse_w + 1e-12)), 2)
+                result["psnr_whole_frame"] = {
+                    "frame": [FRAME_H, FRAME_W], "tile_batch": args.batch_size, "concurrent_streams": n_streams,
+                    "max_abs_diff": round(float((outs[0] - ref_whole).abs().max()), 6),
+                    "against": "oracle tiled_render of the same whole frame on the host cores (the cpu_baseline pass, output kept)"}
     if world > 1:
         import threading
         done = threading.Event()

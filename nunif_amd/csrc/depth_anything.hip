@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -345,6 +346,45 @@ struct Cnv { f16 *w = nullptr; float *b = nullptr; int N = 0, Cin = 0, k = 3, cm
 struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2[4], fc2_full, qkv_ln, fc1_ln; int n_fc2; f16 *fc2c = nullptr; };   // fc2c: fc2_full in the chained k order (depth_mlp.hip)   // *_ln: norm1 / norm2 folded in (ViT-S)   // fc2 (K = 4 D) = 2 or 4 GEMMs of K = 768 / 1024
 struct Rcu { Cnv c1, c2; };
 struct Fus { Rcu r1, r2; Lin out; };
+}  // namespace
+
+namespace {
+// The hidden-split MLP kernel (depth_mlp.hip `da_mlp_split_kernel`) spin-waits on its partner workgroup: both must be resident.
+// One such grid at a time always is (2 groups <= CUs, in-order dispatch); two of them on different streams could interleave on
+// the XCD dispatchers into blocks that all wait for partners the other grid keeps out.  So the split form is LEASED to one stream
+// at a time: a forward() on another stream takes it only once the previous holder's forward has completed on the device
+// (event query), otherwise it runs the one-block-per-tile form.  Same stream = stream order = never two grids at once.
+// (Another PROCESS on the same GPU is not covered: the kernel's bounded spin traps instead of hanging; NUNIF_DA_MLP_SPLIT=0.)
+struct SplitLeaseState {
+    std::mutex mu;
+    hipStream_t owner = nullptr;
+    hipEvent_t done = nullptr;
+    bool has_owner = false, enqueueing = false, recorded = false;
+};
+SplitLeaseState g_split;
+struct SplitLease {
+    hipStream_t s;
+    bool held = false;
+    explicit SplitLease(hipStream_t stream) : s(stream) {
+        std::lock_guard<std::mutex> lk(g_split.mu);
+        bool free_now = !g_split.has_owner;
+        if (!free_now && !g_split.enqueueing) {
+            if (g_split.owner == s) free_now = true;
+            else free_now = !g_split.recorded || hipEventQuery(g_split.done) == hipSuccess;
+        }
+        if (!free_now) return;
+        if (!g_split.done && hipEventCreateWithFlags(&g_split.done, hipEventDisableTiming) != hipSuccess) { g_split.done = nullptr; return; }
+        g_split.owner = s; g_split.has_owner = true; g_split.enqueueing = true;
+        held = true;
+    }
+    ~SplitLease() {
+        if (!held) return;
+        std::lock_guard<std::mutex> lk(g_split.mu);
+        g_split.recorded = hipEventRecord(g_split.done, s) == hipSuccess;
+        if (!g_split.recorded) g_split.has_owner = false;            // nothing to wait for: the next caller re-evaluates
+        g_split.enqueueing = false;
+    }
+};
 }  // namespace
 
 struct nunif_depth_anything {
@@ -758,9 +798,10 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         if (fresh) NUNIF_HIP_CHECK(hipMemsetAsync(h->lnstats.p, 0, h->lnstats.cap, s));
         // the hidden-split MLP kernel's hand-off flags (one per workgroup, raised by the sender and lowered by the receiver: zeroed once)
         const size_t fl_bytes = (size_t)da_mlp_flag_count(T) * sizeof(unsigned);
-        const bool fresh_fl = fl_bytes > h->mlp_flags.cap;
+        // ... and again at the start of every forward: a launch that faulted or was aborted half-way leaves flags raised, and the
+        // next forward must not consume stale partial sums behind them
         if ((rc = h->mlp_flags.ensure(fl_bytes))) return rc;
-        if (fresh_fl) NUNIF_HIP_CHECK(hipMemsetAsync(h->mlp_flags.p, 0, h->mlp_flags.cap, s));
+        NUNIF_HIP_CHECK(hipMemsetAsync(h->mlp_flags.p, 0, h->mlp_flags.cap, s));
     }
     for (int i = 0; i < 4; ++i)
         if ((rc = h->feat[i].ensure(T * kD * e2)) || (rc = h->rnb[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2))) return rc;
@@ -787,6 +828,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     bool fuse_ln = kD / 32 == 12 && gemm_os_consumes_stats(T, 3 * kD, kD) && gemm_os_supported(T, kD, kD) && gemm_os_supported(T, kD, 4 * kD);
     for (const Blk &bk : h->blk) fuse_ln = fuse_ln && bk.qkv_ln.w && bk.fc1_ln.w && bk.n_fc2 == 0;
     const bool use_mlp = !(getenv("NUNIF_DA_MLP") && atoi(getenv("NUNIF_DA_MLP")) == 0);      // read per call (tests A/B it)
+    SplitLease lease(s);
     auto blocks = [](long n) { return (unsigned)((n + 255) / 256); };
 
     {   // patch embedding
@@ -879,7 +921,9 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             memset(&ma, 0, sizeof(ma));
             ma.t = t; ma.M = T; ma.w1 = bk.fc1_ln.w; ma.b1 = bk.fc1_ln.b; ma.ws1 = bk.fc1_ln.ws; ma.w2c = bk.fc2c; ma.b2 = bk.fc2_full.b;
             ma.stats_in = lnstats; ma.stats_out = ln1_next ? lnstats : nullptr; ma.ln_eps = 1e-6f;
-            if (h->mlp_flags.p && (size_t)da_mlp_partial_bytes(T) <= h->hid.cap) {   // the hidden rows' buffer is free on this path
+            // the split form needs BOTH blocks of a pair resident; that holds while it is the only spin-waiting grid on the
+            // device (depth_mlp.hip launch_da_mlp) — `lease`, above
+            if (h->mlp_flags.p && lease.held && (size_t)da_mlp_partial_bytes(T) <= h->hid.cap) {   // the hidden rows' buffer is free on this path
                 ma.partial = hid; ma.flags = (unsigned *)h->mlp_flags.p;
             }
             if ((rc = launch_da_mlp(ma, s))) return rc;

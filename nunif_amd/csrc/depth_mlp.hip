@@ -497,8 +497,14 @@ __global__ void __launch_bounds__(kWavesM * 64) da_mlp_split_kernel(DaMlpArgs a)
         NUNIF_MLP_STAMP(8);
     } else {
         if (lane == 0) {
-            while (__hip_atomic_load(a.flags + (blockIdx.x ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+            // bounded: ~2^24 polls of >= 128 clocks (about a second) is four orders of magnitude beyond the partner's whole run.
+            // A partner that never arrives (the two blocks not co-resident: see launch_da_mlp) must not hang the device: trap,
+            // the launch faults and the host sees it at its next synchronisation
+            unsigned polls = 0;
+            while (__hip_atomic_load(a.flags + (blockIdx.x ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(2);
+                if (++polls > (1u << 24)) __builtin_trap();
+            }
         }
         __builtin_amdgcn_wave_barrier();
         NUNIF_MLP_STAMP(6);

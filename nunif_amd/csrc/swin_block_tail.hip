@@ -105,7 +105,7 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
             const f16 *p;
             if constexpr (WM) {
                 // lane group g holds channels 32 ks + 8 g .. + 7 = head 2 ks + (g >> 1), dims 8 (g & 1) ..:
-                // ((w 6 + head) 36 + t) 16 = 16 r + 2880 w + 576 head   (r = 36 w + t; M < 2^31 checked by the launcher)
+                // ((w 6 + head) 36 + t) 16 = 16 r + 2880 w + 576 head   (r = 36 w + t; 96 M < 2^31 checked by the launcher)
                 const int ri = (int)r, w = ri / 36;
                 pixn[f] = pm[f];
                 p = att + (ri * 16 + w * 2880 + (grp >> 1) * 576 + 8 * (grp & 1));
@@ -338,8 +338,9 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
     WinMap wm;
     memset(&wm, 0, sizeof(wm));
     if (wmap) wm = *wmap;
-    NUNIF_REQUIRE(!wm.on || (wm.pixmap && wm.H % 6 == 0 && wm.W % 6 == 0 && M % ((long)wm.H * wm.W) == 0 && M < (1L << 27)),
-                  "proj_mlp: window map geometry");        // 16 M + 2880 (M / 36) att elements are indexed in 32 bits
+    NUNIF_REQUIRE(!wm.on || (wm.pixmap && wm.H % 6 == 0 && wm.W % 6 == 0 && M % ((long)wm.H * wm.W) == 0 && 96L * M < (1L << 31)),
+                  "proj_mlp: window map geometry");        // 16 M + 2880 (M / 36) = 96 M att elements are indexed in 32 bits (swin_unet.cpp
+                                                           // hands larger launches the pixel-major map)
     constexpr int MF = 2, WAVES = 8;
     static bool configured = false;
     if (!configured) {

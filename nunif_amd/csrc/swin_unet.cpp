@@ -420,7 +420,8 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         }
         // C = 96: att travels in window-major order (full-line stores in the attention kernel, the tail walks its tokens in
         // window order); debug taps want the pixel-major map the oracle has
-        const bool att_wm = dim == 96 && h->att_wm && !h->taps_on;
+        // (the tail indexes the window-major map in 32 bits: 96 tok elements; larger launches take the pixel-major map)
+        const bool att_wm = dim == 96 && h->att_wm && !h->taps_on && 96L * (long)tok < (1L << 31);
         if ((rc = launch_qkv_attn_r(x, att, bl.qkv_res, bl.qkv_rbias, bl.attn_btab32, B, S, S, dim, h->heads, shift, s, next_dir(h),
                                     att_wm ? 1 : 0)))
             return rc;

@@ -94,6 +94,7 @@ def install(registry=True, strict=True):
         raise RuntimeError("nunif_amd is already installed; call uninstall() first")
     report = {"patched": {}, "models": [], "skipped": []}
     bindings = []
+    reg_saved = {}
     try:
         jobs = []
         for ref_name, attr in PATCHES:
@@ -117,7 +118,6 @@ def install(registry=True, strict=True):
                         setattr(mod, key, ours)
                         n += 1
             report["patched"][f"{ref_name}.{attr}"] = n
-        reg_saved = {}
         if registry:
             for ref_models, our_modules in _MODEL_MODULES:
                 try:

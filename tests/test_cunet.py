@@ -114,6 +114,29 @@ def test_hip_config1_512_tile256(hiplib):
 
 
 @pytest.mark.gpu
+def test_hip_cunet_1080p_whole_frame_minibatch_equals_small_minibatches(hiplib):
+    """bench.py's cunet leg renders the 1080p frame (6 x 10 = 60 tiles) in ONE minibatch (tile batch 66) (the conv dispatch is shape-dependent: the
+    DMA conv takes launches of more than 512 patches); the frame must carry the bits of the 16- and 7-tile minibatch renders, and
+    an interior tile meets the oracle bound."""
+    from nunif_amd.waifu2x.models.cunet import CUNet
+    from nunif_amd.nunif.utils.render import tiled_render
+    sd = OC.random_state_dict(202)
+    m = CUNet().eval()
+    m.load_state_dict(sd)
+    m = m.to("cuda:0")
+    img = synth_image(63, 3, 1080, 1920)
+    out = tiled_render(img, m, tile_size=256, batch_size=66)
+    assert out.shape == (3, 1080, 1920)
+    for mb in (16, 7):
+        o = tiled_render(img, m, tile_size=256, batch_size=mb)
+        assert torch.equal(out, o), f"minibatch 66 != minibatch {mb}: {float((out - o).abs().max())}"
+    cfg = OS.create_config(1080, 1920, 1, 28, 256, 0)
+    xp = torch.nn.functional.pad(img[None], cfg["pad"], mode="replicate")[0]
+    z = OC.model_forward(sd, xp[:, 400:656, 800:1056][None])[0]        # tile (2,4) -> output [400:600) x [800:1000)
+    assert psnr(out[:, 400:600, 800:1000].cpu(), z) >= 50.0
+
+
+@pytest.mark.gpu
 def test_dma_staged_conv_is_bit_identical_to_the_register_staged_one(hiplib, monkeypatch):
     """conv3_dma_kernel (persistent, halo + weights by LDS-DMA; launches of more than 512 patches) against conv3_lds_kernel on the
     same engines: same MFMA order over k, so the outputs must be EQUAL — cunet / upcunet on a 12-tile minibatch of 256 x 256

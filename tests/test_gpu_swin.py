@@ -276,6 +276,37 @@ def test_full_size_1080p_properties(hiplib):
     assert out208.shape == out.shape and float(out208.min()) >= 0 and float(out208.max()) <= 1
 
 
+def test_timed_configuration_batch45_two_streams_equals_small_batches(hiplib):
+    """bench.py's timed configuration — 1080p, tile 256, ALL 45 tiles of the frame in one minibatch, two frames in flight on two
+    streams (``ConcurrentRenderer``) — must give the bits of the small-minibatch render the oracle-parity tests above use
+    (batch 8), for both frames; and the (0,0) / interior tiles of that very output meet the oracle bound."""
+    from nunif_amd.nunif.utils.render import tiled_render
+    from nunif_amd.parallel import ConcurrentRenderer
+    from nunif_amd.waifu2x.models import swin_unet as M
+    sd = O.random_state_dict(102, 2)
+
+    def factory():
+        mm = M.SwinUNet2x().eval()
+        mm.load_state_dict(sd, strict=True)
+        return mm
+
+    pool = ConcurrentRenderer(factory, 2, "cuda:0")
+    imgs = [synth_image(77 + i, 3, 1080, 1920).to("cuda:0") for i in range(2)]
+    base = [tiled_render(im, pool.models[0], tile_size=256, batch_size=8).clone() for im in imgs]
+    for rep in range(3):                                            # back to back: the streams overlap from the second round on
+        hs = [pool.submit(lambda m, f: tiled_render(f, m, tile_size=256, batch_size=45), im) for im in imgs]
+        outs = [pool.result(h).clone() for h in hs]
+        torch.cuda.synchronize()
+        for o, b in zip(outs, base):
+            assert torch.equal(o, b), f"tile batch 45 on two streams != tile batch 8 (round {rep}): {float((o - b).abs().max())}"
+    out = outs[0]
+    cfg = OS.create_config(1080, 1920, 2, 16, 256, 8)
+    xp = torch.nn.functional.pad(imgs[0].cpu()[None], cfg["pad"], mode="replicate")[0]
+    z = O.model_forward(sd, xp[:, 2 * 236:2 * 236 + 256, 4 * 236:4 * 236 + 256][None])[0]          # tile (2,4)
+    y0, x0 = 2 * 472, 4 * 472
+    assert psnr(out[:, y0 + 8:y0 + 472, x0 + 8:x0 + 472].cpu(), z[:, 8:472, 8:472]) >= PSNR_MIN
+
+
 def test_full_size_4k_4x_properties(hiplib):
     """BASELINE config 3 geometry: swin_unet 4x on a 2160x3840 frame, tile 256 -> 8640x15360 (170 tiles, 1.6 GB of
     fp32 output).  Whole-frame oracle is minutes of CPU, so: grid facts, determinism across tile batch sizes, range,
