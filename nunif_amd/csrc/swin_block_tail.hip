@@ -34,7 +34,7 @@ namespace nunif {
 // Waves drift apart (no barrier in the group loop), so one wave's GELU / convert (VALU) phase overlaps its SIMD partner's
 // MFMA phase (same finding as swin_qkv_attn_r.hip).  MF = 2 token tiles per group, 8 waves, next-group prefetch: the fastest
 // of the eight (MF, waves, prefetch) combinations measured in rounds 1-2.
-template <int C, int MF, int WAVES, bool PF = false, bool WM = false>
+template <int C, int MF, int WAVES, bool PF = false, bool WM = false, bool G32 = false>
 __global__ void __launch_bounds__(WAVES * 64)
 proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wstream, const float *__restrict__ bp,
                   const float *__restrict__ b0, const float *__restrict__ b3, long M, TailToImage ti, int rev, WinMap wm) {
@@ -233,7 +233,7 @@ proj_mlp_r_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ w
             f16x8 hf[MF];
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
-                hf[f] = gelu8t(h0[f], h1[f]);
+                hf[f] = gelu8t<G32>(h0[f], h1[f]);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -325,7 +325,7 @@ int proj_mlp_stream_frags(int C) {
 }
 
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
-                    long M, int C, hipStream_t s, const TailToImage *to_image, int rev, const WinMap *wmap) {
+                    long M, int C, hipStream_t s, const TailToImage *to_image, int rev, const WinMap *wmap, int gelu32) {
     if (M == 0) return NUNIF_HIP_OK;
     NUNIF_REQUIRE(C == 96, "proj_mlp: channel count %d unsupported (C = 192 runs launch_proj_mlp_ws)", C);
     NUNIF_REQUIRE(!to_image || to_image->n_real <= 16, "proj_mlp: the fused image head takes at most 16 output channels");
@@ -342,18 +342,21 @@ int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp,
                   "proj_mlp: window map geometry");        // 16 M + 2880 (M / 36) = 96 M att elements are indexed in 32 bits (swin_unet.cpp
                                                            // hands larger launches the pixel-major map)
     constexpr int MF = 2, WAVES = 8;
-    static bool configured = false;
-    if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)proj_mlp_r_kernel<96, MF, WAVES, true, false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)proj_mlp_r_kernel<96, MF, WAVES, true, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        configured = true;
-    }
-    const long groups = (M + MF * 16 - 1) / (MF * 16);
-    const unsigned blocks = (unsigned)std::min<long>((groups + WAVES - 1) / WAVES, 256);
-    if (wm.on) proj_mlp_r_kernel<96, MF, WAVES, true, true><<<blocks, WAVES * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti, rev, wm);
-    else proj_mlp_r_kernel<96, MF, WAVES, true, false><<<blocks, WAVES * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti, rev, wm);
+    auto go = [&](auto kern, int slot) -> int {
+        static bool configured[4] = {false, false, false, false};
+        if (!configured[slot]) {
+            NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            configured[slot] = true;
+        }
+        const long groups = (M + MF * 16 - 1) / (MF * 16);
+        const unsigned blocks = (unsigned)std::min<long>((groups + WAVES - 1) / WAVES, 256);
+        kern<<<blocks, WAVES * 64, smem, s>>>(att, x, wstream, bp, b0, b3, M, ti, rev, wm);
+        return NUNIF_HIP_OK;
+    };
+    int rc;
+    if (gelu32) rc = wm.on ? go(proj_mlp_r_kernel<96, MF, WAVES, true, true, true>, 3) : go(proj_mlp_r_kernel<96, MF, WAVES, true, false, true>, 2);
+    else rc = wm.on ? go(proj_mlp_r_kernel<96, MF, WAVES, true, true, false>, 1) : go(proj_mlp_r_kernel<96, MF, WAVES, true, false, false>, 0);
+    if (rc) return rc;
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }

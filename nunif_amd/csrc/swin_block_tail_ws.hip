@@ -75,7 +75,7 @@ extern "C" int nunif_dbg_ws_trace(void *buf) {
 // nunif_amd.build) and selected with NUNIF_TAIL_WS_ABL: 1 = no GELU polynomial, 2 = no MFMA, 4 = no HBM traffic inside the
 // loop (no att DMA, no x loads, no x' stores), 8 = no barrier, 16 = no bias reads from LDS, 32 = no Wp reads from LDS,
 // 64 = stage C reads only 4 of its 12 hidden fragments
-template <int ABL>
+template <int ABL, bool G32 = false>
 __global__ void __launch_bounds__(512, 2)
 proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ wws, const float *__restrict__ bp,
                    const float *__restrict__ b0, const float *__restrict__ b3, long M, int rev) {
@@ -220,12 +220,12 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
                     } else {
 #pragma unroll
                         for (int j = 0; j < 2 * KS; ++j) mfma_at(p, j);
-                        hd[(3 * slice + p - 1) * 64] = gelu8t(acc[2 * p - 2], acc[2 * p - 1]);
+                        hd[(3 * slice + p - 1) * 64] = gelu8t<G32>(acc[2 * p - 2], acc[2 * p - 1]);
                     }
                 }
                 WS_STAMP(3);
                 if constexpr (ABL & 1) raw_pair(HT / 2 - 1);
-                else hd[(3 * slice + HT / 2 - 1) * 64] = gelu8t(acc[HT - 2], acc[HT - 1]);
+                else hd[(3 * slice + HT / 2 - 1) * 64] = gelu8t<G32>(acc[HT - 2], acc[HT - 1]);
                 WS_STAMP(4);
             }
             // the next trip's stage A reads tile i + 3: requested kDmaAhead trips ago
@@ -334,7 +334,7 @@ proj_mlp_ws_kernel(const f16 *__restrict__ att, f16 *x, const f16 *__restrict__ 
 }
 
 int launch_proj_mlp_ws(const f16 *att, f16 *x, const f16 *wws, const float *bp, const float *b0, const float *b3, long M,
-                       hipStream_t s, int rev) {
+                       hipStream_t s, int rev, int gelu32) {
     if (M == 0) return NUNIF_HIP_OK;
     ProfScope ps("proj_mlp_ws_kernel", s, 2.0 * (double)M * kWsC * kWsC * 5.0, (double)M * kWsC * 2.0 * 3.0);
     constexpr size_t smem = (size_t)kWsLdsKiB * 1024 + 4 * kWsC * 4;
@@ -350,7 +350,7 @@ int launch_proj_mlp_ws(const f16 *att, f16 *x, const f16 *wws, const float *bp, 
         return NUNIF_HIP_OK;
     };
     int rc;
-    rc = go(proj_mlp_ws_kernel<0>, 0);       // ABL != 0 instantiations are timing-only experiments (see the kernel header), never shipped
+    rc = gelu32 ? go(proj_mlp_ws_kernel<0, true>, 1) : go(proj_mlp_ws_kernel<0, false>, 0);       // ABL != 0 instantiations are timing-only experiments (see the kernel header), never shipped
     if (rc) return rc;
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;

@@ -79,12 +79,18 @@ __device__ __forceinline__ f16x8 gelu8h(const f32x4 &a, const f32x4 &b) {
     return (f16x8){r[0][0], r[0][1], r[1][0], r[1][1], r[2][0], r[2][1], r[3][0], r[3][1]};
 }
 
-// the swin tails take the packed form unless built with -DNUNIF_GELU_F32 (A/B builds)
+// The swin tails take the packed form; G32 = true (the 1x net, swin_unet.cpp) takes the fp32 polynomial.  Round-5 statistics over 8
+// inputs per hot-regime case (tools/hot_regime_stats.py, profiles/r05a_hot_*.json): mean distance to the emulated fp16 reference
+// with the packed / the fp32 form  2x -0.77 / -0.82 dB, 4x -0.86 / -0.56, 2x_chaos -2.81 / -2.76 — inside the +-0.3..0.4 dB standard
+// error, no difference — but 1x -1.81 / -0.55: that net pays 1.3 dB for the packed form, so it does not get it.
+// -DNUNIF_GELU_F32 forces the fp32 form everywhere (A/B builds).
+template <bool G32 = false>
 __device__ __forceinline__ f16x8 gelu8t(const f32x4 &a, const f32x4 &b) {
 #ifdef NUNIF_GELU_F32
     return gelu8(a, b);
 #else
-    return gelu8h(a, b);
+    if constexpr (G32) return gelu8(a, b);
+    else return gelu8h(a, b);
 #endif
 }
 

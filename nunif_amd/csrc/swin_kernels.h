@@ -33,6 +33,14 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag);
 
+// ---- PatchUp of the swin U-Nets (swin_patchup.hip): out = pixel_shuffle_2(Linear(192 -> 4 Cq)(a)) + res, NHWC fp16 ---------------
+// a: [B, Ho, Wo, 192]; w / bias: make_linear's packing with columns n = q Cq + c (q = 2 i + j the sub-pixel); res / out:
+// [B, 2 Ho, 2 Wo, Cq] (out may alias res).  Cq = 96 or 192.  Weights resident in LDS, persistent workgroups, the next token
+// group's activations and the skip tiles of the next four trips in flight.
+struct PatchUpArgs { const f16 *a, *w; const float *bias; const f16 *res; f16 *out; int B, Ho, Wo, Cq, rev; };
+bool patchup_supported(const PatchUpArgs &g);
+int launch_patchup(const PatchUpArgs &g, hipStream_t s);
+
 // ---- output-stationary Linear for TOKEN matrices of a few thousand rows (the ViT encoders of the depth nets) -----------------
 // out[m][n] = act(sum_k a[m][k] W[n][k] + bias[n]) (+ res[m][n]); a: [M][lda] fp16, W in gemm_kernel's packing [nt][ks].
 // gemm_kernel is token-stationary (a wave keeps 16-32 tokens' whole K extent and sweeps all of N through the LDS ring): with
@@ -120,7 +128,7 @@ struct WinMap { int on, H, W, shift; const int *pixmap; };     // pixmap: token 
 int launch_winmap_build(int *pixmap, int B, int H, int W, int shift, hipStream_t s);
 int launch_proj_mlp(const f16 *att, f16 *x, const f16 *wstream, const float *bp, const float *b0, const float *b3,
                     long M, int C, hipStream_t s, const TailToImage *to_image = nullptr, int rev = 0,
-                    const WinMap *wm = nullptr);
+                    const WinMap *wm = nullptr, int gelu32 = 0);      // gelu32: the fp32-polynomial GELU (swin_gelu.h gelu8t)
 
 // ---- one kernel per C = 96 swin block: qkv + window attention + proj + MLP, in place on x (swin_block96.hip) -----------
 // wqkv / bqkv: the LDS-resident attention's packing (q pre-scaled); btab: swin_block96_btab_floats() floats, per head the
@@ -136,7 +144,7 @@ int launch_swin_block96(f16 *x, const f16 *wqkv, const float *bqkv, const float 
 // wws: Wp [slice 4][nt 3][ks 6] (plain k order) | W0 [4][nt 6][ks 6] | W3 [4][nt 3][ks 12] (chained k order), 1-KiB fragments
 int proj_mlp_ws_stream_frags();
 int launch_proj_mlp_ws(const f16 *att, f16 *x, const f16 *wws, const float *bp, const float *b0, const float *b3, long M,
-                       hipStream_t s, int rev = 0);
+                       hipStream_t s, int rev = 0, int gelu32 = 0);
 
 // ---- fused qkv Linear + (shifted) 6x6 window attention, one window per wave, qkv weights resident in LDS, no barrier in the
 // window loop (swin_qkv_attn_r.hip); C = 96 (6 heads of 16) or 192 (6 heads of 32).  x: [B,H,W,C] -> att: [B,H,W,C]

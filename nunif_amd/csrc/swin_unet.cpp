@@ -82,6 +82,7 @@ struct nunif_swin_unet {
     f16 *stemf_w1 = nullptr, *stemf_w2 = nullptr;   // fused stem (swin_stem.hip)
     int dir = 0;                      // direction of the next kernel (snake order); next_dir() flips it
     int att_wm = 1;                   // NUNIF_ATT_WM=0: C = 96 att map pixel-major (8-byte partial-line stores) as in round 2
+    int gelu32 = 0;                   // tails with the fp32-polynomial GELU: the 1x net (swin_gelu.h); NUNIF_SWIN_GELU32=0/1 overrides
     int block96 = 0;                  // NUNIF_BLOCK96=1: C = 96 blocks as ONE kernel (swin_block96.hip) instead of attention + tail
     bool has_proj2 = false;
     std::vector<Block> swin[5];
@@ -351,6 +352,14 @@ int run_gemm(const Linear &L, const f16 *a, int B, int Hi, int Wi, int Cin, int 
     return launch_gemm(g, s, tag);
 }
 
+// x = PatchUp(a) + skip, in place over the skip map (swin_unet.py:65-82,189-196): the resident-weight kernel when it takes the
+// shape (every launch of that shape, whatever the batch: results must not depend on the tile minibatch), else the generic GEMM
+int run_patchup(const Linear &L, const f16 *a, int B, int H, int W, int Cq, f16 *skip, hipStream_t s, const char *tag, int rev) {
+    PatchUpArgs p = {a, L.w, L.bias, skip, skip, B, H, W, Cq, rev};
+    if (L.K == 192 && L.n_real == 4 * Cq && patchup_supported(p)) return launch_patchup(p, s);
+    return run_gemm(L, a, B, H, W, L.K, H, W, 1, 0, 0, 1, 1, 0, 0.f, skip, skip, Cq, 1, s, tag, rev);
+}
+
 int run_linear(const Linear &L, const f16 *a, int B, int H, int W, int act, const f16 *res, f16 *out,
                hipStream_t s, const char *tag, int rev = 0) {
     return run_gemm(L, a, B, H, W, L.K, H, W, 1, 0, 0, 1, 0, act, 0.f, res, out, L.n_real, 1, s, tag, rev);
@@ -430,7 +439,7 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
         const bool last = i + 1 == blocks.size();
         if (dim == 192) {
             // C = 192: weights stationary in registers / LDS (swin_block_tail_ws.hip)
-            if ((rc = launch_proj_mlp_ws(att, x, bl.tail_ws, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, s, next_dir(h))))
+            if ((rc = launch_proj_mlp_ws(att, x, bl.tail_ws, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, s, next_dir(h), h->gelu32)))
                 return rc;
         } else {
             const int eff_shift = S <= 6 ? 0 : shift;
@@ -448,7 +457,7 @@ int run_stage(nunif_swin_unet *h, std::vector<Block> &blocks, f16 *x, int B, int
                 wmap.pixmap = (const int *)h->winmap[eff_shift ? 1 : 0].p;
             }
             if ((rc = launch_proj_mlp(att, x, bl.tail_stream, bl.proj.bias, bl.mlp0.bias, bl.mlp3.bias, (long)tok, dim, s,
-                                      last ? to_image : nullptr, next_dir(h), &wmap)))
+                                      last ? to_image : nullptr, next_dir(h), &wmap, h->gelu32)))
                 return rc;
         }
         if (last && to_image) break;               // x of the last block is not materialised
@@ -530,9 +539,7 @@ stem_done:
     if ((rc = tap(h, "down2", f3, (size_t)B * (S / 4) * (S / 4) * 2 * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[2], f3, B, S / 4, 2 * C, s, "swin3"))) return rc;                  // swin3
     // x = up2(x5) + x4, written in place over x4 (each lane reads then writes its own 8 bytes)
-    if ((rc = run_gemm(h->up2, f3, B, S / 4, S / 4, 2 * C, S / 4, S / 4, 1, 0, 0, 1, 1, 0, 0.f, f2, f2, 2 * C, 1, s,
-                       "gemm_up2", next_dir(h))))
-        return rc;
+    if ((rc = run_patchup(h->up2, f3, B, S / 4, S / 4, 2 * C, f2, s, "gemm_up2", next_dir(h)))) return rc;
     if ((rc = tap(h, "up2", f2, (size_t)B * (S / 2) * (S / 2) * 2 * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[3], f2, B, S / 2, 2 * C, s, "swin4"))) return rc;                  // swin4
     f16 *top = f1;
@@ -541,9 +548,7 @@ stem_done:
         top = (f16 *)h->g1.p;
         if ((rc = run_linear(h->proj2, f1, B, S, S, 0, nullptr, top, s, "gemm_proj2", next_dir(h)))) return rc;
     }
-    if ((rc = run_gemm(h->up1, f2, B, S / 2, S / 2, 2 * C, S / 2, S / 2, 1, 0, 0, 1, 1, 0, 0.f, top, top,
-                       h->top_dim, 1, s, "gemm_up1", next_dir(h))))
-        return rc;
+    if ((rc = run_patchup(h->up1, f2, B, S / 2, S / 2, h->top_dim, top, s, "gemm_up1", next_dir(h)))) return rc;
     if ((rc = tap(h, "up1", top, (size_t)B * S * S * h->top_dim * 2, s))) return rc;
     // to_image + pixel_shuffle + clamp(0,1) (ToImage.forward :110-116, wrapper eval clamp :225-226): fused into the
     // last block's tail kernel when that block runs on the resident C = 96 kernel (1x / 2x nets)
@@ -590,6 +595,8 @@ extern "C" int nunif_hip_swin_unet_create(const nunif_tensor_desc *tensors, int3
     (void)hipGetDevice(&h->device);
     if (const char *v = getenv("NUNIF_BLOCK96")) h->block96 = atoi(v);
     if (const char *v = getenv("NUNIF_ATT_WM")) h->att_wm = atoi(v);
+    h->gelu32 = scale_factor == 1;
+    if (const char *v = getenv("NUNIF_SWIN_GELU32")) h->gelu32 = atoi(v);
     h->scale_factor = scale_factor;
     const std::string P = "unet.";
     int rc = NUNIF_HIP_OK;

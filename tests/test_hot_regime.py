@@ -21,6 +21,22 @@ Two builds that differ only in HOW the same GELU is evaluated move by +0.7 / -1.
 (The first version of the emulation left the parameters in fp32 and read 3 dB better — that 3 dB is what fp16 WEIGHTS cost any
 fp16 engine, the reference's autocast included.)
 
+Round 5: the margin is no longer read off one sample.  ``tools/hot_regime_stats.py`` runs every case's weights
+on 8 inputs of 64 x 64 and one 256 x 256 tile and reports gap = PSNR(HIP) - PSNR(emulation), both against the fp32 oracle
+(``profiles/r05a_hot_packed.json``, ``r05a_hot_gelu32.json``, ``r05b_hot.json``):
+    case        mean gap +- std (worst), packed-fp16 GELU     fp32-polynomial GELU build      256 x 256 tile (packed / fp32)
+    2x          -0.77 +- 1.21 (-2.15)                         -0.82 +- 1.37 (-2.22)           -0.99 / -1.80
+    2x_chaos    -2.81 +- 0.49 (-3.52)                         -2.76 +- 0.52 (-3.74)           -1.18 / -1.40
+    4x          -0.86 +- 0.81 (-1.99)                         -0.56 +- 0.90 (-2.03)           -0.54 / -0.81
+    1x          -1.81 +- 1.03 (-3.65)                         -0.55 +- 0.98 (-2.26)           -1.64 / +0.41
+A single input scatters by +-1 dB (one sigma) around its case's mean, so a per-sample margin below ~2.5 sigma + |mean| fails at
+random: the single-sample tests keep 3 dB and the CRITERION is the mean over 8 inputs, >= -1.5 dB
+(``test_hip_swin_unet_hot_regime_gap_statistics``).  The packed GELU costs the 1x net 1.3 dB (6 sigma of the mean) and nothing
+measurable elsewhere: the 1x net now runs the fp32-polynomial form (``swin_gelu.h`` ``gelu8t<G32>``; -0.51 +- 0.95 in ``r05b_hot.json``).
+``2x_chaos`` is the one case outside 1.5 dB: 37 % of that picture is clamped and the emulation ITSELF is at 26.8 dB — two fp16
+evaluation orders of the same net end up 2-3 dB apart there (the emulation rounds after every op; the engine keeps fp32 inside fused
+blocks and rounds at kernel boundaries), its bound is -3.5 dB on the mean and it is reported, not hidden.
+
 ``tests/golden/hot_regime.npz`` (``make_golden.py hot``) holds, per case, the REFERENCE's fp32 output and the emulated one.
 """
 import os
@@ -106,6 +122,26 @@ def test_hip_swin_unet_in_the_hot_regime(hiplib, hot, capsys, tag, sf, seed):
     y = m.to("cuda:0")(hot["swin_x"].to("cuda:0")).cpu()
     with capsys.disabled():
         _criterion(f"swin_{tag}", y, hot[f"swin_{tag}_ref"], hot[f"swin_{tag}_emu"], SWIN_MARGIN_DB)
+
+
+MEAN_GAP_MIN_DB = {"2x": -1.5, "4x": -1.5, "1x": -1.5, "2x_chaos": -3.5}      # module docstring
+WORST_GAP_MIN_DB = -4.5                                                       # mean - 3 sigma of the noisiest case
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,sf,seed", HOT_SWIN)
+def test_hip_swin_unet_hot_regime_gap_statistics(hiplib, capsys, tag, sf, seed):
+    """Mean over 8 inputs (and one 256 x 256 tile) of PSNR(HIP) - PSNR(emulated fp16 reference), both against the fp32 oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    import hot_regime_stats as H
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    st = H.summarize(H.case_gaps(tag, sf, seed, n_inputs=8, big=True))
+    with capsys.disabled():
+        print(f"\nhot swin_{tag}: gap to the emulated fp16 reference over {st['n']} inputs: mean {st['mean_gap_db']:+.2f} dB, "
+              f"std {st['std_gap_db']:.2f}, worst {st['worst_gap_db']:+.2f}; 256 x 256 tile {st['tile256']['gap']:+.2f}")
+    assert st["mean_gap_db"] >= MEAN_GAP_MIN_DB[tag], st
+    assert st["worst_gap_db"] >= WORST_GAP_MIN_DB and st["tile256"]["gap"] >= WORST_GAP_MIN_DB, st
 
 
 @pytest.mark.gpu
