@@ -41,6 +41,13 @@ struct PatchUpArgs { const f16 *a, *w; const float *bias; const f16 *res; f16 *o
 bool patchup_supported(const PatchUpArgs &g);
 int launch_patchup(const PatchUpArgs &g, hipStream_t s);
 
+// ---- PatchDown of the swin U-Nets (swin_patchdown.hip): out[b, y, x, 192] = bias + sum over the taps of a 2 x 2 stride-2 patch --------
+// a: [B, 2 Ho, 2 Wo, Cin]; Cin = 96: K = 384 = the four taps (dy, dx) of a token, k = (2 dy + dx) Cin + c; Cin = 192: K = 384 = the
+// two taps of input row 2 y + oy (the other row is a second, accumulating pass on gemm_res_kernel).  w / bias: make_linear's packing.
+struct PatchDownArgs { const f16 *a, *w; const float *bias; f16 *out; int B, Ho, Wo, Cin, oy, rev; };
+bool patchdown_supported(const PatchDownArgs &g);
+int launch_patchdown(const PatchDownArgs &g, hipStream_t s);
+
 // ---- output-stationary Linear for TOKEN matrices of a few thousand rows (the ViT encoders of the depth nets) -----------------
 // out[m][n] = act(sum_k a[m][k] W[n][k] + bias[n]) (+ res[m][n]); a: [M][lda] fp16, W in gemm_kernel's packing [nt][ks].
 // gemm_kernel is token-stationary (a wave keeps 16-32 tokens' whole K extent and sweeps all of N through the LDS ring): with

@@ -34,7 +34,10 @@ constexpr int kNT = 24;                              // 16-column tiles resident
 constexpr int kTrips = kNT / 2;                      // a trip = one 32-channel pair of tiles
 constexpr int kWaves = 8;
 constexpr int kMF = 2;                               // token tiles per wave and group: 32 tokens
-constexpr int kD = 4;                                // depth of the skip-tile ring, in trips
+#ifndef NUNIF_PU_KD
+#define NUNIF_PU_KD 4
+#endif
+constexpr int kD = NUNIF_PU_KD;                      // depth of the skip-tile ring, in trips (A/B builds: -DNUNIF_PU_KD=6)
 constexpr int kWBytes = kNT * kKS * 1024;            // 147 456
 constexpr int kSmem = kWBytes + 384 * 4;             // + bias
 static_assert(kSmem <= 160 * 1024, "LDS");
@@ -121,6 +124,15 @@ __global__ void __launch_bounds__(kWaves * 64) patchup_kernel(PatchUpArgs g) {
 #pragma unroll
     for (int t = 0; t < kD; ++t) load_res(cur, t, rr[t]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // hipcc must KNOW that nothing is pending here: it merges this path's wait counts into the loop header, and with the prologue
+    // loads still on its books the first trips of every group would wait for younger loads than they need
+#pragma unroll
+    for (int f = 0; f < kMF; ++f) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) asm volatile("" : "+v"(xc[f][ks]));
+#pragma unroll
+        for (int t = 0; t < kD; ++t) asm volatile("" : "+v"(rr[t][f]));
+    }
     __syncthreads();
     if (!any) return;
 

@@ -360,6 +360,15 @@ int run_patchup(const Linear &L, const f16 *a, int B, int H, int W, int Cq, f16 
     return run_gemm(L, a, B, H, W, L.K, H, W, 1, 0, 0, 1, 1, 0, 0.f, skip, skip, Cq, 1, s, tag, rev);
 }
 
+// PatchDown pass without a residual (swin_unet.py:45-62): a [B, 2 Ho, 2 Wo, Cin] -> out [B, Ho, Wo, 192], K = 384 = the taps of
+// input row(s) 2 y + oy ..; the K-outer prefetching kernel when it takes the shape (every launch of that shape), else the generic GEMM
+int run_patchdown(const Linear &L, const f16 *a, int B, int Ho, int Wo, int Cin, int oy, f16 *out, hipStream_t s, const char *tag,
+                  int rev) {
+    PatchDownArgs p = {a, L.w, L.bias, out, B, Ho, Wo, Cin, oy, rev};
+    if (L.K == 384 && L.n_real == 192 && patchdown_supported(p)) return launch_patchdown(p, s);
+    return run_gemm(L, a, B, 2 * Ho, 2 * Wo, Cin, Ho, Wo, 2, oy, 0, 2, 0, 0, 0.f, nullptr, out, L.n_real, 1, s, tag, rev);
+}
+
 int run_linear(const Linear &L, const f16 *a, int B, int H, int W, int act, const f16 *res, f16 *out,
                hipStream_t s, const char *tag, int rev = 0) {
     return run_gemm(L, a, B, H, W, L.K, H, W, 1, 0, 0, 1, 0, act, 0.f, res, out, L.n_real, 1, s, tag, rev);
@@ -525,13 +534,13 @@ int forward_impl(nunif_swin_unet *h, const float *x, const float *frame, const n
 stem_done:
     if ((rc = tap(h, "stem", f1, (size_t)B * S * S * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[0], f1, B, S, C, s, "swin1"))) return rc;                          // swin1 -> x3
-    if ((rc = run_gemm(h->down1, f1, B, S, S, C, S / 2, S / 2, 2, 0, 0, 2, 0, 0, 0.f, nullptr, f2, 2 * C, 1, s,
-                       "gemm_down1", next_dir(h))))
-        return rc;
+    if ((rc = run_patchdown(h->down1, f1, B, S / 2, S / 2, C, 0, f2, s, "gemm_down1", next_dir(h)))) return rc;
     if ((rc = tap(h, "down1", f2, (size_t)B * (S / 2) * (S / 2) * 2 * C * 2, s))) return rc;
     if ((rc = run_stage(h, h->swin[1], f2, B, S / 2, 2 * C, s, "swin2"))) return rc;                  // swin2 -> x4
-    if ((rc = run_gemm(h->down2, f2, B, S / 2, S / 2, 2 * C, S / 4, S / 4, 2, 0, 0, 2, 0, 0, 0.f, nullptr, f3,
-                       2 * C, 1, s, "gemm_down2", next_dir(h))))
+    if (h->down2_split) {
+        if ((rc = run_patchdown(h->down2, f2, B, S / 4, S / 4, 2 * C, 0, f3, s, "gemm_down2", next_dir(h)))) return rc;
+    } else if ((rc = run_gemm(h->down2, f2, B, S / 2, S / 2, 2 * C, S / 4, S / 4, 2, 0, 0, 2, 0, 0, 0.f, nullptr, f3,
+                              2 * C, 1, s, "gemm_down2", next_dir(h))))
         return rc;
     if (h->down2_split && (rc = run_gemm(h->down2b, f2, B, S / 2, S / 2, 2 * C, S / 4, S / 4, 2, 1, 0, 2, 0, 0, 0.f, f3, f3,
                                          2 * C, 1, s, "gemm_down2b", next_dir(h))))

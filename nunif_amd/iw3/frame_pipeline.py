@@ -236,6 +236,9 @@ def bind_batch_frame_callback(depth_model, side_model, segment_pts, args, ops=No
         tickets[0] += 1                 # kept for signature parity (the reference's enqueue ticket); order is inherent here
         return (x, pts, flush, tickets[0] - 1)
 
+    # what ShardedFrameCallbackPool (one video on N GPUs) needs to run the same stages across ranks
+    frame_callback.spec = {"depth_model": depth_model, "side_model": side_model, "segment_pts": segment_pts, "args": args,
+                           "ops": ops}
     return frame_callback, preprocess_callback
 
 
@@ -476,103 +479,260 @@ def _replay_scaler(depth_model):
     return EMAMinMaxScaler(decay=decay, buffer_size=buffer_size)
 
 
+class ShardedStereoStream:
+    """Depth + stereo over a STREAM of frames sharded across ranks, batch ``b`` on rank ``b mod world`` (module docstring).
+
+    ``push_round(my_frames, round_pts)`` takes one round = up to ``world`` consecutive batches: ``round_pts[r]`` are the time
+    stamps of the batch rank ``r`` owns, ``my_frames`` the CHW float tensors of THIS rank's batch (empty when the round is short).
+    Per round: depth inference on the own batch, one all-gather of ``[batch_size, 2]`` (min, max) floats per rank, the sequential
+    EMA of ``depth_model``'s scaler replayed over ALL frames (every rank replays the same recurrence, so every rank also knows
+    which frames of which rank just left the look-ahead), stereo on the own frames that did.  ``deliver()`` moves what became
+    ready since the last call to rank ``dst`` (one padded gather) and returns, on ``dst``, the next frames in stream order;
+    ``finish()`` flushes the look-ahead.  ``stereo_fn(x_srcs[B,3,H,W], depths[B,1,h,w], reset_pts) -> list of quantised HWC
+    frames``.  The output is bit-identical to a single process walking the frames in order."""
+
+    def __init__(self, depth_model, stereo_fn, batch_size, segment_pts=(), group=None, dst=0, infer_kwargs=None, device=None):
+        if getattr(depth_model, "has_temporal_state", False):
+            raise ValueError("a depth model with temporal state cannot be sharded by frame; shard by scene segment")
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.depth_model, self.stereo_fn, self.batch_size = depth_model, stereo_fn, batch_size
+        self.segment_pts = set(segment_pts or ())
+        self.infer_kwargs = infer_kwargs or {}
+        self.device = torch.device(device) if device is not None else None
+        self.replay = _replay_scaler(depth_model)
+        self.replay_order = []             # global frame indices waiting inside ``replay``, oldest first
+        self.raw = {}                      # my frames: index -> (source, raw depth)
+        self.ready = []                    # my frames with their range: (index, lo, hi), in frame order
+        self.fresh = []                    # indices (any rank's) that left the look-ahead since the last deliver()
+        self.out_local, self.pts, self.owner = {}, {}, {}
+        self.n = 0                         # frames seen so far
+        self.meta = None                   # (shape, dtype) of an output frame, agreed on at the first delivery
+        self.arrived, self.emit_next = {}, 0
+
+    # -- the replayed recurrence ---------------------------------------------------------------------------------------------
+    def _assign(self, results):
+        for _, lo, hi in results:
+            idx = self.replay_order.pop(0)
+            self.fresh.append(idx)
+            if idx in self.raw:
+                self.ready.append((idx, lo, hi))
+
+    def _feed(self, idx, mn, mx):
+        self.replay_order.append(idx)
+        _, lo, hi = self.replay.update(torch.stack([mn, mx]), return_minmax=True)
+        if lo is not None:
+            self._assign([(None, lo, hi)])
+        if self.pts[idx] in self.segment_pts:
+            self._assign(self.replay.flush(return_minmax=True))
+            self.replay.reset()
+
+    def _run_ready(self):
+        for group_ in chunks(list(self.ready), self.batch_size):
+            xs = torch.stack([self.raw[i][0] for i, _, _ in group_])
+            ds = torch.stack([self.replay.normalize(self.raw[i][1], lo, hi) for i, lo, hi in group_])
+            outs = self.stereo_fn(xs, ds, [self.pts[i] in self.segment_pts for i, _, _ in group_])
+            for (i, _, _), o in zip(group_, outs):
+                self.out_local[i] = o
+                del self.raw[i]
+        self.ready.clear()
+
+    def _dev(self):
+        if self.device is None:
+            dev = getattr(self.depth_model, "device", None)     # a rank that owns no frame at all still joins the collectives
+            self.device = torch.device(dev) if dev is not None else torch.device("cpu")
+        return self.device
+
+    # -- the stream ------------------------------------------------------------------------------------------------------------
+    def push_round(self, my_frames, round_pts):
+        assert 0 < len(round_pts) <= self.world, "a round is at most one batch per rank"
+        ids, base = [], self.n
+        for r, p in enumerate(round_pts):
+            ids.append(list(range(base, base + len(p))))
+            for i, t in zip(ids[-1], p):
+                self.pts[i], self.owner[i] = t, r
+            base += len(p)
+        self.n = base
+        mine = ids[self.rank] if self.rank < len(ids) else []
+        assert len(mine) == len(my_frames), (len(mine), len(my_frames))
+        local = torch.zeros(self.batch_size, 2, dtype=torch.float32)
+        if mine:
+            x = torch.stack(list(my_frames))
+            if self.device is None:
+                self.device = x.device
+            d = self.depth_model.infer(x, **self.infer_kwargs)
+            mm = torch.stack([d.flatten(1).amin(dim=1), d.flatten(1).amax(dim=1)], dim=1).float()
+            local[:len(mine)] = mm.cpu()
+            for k, i in enumerate(mine):
+                self.raw[i] = (x[k], d[k])
+        if self.world > 1:
+            dev = self._dev()
+            buf = [torch.empty_like(local, device=dev) for _ in range(self.world)]
+            dist.all_gather(buf, local.to(dev), group=self.group)
+            table = [b.cpu() for b in buf]
+        else:
+            table = [local]
+        for r, b in enumerate(ids):
+            for k, i in enumerate(b):
+                self._feed(i, table[r][k, 0], table[r][k, 1])
+        self._run_ready()
+
+    def finish(self):
+        self._assign(self.replay.flush(return_minmax=True))
+        self._run_ready()
+        assert not self.raw, "frames left without a range"
+
+    def deliver(self):
+        """Everything that left the look-ahead since the last call goes to ``dst``; returns the next frames of the stream there
+        (``[]`` on the other ranks, and while a frame of an earlier batch is still outstanding)."""
+        fresh, self.fresh = self.fresh, []
+        if not fresh:
+            return []
+        if self.world == 1:
+            return [self.out_local.pop(i) for i in fresh]          # the recurrence releases frames in stream order
+        per = [[i for i in fresh if self.owner[i] == r] for r in range(self.world)]
+        for i in fresh:
+            del self.owner[i], self.pts[i]
+        maxc = max(len(p) for p in per)
+        mine = per[self.rank]
+        if self.meta is None:                                       # (every rank takes this branch in the same call)
+            probe = self.out_local[mine[0]] if mine else None
+            meta = [None] * self.world
+            dist.all_gather_object(meta, None if probe is None else (tuple(probe.shape), str(probe.dtype)), group=self.group)
+            shape, dtype = next(m for m in meta if m is not None)
+            self.meta = (shape, getattr(torch, dtype.split(".")[-1]))
+        shape, dtype = self.meta
+        block = torch.zeros((maxc, *shape), dtype=dtype, device=self._dev())
+        for k, i in enumerate(mine):
+            block[k] = self.out_local.pop(i)
+        if self.rank != self.dst:
+            dist.gather(block, None, dst=self.dst, group=self.group)
+            return []
+        parts = [torch.empty_like(block) for _ in range(self.world)]
+        dist.gather(block, parts, dst=self.dst, group=self.group)
+        for r in range(self.world):
+            for k, i in enumerate(per[r]):
+                self.arrived[i] = parts[r][k]
+        out = []
+        while self.emit_next in self.arrived:
+            out.append(self.arrived.pop(self.emit_next))
+            self.emit_next += 1
+        return out
+
+
 def stereo_frames_sharded(frames, pts, segment_pts, depth_model, stereo_fn, batch_size, group=None, dst=0,
                           infer_kwargs=None):
     """Depth + stereo over ``frames`` (sequence of CHW float tensors on the rank's device; entries a rank does not own may
     be None), batch ``b`` on rank ``b mod world``.  ``stereo_fn(x_srcs[B,3,H,W], depths[B,1,h,w], reset_pts) -> list of
-    quantised HWC frames``.  Returns the ordered list on ``dst`` (None elsewhere).
+    quantised HWC frames``.  Returns the ordered list on ``dst`` (None elsewhere).  The list form of ``ShardedStereoStream``:
+    per round one all-gather of ``[batch_size, 2]`` floats per rank and one gather of the frames that left the look-ahead."""
+    st = ShardedStereoStream(depth_model, stereo_fn, batch_size, segment_pts, group=group, dst=dst, infer_kwargs=infer_kwargs,
+                             device=_any_device(frames, depth_model))
+    batches = list(chunks(list(range(len(frames))), batch_size))
+    out = []
+    for r0 in range(0, len(batches), st.world):
+        rb = batches[r0:r0 + st.world]
+        mine = rb[st.rank] if st.rank < len(rb) else []
+        st.push_round([frames[i] for i in mine], [[pts[i] for i in b] for b in rb])
+        out += st.deliver()
+    st.finish()
+    out += st.deliver()
+    if st.world > 1 and st.rank != dst:
+        return None
+    assert len(out) == len(frames), (len(out), len(frames))
+    return out
 
-    Normalisation is the sequential EMA of ``depth_model``'s scaler over ALL frames (module docstring): per round, one
-    all-gather of ``[batch_size, 2]`` floats per rank."""
-    if getattr(depth_model, "has_temporal_state", False):
-        raise ValueError("a depth model with temporal state cannot be sharded by frame; shard by scene segment")
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    n = len(frames)
-    segment_pts = set(segment_pts or ())
-    infer_kwargs = infer_kwargs or {}
-    batches = list(chunks(list(range(n)), batch_size))
-    replay = _replay_scaler(depth_model)
-    replay_order = []                     # global frame indices waiting inside ``replay``, oldest first
-    raw = {}                              # my frames: index -> (source, raw depth)
-    ready = []                            # my frames with their range: (index, lo, hi), in frame order
-    out_local = {}
 
-    def assign(results):
-        for _, lo, hi in results:
-            idx = replay_order.pop(0)
-            if idx in raw:
-                ready.append((idx, lo, hi))
+class ShardedFrameCallbackPool:
+    """The reference's ``VU.FrameCallbackPool`` (``nunif/utils/video.py:1622-1757``, same constructor arguments) for ONE video on
+    N GPUs, one process per GPU (BASELINE configs[3]): EVERY rank runs the reference's decode loop over the whole file and calls
+    this object once per decoded frame; a frame is uploaded and processed only by the rank that owns its batch (batch ``b`` on
+    rank ``b mod world``), the EMA normalisation is replayed across the ranks (``ShardedStereoStream``) and the finished frames
+    come back, in stream order, from the calls made on rank ``dst`` — the rank whose ``process_video`` encodes.  On the other
+    ranks every call returns ``None`` (their encoders see an empty stream; ``nunif_amd.launch`` points them at a scratch file).
 
-    def feed(idx, mn, mx):
-        replay_order.append(idx)
-        _, lo, hi = replay.update(torch.stack([mn, mx]), return_minmax=True)
-        if lo is not None:
-            assign([(None, lo, hi)])
-        if pts[idx] in segment_pts:
-            assign(replay.flush(return_minmax=True))
-            replay.reset()
+    ``frame_callback`` must be the callback of THIS module's ``bind_batch_frame_callback`` (its ``spec`` attribute names the
+    depth / side model, the scene cuts and the CLI arguments): the sharded flow runs the same stages in another order, it does
+    not call the bound function.  ``to_output(frame_tensor)`` converts a finished HWC tensor for the caller's encoder
+    (``av.VideoFrame.from_ndarray`` in the launcher); default: the tensor itself."""
 
-    def run_ready():
-        for group_ in chunks(list(ready), batch_size):
-            xs = torch.stack([raw[i][0] for i, _, _ in group_])
-            ds = torch.stack([replay.normalize(raw[i][1], lo, hi) for i, lo, hi in group_])
-            outs = stereo_fn(xs, ds, [pts[i] in segment_pts for i, _, _ in group_])
-            for (i, _, _), o in zip(group_, outs):
-                out_local[i] = o
-                del raw[i]
-        ready.clear()
+    def __init__(self, frame_callback, batch_size, device, max_workers=1, max_batch_queue=2, require_pts=False, skip_pts=-1,
+                 require_flush=False, preprocess_callback=None, postprocess_callback=None, use_16bit=False, ops=None,
+                 group=None, dst=0, to_output=None):
+        spec = getattr(frame_callback, "spec", None)
+        if spec is None:
+            raise TypeError("ShardedFrameCallbackPool needs the frame_callback of nunif_amd.iw3.frame_pipeline."
+                            "bind_batch_frame_callback (it carries the models and arguments the sharded flow runs)")
+        devices = list(device) if isinstance(device, (tuple, list)) else [device]
+        if len(devices) != 1:
+            raise ValueError("ShardedFrameCallbackPool: one device per process (the launcher binds --gpu <id> per rank)")
+        self.device = torch.device(devices[0])
+        self.args, self.depth_model, self.side_model = spec["args"], spec["depth_model"], spec["side_model"]
+        if hasattr(self.side_model, "flush"):
+            raise ValueError("a side model with a temporal queue cannot be sharded by frame; shard by scene segment")
+        self.ops = ops or spec["ops"] or PipelineOps()
+        self.batch_size, self.skip_pts, self.use_16bit = batch_size, skip_pts, use_16bit
+        self.postprocess_callback = postprocess_callback
+        self.to_output = to_output or (lambda f: f)
+        a = self.args
+        self.stream = ShardedStereoStream(
+            self.depth_model, self._stereo, batch_size, spec["segment_pts"], group=group, dst=dst, device=self.device,
+            infer_kwargs=dict(tta=getattr(a, "tta", False), low_vram=getattr(a, "low_vram", False),
+                              enable_amp=not getattr(a, "disable_amp", False), edge_dilation=getattr(a, "edge_dilation", 0),
+                              depth_aa=getattr(a, "depth_aa", False)))
+        self.rank, self.world = self.stream.rank, self.stream.world
+        self.round_pts, self.my_frames, self.count = [[]], [], 0
 
-    for r0 in range(0, len(batches), world):
-        round_batches = batches[r0:r0 + world]
-        mine = round_batches[rank] if rank < len(round_batches) else []
-        local = torch.zeros(batch_size, 2, dtype=torch.float32)
-        if mine:
-            x = torch.stack([frames[i] for i in mine])
-            d = depth_model.infer(x, **infer_kwargs)
-            mm = torch.stack([d.flatten(1).amin(dim=1), d.flatten(1).amax(dim=1)], dim=1).float()
-            local[:len(mine)] = mm.cpu()
-            for k, i in enumerate(mine):
-                raw[i] = (x[k], d[k])
-        if world > 1:
-            dev = frames[mine[0]].device if mine else _any_device(frames, depth_model)
-            buf = [torch.empty_like(local, device=dev) for _ in range(world)]
-            dist.all_gather(buf, local.to(dev), group=group)
-            table = [b.cpu() for b in buf]
+    def _stereo(self, x_srcs, depths, reset_pts):
+        a = self.args
+        if getattr(a, "rgbd", False) or getattr(a, "half_rgbd", False):
+            left, right = self.ops.apply_rgbd(x_srcs, depths, mapper=a.mapper)
         else:
-            table = [local]
-        for r, b in enumerate(round_batches):
-            for k, i in enumerate(b):
-                feed(i, table[r][k, 0], table[r][k, 1])
-        run_ready()
-    assign(replay.flush(return_minmax=True))
-    run_ready()
-    assert not raw, "frames left without a range"
+            left, right = self.ops.apply_divergence(depths, x_srcs, a, self.side_model, reset_pts=reset_pts)
+        return [self.ops.stereo_out(left[i], right[i], a, use_16bit=self.use_16bit) for i in range(left.shape[0])]
 
-    if world == 1:
-        return [out_local[i] for i in range(n)]
-    mine_all = [i for bi in shard_indices(len(batches), rank, world) for i in batches[bi]]
-    per_rank = max(len([i for bi in shard_indices(len(batches), r, world) for i in batches[bi]]) for r in range(world))
-    probe = out_local[mine_all[0]] if mine_all else None
-    meta = [None] * world
-    dist.all_gather_object(meta, None if probe is None else (tuple(probe.shape), str(probe.dtype)), group=group)
-    shape, dtype = next(m for m in meta if m is not None)
-    dtype = getattr(torch, dtype.split(".")[-1])
-    dev = probe.device if probe is not None else _any_device(frames, depth_model)
-    block = torch.zeros((per_rank, *shape), dtype=dtype, device=dev)
-    for k, i in enumerate(mine_all):
-        block[k] = out_local[i]
-    if rank == dst:
-        parts = [torch.empty_like(block) for _ in range(world)]
-        dist.gather(block, parts, dst=dst, group=group)
-        out = [None] * n
-        for r in range(world):
-            idxs = [i for bi in shard_indices(len(batches), r, world) for i in batches[bi]]
-            for k, i in enumerate(idxs):
-                out[i] = parts[r][k]
-        return out
-    dist.gather(block, None, dst=dst, group=group)
-    return None
+    def _close_round(self):
+        pts = [p for p in self.round_pts if p]
+        if pts:
+            frames = self.my_frames
+            if frames:
+                frames = list(self.ops.preprocess_image(_stack(frames), self.args))
+            with torch.inference_mode():
+                self.stream.push_round(frames, pts)
+        self.round_pts, self.my_frames = [[]], []
+
+    def _out(self, frames):
+        if self.postprocess_callback is not None:
+            frames = self.postprocess_callback(frames)
+        return [self.to_output(f) for f in (frames or [])]
+
+    def __call__(self, frame):
+        if frame is None:
+            return self.finish()
+        if frame.pts <= self.skip_pts:
+            return None
+        if len(self.round_pts[-1]) == self.batch_size:
+            self.round_pts.append([])
+        owner = len(self.round_pts) - 1
+        self.round_pts[-1].append(frame.pts)
+        if owner == self.rank:
+            self.my_frames.append(self.ops.to_tensor(frame, device=self.device))
+        self.count += 1
+        if owner == self.world - 1 and len(self.round_pts[-1]) == self.batch_size:
+            self._close_round()
+            return self._out(self.stream.deliver()) or None
+        return None
+
+    def finish(self):
+        self._close_round()
+        out = self.stream.deliver()
+        with torch.inference_mode():
+            self.stream.finish()
+        return self._out(out + self.stream.deliver())
+
+    def shutdown(self):
+        self.my_frames, self.round_pts = [], [[]]
 
 
 def _any_device(frames, depth_model=None):
