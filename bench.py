@@ -93,7 +93,7 @@ def relaunch_as_ranks(args):
     os.execvpe(cmd[0], cmd, env)
 
 
-GATHER_TIMEOUT_S = 240          # watchdog of the N > 1 delivery leg (see main)
+GATHER_TIMEOUT_S = 420          # watchdog of the N > 1 legs behind the headline (delivery, iw3, cunet; see main)
 CPU_WHOLE_FRAME_BUDGET_S = 40   # cpu_baseline times a whole 1080p frame on the host when the crop predicts at most this
 
 
@@ -358,6 +358,102 @@ def iw3_record(dev, with_cpu):
                                          f"frame (both eyes), 1 warm-up + median of 3, {dt:.2f} s per pass; the depth "
                                          "network is external to the reference and not part of this baseline"}
     return rec
+
+
+def iw3_sharded_leg(dist, world, rank, dev, barrier, frames_per_rank=48, batch=4, depth_model=None, stereo_fn=None,
+                    frame_hw=None, make_frame=None):
+    """BASELINE's second metric at N GPUs (configs[3]: iw3 DepthAnythingV2 ViT-S + forward_warp SBS, 1080p, frame-parallel): ONE
+    stream of ``frames_per_rank * world`` frames through ``stereo_frames_sharded`` — batch b on rank b mod N, the EMA look-ahead
+    replayed across the ranks from an all-gather of two scalars per frame, finished SBS uint8 frames gathered to rank 0.  Timed
+    between barriers, MAX over ranks; ``value`` = whole-stream input MPix/s.  ``depth_model`` / ``stereo_fn`` / ``make_frame``:
+    stand-ins for the gloo unit test (tests/test_parallel_gloo.py); defaults: the HIP engine as in ``iw3_record``."""
+    import torch
+    from nunif_amd.iw3.frame_pipeline import stereo_frames_sharded
+    H, W = frame_hw or (FRAME_H, FRAME_W)
+    n = frames_per_rank * world
+    n -= n % batch
+    infer_kwargs = None
+    if depth_model is None:
+        infer_kwargs = {"edge_dilation": 2}
+        from nunif_amd.iw3 import utils as U
+        from nunif_amd.iw3.base_depth_model import CallableDepthModel
+        from nunif_amd.iw3.depth_anything_v2 import HipDepthAnythingV2
+        from nunif_amd.iw3.frame_pipeline import PipelineOps
+        from nunif_amd.synthetic import depth_anything_v2_state_dict
+        depth_model = CallableDepthModel(HipDepthAnythingV2(depth_anything_v2_state_dict(601), str(dev)))
+        depth_model.load(gpu=dev.index or 0)
+        a = argparse.Namespace(batch_size=batch, mapper="none", convergence=0.5, divergence=2.0, method="forward_fill",
+                               synthetic_view="both", warp_steps=None, stereo_width=None, preserve_screen_border=False,
+                               disable_amp=False, edge_dilation=2, pix_fmt="yuv420p", state={"device": dev})
+        ops = PipelineOps()
+
+        def stereo_fn(xs, ds, reset_pts):
+            left, right = U.apply_divergence(ds, xs, a, None, reset_pts=reset_pts)
+            return [ops.stereo_out(left[i], right[i], a) for i in range(left.shape[0])]
+    make_frame = make_frame or (lambda i: synth_frame(900 + i % 4, H, W).to(dev))
+    mine = {i for b in range(rank, n // batch, world) for i in range(b * batch, (b + 1) * batch)}
+    pool = {}
+    frames = [None] * n
+    for i in sorted(mine):                                   # a rank holds only the frames of its own batches, resident in HBM
+        frames[i] = pool.setdefault(i % 4, make_frame(i))
+    cuts = {n // 2}
+
+    def one_pass():
+        depth_model.reset()
+        depth_model.enable_ema(0.75, buffer_size=4)
+        return stereo_frames_sharded(frames, list(range(n)), cuts, depth_model, stereo_fn, batch, dst=0, infer_kwargs=infer_kwargs)
+
+    with torch.inference_mode():
+        one_pass()                                           # warm-up (collectives initialised, workspaces allocated)
+        barrier()
+        t0 = time.perf_counter()
+        out = one_pass()
+        barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank != 0:
+        return None
+    return {"config": "BASELINE configs[3] at N GPUs: ONE 1080p stream, Depth-Anything-V2 ViT-S geometry (random-init) + forward_fill "
+                      f"+ SBS uint8, batch {batch}, EMA 0.75 x 4-frame look-ahead, one scene cut, edge_dilation 2; "
+                      "stereo_frames_sharded: batch b on rank b mod N, per round one all-gather of [batch, 2] floats per rank "
+                      "and one gather of finished frames to rank 0 (inside the timed region)",
+            "frame": [H, W], "frames": n, "frames_delivered": len(out), "batch": batch, "world": world, "unit": "input MPix/s",
+            "scaling": "weak", "ms_per_frame": round(1e3 * dt / n, 3), "fps": round(n / dt, 1),
+            "value": round(H * W * n / dt / 1e6, 1)}
+
+
+def cunet_sharded_leg(dist, world, rank, dev, barrier, frames_per_rank=16):
+    """north_star's second generator at N GPUs: every rank renders its own 1080p frames with waifu2x cunet (tile 256, whole frame in
+    one minibatch), no collective inside the timed region; ``value`` = all ranks' input MPix/s over the MAX of the ranks' times."""
+    import torch
+    from nunif_amd.nunif.models import create_model
+    from nunif_amd.nunif.utils.render import tiled_render
+    import nunif_amd.waifu2x.models.cunet  # noqa: F401
+    from nunif_amd.synthetic import cunet_state_dict
+    m = create_model("waifu2x.cunet").eval()
+    m.load_state_dict(cunet_state_dict(201))
+    m = m.to(dev)
+    frame = synth_frame(32 + rank, FRAME_H, FRAME_W).to(dev)
+    for _ in range(3):
+        tiled_render(frame, m, tile_size=TILE, batch_size=66)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(frames_per_rank):
+        tiled_render(frame, m, tile_size=TILE, batch_size=66)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    del m
+    if rank != 0:
+        return None
+    return {"config": "waifu2x cunet (noise geometry, random-init), tile 256, 1080p frames, frame-sharded: every rank renders "
+                      f"{frames_per_rank} frames of its own", "world": world, "frames": frames_per_rank * world,
+            "unit": "input MPix/s", "scaling": "weak", "ms_per_frame_per_gpu": round(1e3 * dt / frames_per_rank, 3),
+            "value": round(FRAME_H * FRAME_W * frames_per_rank * world / dt / 1e6, 1)}
 
 
 def scale4x_record(dev):
@@ -772,6 +868,18 @@ def main():
             tg = torch.tensor([dtg], dtype=torch.float64, device=dev)
             dist.all_reduce(tg, op=dist.ReduceOp.MAX)
             dtg = float(tg.item())
+            # BASELINE's other metrics at N GPUs (each leg is entered by every rank; a rank that fails raises into the handler
+            # below, the others then wait in a collective and the watchdog ends them — the headline line is out either way)
+            if not args.no_iw3:
+                r_iw3 = iw3_sharded_leg(dist, world, rank, dev, barrier)
+                if rank == 0:
+                    result["iw3"] = r_iw3
+                    if r_iw3["frames_delivered"] != r_iw3["frames"]:
+                        result.setdefault("errors", []).append("iw3 leg: frames lost on the way to rank 0")
+            if not args.no_cunet:
+                r_cu = cunet_sharded_leg(dist, world, rank, dev, barrier)
+                if rank == 0:
+                    result["cunet"] = r_cu
             done.set()
             if rank == 0:
                 if delivered[0] != n_g:

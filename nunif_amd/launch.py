@@ -16,16 +16,25 @@ The reference handles ``--gpu 0 1 ...`` inside one process: ``nn.DataParallel`` 
   write exactly what one process would have; there is no collective on this path (frames / files are independent units —
   north_star) and no rank waits for another.
 
-What it refuses, with the reason: ONE video (or one ``.yml`` export config) with several GPUs.  Splitting a single stream needs
-its frames dealt to the ranks and the EMA depth normalisation replayed across them — ``nunif_amd.iw3.frame_pipeline
-.stereo_frames_sharded`` / ``nunif_amd.parallel.render_sharded`` do that behind an API (2- and 3-rank tests), but the
-reference's decode loop (PyAV) cannot be exercised in the build container, so the CLI is not wired to it blind.  A single image
-runs on the first GPU of the list.
+ONE video on N GPUs (``iw3 -i movie.mp4 --gpu 0 1 ...``, BASELINE configs[3]) is FRAME-sharded: every rank runs the reference's own
+decode loop (``VU.process_video``, ``nunif/utils/video.py:956-1170``) over the whole file, and the two names that loop's batch
+route resolves — ``iw3.utils.bind_batch_frame_callback`` and ``VU.FrameCallbackPool`` (``iw3/utils.py:1137-1153``) — are bound to
+``nunif_amd.iw3.frame_pipeline``'s: batch ``b`` is uploaded and processed by rank ``b mod N`` only, the EMA depth normalisation is
+replayed across the ranks from an all-gather of two scalars per frame (``ShardedStereoStream``), finished frames reach rank 0 by a
+gather and leave through ITS encoder; the other ranks' ``process_video`` sees an empty stream and writes a scratch file that is
+removed.  Decoding N times is the price of not touching the reference's loop (a 1080p software decode runs at several hundred
+frames per second per process; the GPUs' share of a frame is ~0.5 ms).
+
+What it still refuses, with the reason: a ``.yml`` export config with several GPUs, and — from inside ``ShardedFrameCallbackPool``
+— a video whose depth or side model carries temporal state (VideoDepthAnything, the video inpaint queue): those shard by scene
+segment, which is not built.  A waifu2x video with several GPUs is refused too (its frames are independent, but its CLI route does
+not pass through the two names above).  A single image runs on the first GPU of the list.
 
 The reference checkout must be importable (``PYTHONPATH=/path/to/nunif``): this is a launcher FOR it, it carries no CLI of its own.
 """
 import mimetypes
 import os
+import shutil
 import socket
 import subprocess
 import sys
@@ -133,12 +142,12 @@ def install_listing_shards(rank, world, input_root):
         vu.list_videos = list_videos
 
 
-def shard_text_list(path, rank, world, tmp_dir):
-    """The reference reads one path per line, ``#`` starts a comment (``iw3/utils.py:2431-2436``, ``waifu2x/ui_utils.py:208``)."""
+def shard_text_list(path, rank, world, out):
+    """The reference reads one path per line, ``#`` starts a comment (``iw3/utils.py:2431-2436``, ``waifu2x/ui_utils.py:208``).
+    ``out``: a file of this run's own (``tempfile.mkstemp``: two launcher runs with the same world size must not share it)."""
     with open(path, mode="r", encoding="utf-8") as f:
         files = [ln.strip() for ln in f.readlines()]
     files = [ln for ln in files if ln and not ln.startswith("#")]
-    out = os.path.join(tmp_dir, f"nunif_amd_shard_{rank}_of_{world}.txt")
     with open(out, mode="w", encoding="utf-8") as f:
         f.write("\n".join(shard(files, rank, world)) + "\n")
     return out
@@ -162,8 +171,38 @@ def replace_option(argv, names, value):
 
 def tool_main(tool):
     import importlib
-    mod = os.environ.get("NUNIF_AMD_LAUNCH_CLI_MODULE") or f"{tool}.cli"       # the override exists for the launcher's own test
+    mod = f"{tool}.cli"
+    if os.environ.get("NUNIF_AMD_LAUNCH_TEST_HOOKS") == "1":                   # the launcher's own tests run a stand-in CLI
+        mod = os.environ.get("NUNIF_AMD_LAUNCH_CLI_MODULE") or mod
     return importlib.import_module(mod).main
+
+
+def _to_av_frame(use_16bit):
+    """Finished HWC tensor -> what the reference's encode loop takes (``VU.to_frame``, nunif/utils/video.py:236-245)."""
+    def convert(frame):
+        import av
+        arr = frame.cpu().numpy()
+        if use_16bit:
+            return av.VideoFrame.from_ndarray(arr.view("uint16") if arr.dtype != "uint16" else arr, format="rgb48le")
+        return av.VideoFrame.from_ndarray(arr, format="rgb24")
+    return convert
+
+
+def install_frame_sharding(rank, world):
+    """One video, ``world`` ranks: bind the batch route of ``iw3.utils.process_video_full`` (iw3/utils.py:1137-1153) to the
+    frame-sharded scheduler.  Needs an initialised process group."""
+    import importlib
+    from nunif_amd.iw3 import frame_pipeline as FP
+    iu = importlib.import_module("iw3.utils")
+    vu = importlib.import_module("nunif.utils.video")
+
+    def sharded_pool(frame_callback, batch_size, device, use_16bit=False, **kw):
+        kw.pop("max_workers", None), kw.pop("max_batch_queue", None)
+        return FP.ShardedFrameCallbackPool(frame_callback, batch_size, device, use_16bit=use_16bit,
+                                           to_output=_to_av_frame(use_16bit), **kw)
+
+    iu.bind_batch_frame_callback = FP.bind_batch_frame_callback
+    vu.FrameCallbackPool = sharded_pool
 
 
 def run_in_process(tool, argv, gpu, rank=0, world=1):
@@ -179,11 +218,30 @@ def run_in_process(tool, argv, gpu, rank=0, world=1):
     main = tool_main(tool)
     if not engine_install.is_installed():
         engine_install.install(strict=False)
+    scratch = []
     if world > 1:
         if kind == "dir":
             install_listing_shards(rank, world, src)
         elif kind == "list":
-            argv = replace_option(argv, ("--input", "-i"), shard_text_list(src, rank, world, tempfile.gettempdir()))
+            fd, lst = tempfile.mkstemp(prefix=f"nunif_amd_shard_{rank}_of_{world}_", suffix=".txt")
+            os.close(fd)
+            scratch.append(lst)
+            argv = replace_option(argv, ("--input", "-i"), shard_text_list(src, rank, world, lst))
+        elif kind == "video" and tool == "iw3":
+            import torch
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                backend = "nccl" if (gpu is not None and gpu >= 0 and torch.cuda.is_available()) else "gloo"
+                if backend == "nccl":
+                    torch.cuda.set_device(gpu)
+                dist.init_process_group(backend)
+            install_frame_sharding(rank, world)
+            if rank > 0:
+                # this rank's encoder sees an empty stream: its file goes to a scratch directory
+                tmp = tempfile.mkdtemp(prefix=f"nunif_amd_rank{rank}_")
+                scratch.append(tmp)
+                argv = replace_option(argv, ("--output", "-o"), tmp)
         elif rank > 0:
             return 0                                  # a single image: the first GPU of the list renders it
     old = sys.argv
@@ -192,6 +250,16 @@ def run_in_process(tool, argv, gpu, rank=0, world=1):
         main()
     finally:
         sys.argv = old
+        for p in scratch:
+            if os.path.isdir(p):
+                shutil.rmtree(p, ignore_errors=True)
+            elif os.path.exists(p):
+                os.remove(p)
+        if world > 1 and kind == "video":
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
     return 0
 
 
@@ -213,12 +281,11 @@ def main(argv=None):
     if len(gpus) <= 1:
         return run_in_process(tool, rest, gpus[0] if gpus else None)
     kind = classify_input(option_value(rest, "--input", "-i"))
-    if kind in ("video", "config", "other", "none"):
+    if kind in ("config", "other", "none") or (kind == "video" and tool != "iw3"):
         sys.stderr.write(
-            f"nunif_amd.launch: --gpu {' '.join(map(str, gpus))} with a single {kind} input.  One process per GPU shards FILES "
-            "(a directory or a text list); the frames of one stream are sharded by nunif_amd.iw3.frame_pipeline."
-            "stereo_frames_sharded / nunif_amd.parallel.render_sharded (API), which the reference's decode loop is not wired to. "
-            "Run it with one GPU, or pass a directory / list of files.\n")
+            f"nunif_amd.launch: --gpu {' '.join(map(str, gpus))} with a single {kind} input for {tool}.  One process per GPU "
+            "shards FILES (a directory or a text list) and, for iw3, the FRAMES of one video (batch b on rank b mod N); this "
+            "input is neither.  Run it with one GPU, or pass a directory / list of files.\n")
         return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={len(gpus)}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "-m", "nunif_amd.launch", _RANK_FLAG, tool,

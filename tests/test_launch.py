@@ -30,14 +30,16 @@ def test_gpu_list_parsing_and_input_kinds(tmp_path):
     assert [L.classify_input(str(p)) for p in (tmp_path / "d", tmp_path / "l.txt", "x.png", "y.mp4", "z.yml")] == \
         ["dir", "list", "image", "video", "config"]
     assert L.shard(range(7), 1, 3) == [1, 4]
-    # one stream on several GPUs is refused with the reason, not silently run on one
-    assert L.main(["iw3", "-i", "movie.mp4", "-o", "out", "--gpu", "0", "1"]) == 2
+    # what one process per GPU cannot shard is refused with the reason, not silently run on one GPU: an export config, and a
+    # waifu2x video (iw3's single video IS sharded, by frame: test_one_video_is_frame_sharded_over_two_ranks)
+    assert L.main(["iw3", "-i", "export.yml", "-o", "out", "--gpu", "0", "1"]) == 2
+    assert L.main(["waifu2x", "-i", "movie.mp4", "-o", "out", "--gpu", "0", "1"]) == 2
 
 
-def _run(args, tmp_path):
+def _run(args, tmp_path, cli="fake_cli.cli"):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), refstub.REFERENCE_ROOT,
                                                        os.environ.get("PYTHONPATH", "")]),
-               NUNIF_AMD_LAUNCH_CLI_MODULE="fake_cli.cli")
+               NUNIF_AMD_LAUNCH_TEST_HOOKS="1", NUNIF_AMD_LAUNCH_CLI_MODULE=cli)
     r = subprocess.run([sys.executable, "-m", "nunif_amd.launch"] + args, env=env, cwd=str(tmp_path), capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -76,3 +78,20 @@ def test_one_gpu_runs_in_process_on_the_whole_input(tmp_path):
     _run(["waifu2x", "-i", str(tmp_path / "in"), "-o", str(out), "--gpu", "3"], tmp_path)
     rec = json.load(open(out / "rank0.json"))
     assert rec["files"] == imgs and rec["gpu"] == [3] and rec["world"] == 1 and rec["tiled_render_module"].startswith("nunif_amd.")
+
+
+@pytest.mark.parametrize("case", ["ema", "cut_last_of_batch"])
+def test_one_video_is_frame_sharded_over_two_ranks(tmp_path, case):
+    """BASELINE configs[3] through the CLI line: ``iw3 -i movie.mp4 --gpu 0 1`` = two ranks, every rank runs the decode loop, batch
+    b is processed on rank b mod 2 (EMA look-ahead replayed across the ranks), rank 0 alone hands frames to its encoder — and
+    they are the frames of the reference's own single-process scheduler (``tests/golden/frame_pool.npz``), bit for bit."""
+    import numpy as np
+    import torch
+    out = tmp_path / "out"
+    _run(["iw3", "-i", "movie.mp4", "-o", str(out), "--gpu", "0", "1", "--case", case], tmp_path, cli="fake_cli.iw3_cli")
+    rec = json.load(open(out / "rank0.json"))
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "frame_pool.npz"))[case + "_frames"]
+    assert rec["world"] == 2 and rec["pool"].endswith("ShardedFrameCallbackPool") and rec["av_frames"]
+    assert rec["frames_encoded"] == golden.shape[0] and sum(rec["calls"]) == golden.shape[0]
+    assert torch.equal(torch.load(out / "frames.pt"), torch.from_numpy(golden))
+    assert not (out / "rank1.json").exists()             # rank 1 encoded nothing and its scratch output is gone

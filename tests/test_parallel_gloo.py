@@ -233,3 +233,54 @@ def test_bench_multi_gpu_evidence_block_on_two_gloo_ranks(tmp_path):
     ev = torch.load(path)
     assert ev["ranks_seen"] == 2 and ev["world_size"] == 2 and ev["distinct_pci_bus_ids"] == 2 and ev["backend"] == "gloo"
     assert [d["rank"] for d in ev["devices"]] == [0, 1]
+
+
+def _iw3_leg_worker(rank, world, port, path):
+    import argparse
+    import importlib.util
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from make_golden_cases import fake_depth_net, frame_pool_frames
+    from nunif_amd.iw3.base_depth_model import BaseDepthModel
+    from oracle.backward_warp import grid_sample_warp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(here), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class FakeDepth(BaseDepthModel):
+        def load_model(self, model_type, resolution=None, device=None, **kw):
+            return None
+
+        def is_metric(self):
+            return False
+
+        def infer(self, x, **kw):
+            return fake_depth_net(x)
+
+    def stereo_fn(xs, ds, reset_pts):
+        le, re = grid_sample_warp(xs, ds, 2.0, 0.5, "both")
+        return [(torch.clamp(torch.cat([le[i], re[i]], dim=2), 0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0) for i in range(xs.shape[0])]
+
+    pool = frame_pool_frames(4)
+    rec = bench.iw3_sharded_leg(dist, world, rank, torch.device("cpu"), dist.barrier, frames_per_rank=8, batch=2,
+                                depth_model=FakeDepth("fake"), stereo_fn=stereo_fn, frame_hw=(24, 40), make_frame=lambda i: pool[i % 4])
+    if rank == 0:
+        torch.save(rec, path)
+    else:
+        assert rec is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_iw3_leg_at_two_ranks_prints_a_record(tmp_path):
+    """``bench.py --gpus N`` carries BASELINE's iw3 metric at N > 1: the leg on two gloo ranks with CPU
+    stand-ins for the depth net and the warp — every frame of the one stream arrives on rank 0, the record names the sharding."""
+    path = str(tmp_path / "rec.pt")
+    mp.spawn(_iw3_leg_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    rec = torch.load(path)
+    assert rec["world"] == 2 and rec["frames"] == 16 and rec["frames_delivered"] == 16 and rec["value"] > 0
+    assert "stereo_frames_sharded" in rec["config"] and rec["unit"] == "input MPix/s"
