@@ -253,13 +253,14 @@ int run_down(const ConvW &c, const f16 *a, int B, int Hi, f16 *out, hipStream_t 
 // the next conv reads ONE input (`conv3(crop(x1) + x2)`, cunet.py:58-60,111-118 — the add used to ride in that conv's staging,
 // which a DMA-staged conv cannot do)
 int run_up(const UpW &u, const f16 *a, int B, int Hi, f16 *out, hipStream_t s, const f16 *skip = nullptr, int skip_side = 0,
-           int crop = 0) {
+           int crop = 0, const float *in_scale = nullptr) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.B = B; g.Hi = Hi; g.Wi = Hi; g.Cin = u.K; g.Ho = Hi; g.Wo = Hi; g.stride = 1; g.kw = 1;
     g.K = u.K; g.w = u.w; g.bias = u.bias; g.N = u.N; g.mode = 1; g.act = 2; g.slope = 0.1f;
     g.out = out; g.ldo = u.cq; g.n_real = u.N; g.ps = 1;
     if (skip) { g.res = skip; g.res_H = skip_side; g.res_W = skip_side; g.res_crop = crop; }
+    g.in_scale = in_scale;                // the squeeze-excitation scale of `a`, applied as the fragments are loaded
     return launch_gemm(g, s, "cunet_up");
 }
 
@@ -271,6 +272,9 @@ int run_deconv4(const UpW &u, const f16 *a, int B, int Hi, float *out, int no_cl
     g.out = out; g.n_real = 4 * u.cq; g.ps = 2; g.oshift = -1; g.OH = 2 * Hi - 4; g.OW = 2 * Hi - 4; g.no_clamp = no_clamp;
     return launch_gemm(g, s, "upcunet_bottom");
 }
+
+// SE blocks whose map has ONE consumer, a transposed-conv GEMM: pooled + MLP here, the channel scale rides in that GEMM's loads
+static inline bool se_fuse_enabled() { const char *e = getenv("NUNIF_CUNET_SE_FUSE"); return e ? atoi(e) != 0 : true; }
 
 static inline bool stem_fused_enabled() { const char *e = getenv("NUNIF_CUNET_STEM"); return e ? atoi(e) != 0 : true; }
 
@@ -371,9 +375,10 @@ int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif
     if ((rc = run_down(h->u1down, tX1, B, x1, tD, s))) return rc;
     if ((rc = run_conv(h->u1c2a, tD, nullptr, 0, 0, B, d1, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u1c2b, tE, nullptr, 0, 0, B, e1, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
-    if ((rc = launch_se(tF, sums, scale, h->u1se2.w1, h->u1se2.b1, h->u1se2.w2, h->u1se2.b2, B, (long)f1 * f1, 64, s))) return rc;
+    const bool sef = se_fuse_enabled();
+    if ((rc = launch_se(tF, sums, scale, h->u1se2.w1, h->u1se2.b1, h->u1se2.w2, h->u1se2.b2, B, (long)f1 * f1, 64, s, sef))) return rc;
     // conv3(crop(x1, 4) + x2): the add happens in the up-GEMM's epilogue
-    if ((rc = run_up(h->u1up, tF, B, f1, tG, s, tX1, x1, 4))) return rc;
+    if ((rc = run_up(h->u1up, tF, B, f1, tG, s, tX1, x1, 4, sef ? scale : nullptr))) return rc;
     if ((rc = run_conv(h->u1c3, tG, nullptr, 0, 0, B, g1, tH, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     // conv_bottom -> z1 (clamped unless no_clip, cunet.py:185-186)
     if (h->up) {
@@ -397,14 +402,14 @@ int forward_impl(nunif_cunet *h, const float *x, const float *frame, const nunif
     if ((rc = run_down(h->u2down2, tX2, B, y2, tD, s))) return rc;
     if ((rc = run_conv(h->u2c3a, tD, nullptr, 0, 0, B, d3, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u2c3b, tE, nullptr, 0, 0, B, e3, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
-    if ((rc = launch_se(tF, sums, scale, h->u2se3.w1, h->u2se3.b1, h->u2se3.w2, h->u2se3.b2, B, (long)f3 * f3, 128, s))) return rc;
+    if ((rc = launch_se(tF, sums, scale, h->u2se3.w1, h->u2se3.b1, h->u2se3.w2, h->u2se3.b2, B, (long)f3 * f3, 128, s, sef))) return rc;
     // conv4(crop(x2, 4) + x3)
-    if ((rc = run_up(h->u2up3, tF, B, f3, tG, s, tX2, y2, 4))) return rc;
+    if ((rc = run_up(h->u2up3, tF, B, f3, tG, s, tX2, y2, 4, sef ? scale : nullptr))) return rc;
     if ((rc = run_conv(h->u2c4a, tG, nullptr, 0, 0, B, g3, tE, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     if ((rc = run_conv(h->u2c4b, tE, nullptr, 0, 0, B, e4, tF, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
-    if ((rc = launch_se(tF, sums, scale, h->u2se4.w1, h->u2se4.b1, h->u2se4.w2, h->u2se4.b2, B, (long)f4 * f4, 64, s))) return rc;
+    if ((rc = launch_se(tF, sums, scale, h->u2se4.w1, h->u2se4.b1, h->u2se4.w2, h->u2se4.b2, B, (long)f4 * f4, 64, s, sef))) return rc;
     // conv5(crop(x1, 16) + x4)
-    if ((rc = run_up(h->u2up4, tF, B, f4, tG, s, tY1, y1, 16))) return rc;
+    if ((rc = run_up(h->u2up4, tF, B, f4, tG, s, tY1, y1, 16, sef ? scale : nullptr))) return rc;
     if ((rc = run_conv(h->u2c5, tG, nullptr, 0, 0, B, g4, tH, nullptr, nullptr, 0, 0, 0, 2, s))) return rc;
     // z = clamp(crop(z1, 20) + conv_bottom(x5), 0, 1)
     if ((rc = run_conv(h->u2bottom, tH, nullptr, 0, 0, B, h5, nullptr, z, z1, T2, 20, 1, 0, s))) return rc;

@@ -348,19 +348,40 @@ int launch_c3_conv(const C3ConvArgs &a, hipStream_t s) {
 constexpr int kSePoolBlocks = 128;
 
 // Deterministic two-stage pooling (no float atomics: the result must not depend on launch order or tile batch).
+// A thread owns 8 consecutive channels of every (256 / (C / 8))-th pixel of its block's share: 16-byte loads, two in flight
+// (round 4 read one fp16 per lane per trip — 128 bytes per wave-load — and the pool, a third of the block's bytes, took most of
+// its time).  The fixed per-thread order and the fixed order of the LDS reduction keep the sums independent of everything but
+// the image.
 __global__ void __launch_bounds__(256) se_pool_kernel(const f16 *__restrict__ x, float *partial, long hw, int C) {
-    // thread = (pixel lane, channel): consecutive threads read consecutive channels of one pixel (coalesced NHWC)
     const int b = blockIdx.y;
-    const int c = threadIdx.x % C, pl = threadIdx.x / C, ppb = 256 / C;
-    const f16 *img = x + (long)b * hw * C;
-    float s = 0.f;
-    for (long p = (long)blockIdx.x * ppb + pl; p < hw; p += (long)gridDim.x * ppb) s += (float)img[p * C + c];
-    __shared__ float sh[256];
-    sh[threadIdx.x] = s;
+    const int C8 = C / 8, ppb = 256 / C8;                   // pixels per block and trip
+    const int c8 = threadIdx.x % C8, pl = threadIdx.x / C8;
+    const f16 *img = x + (long)b * hw * C + c8 * 8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long step = (long)gridDim.x * ppb;
+    long p = (long)blockIdx.x * ppb + pl;
+    for (; p + step < hw; p += 2 * step) {
+        const f16x8 v0 = *reinterpret_cast<const f16x8 *>(img + p * C);
+        const f16x8 v1 = *reinterpret_cast<const f16x8 *>(img + (p + step) * C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += (float)v0[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += (float)v1[j];
+    }
+    if (p < hw) {
+        const f16x8 v0 = *reinterpret_cast<const f16x8 *>(img + p * C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += (float)v0[j];
+    }
+    __shared__ float sh[256 * 8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[threadIdx.x * 8 + j] = s[j];
     __syncthreads();
-    if (pl == 0) {
-        for (int k = 1; k < ppb; ++k) s += sh[k * C + c];
-        partial[((long)b * kSePoolBlocks + blockIdx.x) * C + c] = s;
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x, cc8 = c / 8, j = c % 8;
+        float t = 0.f;
+        for (int k = 0; k < ppb; ++k) t += sh[(k * C8 + cc8) * 8 + j];
+        partial[((long)b * kSePoolBlocks + blockIdx.x) * C + c] = t;
     }
 }
 
@@ -403,12 +424,15 @@ __global__ void __launch_bounds__(256) se_scale_kernel(f16 *x, const float *__re
 }
 
 int launch_se(f16 *x, float *sums, float *scale, const float *w1, const float *b1, const float *w2, const float *b2,
-              int B, long hw, int C, hipStream_t s) {
+              int B, long hw, int C, hipStream_t s, int scale_in_consumer) {
     NUNIF_REQUIRE(C % 8 == 0 && C <= 256 && 256 % C == 0, "se: C=%d unsupported", C);
     ProfScope ps("se_block", s, 0.0, (double)B * hw * C * 2.0 * 3.0);
     dim3 g1(kSePoolBlocks, B);                    // sums: [B][kSePoolBlocks][C] partials
     se_pool_kernel<<<g1, 256, 0, s>>>(x, sums, hw, C);
     se_mlp_kernel<<<B, 256, 0, s>>>(sums, scale, w1, b1, w2, b2, 1.0f / (float)hw, C);
+    // scale_in_consumer: the one consumer of the map multiplies its fragments by `scale` as it loads them (GemmArgs::in_scale):
+    // no read + write of the whole map here
+    if (scale_in_consumer) { NUNIF_LAUNCH_CHECK(); return NUNIF_HIP_OK; }
     const long total8 = (long)B * hw * C / 8;
     se_scale_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, s>>>(x, scale, hw, C, total8);
     NUNIF_LAUNCH_CHECK();

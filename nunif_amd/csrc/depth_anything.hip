@@ -278,8 +278,9 @@ __global__ void __launch_bounds__(256) da_im2col_s2_kernel(const f16 *__restrict
 }
 
 // F.interpolate(bilinear, align_corners=True) on NHWC fp16; one thread = 8 channels of one output pixel
+// add (optional, laid out like y): y = fp16(interp + add) — the refinenet's `path + RCU1(skip)` when RCU1 ran beside the encoder
 __global__ void __launch_bounds__(256) da_upsample_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int B, int Hi,
-                                                          int Wi, int Ho, int Wo, int C) {
+                                                          int Wi, int Ho, int Wo, int C, const f16 *__restrict__ add) {
     const int cq = C / 8;
     const long total = (long)B * Ho * Wo * cq;
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
@@ -296,10 +297,18 @@ __global__ void __launch_bounds__(256) da_upsample_kernel(const f16 *__restrict_
     auto ld = [&](int yy, int xx) { return *reinterpret_cast<const f16x8 *>(x + (((long)b * Hi + yy) * Wi + xx) * C + c8 * 8); };
     const f16x8 a = ld(y0, x0), bq = ld(y0, x1), c = ld(y1, x0), d = ld(y1, x1);
     f16x8 o;
+    const long oidx = (((long)b * Ho + Y) * Wo + X) * C + c8 * 8;
+    if (add) {
+        const f16x8 e = *reinterpret_cast<const f16x8 *>(add + oidx);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        o[j] = (f16)(hy * (hx * (float)a[j] + lx * (float)bq[j]) + ly * (hx * (float)c[j] + lx * (float)d[j]));
-    *reinterpret_cast<f16x8 *>(y + (((long)b * Ho + Y) * Wo + X) * C + c8 * 8) = o;
+        for (int j = 0; j < 8; ++j)
+            o[j] = (f16)(hy * (hx * (float)a[j] + lx * (float)bq[j]) + ly * (hx * (float)c[j] + lx * (float)d[j]) + (float)e[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] = (f16)(hy * (hx * (float)a[j] + lx * (float)bq[j]) + ly * (hx * (float)c[j] + lx * (float)d[j]));
+    }
+    *reinterpret_cast<f16x8 *>(y + oidx) = o;
 }
 
 // relu(conv1x1 32 -> 1) (+ the model's final relu, idempotent) -> fp32 [B,h,w]; metric heads (max_depth > 0) end in a
@@ -399,6 +408,7 @@ struct nunif_depth_anything {
     // the reassemble branch of tap k (project -> resize -> layer_rn conv) on a stream of its own, beside the encoder layers that
     // follow the tap: per-branch temporaries, fork / join events (forward())
     Buf bm1[4], bm2[4], bpart[4];
+    Buf bt1[3], br1[3];               // RCU1 of refinenets 1-3 beside the encoder: conv1's map, RCU1(skip) (forward())
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
 };
@@ -754,6 +764,7 @@ extern "C" void nunif_hip_depth_anything_destroy(nunif_depth_anything *h) {
                    &h->feat[3], &h->rnb[0], &h->rnb[1], &h->rnb[2], &h->rnb[3], &h->m1, &h->m2, &h->m3, &h->m4, &h->m5, &h->part, &h->col};
     for (Buf *b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { h->bm1[i].release(); h->bm2[i].release(); h->bpart[i].release(); }
+    for (int i = 0; i < 3; ++i) { h->bt1[i].release(); h->br1[i].release(); }
     for (int i = 0; i < 3; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
         if (h->ev_fork[i]) (void)hipEventDestroy(h->ev_fork[i]);
@@ -814,6 +825,16 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         if ((rc = h->bm1[i].ensure((size_t)B * N * h->OCP[i] * e2)) || (rc = h->bm2[i].ensure((size_t)B * Hs[i] * Ws[i] * h->OCP[i] * e2))) return rc;
         if (h->rn[i].cmaj && (rc = h->bpart[i].ensure((size_t)(h->rn[i].Cin / h->rn[i].cmaj) * B * Hs[i] * Ws[i] * h->rn[i].N * sizeof(float)))) return rc;
     }
+    // RCU1 of refinenet k + 1 (`residual_layer1` on layer{k+1}_rn, DPT FeatureFusionBlock) depends on the reassembled map only, not
+    // on the path coming down the pyramid: its two 3x3 convs join the branch of tap k and leave the head's critical path; the head
+    // then adds the result where it resizes the path into that stage (da_upsample_kernel `add`).  Needs the out_conv-first order
+    // (the resize is then the last op in front of the stage).  NUNIF_DA_RCU1_BRANCH=0: RCU1 in the head, as before.
+    static const bool conv_first_g = !(getenv("NUNIF_DA_OUTCONV_FIRST") && atoi(getenv("NUNIF_DA_OUTCONV_FIRST")) == 0);
+    const bool rcu1_branch = conv_first_g && !(getenv("NUNIF_DA_RCU1_BRANCH") && atoi(getenv("NUNIF_DA_RCU1_BRANCH")) == 0);
+    if (rcu1_branch)
+        for (int i = 0; i < 3; ++i)
+            if ((rc = h->bt1[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2)) || (rc = h->br1[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2)))
+                return rc;
     if (h->rs3g.w && (rc = h->col.ensure((size_t)B * H4 * W4 * 9 * h->OCP[3] * e2))) return rc;
     if (side_streams && !h->side[0]) {
         for (int i = 0; i < 3; ++i) {
@@ -867,7 +888,15 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             src = m2;
         }
         float *part = h->rn[i].cmaj ? (float *)h->bpart[i].p : nullptr;
-        return run_cnv(h->rn[i], src, B, Hs[i], Ws[i], 1, 1, 0, 0, nullptr, nullptr, rn[i], st, 0, part);
+        if ((rc = run_cnv(h->rn[i], src, B, Hs[i], Ws[i], 1, 1, 0, 0, nullptr, nullptr, rn[i], st, 0, part))) return rc;
+        if (rcu1_branch && i < 3) {
+            // br1 = conv2(relu(conv1(relu(rn)))) + rn
+            const Rcu &r = h->fus[i].r1;
+            f16 *t1 = (f16 *)h->bt1[i].p;
+            if ((rc = run_cnv(r.c1, rn[i], B, Hs[i], Ws[i], 1, 1, 1, 3, nullptr, nullptr, t1, st))) return rc;
+            if ((rc = run_cnv(r.c2, t1, B, Hs[i], Ws[i], 1, 1, 0, 0, rn[i], nullptr, (f16 *)h->br1[i].p, st))) return rc;
+        }
+        return NUNIF_HIP_OK;
     };
     bool forked[4] = {false, false, false, false};
     auto fork = [&](int k) -> int {              // tap k's map is complete on s: its branch starts now, on its own stream
@@ -966,9 +995,9 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         int e = run_cnv(r.c1, in, B, Hc, Wc, 1, 1, 1, 3, nullptr, nullptr, tmp, s);
         return e ? e : run_cnv(r.c2, tmp, B, Hc, Wc, 1, 1, 0, 0, in, extra, out, s);
     };
-    auto upsample = [&](const f16 *in, int Hi_, int Wi_, int Ho_, int Wo_, int C, f16 *out) -> int {
+    auto upsample = [&](const f16 *in, int Hi_, int Wi_, int Ho_, int Wo_, int C, f16 *out, const f16 *add = nullptr) -> int {
         ProfScope ps("da_upsample_kernel", s, 0.0, (double)B * Ho_ * Wo_ * C * 2.0 * 5.0);
-        da_upsample_kernel<<<blocks((long)B * Ho_ * Wo_ * (C / 8)), 256, 0, s>>>(in, out, B, Hi_, Wi_, Ho_, Wo_, C);
+        da_upsample_kernel<<<blocks((long)B * Ho_ * Wo_ * (C / 8)), 256, 0, s>>>(in, out, B, Hi_, Wi_, Ho_, Wo_, C, add);
         NUNIF_LAUNCH_CHECK();
         return NUNIF_HIP_OK;
     };
@@ -982,7 +1011,8 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     static const bool conv_first = !(getenv("NUNIF_DA_OUTCONV_FIRST") && atoi(getenv("NUNIF_DA_OUTCONV_FIRST")) == 0);
     if (conv_first) {
         if ((rc = run_lin(h->fus[3].out, m2, B, W4, W4, 0, 0, nullptr, m3, s, "da_out_conv", 0, 0, 1, H4))) return rc;
-        if ((rc = upsample(m3, H4, W4, H3, W3, F, m4))) return rc;                                                          // path4 in m4
+        // (rcu1_branch: m4 = path4 + RCU1(layer3_rn) right away)
+        if ((rc = upsample(m3, H4, W4, H3, W3, F, m4, rcu1_branch ? (const f16 *)h->br1[2].p : nullptr))) return rc;       // path4 in m4
     } else {
         if ((rc = upsample(m2, H4, W4, H3, W3, F, m3))) return rc;
         if ((rc = run_lin(h->fus[3].out, m3, B, W3, W3, 0, 0, nullptr, m4, s, "da_out_conv", 0, 0, 1, H3))) return rc;      // path4 in m4
@@ -993,11 +1023,15 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     for (int k = 2; k >= 0; --k) {
         const int Hc = Hs[k], Wc = Ws[k];
         const int Hn = k > 0 ? Hs[k - 1] : HF, Wn = k > 0 ? Ws[k - 1] : WF;
-        if ((rc = rcu(h->fus[k].r1, rn[k], Hc, Wc, path, m1, m2))) return rc;        // m2 = path + RCU1(skip)
-        if ((rc = rcu(h->fus[k].r2, m2, Hc, Wc, nullptr, m1, m3))) return rc;        // m3 = RCU2(m2)
+        const f16 *xin = path;                                                         // rcu1_branch: path + RCU1(skip) already
+        if (!rcu1_branch) {
+            if ((rc = rcu(h->fus[k].r1, rn[k], Hc, Wc, path, m1, m2))) return rc;    // m2 = path + RCU1(skip)
+            xin = m2;
+        }
+        if ((rc = rcu(h->fus[k].r2, xin, Hc, Wc, nullptr, m1, m3))) return rc;       // m3 = RCU2(.)
         if (conv_first) {
             if ((rc = run_lin(h->fus[k].out, m3, B, Wc, Wc, 0, 0, nullptr, m1, s, "da_out_conv", 0, 0, 1, Hc))) return rc;
-            if ((rc = upsample(m1, Hc, Wc, Hn, Wn, F, pout))) return rc;
+            if ((rc = upsample(m1, Hc, Wc, Hn, Wn, F, pout, rcu1_branch && k > 0 ? (const f16 *)h->br1[k - 1].p : nullptr))) return rc;
         } else {
             if ((rc = upsample(m3, Hc, Wc, Hn, Wn, F, m2))) return rc;
             if ((rc = run_lin(h->fus[k].out, m2, B, Wn, Wn, 0, 0, nullptr, pout, s, "da_out_conv", 0, 0, 1, Hn))) return rc;

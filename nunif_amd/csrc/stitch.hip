@@ -10,6 +10,8 @@
 // un-contracted fp32 mul/add/div, so for identical tile inputs the result is bit-identical to the reference's
 // cumulative update.  Traffic: read each tile pixel that lands in the frame once + write each output once
 // (~24.5 B per output pixel at 3 channels fp32).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace nunif {
@@ -44,7 +46,12 @@ __device__ __forceinline__ float ramp_at(const StitchParams &p, int t) {
     return d < p.blend ? p.ramp[d] : 1.0f;
 }
 
-template <int VEC>
+// CC > 0: the channel count is a compile-time constant and the channels of a pixel group travel TOGETHER — all CC tile reads of a
+// covering tile are in flight at once and the blend weights (which do not depend on the channel) are computed once.  Round 4's form
+// walked the channels one after the other, one 16-byte load in flight per thread: 204 MB in 47 us = 0.53 of the HBM peak, bound by
+// memory-level parallelism (a thread's whole life was three dependent load -> store round trips).  Per channel the arithmetic and
+// its order are unchanged (bit-identical to the reference's cumulative update, tests/test_gpu_stitch.py).  CC = 0: any C, the old walk.
+template <int VEC, int CC>
 __global__ void __launch_bounds__(256)
 stitch_kernel(const float *__restrict__ tiles, float *__restrict__ y, StitchParams p) {
     // HIP's __fmul_rn/__fadd_rn are plain operators: without this the compiler contracts P*a + t*b into an FMA
@@ -59,25 +66,38 @@ stitch_kernel(const float *__restrict__ tiles, float *__restrict__ y, StitchPara
     const int j_hi = min(X0 / p.ostep, p.wb - 1);
     const int j_lo = X0 < p.To ? 0 : (X0 - p.To) / p.ostep + 1;
     const long plane = (long)p.To * p.To;
+    constexpr int NC = CC > 0 ? CC : 1;
+    const int c_outer = CC > 0 ? 1 : p.C;
 
-    for (int c = 0; c < p.C; ++c) {
-        float P[VEC], Wt[VEC];
+    auto load_vec = [&](const float *src, float (&t)[VEC]) {
+        if constexpr (VEC >= 4) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) { P[v] = 0.f; Wt[v] = 0.f; }
+            for (int u = 0; u < VEC / 4; ++u) {
+                const float4 q = reinterpret_cast<const float4 *>(src)[u];
+                t[4 * u] = q.x; t[4 * u + 1] = q.y; t[4 * u + 2] = q.z; t[4 * u + 3] = q.w;
+            }
+        } else {
+            t[0] = src[0];
+        }
+    };
+    for (int c0 = 0; c0 < c_outer; ++c0) {
+        float P[NC][VEC], Wt[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            Wt[v] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) P[c][v] = 0.f;
+        }
         if (p.blend > 0) {
             for (int i = i_lo; i <= i_hi; ++i) {
                 const int ty = Y - p.ostep * i;
                 const float ry = ramp_at(p, ty);
                 for (int j = j_lo; j <= j_hi; ++j) {
                     const int tx = X0 - p.ostep * j;
-                    const float *src = tiles + ((long)(i * p.wb + j) * p.C + c) * plane + (long)ty * p.To + tx;
-                    float t[VEC];
-                    if (VEC == 4) {
-                        float4 q = *reinterpret_cast<const float4 *>(src);
-                        t[0] = q.x; t[1 % VEC] = q.y; t[2 % VEC] = q.z; t[3 % VEC] = q.w;
-                    } else {
-                        t[0] = src[0];
-                    }
+                    const float *src = tiles + ((long)(i * p.wb + j) * p.C + c0) * plane + (long)ty * p.To + tx;
+                    float t[NC][VEC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) load_vec(src + c * plane, t[c]);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         // seam_blending.py:163-168, same operation order, no FMA contraction
@@ -87,9 +107,12 @@ stitch_kernel(const float *__restrict__ tiles, float *__restrict__ y, StitchPara
                         const float w_new = Wt[v] + F;
                         const float a = Wt[v] / w_new;
                         const float b = 1.0f - a;
-                        const float pa = P[v] * a;
-                        const float tb = t[v] * b;
-                        P[v] = pa + tb;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const float pa = P[c][v] * a;
+                            const float tb = t[c][v] * b;
+                            P[c][v] = pa + tb;
+                        }
                         Wt[v] = w_new;
                     }
                 }
@@ -97,22 +120,25 @@ stitch_kernel(const float *__restrict__ tiles, float *__restrict__ y, StitchPara
         } else {
             // blend_size == 0: plain overwrite in row-major order -> the last covering tile wins (:170-172)
             const int ty = Y - p.ostep * i_hi, tx = X0 - p.ostep * j_hi;
-            const float *src = tiles + ((long)(i_hi * p.wb + j_hi) * p.C + c) * plane + (long)ty * p.To + tx;
-            if (VEC == 4) {
-                float4 q = *reinterpret_cast<const float4 *>(src);
-                P[0] = q.x; P[1 % VEC] = q.y; P[2 % VEC] = q.z; P[3 % VEC] = q.w;
-            } else {
-                P[0] = src[0];
-            }
+            const float *src = tiles + ((long)(i_hi * p.wb + j_hi) * p.C + c0) * plane + (long)ty * p.To + tx;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) load_vec(src + c * plane, P[c]);
         }
-        float *dst = y + ((long)c * p.dst_rows + (Y - (p.dst_rows == p.y_h ? 0 : p.y0))) * p.y_w + X0;
-        if (VEC == 4) {
-            float4 o;
-            o.x = fminf(fmaxf(P[0], 0.f), 1.f); o.y = fminf(fmaxf(P[1 % VEC], 0.f), 1.f);
-            o.z = fminf(fmaxf(P[2 % VEC], 0.f), 1.f); o.w = fminf(fmaxf(P[3 % VEC], 0.f), 1.f);
-            *reinterpret_cast<float4 *>(dst) = o;
-        } else {
-            dst[0] = fminf(fmaxf(P[0], 0.f), 1.f);
+        float *dst = y + ((long)c0 * p.dst_rows + (Y - (p.dst_rows == p.y_h ? 0 : p.y0))) * p.y_w + X0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float *d = dst + (long)c * p.dst_rows * p.y_w;
+            if constexpr (VEC >= 4) {
+#pragma unroll
+                for (int u = 0; u < VEC / 4; ++u) {
+                    float4 o;
+                    o.x = fminf(fmaxf(P[c][4 * u], 0.f), 1.f); o.y = fminf(fmaxf(P[c][4 * u + 1], 0.f), 1.f);
+                    o.z = fminf(fmaxf(P[c][4 * u + 2], 0.f), 1.f); o.w = fminf(fmaxf(P[c][4 * u + 3], 0.f), 1.f);
+                    reinterpret_cast<float4 *>(d)[u] = o;
+                }
+            } else {
+                d[0] = fminf(fmaxf(P[c][0], 0.f), 1.f);
+            }
         }
     }
 }
@@ -136,12 +162,24 @@ int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int
                      ((reinterpret_cast<uintptr_t>(tile_out) | reinterpret_cast<uintptr_t>(y)) % 16 == 0);
     const double bytes = (double)C * rows * p.y_w * 4.0 * 2.0;
     ProfScope ps(vec ? "stitch_kernel<4>" : "stitch_kernel<1>", s, 0.0, bytes);
-    if (vec) {
+    static const bool together = !(getenv("NUNIF_STITCH_TOGETHER") && atoi(getenv("NUNIF_STITCH_TOGETHER")) == 0);   // A/B runs
+    // (8 pixels per thread measured SLOWER than 4 — 44.1 vs 37.6 us on the 1080p 2x frame, profiles/r05e_*: half the waves, and
+    //  the waves were what kept the loads in flight; kept for A/B runs only)
+    static const int vec8_on = getenv("NUNIF_STITCH_VEC8") ? atoi(getenv("NUNIF_STITCH_VEC8")) : 0;
+    const bool vec8 = vec && vec8_on && C == 3 && together && (p.To % 8 == 0) && (p.ostep % 8 == 0) && (p.y_w % 8 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(tile_out) | reinterpret_cast<uintptr_t>(y)) % 32 == 0);
+    if (vec8) {
+        // 8 pixels x 3 channels per thread: six 16-byte loads in flight
+        dim3 grid(cdiv(p.y_w / 8, 128), rows);
+        stitch_kernel<8, 3><<<grid, 128, 0, s>>>(tile_out, y, p);
+    } else if (vec) {
         dim3 grid(cdiv(p.y_w / 4, 256), rows);
-        stitch_kernel<4><<<grid, 256, 0, s>>>(tile_out, y, p);
+        if (C == 3 && together) stitch_kernel<4, 3><<<grid, 256, 0, s>>>(tile_out, y, p);
+        else stitch_kernel<4, 0><<<grid, 256, 0, s>>>(tile_out, y, p);
     } else {
         dim3 grid(cdiv(p.y_w, 256), rows);
-        stitch_kernel<1><<<grid, 256, 0, s>>>(tile_out, y, p);
+        if (C == 3 && together) stitch_kernel<1, 3><<<grid, 256, 0, s>>>(tile_out, y, p);
+        else stitch_kernel<1, 0><<<grid, 256, 0, s>>>(tile_out, y, p);
     }
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;

@@ -30,6 +30,10 @@ struct GemmArgs {
     int rev;                  // 1: walk the token groups downwards (snake order, swin_unet.cpp next_dir)
     int nt_chunk;             // set by the launcher: output tiles per workgroup column (blockIdx.y) for small-M GEMMs
     int res_H = 0, res_W = 0, res_crop = 0;
+    // optional per-IMAGE channel scale of the input (squeeze-excitation, nunif/modules/attention.py:29-44): a value read from
+    // channel c of image b is replaced by fp16(x * in_scale[b * Cin + c]) before it is multiplied — the arithmetic of a separate
+    // scale pass over the map, without the pass (ring form only)
+    const float *in_scale = nullptr;
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s, const char *tag);
 
@@ -222,6 +226,6 @@ int launch_c3_conv(const C3ConvArgs &a, hipStream_t s);
 
 // x[b,:,:,c] *= sigmoid(W2 relu(W1 mean_hw(x[b]) + b1) + b2)   (nunif/modules/attention.py SEBlock :29-44)
 int launch_se(f16 *x, float *sums, float *scale, const float *w1, const float *b1, const float *w2, const float *b2,
-              int B, long hw, int C, hipStream_t s);
+              int B, long hw, int C, hipStream_t s, int scale_in_consumer = 0);
 
 }  // namespace nunif

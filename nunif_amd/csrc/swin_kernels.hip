@@ -89,6 +89,22 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
             xf[f][ks] = *reinterpret_cast<const f16x8 *>(p);
         }
     }
+    if (g.in_scale) {
+        // squeeze-excitation scale of the input map, applied to the fragments as they arrive: (f16)((float)x * s), the rounding
+        // of the separate scale pass
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c0 = (ks * 32) % g.Cin;
+                const float4 *sp = reinterpret_cast<const float4 *>(g.in_scale + (long)tb[f] * g.Cin + c0 + grp * 8);
+                const float4 s0 = sp[0], s1 = sp[1];
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[f][ks][j] = (f16)((float)xf[f][ks][j] * sc[j]);
+            }
+        }
+    }
 
     const int NT = nt_hi - nt_lo;
     if (g.mode == 2) {
@@ -418,7 +434,7 @@ static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym,
     // (384 B in + 192 B out)): the ring form is one 256-token tile per workgroup and all prologue, 1 040 us = 1.9 TB/s; resident
     // 543 us = 3.2 TB/s.  K = 96 measured equal (stays on the ring).
     const bool big_plain = MF == 4 && KS == 6 && g.mode == 0 && M >= gemm_big_m();
-    const bool res = fits && !ring_only && (MF == 2 || big_plain) && g.res_W == 0;     // (the cropped residual exists in the ring form only)
+    const bool res = fits && !ring_only && (MF == 2 || big_plain) && g.res_W == 0 && !g.in_scale;     // (the cropped residual and the input scale exist in the ring form only)
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
     // (NUNIF_PROF_TAGS=1 names the class after the call site instead: separates e.g. the two gemm_kernel<6,4> users)
     ProfScope ps(g_prof_tag ? g_prof_tag : res ? res_sym : ring_sym, s, flops, bytes);

@@ -25,6 +25,7 @@ Nothing is computed here; every tensor operation is a kernel of the engine reach
 inpaint nets' ``infer``.
 """
 import contextlib
+import os
 from dataclasses import dataclass
 from typing import Callable
 
@@ -77,16 +78,25 @@ def _repair_pair(net, left, right, lmask, rmask, view, spec, params):
 
 
 class StereoWindow:
-    """The last ``capacity`` stereo frames (and the masks of the synthesised eyes) in HBM, oldest first."""
+    """The last ``capacity`` stereo frames (and the masks of the synthesised eyes) in HBM, oldest first.
 
-    def __init__(self, view, capacity, frame_shape, mask_shape, dtype, device):
-        self.view, self.capacity, self.level = view, capacity, 0
-        self.tracks = {"left": torch.zeros((capacity, *frame_shape), dtype=dtype, device=device),
-                       "right": torch.zeros((capacity, *frame_shape), dtype=dtype, device=device)}
+    The window is a ``capacity``-frame VIEW that travels along a longer buffer (``span`` frames, default 3 x capacity): ``slide``
+    moves the view's origin instead of the frames, and only when the view reaches the end of the buffer are the kept frames
+    copied back to the front — once every ``(span - capacity) / n`` slides, into a region the source cannot overlap (no staging
+    clone).  Round 4 moved every kept frame on every slide, through a clone: 546 ``copyBuffer`` launches of 58.6 MB in the
+    config-5 profile (``profiles/r04f_pmc_WRITE_SIZE.txt``).  ``get`` hands out a contiguous view either way."""
+
+    def __init__(self, view, capacity, frame_shape, mask_shape, dtype, device, span=None):
+        if span is None:
+            span = int(os.environ.get("NUNIF_STEREO_WINDOW_SPAN", "3")) * capacity
+        assert span >= 2 * capacity or span == capacity, "a copy-back must not overlap its source"
+        self.view, self.capacity, self.span, self.level, self.start = view, capacity, span, 0, 0
+        self.tracks = {"left": torch.zeros((span, *frame_shape), dtype=dtype, device=device),
+                       "right": torch.zeros((span, *frame_shape), dtype=dtype, device=device)}
         if view in ("both", "left"):
-            self.tracks["left_mask"] = torch.zeros((capacity, *mask_shape), dtype=dtype, device=device)
+            self.tracks["left_mask"] = torch.zeros((span, *mask_shape), dtype=dtype, device=device)
         if view in ("both", "right"):
-            self.tracks["right_mask"] = torch.zeros((capacity, *mask_shape), dtype=dtype, device=device)
+            self.tracks["right_mask"] = torch.zeros((span, *mask_shape), dtype=dtype, device=device)
 
     def is_full(self):
         return self.level == self.capacity
@@ -99,33 +109,42 @@ class StereoWindow:
         if self.is_full():
             raise IndexError("StereoWindow.push on a full window")
         for name, buf in self.tracks.items():
-            buf[self.level] = frames[name]
+            buf[self.start + self.level] = frames[name]
         self.level += 1
 
     def pad_with_last(self):
         """Repeat the newest frame until the window is full; returns the number of copies."""
         n = self.capacity - self.level
         if n > 0:
+            a = self.start + self.level
             for buf in self.tracks.values():
-                buf[self.level:] = buf[self.level - 1].clone()
+                buf[a:self.start + self.capacity] = buf[a - 1]
             self.level = self.capacity
         return n
 
     def slide(self, n):
-        """Drop the ``n`` oldest frames; what remains moves to the front."""
+        """Drop the ``n`` oldest frames."""
         keep = self.level - n
         if keep < 0:
             raise IndexError(f"StereoWindow.slide({n}) with {self.level} frames")
-        if keep > 0 and n > 0:
-            for buf in self.tracks.values():
-                buf[:keep] = buf[n:n + keep].clone()
+        self.start += n
         self.level = keep
+        if self.start + self.capacity > self.span:          # no room for a whole window behind the origin: back to the front
+            if keep > 0:
+                if self.start >= keep:
+                    for buf in self.tracks.values():
+                        buf[:keep] = buf[self.start:self.start + keep]
+                else:                                        # (span == capacity: the round-4 behaviour)
+                    for buf in self.tracks.values():
+                        buf[:keep] = buf[self.start:self.start + keep].clone()
+            self.start = 0
 
     def reset(self):
-        self.level = 0
+        self.level = self.start = 0
 
     def get(self, name):
-        return self.tracks.get(name)
+        buf = self.tracks.get(name)
+        return None if buf is None else buf[self.start:self.start + self.capacity]
 
 
 class ImageDriver:
