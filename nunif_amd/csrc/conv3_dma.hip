@@ -418,7 +418,9 @@ bool conv3_dma_applies(const ConvArgs &g) {
     if (!(g.kh == 3 && g.kw == 3 && g.stride == 1) || g.a2 || g.cmaj || (g.out32 && nt != 1) || g.N % 16 != 0) return false;
     if (g.Ho != g.Hi + 2 * pad - 2 || g.Wo != g.Wi + 2 * pad - 2 || g.zpad > 1 || g.rpad > 1 || (g.zpad && g.rpad)) return false;
     // Cin = 128 with 64 outputs: two K halves over one halo space (NUNIF_CONV3_DMA_KSPLIT=0: conv3_lds_kernel as before)
-    const bool ksplit = g.Cin == 128 && nt == 4 && !(getenv("NUNIF_CONV3_DMA_KSPLIT") && atoi(getenv("NUNIF_CONV3_DMA_KSPLIT")) == 0);
+    // (round 5: Cin = 256 as four quarters: cunet's 256 -> 128 conv arrives as two 64-output slices, cunet.cpp run_conv)
+    const bool ksplit = (g.Cin == 128 || g.Cin == 256) && nt == 4 &&
+                        !(getenv("NUNIF_CONV3_DMA_KSPLIT") && atoi(getenv("NUNIF_CONV3_DMA_KSPLIT")) == 0);
     if (!ksplit && (!(g.Cin == 32 || g.Cin == 64) || !(nt == 1 || nt == 2 || nt == 4 || (nt == 8 && g.Cin == 64)))) return false;
     const long n_patches = (long)g.B * ((g.Ho + kTH - 1) / kTH) * ((g.Wo + kTW - 1) / kTW);
     // tiny launches keep the resident-weight form of conv3_lds_kernel.  Threshold sweep on the depth net (4 x 1080p, ViT-S):
@@ -473,6 +475,8 @@ int launch_conv3_dma(const ConvArgs &g, hipStream_t s) {
         if (nt == 2) return g.relu_in ? launch_c3d<2, 64, true>(g, s, "conv3_dma_kernel<2,64>") : launch_c3d<2, 64, false>(g, s, "conv3_dma_kernel<2,64>");
     } else if (g.Cin == 128) {
         if (nt == 4) return g.relu_in ? launch_c3d<4, 64, true, 1, 2, 2>(g, s, "conv3_dma_kernel<4,128>") : launch_c3d<4, 64, false, 1, 2, 2>(g, s, "conv3_dma_kernel<4,128>");
+    } else if (g.Cin == 256) {
+        if (nt == 4) return g.relu_in ? launch_c3d<4, 64, true, 1, 2, 4>(g, s, "conv3_dma_kernel<4,256>") : launch_c3d<4, 64, false, 1, 2, 4>(g, s, "conv3_dma_kernel<4,256>");
     } else if (g.Cin == 32) {
         if (nt == 1) return g.relu_in ? launch_c3d<1, 32, true>(g, s, "conv3_dma_kernel<1,32>") : launch_c3d<1, 32, false>(g, s, "conv3_dma_kernel<1,32>");
         if (nt == 4) return g.relu_in ? launch_c3d<4, 32, true>(g, s, "conv3_dma_kernel<4,32>") : launch_c3d<4, 32, false>(g, s, "conv3_dma_kernel<4,32>");

@@ -37,7 +37,11 @@ struct Buf {
 };
 
 struct ConvW { f16 *stream = nullptr; float *bias = nullptr; int N = 0, n_real = 0, Cin = 0, k = 3, stride = 1;
-               f16 *gemm_w = nullptr; };        // 2x2 stride-2 convs: the same weights in gemm_kernel's [n-tile][k-step] order
+               f16 *gemm_w = nullptr;           // 2x2 stride-2 convs: the same weights in gemm_kernel's [n-tile][k-step] order
+               // 3x3 convs with 128 / 256 inputs and more than 64 outputs (the two bottom convs of unet2): the SAME weights as
+               // streams of 64 output channels each, so that every slice runs on the LDS-DMA conv with K halves
+               // (conv3_dma_kernel<4, 64, ., 1, 2, KS>), writing its channels of the NHWC map through ConvArgs::ldo
+               std::vector<f16 *> slice; };
 struct UpW { f16 *w = nullptr; float *bias = nullptr; int N = 0, K = 0, cq = 0; };       // ConvTranspose2d 2x2 s2
 struct SEW { float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr; int C = 0; };
 struct C3W { float *w = nullptr, *b = nullptr; int C = 0; f16 *frag = nullptr; };   // frag: MFMA A fragments of the fused stem (K = 27 taps + bias)
@@ -110,6 +114,17 @@ int make_conv(nunif_cunet *h, const TMap &m, const std::string &key, int cin, in
     for (int n = 0; n < cout; ++n) bias[n] = b->data[n];
     c->N = N; c->n_real = cout; c->Cin = cin; c->k = k; c->stride = stride;
     if ((rc = upload(h, stream, &c->stream))) return rc;
+    if (k == 3 && stride == 1 && cin_real == cin && (cin == 128 || cin == 256) && cout > 64 && cout % 64 == 0) {
+        for (int sl = 0; sl < cout / 64; ++sl) {
+            std::vector<f16> part((size_t)KS * 4 * 512 + 8192, (f16)0.0f);
+            for (int ks = 0; ks < KS; ++ks)
+                std::copy(stream.begin() + ((size_t)ks * NT + 4 * sl) * 512, stream.begin() + ((size_t)ks * NT + 4 * sl + 4) * 512,
+                          part.begin() + (size_t)ks * 4 * 512);
+            f16 *dev = nullptr;
+            if ((rc = upload(h, part, &dev))) return rc;
+            c->slice.push_back(dev);
+        }
+    }
     if (k == 2 && stride == 2 && cin_real == cin && N == cout && N % 32 == 0) {
         // k = stride: a 2 x 2 gather GEMM (the PatchDown form of gemm_kernel: every input pixel is read exactly once, the token
         // tile's whole K extent sits in registers) instead of the K-looped conv_kernel with its nine-tap machinery
@@ -233,6 +248,18 @@ int run_conv(const ConvW &c, const f16 *a, const f16 *a2, int H2, int crop2, int
     g.act = act; g.slope = 0.1f;
     g.out = out; g.out32 = out32; g.add32 = add32; g.addH = addH; g.addW = addH; g.add_crop = add_crop;
     g.clamp01 = clamp01;
+    // (every launch of such a conv takes the sliced form or none does: a result must not depend on the tile minibatch)
+    static const bool sliced = !(getenv("NUNIF_CUNET_SLICED") && atoi(getenv("NUNIF_CUNET_SLICED")) == 0);
+    if (sliced && !c.slice.empty() && out && !out32 && !a2) {
+        for (size_t sl = 0; sl < c.slice.size(); ++sl) {
+            ConvArgs q = g;
+            q.wstream = c.slice[sl]; q.bias = c.bias + 64 * sl; q.N = 64; q.n_real = 64;
+            q.out = out + 64 * sl; q.ldo = c.n_real;
+            int rc = launch_conv(q, s);
+            if (rc) return rc;
+        }
+        return NUNIF_HIP_OK;
+    }
     return launch_conv(g, s);
 }
 
@@ -241,6 +268,12 @@ static inline bool down_gemm_enabled() { const char *e = getenv("NUNIF_CUNET_DOW
 // Conv2d(k = stride = 2) + LeakyReLU (cunet.py:37,78,81) as a gather GEMM
 int run_down(const ConvW &c, const f16 *a, int B, int Hi, f16 *out, hipStream_t s) {
     if (!c.gemm_w || !down_gemm_enabled()) return run_conv(c, a, nullptr, 0, 0, B, Hi, out, nullptr, nullptr, 0, 0, 0, 2, s);
+    {   // 64 -> 64: the K-outer prefetching kernel of the swin PatchDown (swin_patchdown.hip), every launch of that shape
+        PatchDownArgs p;
+        p.a = a; p.w = c.gemm_w; p.bias = c.bias; p.out = out; p.B = B; p.Ho = Hi / 2; p.Wo = Hi / 2; p.Cin = c.Cin; p.oy = 0;
+        p.rev = 0; p.N = c.N; p.act = 2; p.slope = 0.1f;
+        if (Hi % 2 == 0 && patchdown_supported(p)) return launch_patchdown(p, s);
+    }
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.B = B; g.Hi = Hi; g.Wi = Hi; g.Cin = c.Cin; g.Ho = Hi / 2; g.Wo = Hi / 2; g.stride = 2; g.kw = 2;

@@ -47,8 +47,9 @@ int launch_patchup(const PatchUpArgs &g, hipStream_t s);
 
 // ---- PatchDown of the swin U-Nets (swin_patchdown.hip): out[b, y, x, 192] = bias + sum over the taps of a 2 x 2 stride-2 patch --------
 // a: [B, 2 Ho, 2 Wo, Cin]; Cin = 96: K = 384 = the four taps (dy, dx) of a token, k = (2 dy + dx) Cin + c; Cin = 192: K = 384 = the
-// two taps of input row 2 y + oy (the other row is a second, accumulating pass on gemm_res_kernel).  w / bias: make_linear's packing.
-struct PatchDownArgs { const f16 *a, *w; const float *bias; f16 *out; int B, Ho, Wo, Cin, oy, rev; };
+// two taps of input row 2 y + oy (the other row is a second, accumulating pass on gemm_res_kernel); Cin = 64, N = 64: cunet's
+// Conv2d(64, 64, 2, 2) + LeakyReLU.  w / bias: make_linear's packing ([n-tile][k-step]).
+struct PatchDownArgs { const f16 *a, *w; const float *bias; f16 *out; int B, Ho, Wo, Cin, oy, rev; int N = 192; int act = 0; float slope = 0.f; };     // act 2: LeakyReLU(slope)
 bool patchdown_supported(const PatchDownArgs &g);
 int launch_patchdown(const PatchDownArgs &g, hipStream_t s);
 

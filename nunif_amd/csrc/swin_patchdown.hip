@@ -21,22 +21,20 @@ namespace nunif {
 #define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 namespace {
-constexpr int kKS = 12;                              // K = 384
-constexpr int kNT = 12;                              // N = 192
 constexpr int kWaves = 8;
 constexpr int kMF = 2;
-constexpr int kWBytes = kNT * kKS * 1024;            // 147 456
-constexpr int kSmem = kWBytes + 192 * 4;
-static_assert(kSmem <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ void dma16(const void *src, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
 }
 }  // namespace
 
-template <int CIN>                                    // 96: four taps (2 x 2) of 96 channels; 192: the two taps of ONE row (g.oy)
+// <96, 12, 12>: four taps (2 x 2) of 96 channels -> 192; <192, 12, 12>: the two taps of ONE row (g.oy) -> 192;
+// <64, 8, 4>: cunet's Conv2d(64, 64, 2, 2) + LeakyReLU (waifu2x/models/cunet.py:37,78), 32 KiB of weights: two workgroups per CU
+template <int CIN, int kKS, int kNT, bool LRELU>
 __global__ void __launch_bounds__(kWaves * 64) patchdown_kernel(PatchDownArgs g) {
-    static_assert(CIN == 96 || CIN == 192, "Cin");
+    static_assert(CIN == 64 || CIN == 96 || CIN == 192, "Cin");
+    constexpr int kWBytes = kNT * kKS * 1024;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pd[];
     const f16x8 *wres = reinterpret_cast<const f16x8 *>(smem_pd);
     const float4 *bres = reinterpret_cast<const float4 *>(smem_pd + kWBytes);
@@ -50,7 +48,7 @@ __global__ void __launch_bounds__(kWaves * 64) patchdown_kernel(PatchDownArgs g)
             const int i = wave + kWaves * u;
             dma16(src + (size_t)i * 1024, lds0 + i * 1024);
         }
-        if (tid < 48) reinterpret_cast<float4 *>(smem_pd + kWBytes)[tid] = reinterpret_cast<const float4 *>(g.bias)[tid];
+        if (tid < kNT * 4) reinterpret_cast<float4 *>(smem_pd + kWBytes)[tid] = reinterpret_cast<const float4 *>(g.bias)[tid];
     }
     const unsigned Wo = (unsigned)g.Wo, Ho = (unsigned)g.Ho, Wi = 2 * Wo, Hi = 2 * Ho;
     const unsigned M = (unsigned)g.B * Ho * Wo;
@@ -137,7 +135,14 @@ __global__ void __launch_bounds__(kWaves * 64) patchdown_kernel(PatchDownArgs g)
         for (int p = 0; p < kNT / 2; ++p) {
 #pragma unroll
             for (int f = 0; f < kMF; ++f) {
-                const f32x4 a0 = acc[2 * p][f], a1 = acc[2 * p + 1][f];
+                f32x4 a0 = acc[2 * p][f], a1 = acc[2 * p + 1][f];
+                if constexpr (LRELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        a0[r] = a0[r] >= 0.f ? a0[r] : a0[r] * g.slope;
+                        a1[r] = a1[r] >= 0.f ? a1[r] : a1[r] * g.slope;
+                    }
+                }
                 const f16x8 ov = pair_to_run((f16x4){(f16)a0[0], (f16)a0[1], (f16)a0[2], (f16)a0[3]},
                                              (f16x4){(f16)a1[0], (f16)a1[1], (f16)a1[2], (f16)a1[3]});
                 *reinterpret_cast<f16x8 *>(obase + (size_t)cur.out[f] + p * 64) = ov;
@@ -152,37 +157,40 @@ __global__ void __launch_bounds__(kWaves * 64) patchdown_kernel(PatchDownArgs g)
 bool patchdown_supported(const PatchDownArgs &g) {
     if (const char *e = getenv("NUNIF_PATCHDOWN")) if (atoi(e) == 0) return false;      // read per call (A/B runs)
     const long M = (long)g.B * g.Ho * g.Wo;
-    // byte offsets into the input map (4 M pixels of Cin channels) and the output map (384 B per token) are 32-bit
-    return (g.Cin == 96 || g.Cin == 192) && M > 0 && 4 * M * g.Cin * 2 < (1L << 32) && M * 384 < (1L << 32) &&
-           (g.Cin == 96 ? g.oy == 0 : (g.oy == 0 || g.oy == 1));
+    const bool shape = (g.Cin == 96 && g.N == 192 && g.oy == 0) || (g.Cin == 192 && g.N == 192 && (g.oy == 0 || g.oy == 1)) ||
+                       (g.Cin == 64 && g.N == 64 && g.oy == 0);
+    const bool act_ok = g.Cin == 64 ? g.act == 2 : g.act == 0;               // (the activation is a template parameter)
+    // byte offsets into the input map (4 M pixels of Cin channels) and the output map (2 N bytes per token) are 32-bit
+    return shape && M > 0 && 4 * M * g.Cin * 2 < (1L << 32) && M * g.N * 2 < (1L << 32) && act_ok;
 }
 
-int launch_patchdown(const PatchDownArgs &g, hipStream_t s) {
-    NUNIF_REQUIRE(g.a && g.w && g.bias && g.out && patchdown_supported(g), "patchdown: bad argument");
+template <int CIN, int KS, int NT, bool LRELU>
+static int launch_pd(const PatchDownArgs &g, hipStream_t s, const char *name, int wgs_per_cu) {
+    constexpr int smem = NT * KS * 1024 + NT * 16 * 4;
+    static_assert(smem <= 160 * 1024, "LDS");
     const long M = (long)g.B * g.Ho * g.Wo;
     static bool configured = false;
     static int cus = 256;
     if (!configured) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)patchdown_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)patchdown_kernel<192>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)patchdown_kernel<CIN, KS, NT, LRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         int dev = 0;
         NUNIF_HIP_CHECK(hipGetDevice(&dev));
         NUNIF_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         configured = true;
     }
     const long groups = (M + kMF * 16 - 1) / (kMF * 16);
-    const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((groups + kWaves - 1) / kWaves, cus));
-    const double flops = 2.0 * (double)M * 384.0 * 192.0;
-    const double bytes = (double)M * (384.0 * 2.0 + 192.0 * 2.0);
-    if (g.Cin == 96) {
-        ProfScope ps("patchdown_kernel<96>", s, flops, bytes);
-        patchdown_kernel<96><<<grid, kWaves * 64, kSmem, s>>>(g);
-    } else {
-        ProfScope ps("patchdown_kernel<192>", s, flops, bytes);
-        patchdown_kernel<192><<<grid, kWaves * 64, kSmem, s>>>(g);
-    }
+    const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((groups + kWaves - 1) / kWaves, (long)cus * wgs_per_cu));
+    ProfScope ps(name, s, 2.0 * (double)M * (KS * 32.0) * (NT * 16.0), (double)M * (KS * 32.0 + NT * 16.0) * 2.0);
+    patchdown_kernel<CIN, KS, NT, LRELU><<<grid, kWaves * 64, smem, s>>>(g);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
+}
+
+int launch_patchdown(const PatchDownArgs &g, hipStream_t s) {
+    NUNIF_REQUIRE(g.a && g.w && g.bias && g.out && patchdown_supported(g), "patchdown: bad argument");
+    if (g.Cin == 96) return launch_pd<96, 12, 12, false>(g, s, "patchdown_kernel<96>", 1);
+    if (g.Cin == 192) return launch_pd<192, 12, 12, false>(g, s, "patchdown_kernel<192>", 1);
+    return launch_pd<64, 8, 4, true>(g, s, "patchdown_kernel<64>", 2);
 }
 
 }  // namespace nunif

@@ -364,7 +364,8 @@ int run_patchup(const Linear &L, const f16 *a, int B, int H, int W, int Cq, f16 
 // input row(s) 2 y + oy ..; the K-outer prefetching kernel when it takes the shape (every launch of that shape), else the generic GEMM
 int run_patchdown(const Linear &L, const f16 *a, int B, int Ho, int Wo, int Cin, int oy, f16 *out, hipStream_t s, const char *tag,
                   int rev) {
-    PatchDownArgs p = {a, L.w, L.bias, out, B, Ho, Wo, Cin, oy, rev};
+    PatchDownArgs p;
+    p.a = a; p.w = L.w; p.bias = L.bias; p.out = out; p.B = B; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin; p.oy = oy; p.rev = rev;
     if (L.K == 384 && L.n_real == 192 && patchdown_supported(p)) return launch_patchdown(p, s);
     return run_gemm(L, a, B, 2 * Ho, 2 * Wo, Cin, Ho, Wo, 2, oy, 0, 2, 0, 0, 0.f, nullptr, out, L.n_real, 1, s, tag, rev);
 }

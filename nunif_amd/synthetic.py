@@ -258,9 +258,12 @@ def cunet_state_dict(seed, up=False, in_channels=3, out_channels=3, regime="beni
     return sd
 
 
-def row_flow_v3_state_dict(seed):
+def row_flow_v3_state_dict(seed, regime="benign"):
     """Seeded weights in the reference's key layout, every bias non-zero; the last layer is scaled so that delta sits
-    in the range of a trained model's (a few depth pixels), i.e. the warp really moves pixels."""
+    in the range of a trained model's (a few depth pixels), i.e. the warp really moves pixels.
+    ``regime="hot"`` (tests/test_hot_regime.py): the residual branches undamped (x2), qkv x2.5 (window logits of tens of units), the
+    relative-position bias MLP x3 — the same generator draws, scaled after the fact."""
+    assert regime in ("benign", "hot")
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
@@ -286,7 +289,20 @@ def row_flow_v3_state_dict(seed):
         sd[p + "bias.index"], sd[p + "bias.delta"] = index, delta
     lin("last_layer.1", 1, 8, 3, std=2.0 * math.sqrt(1.0 / 72), bstd=1.0)
     sd["delta_scale"] = torch.tensor(1.0 / 127.0)
+    if regime == "hot":
+        _heat_window_net(sd)
     return sd
+
+
+def _heat_window_net(sd, qkv=2.5, branch=2.0, bias=1.75):
+    """The window-attention nets of iw3 (row_flow_v3, mlbw) in the regime of a trained net: see row_flow_v3_state_dict."""
+    for k in list(sd):
+        if k.endswith("mha.mha.qkv_proj.weight"):
+            sd[k] = sd[k] * qkv
+        elif k.endswith(("mha.mha.head_proj.weight", "conv_mlp.3.weight")):
+            sd[k] = sd[k] * branch
+        elif k.endswith(("bias.to_bias.0.weight", "bias.to_bias.2.weight")):
+            sd[k] = sd[k] * bias
 
 
 def conv_stack_state_dict(seed, kind):
@@ -307,10 +323,13 @@ def conv_stack_state_dict(seed, kind):
     return sd
 
 
-def light_inpaint_state_dict(seed):
+def light_inpaint_state_dict(seed, regime="benign"):
     """Seeded weights of inpaint.light_inpaint_v1 in the reference's key layout: every bias non-zero, LayerNorm weights
     around 1, the token-mixing matrices (proj_spatial) strong enough to matter (the reference initialises them ~1e-5 with
-    bias 1), to_image centred on 0.5 so that the net output sits in the image range."""
+    bias 1), to_image centred on 0.5 so that the net output sits in the image range.
+    ``regime="hot"`` (tests/test_hot_regime.py): stronger residual branches and token mixing (proj_out, glu_conv.w2, proj_spatial x1.7), LayerNorm
+    gains spread (x [0.5, 2.5]), the image head rescaled to keep the picture in range."""
+    assert regime in ("benign", "hot")
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
@@ -344,6 +363,14 @@ def light_inpaint_state_dict(seed):
     lin("up", 384, 192, 1, 1)
     block("dec1.", 96, 16)
     lin("to_image.1", 48, 96, 3, 3, std=0.0028 * math.sqrt(1.0 / (9 * 96)), bstd=0.05, bmean=0.5)
+    if regime == "hot":
+        for k in list(sd):
+            if k.endswith(("gmlp.gmlp.proj_out.weight", "glu_conv.w2.weight", "gmlp.gmlp.proj_spatial.weight")):
+                sd[k] = sd[k] * 1.7
+            elif k.endswith(("norm1.weight", "norm2.weight")):
+                n = sd[k].numel()
+                sd[k] = sd[k] * torch.linspace(0.5, 2.5, n)[torch.randperm(n, generator=g)]
+        sd["to_image.1.weight"] = sd["to_image.1.weight"] * 0.4
     return sd
 
 
@@ -387,9 +414,11 @@ def light_video_inpaint_state_dict(seed, base_dim=96, lv2_mlp_ratio=1):
     return sd
 
 
-def mlbw_state_dict(seed, num_layers=2, small=False, hole_mask=False):
+def mlbw_state_dict(seed, num_layers=2, small=False, hole_mask=False, regime="benign"):
     """Seeded weights in the reference's key layout (every bias non-zero); the output conv is scaled so that the layer
-    deltas differ by a few depth pixels and the layer-weight logits really select between them."""
+    deltas differ by a few depth pixels and the layer-weight logits really select between them.  ``regime="hot"``: as
+    row_flow_v3_state_dict."""
+    assert regime in ("benign", "hot")
     g = torch.Generator().manual_seed(seed)
     C = 32 * num_layers
     sd = {}
@@ -418,6 +447,8 @@ def mlbw_state_dict(seed, num_layers=2, small=False, hole_mask=False):
         bstd=1.0)
     if hole_mask:
         sd["lv1_out.1.bias"][2 * num_layers] = -1.7     # logit(0.15): the default threshold cuts through the map
+    if regime == "hot":
+        _heat_window_net(sd, qkv=2.0, branch=1.5, bias=1.5)       # four blocks deep: milder per block than row_flow's two
     return sd
 
 
