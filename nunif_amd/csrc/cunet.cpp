@@ -287,6 +287,11 @@ int run_down(const ConvW &c, const f16 *a, int B, int Hi, f16 *out, hipStream_t 
 // which a DMA-staged conv cannot do)
 int run_up(const UpW &u, const f16 *a, int B, int Hi, f16 *out, hipStream_t s, const f16 *skip = nullptr, int skip_side = 0,
            int crop = 0, const float *in_scale = nullptr) {
+    if (u.K == 64 && u.cq == 64 && skip) {
+        // 64 -> 4 x 64 with a cropped skip: the resident-weight prefetching kernel (cunet_up.hip), every launch of that shape
+        CunetUpArgs cu = {a, u.w, u.bias, skip, out, in_scale, B, Hi, skip_side, crop, 0.1f};
+        if (cunet_up_supported(cu)) return launch_cunet_up(cu, s);
+    }
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.B = B; g.Hi = Hi; g.Wi = Hi; g.Cin = u.K; g.Ho = Hi; g.Wo = Hi; g.stride = 1; g.kw = 1;

@@ -875,7 +875,12 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
         g.a = x2; g.B = B; g.Hi = h2; g.Wi = w2; g.Cin = C2; g.Ho = h2; g.Wo = w2; g.stride = 1; g.kw = 1;
         g.K = C2; g.w = h->up.w; g.bias = h->up.bias; g.N = h->up.N; g.mode = 1; g.res = x1; g.out = x1; g.ldo = C; g.n_real = 4 * C;
         g.ps = 1;
-        if ((rc = launch_gemm(g, s, "li_up"))) return rc;
+        // K = 192 -> 4 x 96 / 4 x 192 with the skip map as residual is the swin PatchUp's shape: its resident-weight kernel with
+        // the skip tiles four trips ahead (swin_patchup.hip) takes it — every launch of that shape
+        PatchUpArgs pu = {x2, h->up.w, h->up.bias, x1, x1, B, h2, w2, C, 0};
+        if (C2 == 192 && h->up.N == 4 * C && patchup_supported(pu)) {
+            if ((rc = launch_patchup(pu, s))) return rc;
+        } else if ((rc = launch_gemm(g, s, "li_up"))) return rc;
     }
     if ((rc = run_gblock_any(h, h->dec1, x1, B, h1, w1, s))) return rc;
     if (h->video) {

@@ -53,6 +53,14 @@ struct PatchDownArgs { const f16 *a, *w; const float *bias; f16 *out; int B, Ho,
 bool patchdown_supported(const PatchDownArgs &g);
 int launch_patchdown(const PatchDownArgs &g, hipStream_t s);
 
+// ---- cunet's up step (cunet_up.hip): out[B, 2S, 2S, 64] = LeakyReLU(pixel_shuffle_2(Linear(64 -> 256)(in_scale * a))) + crop(res) ---
+// a: [B, S, S, 64]; w / bias: make_up's packing (cunet.cpp: columns n = q 64 + c, [n-tile][k-step]); res: [B, res_S, res_S, 64], the
+// skip map, read at (y + crop, x + crop); in_scale: optional [B][64] squeeze-excitation scale of a.
+struct CunetUpArgs { const f16 *a, *w; const float *bias; const f16 *res; f16 *out; const float *in_scale; int B, S, res_S, crop;
+                     float slope; };
+bool cunet_up_supported(const CunetUpArgs &g);
+int launch_cunet_up(const CunetUpArgs &g, hipStream_t s);
+
 // ---- output-stationary Linear for TOKEN matrices of a few thousand rows (the ViT encoders of the depth nets) -----------------
 // out[m][n] = act(sum_k a[m][k] W[n][k] + bias[n]) (+ res[m][n]); a: [M][lda] fp16, W in gemm_kernel's packing [nt][ks].
 // gemm_kernel is token-stationary (a wave keeps 16-32 tokens' whole K extent and sweeps all of N through the LDS ring): with
