@@ -36,6 +36,7 @@ gather_tiles_kernel(const float *__restrict__ x, float *__restrict__ tiles, int 
 
 struct StitchParams {
     int C, y_h, y_w, hb, wb, ostep, To, blend;
+    int fast1;       // 1: pixel groups with one covering tile skip the recurrence (NUNIF_STITCH_FAST=0 turns it off: A/B runs)
     int y0;          // first output row of this launch (tile-row sharding: a band of the image), 0 for the whole image
     int dst_rows;    // rows per channel plane of the destination: y_h for the whole image, the band height for a compact band
     float ramp[64];
@@ -88,7 +89,14 @@ stitch_kernel(const float *__restrict__ tiles, float *__restrict__ y, StitchPara
 #pragma unroll
             for (int c = 0; c < NC; ++c) P[c][v] = 0.f;
         }
-        if (p.blend > 0) {
+        if (p.fast1 && p.blend > 0 && i_lo == i_hi && j_lo == j_hi) {
+            // ONE covering tile (> 95 % of a frame): the recurrence starts from P = 0, W = 0, so a = 0 / F = 0, b = 1 and
+            // P = 0 * 0 + t * 1 = t whatever the ramp value F > 0 is — the tile's pixel, without the four divisions
+            const int ty = Y - p.ostep * i_lo, tx = X0 - p.ostep * j_lo;
+            const float *src = tiles + ((long)(i_lo * p.wb + j_lo) * p.C + c0) * plane + (long)ty * p.To + tx;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) load_vec(src + c * plane, P[c]);
+        } else if (p.blend > 0) {
             for (int i = i_lo; i <= i_hi; ++i) {
                 const int ty = Y - p.ostep * i;
                 const float ry = ramp_at(p, ty);
@@ -151,6 +159,7 @@ int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int
     NUNIF_REQUIRE(y0 >= 0 && rows >= 0 && y0 + rows <= g->y_h, "stitch: row band [%d, %d) outside the image", y0, y0 + rows);
     if (rows == 0) return NUNIF_HIP_OK;
     p.y0 = y0;
+    p.fast1 = !(getenv("NUNIF_STITCH_FAST") && atoi(getenv("NUNIF_STITCH_FAST")) == 0);
     p.C = C; p.y_h = g->y_h; p.y_w = g->y_w; p.hb = g->h_blocks; p.wb = g->w_blocks;
     p.ostep = g->output_tile_step; p.To = g->out_tile_size; p.blend = g->blend_size;
     NUNIF_REQUIRE(g->blend_size <= 64, "blend_size %d > 64 unsupported", g->blend_size);
@@ -173,9 +182,16 @@ int launch_stitch(const float *tile_out, float *y, const nunif_tile_grid *g, int
         dim3 grid(cdiv(p.y_w / 8, 128), rows);
         stitch_kernel<8, 3><<<grid, 128, 0, s>>>(tile_out, y, p);
     } else if (vec) {
-        dim3 grid(cdiv(p.y_w / 4, 256), rows);
-        if (C == 3 && together) stitch_kernel<4, 3><<<grid, 256, 0, s>>>(tile_out, y, p);
-        else stitch_kernel<4, 0><<<grid, 256, 0, s>>>(tile_out, y, p);
+        // a row is y_w / 4 pixel groups: 960 for a 1080p 2x frame = 3.75 workgroups of 256 (a quarter of every fourth one idle), but
+        // exactly 5 of 192 — take the largest wave multiple that divides the row (NUNIF_STITCH_BS forces one; A/B runs)
+        static const int bs_env = getenv("NUNIF_STITCH_BS") ? atoi(getenv("NUNIF_STITCH_BS")) : 0;
+        int bs = 256;
+        const int groups = p.y_w / 4;
+        if (bs_env == 64 || bs_env == 128 || bs_env == 192 || bs_env == 256) bs = bs_env;
+        else if (groups % 256 != 0) { if (groups % 192 == 0) bs = 192; else if (groups % 128 == 0) bs = 128; }
+        dim3 grid(cdiv(groups, bs), rows);
+        if (C == 3 && together) stitch_kernel<4, 3><<<grid, bs, 0, s>>>(tile_out, y, p);
+        else stitch_kernel<4, 0><<<grid, bs, 0, s>>>(tile_out, y, p);
     } else {
         dim3 grid(cdiv(p.y_w, 256), rows);
         if (C == 3 && together) stitch_kernel<1, 3><<<grid, 256, 0, s>>>(tile_out, y, p);
