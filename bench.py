@@ -172,7 +172,7 @@ def cpu_baseline(sd, frame):
 
 # PMC summaries of workloads other than the headline bench: the same kernel symbol runs other shapes there, so they are looked up
 # by name only (profiles/<tag>_pmc_{FETCH,WRITE}_SIZE.txt, written by tools/profile_cunet.sh / tools/profile_config5.sh)
-WORKLOAD_PMC = {"cunet": "r04c", "config5": "r04f"}
+WORKLOAD_PMC = {"cunet": "r05c", "config5": "r05f"}
 
 
 def pmc_traffic_bytes(symbol, only=None):
