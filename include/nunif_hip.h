@@ -232,6 +232,12 @@ int nunif_hip_light_inpaint_create(const nunif_tensor_desc *tensors, int32_t n_t
 void nunif_hip_light_inpaint_destroy(nunif_light_inpaint *handle);
 int nunif_hip_light_inpaint_infer(nunif_light_inpaint *handle, const float *x, const uint8_t *mask, float *out, int32_t B,
                                   int32_t H, int32_t W, int32_t closing, int32_t inner_iter, int32_t outer_iter, void *stream);
+/* mirror_x = 1: out = flip(infer(flip(x), mask)) along the width, with `mask` given in the FLIPPED frame — the nets are trained on
+ * the right view, so the reference feeds the left eye mirrored (forward_left: iw3/forward_inpaint.py:29-40, iw3/mlbw_inpaint.py:
+ * 60-76 flip -> infer -> flip); here the picture is read and written at column W - 1 - x instead of two flip passes over it. */
+int nunif_hip_light_inpaint_infer_ex(nunif_light_inpaint *handle, const float *x, const uint8_t *mask, float *out, int32_t B,
+                                     int32_t H, int32_t W, int32_t closing, int32_t inner_iter, int32_t outer_iter,
+                                     int32_t mirror_x, void *stream);
 
 /* iw3 output formats.
  * anaglyph: iw3/anaglyph.py apply_anaglyph_redcyan :96-110; left, right, out: [3,H,W] f32; mode 0 color, 1 gray, 2 half-color,

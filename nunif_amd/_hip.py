@@ -86,6 +86,7 @@ SIGNATURES = {
     "nunif_hip_light_inpaint_create": (c_int32, [ctypes.POINTER(TensorDesc), c_int32, ctypes.POINTER(c_void_p)]),
     "nunif_hip_light_inpaint_destroy": (None, [c_void_p]),
     "nunif_hip_light_inpaint_infer": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p]),
+    "nunif_hip_light_inpaint_infer_ex": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
     "nunif_hip_anaglyph": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "nunif_hip_equirectangular": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "nunif_hip_mlbw_has_hole_mask": (c_int32, [c_void_p]),

@@ -93,9 +93,12 @@ __global__ void __launch_bounds__(256) li_blur_kernel(const float *__restrict__ 
 // ---- patch embedding input: (x (1 - m) - 0.5) / 0.5, replicate padding to the 64-pixel grid, pixel_unshuffle(4) -----------
 // out: [B,h1,w1,64] fp16 (48 real channels c*16 + iy*4 + ix, rest 0); mtok: the token is masked if any of its 16 pixels of the
 // soft mask exceeds 0.99 (light_inpaint_v1.py:116)
+// mirror: the picture x is read (and, in li_compose_kernel, written) at column W - 1 - xx — the net sees flip(x) without a flip pass;
+// the masks are in the mirrored frame already
 __global__ void __launch_bounds__(256) li_patch_in_kernel(const float *__restrict__ x, const float *__restrict__ hard,
                                                            const float *__restrict__ soft, f16 *__restrict__ out,
-                                                           uint8_t *__restrict__ mtok, int B, int H, int W, int h1, int w1) {
+                                                           uint8_t *__restrict__ mtok, int B, int H, int W, int h1, int w1,
+                                                           int mirror) {
     const long n = (long)B * h1 * w1, id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= n) return;
     const int tx = (int)(id % w1);
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(256) li_patch_in_kernel(const float *__restric
             mmax = fmaxf(mmax, soft[pix]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float px = x[(((long)b * 3 + c) * H + yy) * W + xx] * keep;
+                const float px = x[(((long)b * 3 + c) * H + yy) * W + (mirror ? W - 1 - xx : xx)] * keep;
                 v[c * 16 + iy * 4 + ix] = (f16)((px - 0.5f) / 0.5f);
             }
         }
@@ -395,7 +398,7 @@ __global__ void __launch_bounds__(256) li_glu_kernel(const f16 *__restrict__ y, 
 __global__ void __launch_bounds__(256) li_compose_kernel(const float *__restrict__ x, const float *__restrict__ hard,
                                                           const float *__restrict__ soft, const f16 *__restrict__ ti,
                                                           float *__restrict__ out, int B, int H, int W, int h1, int w1,
-                                                          int ti_stride) {
+                                                          int ti_stride, int mirror) {
     const long n = (long)B * H * W, id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= n) return;
     const int xx = (int)(id % W);
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(256) li_compose_kernel(const float *__restrict
     const f16 *tv = ti + (((long)b * h1 + yy / 4) * w1 + xx / 4) * ti_stride + (yy & 3) * 4 + (xx & 3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const long o = (((long)b * 3 + c) * H + yy) * W + xx;
+        const long o = (((long)b * 3 + c) * H + yy) * W + (mirror ? W - 1 - xx : xx);
         const float src = x[o] * keep;
         out[o] = fminf(fmaxf(src * (1.f - m) + (float)tv[c * 16] * m, 0.f), 1.f);
     }
@@ -806,7 +809,13 @@ extern "C" void nunif_hip_light_inpaint_destroy(nunif_light_inpaint *h) {
 extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float *x, const uint8_t *mask, float *out, int32_t B,
                                              int32_t H, int32_t W, int32_t closing, int32_t inner_iter, int32_t outer_iter,
                                              void *stream) {
-    NUNIF_REQUIRE(h && x && mask && out && B > 0 && H > 0 && W > 0 && inner_iter >= 0 && outer_iter >= 0,
+    return nunif_hip_light_inpaint_infer_ex(h, x, mask, out, B, H, W, closing, inner_iter, outer_iter, 0, stream);
+}
+
+extern "C" int nunif_hip_light_inpaint_infer_ex(nunif_light_inpaint *h, const float *x, const uint8_t *mask, float *out, int32_t B,
+                                                int32_t H, int32_t W, int32_t closing, int32_t inner_iter, int32_t outer_iter,
+                                                int32_t mirror_x, void *stream) {
+    NUNIF_REQUIRE(h && x && mask && out && B > 0 && H > 0 && W > 0 && inner_iter >= 0 && outer_iter >= 0 && x != out,
                   "light_inpaint_infer: bad argument");
     NUNIF_REQUIRE(!h->video || B == 12, "light_inpaint_infer: the video net takes exactly 12 frames per call (got %d)", B);
     hipStream_t s = (hipStream_t)stream;
@@ -849,7 +858,7 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
     uint8_t *mtok = (uint8_t *)h->mtok.p;
     {
         ProfScope ps("li_patch_in_kernel", s, 0.0, (double)px * 20.0);
-        li_patch_in_kernel<<<(unsigned)((t1 + 255) / 256), 256, 0, s>>>(x, hard, soft, a, mtok, B, H, W, h1, w1);
+        li_patch_in_kernel<<<(unsigned)((t1 + 255) / 256), 256, 0, s>>>(x, hard, soft, a, mtok, B, H, W, h1, w1, mirror_x);
     }
     // NOTE: the replicate padding of the soft mask is the clamp of the pixel coordinate inside li_patch_in_kernel
     if ((rc = lin(h->patch, a, t1, C, 2, h->video ? 0.1f : 0.2f, nullptr, x1, s, "li_patch"))) return rc;
@@ -895,7 +904,7 @@ extern "C" int nunif_hip_light_inpaint_infer(nunif_light_inpaint *h, const float
     }
     {
         ProfScope ps("li_compose_kernel", s, 0.0, (double)px * 36.0);
-        li_compose_kernel<<<pb, 256, 0, s>>>(x, hard, soft, ti, out, B, H, W, h1, w1, h->video ? 64 : 48);
+        li_compose_kernel<<<pb, 256, 0, s>>>(x, hard, soft, ti, out, B, H, W, h1, w1, h->video ? 64 : 48, mirror_x);
     }
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;

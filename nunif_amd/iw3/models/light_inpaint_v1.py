@@ -80,14 +80,15 @@ class HipLightInpaintEngine:
             except Exception:
                 pass
 
-    def infer(self, x, mask, closing, inner_iter, outer_iter):
+    def infer(self, x, mask, closing, inner_iter, outer_iter, mirror_x=False):
         B, C, H, W = x.shape
         assert C == 3 and tuple(mask.shape) == (B, 1, H, W)
         out = torch.empty_like(x)
         with torch.cuda.device(self.device):
-            _hip.check(_hip.lib().nunif_hip_light_inpaint_infer(
+            _hip.check(_hip.lib().nunif_hip_light_inpaint_infer_ex(
                 self.handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                B, H, W, 1 if closing else 0, int(inner_iter), int(outer_iter), _hip.current_stream_ptr(self.device)))
+                B, H, W, 1 if closing else 0, int(inner_iter), int(outer_iter), 1 if mirror_x else 0,
+                _hip.current_stream_ptr(self.device)))
         return out
 
 
@@ -138,8 +139,11 @@ class LightInpaintV1(I2IBaseModel):
             self._engine = HipLightInpaintEngine(self._weights, dev)
         return self._engine
 
-    def infer(self, x, mask, closing=False, inner_dilation=0, outer_dilation=0, base_width=None):
-        """x [B,3,H,W] float in [0,1], mask [B,1,H,W] bool (True = hole) -> inpainted [B,3,H,W]."""
+    supports_mirror_x = True
+
+    def infer(self, x, mask, closing=False, inner_dilation=0, outer_dilation=0, base_width=None, mirror_x=False):
+        """x [B,3,H,W] float in [0,1], mask [B,1,H,W] bool (True = hole) -> inpainted [B,3,H,W].
+        ``mirror_x`` (not in the reference): ``flip(infer(flip(x), mask))`` with ``mask`` given in the flipped frame, no flip passes."""
         if self.training:
             raise RuntimeError("the HIP engine is inference-only; call .eval()")
         dev = self.get_device()
@@ -150,10 +154,15 @@ class LightInpaintV1(I2IBaseModel):
                 return 0
             return max(round(W / base_width * n), 1) if base_width is not None else n
         m = mask.to(device=dev)
-        m = (m > 0 if m.dtype != torch.bool else m).to(torch.uint8).contiguous()
+        # the engine takes a byte per pixel, hole = non-zero: a bool mask IS that (zero-copy view), a uint8 mask passes as it is
+        if m.dtype == torch.bool:
+            m = m.contiguous().view(torch.uint8)
+        elif m.dtype != torch.uint8:
+            m = (m > 0).to(torch.uint8)
+        m = m.contiguous()
         dtype = x.dtype
         out = self.engine().infer(x.to(device=dev, dtype=torch.float32).contiguous(), m, closing,
-                                  n_iter(inner_dilation), n_iter(outer_dilation))
+                                  n_iter(inner_dilation), n_iter(outer_dilation), mirror_x=mirror_x)
         return out.to(dtype)
 
     def forward(self, x, mask, skip_i2i_offset=False):

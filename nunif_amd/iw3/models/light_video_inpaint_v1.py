@@ -105,8 +105,11 @@ class LightVideoInpaintV1(I2IBaseModel):
             self._engine = HipLightInpaintEngine(self._weights, dev)
         return self._engine
 
-    def infer(self, x, mask, closing=False, inner_dilation=0, outer_dilation=0, base_width=None):
-        """x [N,3,H,W] (N <= 12 consecutive frames), mask [N,1,H,W] bool -> inpainted [N,3,H,W]  (reference :140-164)."""
+    supports_mirror_x = True
+
+    def infer(self, x, mask, closing=False, inner_dilation=0, outer_dilation=0, base_width=None, mirror_x=False):
+        """x [N,3,H,W] (N <= 12 consecutive frames), mask [N,1,H,W] bool -> inpainted [N,3,H,W]  (reference :140-164).
+        ``mirror_x`` (not in the reference): ``flip(infer(flip(x), mask))`` with ``mask`` given in the flipped frame, no flip passes."""
         if self.training:
             raise RuntimeError("the HIP engine is inference-only; call .eval()")
         dev = self.get_device()
@@ -126,10 +129,15 @@ class LightVideoInpaintV1(I2IBaseModel):
                 return 0
             return max(round(W / base_width * k), 1) if base_width is not None else k
         m = mask.to(device=dev)
-        m = (m > 0 if m.dtype != torch.bool else m).to(torch.uint8).contiguous()
+        # the engine takes a byte per pixel, hole = non-zero: a bool mask IS that (zero-copy view), a uint8 mask passes as it is
+        if m.dtype == torch.bool:
+            m = m.contiguous().view(torch.uint8)
+        elif m.dtype != torch.uint8:
+            m = (m > 0).to(torch.uint8)
+        m = m.contiguous()
         dtype = x.dtype
         out = self.engine().infer(x.to(device=dev, dtype=torch.float32).contiguous(), m, closing,
-                                  n_iter(inner_dilation), n_iter(outer_dilation)).to(dtype)
+                                  n_iter(inner_dilation), n_iter(outer_dilation), mirror_x=mirror_x).to(dtype)
         return out[pad_b1:out.shape[0] - pad_b2]
 
     def forward(self, x, mask, skip_i2i_offset=False, micro_batch_size=SEQ_LEN):

@@ -63,6 +63,10 @@ def limit_width(x, max_width):
 def _repair(net, eye, raw_mask, spec, params, mirrored):
     """One eye through the inpaint net.  The nets are trained on the RIGHT view, so the left eye goes through mirrored
     (``forward_left``, ``iw3/forward_inpaint.py:29-40``)."""
+    if mirrored and getattr(net, "supports_mirror_x", False) and os.environ.get("NUNIF_INPAINT_MIRROR", "1") != "0":
+        # the engine reads and writes the picture mirrored (two flip passes over the eye saved: 0.8 GB each way per 12-frame 4K
+        # window); only the raw mask — small at depth resolution — is flipped, its post-processing is directional
+        return net.infer(eye, spec.hole_mask(raw_mask.flip(-1), eye.shape[-2:], params), mirror_x=True)
     if mirrored:
         eye, raw_mask = eye.flip(-1), raw_mask.flip(-1)
     out = net.infer(eye, spec.hole_mask(raw_mask, eye.shape[-2:], params))

@@ -67,6 +67,24 @@ def test_hip_light_inpaint(hiplib, g):
 
 
 @pytest.mark.gpu
+def test_mirrored_infer_equals_flip_infer_flip_bit_for_bit(hiplib, g, gv):
+    """``infer(x, mask, mirror_x=True)`` (``nunif_hip_light_inpaint_infer_ex``: the picture read and written at column W - 1 - x)
+    == ``flip(infer(flip(x), mask))`` with the mask given in the flipped frame — what the side-model driver feeds the left eye
+    (iw3/mlbw_inpaint.py:60-76) — for the image net and the 12-frame video net; and the driver's two routes give the same eyes."""
+    from nunif_amd.nunif.models import create_model
+    mi, _ = _models()
+    x, mask = g["x"].to("cuda:0"), g["mask"].to("cuda:0")
+    a = mi.infer(x.flip(-1).contiguous(), mask, closing=True, inner_dilation=1, outer_dilation=2, base_width=50).flip(-1)
+    b = mi.infer(x, mask, closing=True, inner_dilation=1, outer_dilation=2, base_width=50, mirror_x=True)
+    assert torch.equal(a, b) and not torch.equal(b, mi.infer(x, mask, closing=True, inner_dilation=1, outer_dilation=2, base_width=50))
+    mv = create_model("inpaint.light_video_inpaint_v1").eval()
+    mv.load_state_dict(OL.video_random_state_dict(702), strict=True)
+    mv = mv.to("cuda:0")
+    xv, mk = gv["x"].to("cuda:0"), gv["mask"].to("cuda:0")
+    assert torch.equal(mv.infer(xv.flip(-1).contiguous(), mk).flip(-1), mv.infer(xv, mk, mirror_x=True))
+
+
+@pytest.mark.gpu
 def test_hip_mlbw_inpaint_image(hiplib, g):
     from nunif_amd.iw3.mlbw_inpaint import MLBWInpaint
     mi, mm = _models()
