@@ -417,7 +417,9 @@ def iw3_sharded_leg(dist, world, rank, dev, barrier, frames_per_rank=48, batch=4
     pool = {}
     frames = [None] * n
     for i in sorted(mine):                                   # a rank holds only the frames of its own batches, resident in HBM
-        frames[i] = pool.setdefault(i % 4, make_frame(i))
+        if i % 4 not in pool:
+            pool[i % 4] = make_frame(i)
+        frames[i] = pool[i % 4]
     cuts = {n // 2}
 
     def one_pass():
