@@ -1,19 +1,20 @@
 set -u
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r05t_gpu_suite.log 2>&1
-echo "suite rc=$?" >> gpurun_out/r05t_gpu_suite.log
-tail -3 gpurun_out/r05t_gpu_suite.log
-python bench.py > gpurun_out/r05t_bench_line.json 2> gpurun_out/r05t_bench.err
-echo "bench rc=$?"
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r05t_smoke.log 2>&1
-tail -2 gpurun_out/r05t_smoke.log
+timeout 900 python -m pytest tests/test_gpu_swin.py tests/test_cunet.py tests/test_gpu_waifu2x_api.py -m gpu -x -q > gpurun_out/r05u_tests.log 2>&1
+echo "rc=$?" >> gpurun_out/r05u_tests.log; tail -3 gpurun_out/r05u_tests.log
+BENCH="python bench.py --no-cpu-baseline --no-host-frames --no-iw3 --no-4k --no-cunet --no-config5 --steps 40 --warmup 5"
+for i in 1 2; do
+  NUNIF_STEM_ROWS=2 timeout 600 $BENCH > gpurun_out/r05u_ab_base_$i.json 2> gpurun_out/r05u_ab_base_$i.err
+  timeout 600 $BENCH > gpurun_out/r05u_ab_new_$i.json 2> gpurun_out/r05u_ab_new_$i.err
+  NUNIF_STEM_ROWS_CUNET=2 CUNET_BATCH=66 CUNET_ITERS=30 CUNET_ONLY=cunet CUNET_PROF=1 timeout 300 python tools/cunet_probe.py > gpurun_out/r05u_cunet_base_$i.txt 2>&1
+  CUNET_BATCH=66 CUNET_ITERS=30 CUNET_ONLY=cunet CUNET_PROF=1 timeout 300 python tools/cunet_probe.py > gpurun_out/r05u_cunet_new_$i.txt 2>&1
+done
 python - <<'PY'
-import json
-r=json.loads([l for l in open('gpurun_out/r05t_bench_line.json') if l.startswith('{')][-1])
-print({k:r.get(k) for k in ('value','ms_per_step','single_stream','psnr_vs_oracle_db','psnr_whole_frame_db','model_mfma_frac','ok','errors')})
-print(r['psnr_whole_frame'])
-print('cunet', r['cunet']['frame_1080p'], r['cunet']['frame_1080p_batch16'], r['cunet']['model_mfma_frac'])
-print('iw3', r['iw3']['forward_fill'], r['iw3']['row_flow_v3'], r['iw3']['depth_infer_fps'], r['iw3']['cpu_baseline'])
-print('4k', r['scale4x_4k']['ms_per_frame'], 'config5', r['config5']['ms_per_frame'])
-for k in r['kernel_classes']: print(k['kernel'], k['avg_us'])
+import json, glob
+for f in sorted(glob.glob('gpurun_out/r05u_ab_*.json')):
+    try:
+        r=json.loads([l for l in open(f) if l.startswith('{')][-1])
+        print(f, r['value'], r['single_stream']['value'], [ (k['kernel'],k['avg_us']) for k in r['kernel_classes'] if 'stem' in k['kernel']])
+    except Exception as e: print(f, 'ERR', e)
 PY
+grep -H "MPix\|stem" gpurun_out/r05u_cunet_*.txt
