@@ -575,9 +575,11 @@ def cunet_record(dev, with_cpu):
 
 def config5_record(dev):
     """BASELINE configs[4] shape on ONE GPU: 4K frames in batches of 3 -> ``VideoDepthAnythingStreamingModel`` wrapper (pre / post
-    kernels of the reference's wrapper around a PER-FRAME ViT-S STAND-IN: the external streaming network's temporal head is not
-    restated) -> min-max -> mask-MLBW backward warp (``sbs.mask_mlbw_l2``) -> 12-frame ``FrameQueue`` ->
-    ``inpaint.light_video_inpaint_v1`` on both eyes -> SBS uint8.  Reference call sites: iw3/mlbw_inpaint.py:296-360."""
+    kernels of the reference's wrapper) around the Video-Depth-Anything ViT-S streaming network (DINOv2 encoder + DPT head with four
+    temporal modules over a 32-frame window: published architecture, random-init, PARITY UNPINNED — DESIGN.md 8;
+    ``NUNIF_CONFIG5_PERFRAME=1``: round 4's per-frame ViT-S stand-in, for the A/B) -> min-max -> mask-MLBW backward warp
+    (``sbs.mask_mlbw_l2``) -> 12-frame ``FrameQueue`` -> ``inpaint.light_video_inpaint_v1`` on both eyes -> SBS uint8.
+    Reference call sites: iw3/video_depth_anything_streaming_model.py:77-103, iw3/mlbw_inpaint.py:296-360."""
     import torch
     from nunif_amd import _hip
     from nunif_amd.iw3 import _ops
@@ -588,12 +590,18 @@ def config5_record(dev):
     from nunif_amd.iw3.models.light_video_inpaint_v1 import LightVideoInpaintV1
     from nunif_amd.iw3.models.mlbw import MLBW
     from nunif_amd.iw3.video_depth_anything_streaming_model import VideoDepthAnythingStreamingModel
+    from nunif_amd.iw3.video_depth_anything_net import HipVideoDepthAnythingStreaming
     from nunif_amd.synthetic import (depth_anything_v2_state_dict, light_inpaint_state_dict, light_video_inpaint_state_dict,
-                                     mlbw_state_dict)
+                                     mlbw_state_dict, video_depth_anything_state_dict)
     H5, W5, batch = 2160, 3840, 3
-    depth_model = CallableDepthModel(HipDepthAnythingV2(depth_anything_v2_state_dict(601), str(dev)))
-    depth_model.load(gpu=dev.index or 0)
-    vda = VideoDepthAnythingStreamingModel("VDA_Stream_S", backbone=depth_model.model).load(gpu=dev.index or 0)
+    per_frame = os.environ.get("NUNIF_CONFIG5_PERFRAME") == "1"
+    if per_frame:
+        depth_model = CallableDepthModel(HipDepthAnythingV2(depth_anything_v2_state_dict(601), str(dev)))
+        depth_model.load(gpu=dev.index or 0)
+        backbone = depth_model.model
+    else:
+        backbone = HipVideoDepthAnythingStreaming(video_depth_anything_state_dict(601), str(dev))
+    vda = VideoDepthAnythingStreamingModel("VDA_Stream_S", backbone=backbone).load(gpu=dev.index or 0)
     inp = LightInpaintV1().eval()
     inp.load_state_dict(light_inpaint_state_dict(701))
     mm = MLBW(num_layers=2, base_dim=32, hole_mask=True).eval()
@@ -615,7 +623,7 @@ def config5_record(dev):
             _ops.stereo_to_frame(left[k], right[k], "sbs")
             n_out[0] += 1
 
-    for i in range(4):
+    for i in range(4 if per_frame else 11):       # 33 frames: the temporal network's 32-frame window is full when the clock starts
         step(i)
     torch.cuda.synchronize(dev)
     n_out[0] = 0
@@ -626,9 +634,13 @@ def config5_record(dev):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     n_in = n_calls * batch
-    rec = {"config": "BASELINE configs[4] shape on one GPU: 4K frames (batches of 3) -> VideoDepthAnythingStreaming WRAPPER around a "
-                     "per-frame ViT-S stand-in (temporal head not restated; random-init) -> min-max -> sbs.mask_mlbw_l2 backward "
+    net_desc = ("a per-frame ViT-S stand-in (NUNIF_CONFIG5_PERFRAME=1; no temporal head)" if per_frame else
+                "the Video-Depth-Anything ViT-S streaming network (4 temporal modules, 32-frame window full; published architecture, "
+                "random-init, parity unpinned)")
+    rec = {"config": "BASELINE configs[4] shape on one GPU: 4K frames (batches of 3) -> VideoDepthAnythingStreaming wrapper around "
+                     + net_desc + " -> min-max -> sbs.mask_mlbw_l2 backward "
                      "warp -> 12-frame queue -> inpaint.light_video_inpaint_v1 (both eyes) -> SBS uint8",
+           "depth_net": "per_frame_vits" if per_frame else "vda_streaming_vits",
            "frame": [H5, W5], "frames_in": n_in, "frames_out": n_out[0], "ms_per_frame": round(1e3 * dt / n_in, 2),
            "fps": round(n_in / dt, 1), "value": round(H5 * W5 * n_in / dt / 1e6, 1), "unit": "input MPix/s",
            "target": "4K @ 30 fps on 8 GPUs (BASELINE configs[4]); this is one GPU"}

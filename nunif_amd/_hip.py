@@ -104,6 +104,8 @@ SIGNATURES = {
                                                      ctypes.POINTER(c_void_p)]),
     "nunif_hip_depth_anything_destroy": (None, [c_void_p]),
     "nunif_hip_depth_anything_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "nunif_hip_depth_anything_reset_state": (c_int32, [c_void_p]),
+    "nunif_hip_depth_anything_is_temporal": (c_int32, [c_void_p]),
     "nunif_hip_tta_view": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "nunif_hip_tta_merge": (c_int32, [ctypes.POINTER(c_void_p), c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "nunif_hip_alpha_border_padding": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

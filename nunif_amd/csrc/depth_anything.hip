@@ -355,6 +355,12 @@ struct Cnv { f16 *w = nullptr; float *b = nullptr; int N = 0, Cin = 0, k = 3, cm
 struct Blk { float *g1, *b1, *g2, *b2; Lin qkv, proj, fc1, fc2[4], fc2_full, qkv_ln, fc1_ln; int n_fc2; f16 *fc2c = nullptr; };   // fc2c: fc2_full in the chained k order (depth_mlp.hip)   // *_ln: norm1 / norm2 folded in (ViT-S)   // fc2 (K = 4 D) = 2 or 4 GEMMs of K = 768 / 1024
 struct Rcu { Cnv c1, c2; };
 struct Fus { Rcu r1, r2; Lin out; };
+// Video-Depth-Anything's temporal modules (depth_temporal.hip): a temporal attention block = LayerNorm + [Wq | Wk | Wv] (no bias, Wq
+// scaled by hd^-1/2 log2 e) + to_out, the three position tables, the K0 / V0 ring caches of the window; a module = GroupNorm,
+// proj_in, two attention blocks, GEGLU feed-forward (ff1: C -> 8 C, ff2: 4 C -> C), proj_out
+struct TAtt { Lin qkv, out; float *g = nullptr, *b = nullptr, *pq = nullptr, *pk = nullptr, *pv = nullptr; Buf kc, vc; };
+struct TMod { int C = 0; float *gn_g = nullptr, *gn_b = nullptr, *ff_g = nullptr, *ff_b = nullptr; Lin proj_in, proj_out, ff1, ff2; TAtt at[2]; };
+constexpr int kTLen = 32;                // temporal_max_len: the attention window (this frame + 31 cached)
 }  // namespace
 
 namespace {
@@ -411,6 +417,13 @@ struct nunif_depth_anything {
     Buf bt1[3], br1[3];               // RCU1 of refinenets 1-3 beside the encoder: conv1's map, RCU1(skip) (forward())
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
+    // Video-Depth-Anything (streaming): four temporal modules (on layer_3, layer_4, path_4, path_3) and the state of the window —
+    // t_len cached frames (<= 31) whose K0 / V0 sit in ring slots t_start .. of every attention block's caches; t_P: the pixel
+    // counts the caches were laid out for (a resolution change starts a new window)
+    bool temporal = false;
+    TMod tm[4];
+    int t_len = 0, t_start = 0, t_P[4] = {0, 0, 0, 0};
+    Buf ta, th, tqkv, tatt, thid, tgg, tpart;
 };
 
 namespace {
@@ -745,7 +758,90 @@ extern "C" int nunif_hip_depth_anything_create_ex(const nunif_tensor_desc *tenso
         std::vector<float> wf(33);
         for (int k = 0; k < 32; ++k) wf[k] = w->data[k];
         wf[32] = b->data[0];
-        rc = upload(h, wf, &h->w_final);
+        if ((rc = upload(h, wf, &h->w_final))) break;
+        // ---- Video-Depth-Anything: head.motion_modules.{0..3} (published key layout; the caller maps `head.` to `depth_head.`)
+        if (m.find(H + "motion_modules.0.temporal_transformer.proj_in.weight") == m.end()) break;
+        h->temporal = true;
+        const int chans[4] = {h->OC[2], h->OC[3], F, F};
+        for (int i = 0; i < 4 && !rc; ++i) {
+            const int C = chans[i], hd = C / 8;
+            TMod &tmod = h->tm[i];
+            tmod.C = C;
+            if (C % 64 || hd % 8) { set_error("motion_modules.%d: %d channels unsupported (a multiple of 64)", i, C); rc = NUNIF_HIP_EUNSUPPORTED; break; }
+            const std::string T = H + "motion_modules." + std::to_string(i) + ".temporal_transformer.", B0 = T + "transformer_blocks.0.";
+            const HostT *g1, *b1, *wi, *bi, *wo, *bo, *fg, *fb, *w1, *bb1, *w2, *bb2;
+            if ((rc = find(m, T + "norm.weight", &g1)) || (rc = find(m, T + "norm.bias", &b1)) ||
+                (rc = find(m, T + "proj_in.weight", &wi)) || (rc = find(m, T + "proj_in.bias", &bi)) ||
+                (rc = find(m, T + "proj_out.weight", &wo)) || (rc = find(m, T + "proj_out.bias", &bo)) ||
+                (rc = find(m, B0 + "ff_norm.weight", &fg)) || (rc = find(m, B0 + "ff_norm.bias", &fb)) ||
+                (rc = find(m, B0 + "ff.net.0.proj.weight", &w1)) || (rc = find(m, B0 + "ff.net.0.proj.bias", &bb1)) ||
+                (rc = find(m, B0 + "ff.net.2.weight", &w2)) || (rc = find(m, B0 + "ff.net.2.bias", &bb2)))
+                break;
+            if (g1->numel != C || wi->numel != (int64_t)C * C || wo->numel != (int64_t)C * C || w1->numel != (int64_t)8 * C * C ||
+                w2->numel != (int64_t)4 * C * C) {
+                set_error("motion_modules.%d: unexpected shapes for %d channels", i, C); rc = NUNIF_HIP_EINVAL; break;
+            }
+            if ((rc = up_f32(h, g1, &tmod.gn_g)) || (rc = up_f32(h, b1, &tmod.gn_b)) || (rc = up_f32(h, fg, &tmod.ff_g)) ||
+                (rc = up_f32(h, fb, &tmod.ff_b)))
+                break;
+            auto plain = [&](const HostT *w, const HostT *b, int N, int K, Lin *L) {
+                const float *wd = w->data, *bd = b ? b->data : nullptr;
+                return make_lin(h, N, K, [=](int n, int k) { return wd[(size_t)n * K + k]; }, [=](int n) { return bd ? bd[n] : 0.f; }, L);
+            };
+            if ((rc = plain(wi, bi, C, C, &tmod.proj_in)) || (rc = plain(wo, bo, C, C, &tmod.proj_out)) ||
+                (rc = plain(w1, bb1, 8 * C, C, &tmod.ff1)) || (rc = plain(w2, bb2, C, 4 * C, &tmod.ff2)))
+                break;
+            const float qs = (1.0f / sqrtf((float)hd)) * 1.4426950408889634f;
+            for (int a = 0; a < 2 && !rc; ++a) {
+                TAtt &at = tmod.at[a];
+                const std::string A = B0 + "attention_blocks." + std::to_string(a) + ".";
+                const HostT *ng, *nb, *wq, *wk, *wv, *wo2, *bo2;
+                if ((rc = find(m, B0 + "norms." + std::to_string(a) + ".weight", &ng)) ||
+                    (rc = find(m, B0 + "norms." + std::to_string(a) + ".bias", &nb)) || (rc = find(m, A + "to_q.weight", &wq)) ||
+                    (rc = find(m, A + "to_k.weight", &wk)) || (rc = find(m, A + "to_v.weight", &wv)) ||
+                    (rc = find(m, A + "to_out.0.weight", &wo2)) || (rc = find(m, A + "to_out.0.bias", &bo2)))
+                    break;
+                if (wq->numel != (int64_t)C * C || wk->numel != (int64_t)C * C || wv->numel != (int64_t)C * C || wo2->numel != (int64_t)C * C) {
+                    set_error("%s: unexpected shapes for %d channels", A.c_str(), C); rc = NUNIF_HIP_EINVAL; break;
+                }
+                if ((rc = up_f32(h, ng, &at.g)) || (rc = up_f32(h, nb, &at.b)) || (rc = plain(wo2, bo2, C, C, &at.out))) break;
+                const float *q = wq->data, *k = wk->data, *v = wv->data;
+                if ((rc = make_lin(h, 3 * C, C, [=](int n, int kk) {
+                        return n < C ? q[(size_t)n * C + kk] * qs : n < 2 * C ? k[(size_t)(n - C) * C + kk] : v[(size_t)(n - 2 * C) * C + kk]; },
+                        [](int) { return 0.f; }, &at.qkv)))
+                    break;
+                // the sinusoidal code of window position j (AnimateDiff PositionalEncoding; the checkpoint's `pos_encoder.pe` buffer
+                // when it is there) through the three projections: [32][C] fp32 tables
+                std::vector<double> pe((size_t)kTLen * C);
+                auto it = m.find(A + "pos_encoder.pe");
+                if (it != m.end() && it->second.numel >= (int64_t)kTLen * C) {
+                    for (size_t e = 0; e < pe.size(); ++e) pe[e] = it->second.data[e];
+                } else {
+                    for (int j = 0; j < kTLen; ++j)
+                        for (int c2 = 0; c2 < C; c2 += 2) {
+                            // float arithmetic like torch.exp(arange * (-ln 1e4 / d)) in fp32
+                            const float div = expf((float)c2 * (-logf(10000.0f) / (float)C));
+                            pe[(size_t)j * C + c2] = sinf((float)j * div);
+                            pe[(size_t)j * C + c2 + 1] = cosf((float)j * div);
+                        }
+                }
+                std::vector<float> tq((size_t)kTLen * C), tk((size_t)kTLen * C), tv((size_t)kTLen * C);
+                for (int j = 0; j < kTLen; ++j)
+                    for (int n = 0; n < C; ++n) {
+                        double aq = 0.0, ak = 0.0, av = 0.0;
+                        for (int kk = 0; kk < C; ++kk) {
+                            const double e = pe[(size_t)j * C + kk];
+                            aq += (double)q[(size_t)n * C + kk] * e;
+                            ak += (double)k[(size_t)n * C + kk] * e;
+                            av += (double)v[(size_t)n * C + kk] * e;
+                        }
+                        tq[(size_t)j * C + n] = (float)(aq * qs);
+                        tk[(size_t)j * C + n] = (float)ak;
+                        tv[(size_t)j * C + n] = (float)av;
+                    }
+                if ((rc = upload(h, tq, &at.pq)) || (rc = upload(h, tk, &at.pk)) || (rc = upload(h, tv, &at.pv))) break;
+            }
+        }
     } while (0);
     if (rc) { nunif_hip_depth_anything_destroy(h); return rc; }
     *handle = h;
@@ -765,6 +861,9 @@ extern "C" void nunif_hip_depth_anything_destroy(nunif_depth_anything *h) {
     for (Buf *b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { h->bm1[i].release(); h->bm2[i].release(); h->bpart[i].release(); }
     for (int i = 0; i < 3; ++i) { h->bt1[i].release(); h->br1[i].release(); }
+    for (TMod &tmod : h->tm)
+        for (TAtt &at : tmod.at) { at.kc.release(); at.vc.release(); }
+    for (Buf *b : {&h->ta, &h->th, &h->tqkv, &h->tatt, &h->thid, &h->tgg, &h->tpart}) b->release();
     for (int i = 0; i < 3; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
         if (h->ev_fork[i]) (void)hipEventDestroy(h->ev_fork[i]);
@@ -788,6 +887,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     const int H1 = gh * 4, W1 = gw * 4, H2 = gh * 2, W2 = gw * 2, H3 = gh, W3 = gw, H4 = (gh + 2 - 3) / 2 + 1, W4 = (gw + 2 - 3) / 2 + 1;
     const int HF = 2 * H1, WF = 2 * W1;
     const int Hs[4] = {H1, H2, H3, H4}, Ws[4] = {W1, W2, W3, W4};
+    NUNIF_REQUIRE(!h->temporal || B == 1, "depth_anything_forward: a Video-Depth-Anything engine is a stream — one frame per call (B = %d)", B);
     const int ocp_max = std::max(std::max(h->OCP[0], h->OCP[1]), std::max(h->OCP[2], h->OCP[3]));
     size_t big = std::max<size_t>((size_t)B * HF * WF * F, (size_t)B * hh * ww * std::max(32, F / 2));
     big = std::max<size_t>(big, (size_t)B * N * ocp_max);
@@ -820,7 +920,8 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     // three small launches (43 / 22 / up to 392 workgroups) that nothing needs before the refinenets: they run on side streams
     // while the encoder goes on (its launches leave a quarter to a third of the CUs idle).  Everything is allocated here, before
     // the first fork (hipMalloc synchronises the device).  NUNIF_DA_BRANCH_STREAMS=0: everything on the caller's stream.
-    const bool side_streams = !(getenv("NUNIF_DA_BRANCH_STREAMS") && atoi(getenv("NUNIF_DA_BRANCH_STREAMS")) == 0);
+    // (a temporal engine keeps everything on the caller's stream: its modules share scratch buffers and sit inside the branches)
+    const bool side_streams = !h->temporal && !(getenv("NUNIF_DA_BRANCH_STREAMS") && atoi(getenv("NUNIF_DA_BRANCH_STREAMS")) == 0);
     for (int i = 0; i < 4; ++i) {
         if ((rc = h->bm1[i].ensure((size_t)B * N * h->OCP[i] * e2)) || (rc = h->bm2[i].ensure((size_t)B * Hs[i] * Ws[i] * h->OCP[i] * e2))) return rc;
         if (h->rn[i].cmaj && (rc = h->bpart[i].ensure((size_t)(h->rn[i].Cin / h->rn[i].cmaj) * B * Hs[i] * Ws[i] * h->rn[i].N * sizeof(float)))) return rc;
@@ -830,7 +931,8 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     // then adds the result where it resizes the path into that stage (da_upsample_kernel `add`).  Needs the out_conv-first order
     // (the resize is then the last op in front of the stage).  NUNIF_DA_RCU1_BRANCH=0: RCU1 in the head, as before.
     static const bool conv_first_g = !(getenv("NUNIF_DA_OUTCONV_FIRST") && atoi(getenv("NUNIF_DA_OUTCONV_FIRST")) == 0);
-    const bool rcu1_branch = conv_first_g && !(getenv("NUNIF_DA_RCU1_BRANCH") && atoi(getenv("NUNIF_DA_RCU1_BRANCH")) == 0);
+    // (a temporal module works on path_4 / path_3 BEFORE the skip joins them: RCU1 stays in the head there)
+    const bool rcu1_branch = !h->temporal && conv_first_g && !(getenv("NUNIF_DA_RCU1_BRANCH") && atoi(getenv("NUNIF_DA_RCU1_BRANCH")) == 0);
     if (rcu1_branch)
         for (int i = 0; i < 3; ++i)
             if ((rc = h->bt1[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2)) || (rc = h->br1[i].ensure((size_t)B * Hs[i] * Ws[i] * F * e2)))
@@ -851,6 +953,47 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     const bool use_mlp = !(getenv("NUNIF_DA_MLP") && atoi(getenv("NUNIF_DA_MLP")) == 0);      // read per call (tests A/B it)
     SplitLease lease(s);
     auto blocks = [](long n) { return (unsigned)((n + 255) / 256); };
+
+    // ---- Video-Depth-Anything: the window state and one temporal module on one frame's map (depth_temporal.hip) ------------------
+    const int tP[4] = {H3 * W3, H4 * W4, H3 * W3, H2 * W2};          // layer_3, layer_4, path_4, path_3
+    int t_idx = 0;
+    if (h->temporal) {
+        bool same = true;
+        for (int i = 0; i < 4; ++i) same = same && h->t_P[i] == tP[i];
+        if (!same) { h->t_len = 0; h->t_start = 0; for (int i = 0; i < 4; ++i) h->t_P[i] = tP[i]; }     // another resolution: a new window
+        t_idx = h->t_len;
+        size_t pc = 0;
+        for (int i = 0; i < 4; ++i) {
+            pc = std::max(pc, (size_t)tP[i] * h->tm[i].C);
+            for (TAtt &at : h->tm[i].at)
+                if ((rc = at.kc.ensure((size_t)kTLen * tP[i] * h->tm[i].C * e2)) || (rc = at.vc.ensure((size_t)kTLen * tP[i] * h->tm[i].C * e2))) return rc;
+        }
+        if ((rc = h->ta.ensure(pc * e2)) || (rc = h->th.ensure(pc * e2)) || (rc = h->tatt.ensure(pc * e2)) || (rc = h->tqkv.ensure(3 * pc * e2)) ||
+            (rc = h->thid.ensure(8 * pc * e2)) || (rc = h->tgg.ensure(4 * pc * e2)) || (rc = h->tpart.ensure((size_t)kVdaGnBlocks * 1024 * sizeof(float2))))
+            return rc;
+    }
+    auto run_tmod = [&](int i, f16 *x, hipStream_t st) -> int {          // x: [tP[i]][C], updated in place
+        TMod &tm = h->tm[i];
+        const int C = tm.C, P = tP[i];
+        f16 *a = (f16 *)h->ta.p, *hs = (f16 *)h->th.p, *tq = (f16 *)h->tqkv.p, *ta = (f16 *)h->tatt.p, *hid = (f16 *)h->thid.p, *gg = (f16 *)h->tgg.p;
+        int rc;
+        if ((rc = launch_vda_groupnorm(x, tm.gn_g, tm.gn_b, a, (float2 *)h->tpart.p, P, C, 1e-6f, st))) return rc;
+        if ((rc = run_tok(tm.proj_in, a, P, 0, nullptr, hs, st, "vda_proj_in"))) return rc;
+        for (TAtt &at : tm.at) {
+            if ((rc = launch_vda_layernorm(hs, at.g, at.b, a, P, C, 1e-5f, st))) return rc;
+            if ((rc = run_tok(at.qkv, a, P, 0, nullptr, tq, st, "vda_qkv"))) return rc;
+            VdaTattnArgs ga;
+            ga.qkv = tq; ga.kc = (f16 *)at.kc.p; ga.vc = (f16 *)at.vc.p; ga.pq = at.pq; ga.pk = at.pk; ga.pv = at.pv; ga.att = ta;
+            ga.P = P; ga.C = C; ga.hd = C / 8; ga.start = h->t_start; ga.idx = t_idx;
+            if ((rc = launch_vda_tattn(ga, st))) return rc;
+            if ((rc = run_tok(at.out, ta, P, 0, hs, hs, st, "vda_to_out"))) return rc;                 // hs += to_out(att)
+        }
+        if ((rc = launch_vda_layernorm(hs, tm.ff_g, tm.ff_b, a, P, C, 1e-5f, st))) return rc;
+        if ((rc = run_tok(tm.ff1, a, P, 0, nullptr, hid, st, "vda_ff1"))) return rc;
+        if ((rc = launch_vda_geglu(hid, gg, P, 4 * C, st))) return rc;
+        if ((rc = run_tok(tm.ff2, gg, P, 0, hs, hs, st, "vda_ff2"))) return rc;                        // hs += ff2(geglu(ff1(norm(hs))))
+        return run_tok(tm.proj_out, hs, P, 0, x, x, st, "vda_proj_out");                               // x += proj_out(hs)
+    };
 
     {   // patch embedding
         ProfScope ps("da_im2col_kernel", s, 0.0, (double)B * N * (kKp * 2.0 + 588 * 4.0));
@@ -887,6 +1030,8 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             }
             src = m2;
         }
+        // Video-Depth-Anything: motion_modules[0] on layer_3, [1] on layer_4 (after resize_layers, before layer{3,4}_rn)
+        if (h->temporal && i >= 2 && (rc = run_tmod(i - 2, i == 2 ? m1 : m2, st))) return rc;
         float *part = h->rn[i].cmaj ? (float *)h->bpart[i].p : nullptr;
         if ((rc = run_cnv(h->rn[i], src, B, Hs[i], Ws[i], 1, 1, 0, 0, nullptr, nullptr, rn[i], st, 0, part))) return rc;
         if (rcu1_branch && i < 3) {
@@ -1017,6 +1162,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         if ((rc = upsample(m2, H4, W4, H3, W3, F, m3))) return rc;
         if ((rc = run_lin(h->fus[3].out, m3, B, W3, W3, 0, 0, nullptr, m4, s, "da_out_conv", 0, 0, 1, H3))) return rc;      // path4 in m4
     }
+    if (h->temporal && (rc = run_tmod(2, m4, s))) return rc;                     // motion_modules[2] on path_4
     // path3 .. path1
     const f16 *path = m4;
     f16 *pout = m5;
@@ -1036,6 +1182,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
             if ((rc = upsample(m3, Hc, Wc, Hn, Wn, F, m2))) return rc;
             if ((rc = run_lin(h->fus[k].out, m2, B, Wn, Wn, 0, 0, nullptr, pout, s, "da_out_conv", 0, 0, 1, Hn))) return rc;
         }
+        if (h->temporal && k == 2 && (rc = run_tmod(3, pout, s))) return rc;      // motion_modules[3] on path_3
         path = pout;
         pout = (pout == m5) ? m4 : m5;
     }
@@ -1049,5 +1196,22 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         da_final_kernel<<<blocks(n), 256, 0, s>>>(m3, h->w_final, depth, n, h->max_depth);
         NUNIF_LAUNCH_CHECK();
     }
+    if (h->temporal) {
+        // this frame joined the window at position t_idx; beyond 31 cached frames the oldest leaves (its slot is the next one written)
+        if (h->t_len + 1 > kTLen - 1) h->t_start = (h->t_start + 1) & (kTLen - 1);
+        else ++h->t_len;
+    }
     return NUNIF_HIP_OK;
 }
+
+// `model.reset_state()` (iw3/video_depth_anything_streaming_model.py:74-75, at scene cuts): the next frame starts a new window.
+// Host state only — the caches are overwritten slot by slot — so it is ordered with the forwards by the CALLER's program order.
+extern "C" int nunif_hip_depth_anything_reset_state(nunif_depth_anything *h) {
+    NUNIF_REQUIRE(h, "depth_anything_reset_state: NULL handle");
+    h->t_len = 0;
+    h->t_start = 0;
+    return NUNIF_HIP_OK;
+}
+
+// 1: the checkpoint carried head.motion_modules (Video-Depth-Anything), 0: a per-frame Depth-Anything engine
+extern "C" int nunif_hip_depth_anything_is_temporal(const nunif_depth_anything *h) { return h && h->temporal ? 1 : 0; }

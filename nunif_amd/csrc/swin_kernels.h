@@ -100,6 +100,17 @@ struct DaMlpArgs {
     void *partial; unsigned *flags;
 };
 bool da_mlp_supported(int D, int hidden);
+
+// ---- the temporal modules of Video-Depth-Anything's head, streaming form (depth_temporal.hip) ----------------------------------------
+constexpr int kVdaGnBlocks = 64;                  // GroupNorm partial-sum blocks: `part` holds kVdaGnBlocks * C float2
+int launch_vda_groupnorm(const f16 *x, const float *gamma, const float *beta, f16 *y, float2 *part, int P, int C, float eps, hipStream_t s);
+int launch_vda_layernorm(const f16 *x, const float *gamma, const float *beta, f16 *y, long T, int C, float eps, hipStream_t s);
+int launch_vda_geglu(const f16 *h, f16 *out, long T, int I, hipStream_t s);
+// qkv: this frame's [P][3 C] rows (q0 | K0 | V0; Wq pre-scaled by hd^-1/2 log2 e); kc / vc: [32][P][C] ring caches, logical window
+// position j lives in slot (start + j) & 31; idx = this frame's position (= number of cached frames, <= 31); pq / pk / pv: [32][C]
+// fp32 = Wq pe_j (scaled like Wq), Wk pe_j, Wv pe_j; att: [P][C]
+struct VdaTattnArgs { const f16 *qkv; f16 *kc, *vc; const float *pq, *pk, *pv; f16 *att; int P, C, hd, start, idx; };
+int launch_vda_tattn(const VdaTattnArgs &g, hipStream_t s);
 long da_mlp_partial_bytes(long M);
 long da_mlp_flag_count(long M);
 int launch_da_mlp(const DaMlpArgs &a, hipStream_t s);

@@ -563,6 +563,48 @@ def depth_anything_v2_state_dict(seed, grid=37, encoder="vits", regime="benign")
     return sd
 
 
+def video_depth_anything_state_dict(seed, grid=37, encoder="vits"):
+    """Seeded weights in the published Video-Depth-Anything checkpoint layout: ``pretrained.*`` (DINOv2) + ``head.*`` = the DPT
+    head of Depth-Anything V2 plus ``head.motion_modules.{0..3}`` (temporal attention on layer_3, layer_4, path_4, path_3;
+    channels out_channels[2], out_channels[3], features, features).  ``proj_out`` is zero-initialised in an UNTRAINED module
+    (the module is then the identity); a trained one is not, so it gets weights here and the temporal path changes the output
+    by a measurable amount (tests).  The ``pos_encoder.pe`` buffers are left out: they are the sinusoidal table, recomputed."""
+    base = depth_anything_v2_state_dict(seed, grid=grid, encoder=encoder)
+    sd = {(("head." + k[len("depth_head."):]) if k.startswith("depth_head.") else k): v for k, v in base.items()}
+    cfg = DEPTH_ANYTHING_ENCODERS[encoder]
+    g = torch.Generator().manual_seed(seed + 7919)
+
+    def rnd(*shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    chans = (cfg["out_channels"][2], cfg["out_channels"][3], cfg["features"], cfg["features"])
+    for i, C in enumerate(chans):
+        t = f"head.motion_modules.{i}.temporal_transformer."
+        sd[t + "norm.weight"] = 1.0 + rnd(C, std=0.1)
+        sd[t + "norm.bias"] = rnd(C, std=0.05)
+        sd[t + "proj_in.weight"] = rnd(C, C, std=math.sqrt(1.0 / C))
+        sd[t + "proj_in.bias"] = rnd(C, std=0.02)
+        b = t + "transformer_blocks.0."
+        for a in range(2):
+            ab = f"{b}attention_blocks.{a}."
+            sd[ab + "to_q.weight"] = rnd(C, C, std=2.0 * math.sqrt(1.0 / C))       # logits of a few units: a softmax that selects
+            sd[ab + "to_k.weight"] = rnd(C, C, std=2.0 * math.sqrt(1.0 / C))
+            sd[ab + "to_v.weight"] = rnd(C, C, std=math.sqrt(1.0 / C))
+            sd[ab + "to_out.0.weight"] = rnd(C, C, std=0.7 * math.sqrt(1.0 / C))
+            sd[ab + "to_out.0.bias"] = rnd(C, std=0.02)
+            sd[f"{b}norms.{a}.weight"] = 1.0 + rnd(C, std=0.1)
+            sd[f"{b}norms.{a}.bias"] = rnd(C, std=0.05)
+        sd[b + "ff_norm.weight"] = 1.0 + rnd(C, std=0.1)
+        sd[b + "ff_norm.bias"] = rnd(C, std=0.05)
+        sd[b + "ff.net.0.proj.weight"] = rnd(8 * C, C, std=math.sqrt(1.0 / C))
+        sd[b + "ff.net.0.proj.bias"] = rnd(8 * C, std=0.02)
+        sd[b + "ff.net.2.weight"] = rnd(C, 4 * C, std=0.7 * math.sqrt(1.0 / (4 * C)))
+        sd[b + "ff.net.2.bias"] = rnd(C, std=0.02)
+        sd[t + "proj_out.weight"] = rnd(C, C, std=0.5 * math.sqrt(1.0 / C))
+        sd[t + "proj_out.bias"] = rnd(C, std=0.02)
+    return sd
+
+
 def synth_depth(seed, b, h, w, kind="edges"):
     """Synthetic normalised depth maps: the step pattern of the reference's ``_bench`` (forward_warp.py:309-316)
     blurred, plus a ramp / smooth noise so that floor/ceil collisions, holes and layered holes all occur."""
