@@ -969,7 +969,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
                 if ((rc = at.kc.ensure((size_t)kTLen * tP[i] * h->tm[i].C * e2)) || (rc = at.vc.ensure((size_t)kTLen * tP[i] * h->tm[i].C * e2))) return rc;
         }
         if ((rc = h->ta.ensure(pc * e2)) || (rc = h->th.ensure(pc * e2)) || (rc = h->tatt.ensure(pc * e2)) || (rc = h->tqkv.ensure(3 * pc * e2)) ||
-            (rc = h->thid.ensure(8 * pc * e2)) || (rc = h->tgg.ensure(4 * pc * e2)) || (rc = h->tpart.ensure((size_t)kVdaGnBlocks * 1024 * sizeof(float2))))
+            (rc = h->thid.ensure(8 * pc * e2)) || (rc = h->tgg.ensure(4 * pc * e2)) || (rc = h->tpart.ensure((size_t)(kVdaGnBlocks + 1) * 1024 * sizeof(float2))))
             return rc;
     }
     auto run_tmod = [&](int i, f16 *x, hipStream_t st) -> int {          // x: [tP[i]][C], updated in place

@@ -15,30 +15,48 @@
 // computed when the weights are loaded.  Per frame the attention then reads the two caches once — 2 x 32 x P x C x 2 bytes, the
 // algorithmic minimum for this step — and the Linears see P tokens, not 32 P.
 #include <algorithm>
+#include <cstdlib>
 
 #include "swin_kernels.h"
 
 namespace nunif {
 
 // ---- GroupNorm(32 groups) over one frame's [P][C] map --------------------------------------------------------------------------
-// pass 1: block b sums rows [b R, (b + 1) R) per channel (thread = channel: a wave reads 128 contiguous bytes of a row)
-__global__ void vda_gn_partial_kernel(const f16 *__restrict__ x, float2 *__restrict__ part, int P, int C, int R) {
-    const int c = threadIdx.x, b = blockIdx.x;
+// Three small launches (the first form — 64 blocks whose threads walked 88 rows of 2-byte loads twice — took 35 us per module; a
+// 256-block form whose single finalising block then added 256 partials per thread, 50):
+// pass 1: a block of RL x C / 8 threads sums its R rows with 16-byte loads (thread = row lane x 8-channel octet), the row lanes meet
+// in LDS in a fixed order, and the block writes one (sum, sum of squares) per channel
+__global__ void __launch_bounds__(256) vda_gn_partial_kernel(const f16 *__restrict__ x, float2 *__restrict__ part, int P, int C, int R) {
+    __shared__ float2 red[2048];                        // [RL][C], RL * C / 8 <= 256
+    const int CL = C >> 3, RL = 256 / CL, tid = threadIdx.x, b = blockIdx.x;
+    const int rl = tid / CL, cl = tid - rl * CL;
     const int p0 = b * R, p1 = min(P, p0 + R);
-    float s = 0.f, q = 0.f;
-    for (int p = p0; p < p1; ++p) {
-        const float v = (float)x[(long)p * C + c];
-        s += v;
-        q = fmaf(v, v, q);
+    if (rl < RL) {
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        for (int p = p0 + rl; p < p1; p += RL) {
+            const f16x8 v = *reinterpret_cast<const f16x8 *>(x + (long)p * C + cl * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] = fmaf(f, f, q[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rl * C + cl * 8 + e] = make_float2(s[e], q[e]);
     }
-    part[(long)b * C + c] = make_float2(s, q);
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float ss = 0.f, qq = 0.f;
+        for (int i = 0; i < RL; ++i) { const float2 v = red[i * C + c]; ss += v.x; qq += v.y; }
+        part[(long)b * C + c] = make_float2(ss, qq);
+    }
 }
-// pass 2: every block adds the NB partials in the same fixed order (deterministic, no atomics), in double — the group statistics are
-// E[x^2] - mean^2 over P * C / 32 values — then normalises its rows: y = (x - mean_g) rstd_g gamma_c + beta_c
-__global__ void vda_gn_apply_kernel(const f16 *__restrict__ x, const float2 *__restrict__ part, const float *__restrict__ gamma,
-                                    const float *__restrict__ beta, f16 *__restrict__ y, int P, int C, int R, int NB, float eps) {
+// pass 2 (one block): the NB partials of a channel added in a fixed order (deterministic, no atomics), in double — the group
+// statistics are E[x^2] - mean^2 over P * C / 32 values — then per CHANNEL the affine map of the norm: y = x a_c + b_c with
+// a_c = rstd_g gamma_c, b_c = beta_c - mean_g a_c
+__global__ void vda_gn_finalize_kernel(const float2 *__restrict__ part, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                       float2 *__restrict__ coef, int P, int C, int NB, float eps) {
     __shared__ double cs[1024], cq[1024];
-    const int c = threadIdx.x, b = blockIdx.x;
+    const int c = threadIdx.x;
     double s = 0.0, q = 0.0;
     for (int i = 0; i < NB; ++i) {
         const float2 v = part[(long)i * C + c];
@@ -54,25 +72,40 @@ __global__ void vda_gn_apply_kernel(const f16 *__restrict__ x, const float2 *__r
     const double n = (double)P * cpg, mean = gs / n;
     double var = gq / n - mean * mean;
     if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps)), mu = (float)mean;
-    const float ga = gamma[c], be = beta[c];
-    const int p0 = b * R, p1 = min(P, p0 + R);
-    for (int p = p0; p < p1; ++p) {
-        const float v = (float)x[(long)p * C + c];
-        y[(long)p * C + c] = (f16)((v - mu) * rstd * ga + be);
+    const float a = (float)(1.0 / sqrt(var + (double)eps)) * gamma[c];
+    coef[c] = make_float2(a, beta[c] - (float)mean * a);
+}
+// pass 3: elementwise, 8 channels per thread
+__global__ void __launch_bounds__(256) vda_gn_apply_kernel(const f16 *__restrict__ x, const float2 *__restrict__ coef, f16 *__restrict__ y,
+                                                           long total8, int C8) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total8) return;
+    const int o = (int)(id % C8);
+    const f16x8 v = *reinterpret_cast<const f16x8 *>(x + id * 8);
+    f16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float2 ab = coef[o * 8 + e];
+        r[e] = (f16)fmaf((float)v[e], ab.x, ab.y);
     }
+    *reinterpret_cast<f16x8 *>(y + id * 8) = r;
 }
 
 int launch_vda_groupnorm(const f16 *x, const float *gamma, const float *beta, f16 *y, float2 *part, int P, int C, float eps,
                          hipStream_t s) {
     NUNIF_REQUIRE(P > 0 && C % 32 == 0 && C >= 32 && C <= 1024, "vda_groupnorm: %d channels unsupported (a multiple of 32, <= 1024)", C);
-    int NB = std::min(kVdaGnBlocks, (P + 15) / 16);
+    const int RL = 256 / (C / 8);                              // row lanes of a block: ~4 rows per lane
+    int NB = std::min(kVdaGnBlocks, (P + 4 * RL - 1) / (4 * RL));
     const int R = (P + NB - 1) / NB;
     NB = (P + R - 1) / R;
+    float2 *coef = part + (size_t)kVdaGnBlocks * C;              // behind the partials (the caller's buffer holds (kVdaGnBlocks + 1) * C)
     ProfScope ps("vda_groupnorm", s, 0.0, (double)P * C * 6.0);
-    vda_gn_partial_kernel<<<NB, C, 0, s>>>(x, part, P, C, R);
+    vda_gn_partial_kernel<<<NB, 256, 0, s>>>(x, part, P, C, R);
     NUNIF_LAUNCH_CHECK();
-    vda_gn_apply_kernel<<<NB, C, 0, s>>>(x, part, gamma, beta, y, P, C, R, NB, eps);
+    vda_gn_finalize_kernel<<<1, C, 0, s>>>(part, gamma, beta, coef, P, C, NB, eps);
+    NUNIF_LAUNCH_CHECK();
+    const long total8 = (long)P * (C / 8);
+    vda_gn_apply_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, s>>>(x, coef, y, total8, C / 8);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }
@@ -206,13 +239,148 @@ __global__ void __launch_bounds__(256) vda_tattn_kernel(VdaTattnArgs g) {
     }
 }
 
+// ---- the same attention, laid out for memory-level parallelism (C <= 384) ----------------------------------------------------------
+// The form above is one thread per (pixel, head) walking 2 x 32 x hd / 8 dependent 16-byte loads: P = 1 400 pixels are 175 waves for
+// 1 024 SIMDs, every load waited for on its own — 100 us per launch for 17-70 MB (0.28 TB/s).  Here a thread is one (pixel, 8-channel
+// CHUNK): hd / 8 times the threads, a pixel's C / 8 chunk-lanes read whole contiguous rows, the window is walked in batches of 8
+// unconditional loads (positions beyond the window re-read a valid slot and are masked), and the position tables PK / PV sit in LDS
+// (rows 0 .. idx, staged once per workgroup) instead of being re-read from global memory by every thread.  The chunk-lanes of a
+// head exchange their partial scores through LDS.  A workgroup = NPX pixels x C / 8 lanes.
+template <int C>
+__global__ void __launch_bounds__(C <= 64 ? 256 : (C / 8) * (C <= 128 ? 16 : C <= 192 ? 8 : 4)) vda_tattn2_kernel(VdaTattnArgs g) {
+    constexpr int CL = C / 8, NPX = C <= 64 ? 32 : C <= 128 ? 16 : C <= 192 ? 8 : 4, NT = CL * NPX, SP = 33;
+    __shared__ __attribute__((aligned(16))) float pk[32 * C];
+    __shared__ __attribute__((aligned(16))) float pv[32 * C];
+    __shared__ float sp[NT * SP];
+    const int tid = threadIdx.x, idx = g.idx, nch = g.hd >> 3;
+    for (int i = tid; i < (idx + 1) * (C / 4); i += NT) {
+        reinterpret_cast<f32x4 *>(pk)[i] = reinterpret_cast<const f32x4 *>(g.pk)[i];
+        reinterpret_cast<f32x4 *>(pv)[i] = reinterpret_cast<const f32x4 *>(g.pv)[i];
+    }
+    const int px = tid / CL, cc = tid - px * CL;
+    long p = (long)blockIdx.x * NPX + px;
+    const bool live = p < g.P;
+    if (!live) p = g.P - 1;
+    const long row = p * C + cc * 8, slot = (long)g.P * C;
+    const f16 *qrow = g.qkv + p * 3 * C + cc * 8;
+    const f16x8 qh = *reinterpret_cast<const f16x8 *>(qrow);
+    const f16x8 kcur = *reinterpret_cast<const f16x8 *>(qrow + C);
+    const f16x8 vcur = *reinterpret_cast<const f16x8 *>(qrow + 2 * C);
+    const int cur = (g.start + idx) & 31;
+    if (live) {
+        *reinterpret_cast<f16x8 *>(g.kc + cur * slot + row) = kcur;
+        *reinterpret_cast<f16x8 *>(g.vc + cur * slot + row) = vcur;
+    }
+    float q[8];
+    {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(g.pq + (long)idx * C + cc * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(g.pq + (long)idx * C + cc * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { q[e] = (float)qh[e] + a[e]; q[4 + e] = (float)qh[4 + e] + b[e]; }
+    }
+    __syncthreads();                                     // the tables are staged
+    // positions j > idx read position jlast (an older valid slot; with an empty window the slot being written: never used)
+    const int jlast = idx > 0 ? idx - 1 : 0;
+#pragma unroll
+    for (int jb = 0; jb < 32; jb += 8) {
+        float d[8];
+        if (jb <= idx) {                                  // uniform
+            f16x8 kh[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                kh[u] = *reinterpret_cast<const f16x8 *>(g.kc + (long)((g.start + min(jb + u, jlast)) & 31) * slot + row);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = jb + u;
+                const f16x8 kk = j == idx ? kcur : kh[u];
+                const f32x4 ta = *reinterpret_cast<const f32x4 *>(pk + min(j, idx) * C + cc * 8);
+                const f32x4 tb = *reinterpret_cast<const f32x4 *>(pk + min(j, idx) * C + cc * 8 + 4);
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = fmaf(q[e], (float)kk[e] + ta[e], acc);
+                    acc = fmaf(q[4 + e], (float)kk[4 + e] + tb[e], acc);
+                }
+                d[u] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sp[tid * SP + jb + u] = d[u];
+    }
+    __syncthreads();
+    // the head's score = the sum over its nch chunk-lanes (every lane of the head computes the same softmax)
+    const int base = (px * CL + cc / nch * nch) * SP;
+    float s[32];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        float t = 0.f;
+        for (int i = 0; i < nch; ++i) t += sp[base + i * SP + j];
+        s[j] = t;
+        if (j <= idx) m = fmaxf(m, t);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        s[j] = j <= idx ? exp2f(s[j] - m) : 0.f;
+        sum += s[j];
+    }
+    const float inv = 1.0f / sum;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 32; jb += 8) {
+        if (jb <= idx) {
+            f16x8 vh[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                vh[u] = *reinterpret_cast<const f16x8 *>(g.vc + (long)((g.start + min(jb + u, jlast)) & 31) * slot + row);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = jb + u;
+                const f16x8 vv = j == idx ? vcur : vh[u];
+                const f32x4 ta = *reinterpret_cast<const f32x4 *>(pv + min(j, idx) * C + cc * 8);
+                const f32x4 tb = *reinterpret_cast<const f32x4 *>(pv + min(j, idx) * C + cc * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[e] = fmaf(s[j], (float)vv[e] + ta[e], acc[e]);
+                    acc[4 + e] = fmaf(s[j], (float)vv[4 + e] + tb[e], acc[4 + e]);
+                }
+            }
+        }
+    }
+    if (live) {
+        f16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (f16)(acc[e] * inv);
+        *reinterpret_cast<f16x8 *>(g.att + row) = r;
+    }
+}
+
+template <int C>
+static void launch_tattn2(const VdaTattnArgs &g, hipStream_t s) {
+    constexpr int NPX = C <= 64 ? 32 : C <= 128 ? 16 : C <= 192 ? 8 : 4;
+    vda_tattn2_kernel<C><<<(unsigned)((g.P + NPX - 1) / NPX), (C / 8) * NPX, 0, s>>>(g);
+}
+
 int launch_vda_tattn(const VdaTattnArgs &g, hipStream_t s) {
     NUNIF_REQUIRE(g.P > 0 && g.C == 8 * g.hd && g.hd % 8 == 0 && g.idx >= 0 && g.idx < 32 && g.start >= 0 && g.start < 32,
                   "vda_tattn: C=%d hd=%d idx=%d start=%d unsupported (8 heads, head width a multiple of 8, window <= 32)", g.C, g.hd,
                   g.idx, g.start);
     // per launch: the window's K0 / V0 once, this frame's qkv row, the att row
     ProfScope ps("vda_tattn_kernel", s, 4.0 * g.P * (double)g.C * (g.idx + 1), (double)g.P * g.C * 2.0 * (2.0 * g.idx + 3.0 + 2.0 + 1.0));
-    vda_tattn_kernel<<<(unsigned)(((long)g.P * 8 + 255) / 256), 256, 0, s>>>(g);
+    // NUNIF_VDA_TATTN=1: the one-thread-per-head form for every width (A/B; the only form for C > 384, where the tables outgrow LDS)
+    const bool v1 = getenv("NUNIF_VDA_TATTN") && atoi(getenv("NUNIF_VDA_TATTN")) == 1;      // read per call (tests A/B it)
+    if (!v1 && g.C == 64) launch_tattn2<64>(g, s);
+    else if (!v1 && g.C == 128) launch_tattn2<128>(g, s);
+    else if (!v1 && g.C == 192) launch_tattn2<192>(g, s);
+    else if (!v1 && g.C == 256) launch_tattn2<256>(g, s);
+    else if (!v1 && g.C == 384) launch_tattn2<384>(g, s);
+    else vda_tattn_kernel<<<(unsigned)(((long)g.P * 8 + 255) / 256), 256, 0, s>>>(g);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }

@@ -102,7 +102,7 @@ struct DaMlpArgs {
 bool da_mlp_supported(int D, int hidden);
 
 // ---- the temporal modules of Video-Depth-Anything's head, streaming form (depth_temporal.hip) ----------------------------------------
-constexpr int kVdaGnBlocks = 64;                  // GroupNorm partial-sum blocks: `part` holds kVdaGnBlocks * C float2
+constexpr int kVdaGnBlocks = 256;                 // GroupNorm partial-sum blocks: `part` holds (kVdaGnBlocks + 1) * C float2 (the last row: per-channel coefficients)
 int launch_vda_groupnorm(const f16 *x, const float *gamma, const float *beta, f16 *y, float2 *part, int P, int C, float eps, hipStream_t s);
 int launch_vda_layernorm(const f16 *x, const float *gamma, const float *beta, f16 *y, long T, int C, float eps, hipStream_t s);
 int launch_vda_geglu(const f16 *h, f16 *out, long T, int I, hipStream_t s);

@@ -155,6 +155,21 @@ def test_hip_streaming_network_vs_oracle_over_two_windows(vda_net):
 
 
 @pytest.mark.gpu
+def test_the_two_temporal_attention_kernels_agree(vda_net, monkeypatch):
+    """``vda_tattn2_kernel`` (a thread per pixel and 8-channel chunk, position tables in LDS) against ``vda_tattn_kernel`` (a thread
+    per pixel and head; NUNIF_VDA_TATTN=1): the same sums in another order."""
+    sd, net = vda_net
+    frames = clip(9, 34, 70, 98)
+    outs = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("NUNIF_VDA_TATTN", form)
+        net.reset_state()
+        outs[form] = torch.stack([net.infer_video_depth_one(f.to("cuda:0")).cpu() for f in frames])
+    span = float(outs["0"].max() - outs["0"].min())
+    assert float(outs["0"].std()) > 1e-3 and float((outs["0"] - outs["1"]).abs().max()) < 2e-3 * span, float((outs["0"] - outs["1"]).abs().max()) / span
+
+
+@pytest.mark.gpu
 def test_hip_streaming_network_resolution_change_and_batch(vda_net):
     sd, net = vda_net
     net.reset_state()
