@@ -279,37 +279,32 @@ __global__ void __launch_bounds__(C <= 64 ? 256 : (C / 8) * (C <= 128 ? 16 : C <
         for (int e = 0; e < 4; ++e) { q[e] = (float)qh[e] + a[e]; q[4 + e] = (float)qh[4 + e] + b[e]; }
     }
     __syncthreads();                                     // the tables are staged
-    // positions j > idx read position jlast (an older valid slot; with an empty window the slot being written: never used)
+    // The window is read with UNCONDITIONAL loads, all 32 positions of K in flight at once (P = 1 400 pixels x 8 chunk-lanes are 175
+    // waves: the 12-46 MB of a launch only move at HBM speed with ~30 loads per lane outstanding), then all 32 of V, issued BEFORE the
+    // score exchange and the softmax so that they fly behind them.  Positions beyond the window (j > idx: only in the first 31 frames
+    // after a reset) re-read position jlast — an older valid slot; with an empty window the slot being written, whose value is never
+    // used — and are masked by selects, never by arithmetic.
     const int jlast = idx > 0 ? idx - 1 : 0;
+    const f16 *kbase = g.kc + row, *vbase = g.vc + row;
+    f16x8 kh[32];
 #pragma unroll
-    for (int jb = 0; jb < 32; jb += 8) {
-        float d[8];
-        if (jb <= idx) {                                  // uniform
-            f16x8 kh[8];
+    for (int j = 0; j < 32; ++j) kh[j] = *reinterpret_cast<const f16x8 *>(kbase + (long)((g.start + min(j, jlast)) & 31) * slot);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                kh[u] = *reinterpret_cast<const f16x8 *>(g.kc + (long)((g.start + min(jb + u, jlast)) & 31) * slot + row);
+    for (int j = 0; j < 32; ++j) {
+        const f16x8 kk = j == idx ? kcur : kh[j];
+        const f32x4 ta = *reinterpret_cast<const f32x4 *>(pk + min(j, idx) * C + cc * 8);
+        const f32x4 tb = *reinterpret_cast<const f32x4 *>(pk + min(j, idx) * C + cc * 8 + 4);
+        float acc = 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = jb + u;
-                const f16x8 kk = j == idx ? kcur : kh[u];
-                const f32x4 ta = *reinterpret_cast<const f32x4 *>(pk + min(j, idx) * C + cc * 8);
-                const f32x4 tb = *reinterpret_cast<const f32x4 *>(pk + min(j, idx) * C + cc * 8 + 4);
-                float acc = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc = fmaf(q[e], (float)kk[e] + ta[e], acc);
-                    acc = fmaf(q[4 + e], (float)kk[4 + e] + tb[e], acc);
-                }
-                d[u] = acc;
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) d[u] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            acc = fmaf(q[e], (float)kk[e] + ta[e], acc);
+            acc = fmaf(q[4 + e], (float)kk[4 + e] + tb[e], acc);
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sp[tid * SP + jb + u] = d[u];
+        sp[tid * SP + j] = acc;
     }
+    f16x8 vh[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) vh[j] = *reinterpret_cast<const f16x8 *>(vbase + (long)((g.start + min(j, jlast)) & 31) * slot);
     __syncthreads();
     // the head's score = the sum over its nch chunk-lanes (every lane of the head computes the same softmax)
     const int base = (px * CL + cc / nch * nch) * SP;
@@ -333,24 +328,16 @@ __global__ void __launch_bounds__(C <= 64 ? 256 : (C / 8) * (C <= 128 ? 16 : C <
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int jb = 0; jb < 32; jb += 8) {
-        if (jb <= idx) {
-            f16x8 vh[8];
+    for (int j = 0; j < 32; ++j) {
+        const f16x8 vv = j == idx ? vcur : vh[j];
+        const f32x4 ta = *reinterpret_cast<const f32x4 *>(pv + min(j, idx) * C + cc * 8);
+        const f32x4 tb = *reinterpret_cast<const f32x4 *>(pv + min(j, idx) * C + cc * 8 + 4);
+        // (p_j = 0 for j > idx, but 0 x garbage could be NaN: select the operand as well)
+        const float pj = s[j];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                vh[u] = *reinterpret_cast<const f16x8 *>(g.vc + (long)((g.start + min(jb + u, jlast)) & 31) * slot + row);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = jb + u;
-                const f16x8 vv = j == idx ? vcur : vh[u];
-                const f32x4 ta = *reinterpret_cast<const f32x4 *>(pv + min(j, idx) * C + cc * 8);
-                const f32x4 tb = *reinterpret_cast<const f32x4 *>(pv + min(j, idx) * C + cc * 8 + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[e] = fmaf(s[j], (float)vv[e] + ta[e], acc[e]);
-                    acc[4 + e] = fmaf(s[j], (float)vv[4 + e] + tb[e], acc[4 + e]);
-                }
-            }
+        for (int e = 0; e < 4; ++e) {
+            acc[e] = j <= idx ? fmaf(pj, (float)vv[e] + ta[e], acc[e]) : acc[e];
+            acc[4 + e] = j <= idx ? fmaf(pj, (float)vv[4 + e] + tb[e], acc[4 + e]) : acc[4 + e];
         }
     }
     if (live) {
