@@ -41,7 +41,8 @@ struct ConvW { f16 *stream = nullptr; float *bias = nullptr; int N = 0, n_real =
                // 3x3 convs with 128 / 256 inputs and more than 64 outputs (the two bottom convs of unet2): the SAME weights as
                // streams of 64 output channels each, so that every slice runs on the LDS-DMA conv with K halves
                // (conv3_dma_kernel<4, 64, ., 1, 2, KS>), writing its channels of the NHWC map through ConvArgs::ldo
-               std::vector<f16 *> slice; };
+               std::vector<f16 *> slice;
+               f16 *head_w = nullptr; };        // 64 -> 3 image heads: the tap-scatter form's fragments (cunet_head.hip), row n = 3 tap + c
 struct UpW { f16 *w = nullptr; float *bias = nullptr; int N = 0, K = 0, cq = 0; };       // ConvTranspose2d 2x2 s2
 struct SEW { float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr; int C = 0; };
 struct C3W { float *w = nullptr, *b = nullptr; int C = 0; f16 *frag = nullptr; };   // frag: MFMA A fragments of the fused stem (K = 27 taps + bias)
@@ -124,6 +125,17 @@ int make_conv(nunif_cunet *h, const TMap &m, const std::string &key, int cin, in
             if ((rc = upload(h, part, &dev))) return rc;
             c->slice.push_back(dev);
         }
+    }
+    if (k == 3 && stride == 1 && cin_real == 64 && cin == 64 && cout == 3) {
+        std::vector<f16> hw((size_t)4 * 512 + 8192, (f16)0.0f);
+        for (int nt = 0; nt < 2; ++nt)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = nt * 16 + (l & 15), ci = ks * 32 + (l >> 4) * 8 + j, tap = n / 3, co = n % 3;
+                        hw[(((size_t)nt * 2 + ks) * 64 + l) * 8 + j] = n < 27 ? (f16)w->data[((size_t)co * 64 + ci) * 9 + tap] : (f16)0.0f;
+                    }
+        if ((rc = upload(h, hw, &c->head_w))) return rc;
     }
     if (k == 2 && stride == 2 && cin_real == cin && N == cout && N % 32 == 0) {
         // k = stride: a 2 x 2 gather GEMM (the PatchDown form of gemm_kernel: every input pixel is read exactly once, the token
@@ -248,6 +260,11 @@ int run_conv(const ConvW &c, const f16 *a, const f16 *a2, int H2, int crop2, int
     g.act = act; g.slope = 0.1f;
     g.out = out; g.out32 = out32; g.add32 = add32; g.addH = addH; g.addW = addH; g.add_crop = add_crop;
     g.clamp01 = clamp01;
+    if (c.head_w && out32 && !out && !a2 && act == 0) {
+        // the 64 -> 3 image heads in tap-scatter form (cunet_head.hip), every launch of that shape
+        CunetHeadArgs hg = {a, c.head_w, c.bias, out32, add32, B, Hi, Hi, g.Ho, g.Wo, addH, addH, add_crop, clamp01};
+        if (cunet_head_supported(hg)) return launch_cunet_head(hg, s);
+    }
     // (every launch of such a conv takes the sliced form or none does: a result must not depend on the tile minibatch)
     static const bool sliced = !(getenv("NUNIF_CUNET_SLICED") && atoi(getenv("NUNIF_CUNET_SLICED")) == 0);
     if (sliced && !c.slice.empty() && out && !out32 && !a2) {

@@ -101,6 +101,13 @@ struct DaMlpArgs {
 };
 bool da_mlp_supported(int D, int hidden);
 
+// ---- cunet's image heads (cunet_head.hip): out32[b][c][y][x] = bias[c] + sum over the 3 x 3 taps and 64 channels (+ crop(add32), clamp) --------
+// a: [B, Hi, Wi, 64] NHWC fp16; w: 4 MFMA A fragments [n-tile 2][k-step 2][64 lanes][8], row n = 3 tap + c (27 of 32), k = ci;
+// out32: [B, 3, Ho = Hi - 2, Wo = Wi - 2] fp32; add32: optional [B, 3, addH, addW], read at (y + add_crop, x + add_crop)
+struct CunetHeadArgs { const f16 *a, *w; const float *bias; float *out32; const float *add32; int B, Hi, Wi, Ho, Wo, addH, addW, add_crop, clamp01; };
+bool cunet_head_supported(const CunetHeadArgs &g);
+int launch_cunet_head(const CunetHeadArgs &g, hipStream_t s);
+
 // ---- the temporal modules of Video-Depth-Anything's head, streaming form (depth_temporal.hip) ----------------------------------------
 constexpr int kVdaGnBlocks = 256;                 // GroupNorm partial-sum blocks: `part` holds (kVdaGnBlocks + 1) * C float2 (the last row: per-channel coefficients)
 int launch_vda_groupnorm(const f16 *x, const float *gamma, const float *beta, f16 *y, float2 *part, int P, int C, float eps, hipStream_t s);
