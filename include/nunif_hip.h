@@ -193,9 +193,11 @@ int nunif_hip_depth_anything_forward(nunif_depth_anything *handle, const float *
 /* Video-Depth-Anything, streaming (iw3/video_depth_anything_streaming_model.py:58-103: torch.hub
  * "nagadomi/Video-Depth-Anything_iw3" `VideoDepthAnythingStreaming`; `model.infer_video_depth_one(frame)` :94 and
  * `model.reset_state()` :75).  When the tensors given to _create_ex carry `depth_head.motion_modules.{0..3}.*` (the published
- * checkpoint's `head.motion_modules.*`; the caller renames `head.` to `depth_head.`) the engine is TEMPORAL: _forward takes ONE
- * frame per call (B = 1) and is `infer_video_depth_one` — each of the 8 temporal attention blocks attends to the previous <= 31
- * frames through K / V caches the engine owns — and _reset_state starts a new window.  A change of resolution also does.
+ * checkpoint's `head.motion_modules.*`; the caller renames `head.` to `depth_head.`) the engine is TEMPORAL: _forward with B = 1 is
+ * `infer_video_depth_one` — each of the 8 temporal attention blocks attends to the previous <= 31 frames through K / V caches the
+ * engine owns — and with B > 1 it is B such calls on CONSECUTIVE frames of the stream in one pass (the reference's per-frame loop
+ * :92-95 collapsed: encoder, convs and Linears run over the B frames at once, only the temporal attention steps frame by frame);
+ * _reset_state starts a new window.  A change of resolution also does.
  * The network is not in the reference tree; oracle/video_depth_anything_net.py restates the published architecture, PARITY UNPINNED. */
 int nunif_hip_depth_anything_reset_state(nunif_depth_anything *handle);
 int nunif_hip_depth_anything_is_temporal(const nunif_depth_anything *handle);

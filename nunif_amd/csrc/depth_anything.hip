@@ -887,7 +887,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
     const int H1 = gh * 4, W1 = gw * 4, H2 = gh * 2, W2 = gw * 2, H3 = gh, W3 = gw, H4 = (gh + 2 - 3) / 2 + 1, W4 = (gw + 2 - 3) / 2 + 1;
     const int HF = 2 * H1, WF = 2 * W1;
     const int Hs[4] = {H1, H2, H3, H4}, Ws[4] = {W1, W2, W3, W4};
-    NUNIF_REQUIRE(!h->temporal || B == 1, "depth_anything_forward: a Video-Depth-Anything engine is a stream — one frame per call (B = %d)", B);
+    // (a Video-Depth-Anything engine takes the B frames as CONSECUTIVE frames of its stream: the same results as B calls with one)
     const int ocp_max = std::max(std::max(h->OCP[0], h->OCP[1]), std::max(h->OCP[2], h->OCP[3]));
     size_t big = std::max<size_t>((size_t)B * HF * WF * F, (size_t)B * hh * ww * std::max(32, F / 2));
     big = std::max<size_t>(big, (size_t)B * N * ocp_max);
@@ -956,43 +956,57 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
 
     // ---- Video-Depth-Anything: the window state and one temporal module on one frame's map (depth_temporal.hip) ------------------
     const int tP[4] = {H3 * W3, H4 * W4, H3 * W3, H2 * W2};          // layer_3, layer_4, path_4, path_3
-    int t_idx = 0;
+    // the window position / ring start of each frame of the batch, and the state behind the last one
+    std::vector<int> t_idx(B, 0), t_st(B, 0);
+    int t_len_end = h->t_len, t_start_end = h->t_start;
     if (h->temporal) {
         bool same = true;
         for (int i = 0; i < 4; ++i) same = same && h->t_P[i] == tP[i];
         if (!same) { h->t_len = 0; h->t_start = 0; for (int i = 0; i < 4; ++i) h->t_P[i] = tP[i]; }     // another resolution: a new window
-        t_idx = h->t_len;
+        t_len_end = h->t_len; t_start_end = h->t_start;
+        for (int f = 0; f < B; ++f) {
+            // frame f joins the window at position t_len; beyond 31 cached frames the oldest leaves (its slot is the next one written)
+            t_idx[f] = t_len_end; t_st[f] = t_start_end;
+            if (t_len_end + 1 > kTLen - 1) t_start_end = (t_start_end + 1) & (kTLen - 1);
+            else ++t_len_end;
+        }
         size_t pc = 0;
         for (int i = 0; i < 4; ++i) {
-            pc = std::max(pc, (size_t)tP[i] * h->tm[i].C);
+            pc = std::max(pc, (size_t)B * tP[i] * h->tm[i].C);
             for (TAtt &at : h->tm[i].at)
                 if ((rc = at.kc.ensure((size_t)kTLen * tP[i] * h->tm[i].C * e2)) || (rc = at.vc.ensure((size_t)kTLen * tP[i] * h->tm[i].C * e2))) return rc;
         }
         if ((rc = h->ta.ensure(pc * e2)) || (rc = h->th.ensure(pc * e2)) || (rc = h->tatt.ensure(pc * e2)) || (rc = h->tqkv.ensure(3 * pc * e2)) ||
-            (rc = h->thid.ensure(8 * pc * e2)) || (rc = h->tgg.ensure(4 * pc * e2)) || (rc = h->tpart.ensure((size_t)(kVdaGnBlocks + 1) * 1024 * sizeof(float2))))
+            (rc = h->thid.ensure(8 * pc * e2)) || (rc = h->tgg.ensure(4 * pc * e2)) ||
+            (rc = h->tpart.ensure((size_t)B * (kVdaGnBlocks + 1) * 1024 * sizeof(float2))))
             return rc;
     }
-    auto run_tmod = [&](int i, f16 *x, hipStream_t st) -> int {          // x: [tP[i]][C], updated in place
+    // x: the B frames' maps [B][tP[i]][C], updated in place.  Everything per token runs once over the B * P tokens; GroupNorm is per
+    // frame (blockIdx.y); the attention is the one sequential step — frame f attends to the window as frames 0 .. f - 1 left it
+    auto run_tmod = [&](int i, f16 *x, hipStream_t st) -> int {
         TMod &tm = h->tm[i];
         const int C = tm.C, P = tP[i];
+        const long T = (long)B * P;
         f16 *a = (f16 *)h->ta.p, *hs = (f16 *)h->th.p, *tq = (f16 *)h->tqkv.p, *ta = (f16 *)h->tatt.p, *hid = (f16 *)h->thid.p, *gg = (f16 *)h->tgg.p;
         int rc;
-        if ((rc = launch_vda_groupnorm(x, tm.gn_g, tm.gn_b, a, (float2 *)h->tpart.p, P, C, 1e-6f, st))) return rc;
-        if ((rc = run_tok(tm.proj_in, a, P, 0, nullptr, hs, st, "vda_proj_in"))) return rc;
+        if ((rc = launch_vda_groupnorm(x, tm.gn_g, tm.gn_b, a, (float2 *)h->tpart.p, B, P, C, 1e-6f, st))) return rc;
+        if ((rc = run_tok(tm.proj_in, a, T, 0, nullptr, hs, st, "vda_proj_in"))) return rc;
         for (TAtt &at : tm.at) {
-            if ((rc = launch_vda_layernorm(hs, at.g, at.b, a, P, C, 1e-5f, st))) return rc;
-            if ((rc = run_tok(at.qkv, a, P, 0, nullptr, tq, st, "vda_qkv"))) return rc;
-            VdaTattnArgs ga;
-            ga.qkv = tq; ga.kc = (f16 *)at.kc.p; ga.vc = (f16 *)at.vc.p; ga.pq = at.pq; ga.pk = at.pk; ga.pv = at.pv; ga.att = ta;
-            ga.P = P; ga.C = C; ga.hd = C / 8; ga.start = h->t_start; ga.idx = t_idx;
-            if ((rc = launch_vda_tattn(ga, st))) return rc;
-            if ((rc = run_tok(at.out, ta, P, 0, hs, hs, st, "vda_to_out"))) return rc;                 // hs += to_out(att)
+            if ((rc = launch_vda_layernorm(hs, at.g, at.b, a, T, C, 1e-5f, st))) return rc;
+            if ((rc = run_tok(at.qkv, a, T, 0, nullptr, tq, st, "vda_qkv"))) return rc;
+            for (int f = 0; f < B; ++f) {
+                VdaTattnArgs ga;
+                ga.qkv = tq + (size_t)f * P * 3 * C; ga.kc = (f16 *)at.kc.p; ga.vc = (f16 *)at.vc.p; ga.pq = at.pq; ga.pk = at.pk; ga.pv = at.pv;
+                ga.att = ta + (size_t)f * P * C; ga.P = P; ga.C = C; ga.hd = C / 8; ga.start = t_st[f]; ga.idx = t_idx[f];
+                if ((rc = launch_vda_tattn(ga, st))) return rc;
+            }
+            if ((rc = run_tok(at.out, ta, T, 0, hs, hs, st, "vda_to_out"))) return rc;                 // hs += to_out(att)
         }
-        if ((rc = launch_vda_layernorm(hs, tm.ff_g, tm.ff_b, a, P, C, 1e-5f, st))) return rc;
-        if ((rc = run_tok(tm.ff1, a, P, 0, nullptr, hid, st, "vda_ff1"))) return rc;
-        if ((rc = launch_vda_geglu(hid, gg, P, 4 * C, st))) return rc;
-        if ((rc = run_tok(tm.ff2, gg, P, 0, hs, hs, st, "vda_ff2"))) return rc;                        // hs += ff2(geglu(ff1(norm(hs))))
-        return run_tok(tm.proj_out, hs, P, 0, x, x, st, "vda_proj_out");                               // x += proj_out(hs)
+        if ((rc = launch_vda_layernorm(hs, tm.ff_g, tm.ff_b, a, T, C, 1e-5f, st))) return rc;
+        if ((rc = run_tok(tm.ff1, a, T, 0, nullptr, hid, st, "vda_ff1"))) return rc;
+        if ((rc = launch_vda_geglu(hid, gg, T, 4 * C, st))) return rc;
+        if ((rc = run_tok(tm.ff2, gg, T, 0, hs, hs, st, "vda_ff2"))) return rc;                        // hs += ff2(geglu(ff1(norm(hs))))
+        return run_tok(tm.proj_out, hs, T, 0, x, x, st, "vda_proj_out");                               // x += proj_out(hs)
     };
 
     {   // patch embedding
@@ -1196,11 +1210,7 @@ extern "C" int nunif_hip_depth_anything_forward(nunif_depth_anything *h, const f
         da_final_kernel<<<blocks(n), 256, 0, s>>>(m3, h->w_final, depth, n, h->max_depth);
         NUNIF_LAUNCH_CHECK();
     }
-    if (h->temporal) {
-        // this frame joined the window at position t_idx; beyond 31 cached frames the oldest leaves (its slot is the next one written)
-        if (h->t_len + 1 > kTLen - 1) h->t_start = (h->t_start + 1) & (kTLen - 1);
-        else ++h->t_len;
-    }
+    if (h->temporal) { h->t_len = t_len_end; h->t_start = t_start_end; }                    // the B frames joined the window
     return NUNIF_HIP_OK;
 }
 

@@ -26,9 +26,12 @@ namespace nunif {
 // 256-block form whose single finalising block then added 256 partials per thread, 50):
 // pass 1: a block of RL x C / 8 threads sums its R rows with 16-byte loads (thread = row lane x 8-channel octet), the row lanes meet
 // in LDS in a fixed order, and the block writes one (sum, sum of squares) per channel
+// (blockIdx.y = the frame of a batch: maps [F][P][C], partials / coefficients [F][kVdaGnBlocks + 1][C])
 __global__ void __launch_bounds__(256) vda_gn_partial_kernel(const f16 *__restrict__ x, float2 *__restrict__ part, int P, int C, int R) {
     __shared__ float2 red[2048];                        // [RL][C], RL * C / 8 <= 256
     const int CL = C >> 3, RL = 256 / CL, tid = threadIdx.x, b = blockIdx.x;
+    x += (long)blockIdx.y * P * C;
+    part += (long)blockIdx.y * (kVdaGnBlocks + 1) * C;
     const int rl = tid / CL, cl = tid - rl * CL;
     const int p0 = b * R, p1 = min(P, p0 + R);
     if (rl < RL) {
@@ -53,10 +56,12 @@ __global__ void __launch_bounds__(256) vda_gn_partial_kernel(const f16 *__restri
 // pass 2 (one block): the NB partials of a channel added in a fixed order (deterministic, no atomics), in double — the group
 // statistics are E[x^2] - mean^2 over P * C / 32 values — then per CHANNEL the affine map of the norm: y = x a_c + b_c with
 // a_c = rstd_g gamma_c, b_c = beta_c - mean_g a_c
-__global__ void vda_gn_finalize_kernel(const float2 *__restrict__ part, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                       float2 *__restrict__ coef, int P, int C, int NB, float eps) {
+__global__ void vda_gn_finalize_kernel(const float2 *part, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                       int P, int C, int NB, float eps) {
     __shared__ double cs[1024], cq[1024];
     const int c = threadIdx.x;
+    part += (long)blockIdx.x * (kVdaGnBlocks + 1) * C;                       // blockIdx.x = frame
+    float2 *coef = const_cast<float2 *>(part) + (long)kVdaGnBlocks * C;       // behind the frame's partials
     double s = 0.0, q = 0.0;
     for (int i = 0; i < NB; ++i) {
         const float2 v = part[(long)i * C + c];
@@ -76,11 +81,13 @@ __global__ void vda_gn_finalize_kernel(const float2 *__restrict__ part, const fl
     coef[c] = make_float2(a, beta[c] - (float)mean * a);
 }
 // pass 3: elementwise, 8 channels per thread
-__global__ void __launch_bounds__(256) vda_gn_apply_kernel(const f16 *__restrict__ x, const float2 *__restrict__ coef, f16 *__restrict__ y,
+__global__ void __launch_bounds__(256) vda_gn_apply_kernel(const f16 *__restrict__ x, const float2 *__restrict__ part, f16 *__restrict__ y,
                                                            long total8, int C8) {
-    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    long id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= total8) return;
     const int o = (int)(id % C8);
+    const float2 *coef = part + ((long)blockIdx.y * (kVdaGnBlocks + 1) + kVdaGnBlocks) * C8 * 8;
+    id += (long)blockIdx.y * total8;
     const f16x8 v = *reinterpret_cast<const f16x8 *>(x + id * 8);
     f16x8 r;
 #pragma unroll
@@ -91,21 +98,21 @@ __global__ void __launch_bounds__(256) vda_gn_apply_kernel(const f16 *__restrict
     *reinterpret_cast<f16x8 *>(y + id * 8) = r;
 }
 
-int launch_vda_groupnorm(const f16 *x, const float *gamma, const float *beta, f16 *y, float2 *part, int P, int C, float eps,
+int launch_vda_groupnorm(const f16 *x, const float *gamma, const float *beta, f16 *y, float2 *part, int frames, int P, int C, float eps,
                          hipStream_t s) {
-    NUNIF_REQUIRE(P > 0 && C % 32 == 0 && C >= 32 && C <= 1024, "vda_groupnorm: %d channels unsupported (a multiple of 32, <= 1024)", C);
+    NUNIF_REQUIRE(frames > 0 && frames <= 65535 && P > 0 && C % 32 == 0 && C >= 32 && C <= 1024,
+                  "vda_groupnorm: %d channels unsupported (a multiple of 32, <= 1024)", C);
     const int RL = 256 / (C / 8);                              // row lanes of a block: ~4 rows per lane
     int NB = std::min(kVdaGnBlocks, (P + 4 * RL - 1) / (4 * RL));
     const int R = (P + NB - 1) / NB;
     NB = (P + R - 1) / R;
-    float2 *coef = part + (size_t)kVdaGnBlocks * C;              // behind the partials (the caller's buffer holds (kVdaGnBlocks + 1) * C)
-    ProfScope ps("vda_groupnorm", s, 0.0, (double)P * C * 6.0);
-    vda_gn_partial_kernel<<<NB, 256, 0, s>>>(x, part, P, C, R);
+    ProfScope ps("vda_groupnorm", s, 0.0, (double)frames * P * C * 6.0);
+    vda_gn_partial_kernel<<<dim3(NB, frames), 256, 0, s>>>(x, part, P, C, R);
     NUNIF_LAUNCH_CHECK();
-    vda_gn_finalize_kernel<<<1, C, 0, s>>>(part, gamma, beta, coef, P, C, NB, eps);
+    vda_gn_finalize_kernel<<<frames, C, 0, s>>>(part, gamma, beta, P, C, NB, eps);
     NUNIF_LAUNCH_CHECK();
     const long total8 = (long)P * (C / 8);
-    vda_gn_apply_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, s>>>(x, coef, y, total8, C / 8);
+    vda_gn_apply_kernel<<<dim3((unsigned)((total8 + 255) / 256), frames), 256, 0, s>>>(x, part, y, total8, C / 8);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }

@@ -110,7 +110,7 @@ int launch_cunet_head(const CunetHeadArgs &g, hipStream_t s);
 
 // ---- the temporal modules of Video-Depth-Anything's head, streaming form (depth_temporal.hip) ----------------------------------------
 constexpr int kVdaGnBlocks = 256;                 // GroupNorm partial-sum blocks: `part` holds (kVdaGnBlocks + 1) * C float2 (the last row: per-channel coefficients)
-int launch_vda_groupnorm(const f16 *x, const float *gamma, const float *beta, f16 *y, float2 *part, int P, int C, float eps, hipStream_t s);
+int launch_vda_groupnorm(const f16 *x, const float *gamma, const float *beta, f16 *y, float2 *part, int frames, int P, int C, float eps, hipStream_t s);   // x, y: [frames][P][C]; part: frames * (kVdaGnBlocks + 1) * C float2
 int launch_vda_layernorm(const f16 *x, const float *gamma, const float *beta, f16 *y, long T, int C, float eps, hipStream_t s);
 int launch_vda_geglu(const f16 *h, f16 *out, long T, int I, hipStream_t s);
 // qkv: this frame's [P][3 C] rows (q0 | K0 | V0; Wq pre-scaled by hd^-1/2 log2 e); kc / vc: [32][P][C] ring caches, logical window

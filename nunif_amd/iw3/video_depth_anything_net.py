@@ -47,3 +47,13 @@ class HipVideoDepthAnythingStreaming(HipDepthAnythingV2):
             raise ValueError(f"infer_video_depth_one takes one CHW frame, got {tuple(frame.shape)}")
         self.frame_id += 1
         return self(frame.unsqueeze(0))
+
+    @torch.inference_mode()
+    def infer_video_depth_batch(self, frames, use_amp=True):
+        """frames: [B, 3, h, w], B CONSECUTIVE frames of the stream -> [B, h, w]: what B calls of ``infer_video_depth_one`` return, in one
+        pass of the engine (encoder, convs and Linears over the B frames at once; only the temporal attention steps frame by frame).
+        Not part of the hub object's interface — ``VideoDepthAnythingStreamingModel.infer`` takes it when the network offers it."""
+        if frames.dim() != 4:
+            raise ValueError(f"infer_video_depth_batch takes BCHW frames, got {tuple(frames.shape)}")
+        self.frame_id += frames.shape[0]
+        return self(frames)

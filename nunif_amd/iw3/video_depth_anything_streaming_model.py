@@ -15,6 +15,8 @@ object with the hub model's streaming interface —
 the same encoder family, no temporal modules) to it as a stand-in so that the whole config-5 path runs on the GPU.
 State is per instance and sequential: shard by scene segment or file across ranks, never by frame.
 """
+import os
+
 import torch
 
 from . import _ops  # noqa: F401
@@ -91,8 +93,12 @@ class VideoDepthAnythingStreamingModel(BaseDepthModel):
             x = x.unsqueeze(0)
         x = batch_preprocess(x.to(self.device), self.model.prep_lower_bound, metric_depth=self.metric_depth,
                              limit_resolution=self.limit_resolution)
-        outputs = [self.model.infer_video_depth_one(frame, use_amp=enable_amp).to(torch.float32) for frame in x]
-        depth = torch.stack(outputs).squeeze(1)          # (B, 1, H, W) -> (B, H, W)
+        if hasattr(self.model, "infer_video_depth_batch") and os.environ.get("NUNIF_VDA_BATCH", "1") != "0":
+            # the engine's streaming network takes the batch as consecutive frames in one pass: the results of the loop below
+            depth = self.model.infer_video_depth_batch(x, use_amp=enable_amp).to(torch.float32)
+        else:
+            outputs = [self.model.infer_video_depth_one(frame, use_amp=enable_amp).to(torch.float32) for frame in x]
+            depth = torch.stack(outputs).squeeze(1)          # (B, 1, H, W) -> (B, H, W)
         depth = postprocess(depth, edge_dilation=edge_dilation, depth_aa=aa, metric_depth=self.metric_depth,
                             force_disparity=self.force_disparity, enable_amp=enable_amp)
         return depth if batch else depth.squeeze(0)

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from nunif_amd import build  # noqa: E402
 
-FILES = ["swin_qkv_attn_r.hip", "swin_block_tail.hip", "swin_block_tail_ws.hip", "conv3_dma.hip", "depth_mlp.hip", "iw3_warp.hip"]
+FILES = ["swin_qkv_attn_r.hip", "swin_block_tail.hip", "swin_block_tail_ws.hip", "conv3_dma.hip", "depth_mlp.hip", "iw3_warp.hip",
+         "cunet_head.hip"]
 
 
 def _asm(fname):
@@ -64,6 +65,12 @@ def test_forward_warp_keeps_two_rows_per_cu(kernels):
     # SIMD whatever the occupancy API says: measured 129 vs 87 us, profiles/r04_fw_trace.txt)
     for name, (body, sg, vg, sp) in _pick(kernels, "forward_warp_kernel"):
         assert vg <= 64 and sg <= 80, (name, vg, sg)
+
+
+def test_cunet_head_keeps_four_workgroups_per_cu(kernels):
+    # 16 x 16 tiles: 37 KiB of LDS = four workgroups of four waves per CU = four waves per SIMD: <= 128 VGPRs
+    for name, (body, sg, vg, sp) in _pick(kernels, "cunet_head_kernel", "ILi16E"):
+        assert vg <= 128 and body.count("v_mfma") == 24, (name, vg)           # 6 pixel groups x 2 n-tiles x 2 k-steps
 
 
 def test_level1_swin_kernels_hold_their_occupancy_and_address_spaces(kernels):

@@ -170,7 +170,7 @@ def test_the_two_temporal_attention_kernels_agree(vda_net, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_hip_streaming_network_resolution_change_and_batch(vda_net):
+def test_hip_streaming_network_resolution_change(vda_net):
     sd, net = vda_net
     net.reset_state()
     for f in clip(4, 3, 126, 154):
@@ -181,13 +181,35 @@ def test_hip_streaming_network_resolution_change_and_batch(vda_net):
     ref = VN.infer_video_depth_one(sd, f2, VN.new_state())
     span = float(ref.max() - ref.min())
     assert psnr(y / span, ref / span) >= 50.0
-    # the engine is a stream: one frame per call
-    with pytest.raises(RuntimeError):
-        net(torch.zeros(2, 3, 70, 98, device="cuda:0"))
 
 
 @pytest.mark.gpu
-def test_streaming_model_wrapper_with_the_temporal_network(vda_net):
+def test_batches_of_consecutive_frames_equal_the_per_frame_stream(vda_net):
+    """``infer_video_depth_batch``: 35 frames as batches of 3 / 1 / 4 / ... (the window fills and slides INSIDE batches) against the
+    same frames one per call — the same arithmetic per token (a GEMM may tile another way at another M: a tolerance, not bits) — and
+    against the oracle."""
+    sd, net = vda_net
+    frames = clip(12, 35, 70, 98)
+    net.reset_state()
+    one = torch.cat([net.infer_video_depth_one(f.to("cuda:0")).cpu() for f in frames])
+    net.reset_state()
+    outs, i = [], 0
+    for n in (3, 1, 4, 3, 3, 5, 3, 3, 2, 3, 3, 2):
+        outs.append(net.infer_video_depth_batch(frames[i:i + n].to("cuda:0")).cpu())
+        i += n
+    assert i == 35
+    bat = torch.cat(outs)
+    span = float(one.max() - one.min())
+    assert bat.shape == one.shape and float((bat - one).abs().max()) < 2e-3 * span, float((bat - one).abs().max()) / span
+    st = VN.new_state()
+    for k, f in enumerate(frames):
+        ref = VN.infer_video_depth_one(sd, f, st)[0]
+        sp = float(ref.max() - ref.min())
+        assert psnr(bat[k] / sp, ref / sp) >= 50.0, k
+
+
+@pytest.mark.gpu
+def test_streaming_model_wrapper_with_the_temporal_network(vda_net, monkeypatch):
     """``VideoDepthAnythingStreamingModel.infer`` (iw3/video_depth_anything_streaming_model.py:77-103) around the temporal network:
     pre-processing, the per-frame loop, post-processing — against the oracle's loop around the oracle's network."""
     from nunif_amd.iw3.video_depth_anything_streaming_model import VideoDepthAnythingStreamingModel
@@ -204,3 +226,8 @@ def test_streaming_model_wrapper_with_the_temporal_network(vda_net):
     assert y.shape == ref.shape
     span = float(ref.max() - ref.min())
     assert psnr(y / span, ref / span) >= 45.0, psnr(y / span, ref / span)
+    # NUNIF_VDA_BATCH=0: the reference's per-frame loop around infer_video_depth_one
+    monkeypatch.setenv("NUNIF_VDA_BATCH", "0")
+    model.reset_state()
+    y1 = model.infer(x.to("cuda:0"), edge_dilation=0).cpu()
+    assert psnr(y1 / span, y / span) >= 55.0

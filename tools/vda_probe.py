@@ -37,6 +37,11 @@ t_da = timed(lambda f: da(f.unsqueeze(0)))
 t_vda = timed(vda.infer_video_depth_one)
 print(f"per-frame ViT-S (B = 1, {h} x {w}): {t_da:.3f} ms/frame;  VDA streaming ViT-S: {t_vda:.3f} ms/frame "
       f"(temporal part {t_vda - t_da:+.3f} ms)")
+for nb in (3, 4, 8):
+    xb = torch.stack([frames[i % 4] for i in range(nb)])
+    t_b = timed(lambda f: vda.infer_video_depth_batch(xb), n=30) / nb
+    t_d = timed(lambda f: da(xb), n=30) / nb
+    print(f"batches of {nb} consecutive frames: VDA streaming {t_b:.3f} ms/frame, per-frame ViT-S {t_d:.3f} ms/frame")
 _hip.profile_read(reset=True)
 _hip.profile_enable(True)
 for i in range(8):
