@@ -1,24 +1,19 @@
 #!/bin/bash
-# call 31: batched streaming forward: tests, probe, config 5 A/B (batch route vs per-frame loop vs per-frame stand-in)
+# call 32: end-of-round evidence at the final HEAD: full GPU suite, round_final (kernel stats, PMC, bench line, smoke), VDA PMC
 cd /root/repo
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_video_depth_anything_net.py tests/test_video_depth_anything.py tests/test_depth_anything.py -m gpu -x -q -s 2>&1 | tail -8 > gpurun_out/r05aa_vda_tests.log
-echo "rc=$?" >> gpurun_out/r05aa_vda_tests.log
-cat gpurun_out/r05aa_vda_tests.log
-timeout 300 python tools/vda_probe.py > gpurun_out/r05aa_vda_probe.txt 2>&1
-head -6 gpurun_out/r05aa_vda_probe.txt
-for leg in batch loop perframe; do
-  unset NUNIF_CONFIG5_PERFRAME NUNIF_VDA_BATCH
-  if [ $leg = perframe ]; then export NUNIF_CONFIG5_PERFRAME=1; fi
-  if [ $leg = loop ]; then export NUNIF_VDA_BATCH=0; fi
-  timeout 600 python - > gpurun_out/r05aa_c5_$leg.json 2> gpurun_out/r05aa_c5_$leg.err <<'PY'
-import json, torch, bench
-rec = bench.config5_record(torch.device("cuda:0"))
-print(json.dumps(rec))
-PY
-  python - <<PY
-import json
-r = json.load(open("gpurun_out/r05aa_c5_$leg.json"))
-print("$leg", r["ms_per_frame"], r["fps"], r.get("depth_net"))
-PY
+REPO=$(pwd); OUT=$REPO/gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r05fin_gpu_suite.log
+echo "suite rc=$?" >> gpurun_out/r05fin_gpu_suite.log
+cat gpurun_out/r05fin_gpu_suite.log
+timeout 1500 bash tools/round_final.sh r05fin
+cd /tmp && export TMPDIR=/tmp
+for ctr in FETCH_SIZE WRITE_SIZE; do
+    d=/tmp/pv_$ctr; rm -rf $d
+    timeout 180 rocprofv3 --pmc $ctr --output-format csv -d $d -o pmc -- python $REPO/tools/vda_pmc_probe.py > "$OUT/r05v_pmc_$ctr.log" 2>&1
+    f=$(find $d -name '*counter_collection.csv' | head -1)
+    [ -n "$f" ] && python $REPO/tools/aggregate_pmc.py "$f" $ctr > "$OUT/r05v_pmc_${ctr}.txt"
 done
+cd $REPO
+grep -h "vda_tattn" gpurun_out/r05v_pmc_*.txt | head
+head -c 600 gpurun_out/r05fin_bench_line.json
