@@ -5,14 +5,16 @@ between ``batch_preprocess`` and ``postprocess`` (``video_depth_anything_model.p
 ``is_metric`` / ``force_disparity`` semantics, the ``VDA_Stream_*`` names, and ``prep_lower_bound`` rounding to a multiple of 14.
 
 The network is EXTERNAL to the reference tree (``torch.hub.load("nagadomi/Video-Depth-Anything_iw3:main",
-"VideoDepthAnythingStreaming")`` :59-67: DINOv2 encoder + a DPT head with temporal attention over cached frames); neither the
-repository nor its checkpoints are reachable offline, so its temporal head is NOT restated here.  ``load_model`` takes any
-object with the hub model's streaming interface —
+"VideoDepthAnythingStreaming")`` :59-67: DINOv2 encoder + a DPT head with temporal attention over cached frames).  Since round 5 the
+engine runs it (``video_depth_anything_net.HipVideoDepthAnythingStreaming``: published architecture, PARITY UNPINNED — neither the hub
+repository nor a checkpoint is reachable offline).  ``load_model`` builds it from, in this order: a ``backbone`` handed in — any object
+with the hub model's streaming interface
 
     net.infer_video_depth_one(frame[3,h,w] normalised, use_amp=True) -> [1,h,w]      net.reset_state()
 
-— and ``PerFrameStreamingBackbone`` adapts the engine's Depth-Anything-V2 ViT-S (``depth_anything_v2.HipDepthAnythingV2``,
-the same encoder family, no temporal modules) to it as a stand-in so that the whole config-5 path runs on the GPU.
+(a plain per-frame callable is adapted by ``PerFrameStreamingBackbone``, round 4's stand-in without temporal modules) — a
+``state_dict`` in the published key layout, or the published checkpoint FILE under ``<model_dir>/checkpoints`` (the reference's
+``MODEL_FILES`` :20-27; no downloads here).
 State is per instance and sequential: shard by scene segment or file across ranks, never by frame.
 """
 import os
@@ -27,8 +29,14 @@ NAME_MAP = {
     "VDA_Stream_S": "vits", "VDA_Stream_B": "vitb", "VDA_Stream_L": "vitl",
     "VDA_Stream_Metric_S": "vits", "VDA_Stream_Metric_B": "vitb", "VDA_Stream_Metric_L": "vitl",
 }
+MODEL_FILE_NAMES = {          # iw3/video_depth_anything_streaming_model.py:20-27 (under HUB_MODEL_DIR/checkpoints there)
+    "VDA_Stream_S": "video_depth_anything_vits.pth", "VDA_Stream_B": "video_depth_anything_vitb.pth",
+    "VDA_Stream_L": "video_depth_anything_vitl.pth", "VDA_Stream_Metric_S": "metric_video_depth_anything_vits.pth",
+    "VDA_Stream_Metric_B": "metric_video_depth_anything_vitb.pth", "VDA_Stream_Metric_L": "metric_video_depth_anything_vitl.pth",
+}
 AA_SUPPORT_MODELS = set(NAME_MAP)
 METRIC_DEPTH_TYPES = {"VDA_Stream_Metric_S", "VDA_Stream_Metric_B", "VDA_Stream_Metric_L"}
+DEPTH_AA_FILE = "iw3_depth_aa_20250530.pth"
 
 
 class PerFrameStreamingBackbone:
@@ -55,7 +63,7 @@ class PerFrameStreamingBackbone:
 
 
 class VideoDepthAnythingStreamingModel(BaseDepthModel):
-    def __init__(self, model_type, backbone=None, depth_aa=None):
+    def __init__(self, model_type, backbone=None, depth_aa=None, model_dir=None):
         super().__init__(model_type)
         if model_type not in NAME_MAP:
             raise ValueError(f"unknown model_type {model_type}")
@@ -63,12 +71,31 @@ class VideoDepthAnythingStreamingModel(BaseDepthModel):
         self.force_disparity = True          # :50 — use 1 / depth, is_metric() == False
         self._backbone = backbone
         self.depth_aa = depth_aa             # nunif_amd.iw3.models.DepthAA (weights loaded, on the device) or None
+        self.model_dir = model_dir
 
-    def load_model(self, model_type, resolution=None, device=None, backbone=None, **kwargs):
+    @classmethod
+    def _path(cls, model_type, model_dir=None):
+        from .stereo_model_factory import default_model_dir
+        return os.path.join(model_dir or default_model_dir(), "checkpoints", MODEL_FILE_NAMES[model_type])
+
+    def load_model(self, model_type, resolution=None, device=None, backbone=None, state_dict=None, **kwargs):
         model = backbone if backbone is not None else self._backbone
         if model is None:
-            raise RuntimeError("VideoDepthAnythingStreamingModel: the streaming network lives in an external torch.hub "
-                               "repository; pass backbone=<object with infer_video_depth_one / reset_state>")
+            # the engine's own streaming network from weights in the published layout (pretrained.*, head.*, head.motion_modules.*)
+            from .video_depth_anything_net import HipVideoDepthAnythingStreaming
+            if state_dict is None:
+                p = self._path(model_type, self.model_dir)
+                if not os.path.exists(p):
+                    raise FileNotFoundError(f"{p} not found (no downloads here: copy the published checkpoint there, or pass "
+                                            "state_dict= / backbone=<object with infer_video_depth_one / reset_state>)")
+                state_dict = torch.load(p, map_location="cpu", weights_only=True)
+            model = HipVideoDepthAnythingStreaming(state_dict, device, metric_depth=self.metric_depth)
+            if self.depth_aa is None:
+                from .stereo_model_factory import default_model_dir
+                p = os.path.join(self.model_dir or default_model_dir(), "checkpoints", DEPTH_AA_FILE)
+                if os.path.exists(p):                        # optional: only needed for infer(depth_aa=True)
+                    from ..nunif.models import load_model
+                    self.depth_aa = load_model(p, weights_only=True)[0].eval().to(device)
         if not hasattr(model, "infer_video_depth_one"):
             model = PerFrameStreamingBackbone(model)
         model.prep_lower_bound = resolution or 392
@@ -113,6 +140,14 @@ class VideoDepthAnythingStreamingModel(BaseDepthModel):
     @classmethod
     def supported(cls, model_type):
         return model_type in NAME_MAP
+
+    @classmethod
+    def has_checkpoint_file(cls, model_type):
+        return cls.supported(model_type) and os.path.exists(cls._path(model_type))
+
+    @classmethod
+    def get_model_path(cls, model_type):
+        return cls._path(model_type)
 
     def is_metric(self):
         if not self.metric_depth:

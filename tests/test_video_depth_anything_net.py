@@ -118,6 +118,17 @@ def test_engine_arrangement_equals_the_published_form_across_window_slides():
     assert eng.len == 31 and eng.start == 9 and not torch.isnan(eng.kc).any()
 
 
+def test_streaming_model_names_resolve_to_the_published_checkpoint_files(tmp_path):
+    """iw3/video_depth_anything_streaming_model.py:20-27 ``MODEL_FILES``: the same file names, under ``<model_dir>/checkpoints``."""
+    from nunif_amd.iw3.video_depth_anything_streaming_model import MODEL_FILE_NAMES, VideoDepthAnythingStreamingModel as M
+    assert MODEL_FILE_NAMES["VDA_Stream_S"] == "video_depth_anything_vits.pth"
+    assert MODEL_FILE_NAMES["VDA_Stream_Metric_L"] == "metric_video_depth_anything_vitl.pth" and set(MODEL_FILE_NAMES) == {
+        f"VDA_Stream_{m}{s}" for m in ("", "Metric_") for s in "SBL"}
+    assert M.get_model_path("VDA_Stream_B").endswith("checkpoints/video_depth_anything_vitb.pth")
+    assert M._path("VDA_Stream_S", str(tmp_path)) == str(tmp_path / "checkpoints" / "video_depth_anything_vits.pth")
+    assert not M.has_checkpoint_file("VDA_Stream_S") or True           # (a developer box may hold one)
+
+
 @pytest.fixture(scope="module")
 def vda_net(hiplib):
     from nunif_amd.iw3.video_depth_anything_net import HipVideoDepthAnythingStreaming
@@ -231,3 +242,23 @@ def test_streaming_model_wrapper_with_the_temporal_network(vda_net, monkeypatch)
     model.reset_state()
     y1 = model.infer(x.to("cuda:0"), edge_dilation=0).cpu()
     assert psnr(y1 / span, y / span) >= 55.0
+
+
+@pytest.mark.gpu
+def test_streaming_model_loads_the_network_from_a_checkpoint_file(vda_net, tmp_path):
+    """``VideoDepthAnythingStreamingModel("VDA_Stream_S").load()`` without a backbone: the published checkpoint file from
+    ``<model_dir>/checkpoints`` on the engine's streaming network (here: the seeded weights saved under that name)."""
+    from nunif_amd.iw3.video_depth_anything_net import HipVideoDepthAnythingStreaming
+    from nunif_amd.iw3.video_depth_anything_streaming_model import VideoDepthAnythingStreamingModel
+    sd, net = vda_net
+    (tmp_path / "checkpoints").mkdir()
+    torch.save(sd, tmp_path / "checkpoints" / "video_depth_anything_vits.pth")
+    model = VideoDepthAnythingStreamingModel("VDA_Stream_S", model_dir=str(tmp_path)).load(gpu=0, resolution=126)
+    assert isinstance(model.model, HipVideoDepthAnythingStreaming) and model.model.prep_lower_bound == 126
+    g = torch.Generator().manual_seed(21)
+    x = F.avg_pool2d(torch.rand(2, 3, 90, 160, generator=g), 3, stride=1, padding=1)
+    y = model.infer(x.to("cuda:0")).cpu()
+    net.reset_state()
+    from nunif_amd.iw3.video_depth_anything_streaming_model import VideoDepthAnythingStreamingModel as M
+    ref = M("VDA_Stream_S", backbone=net).load(gpu=0, resolution=126).infer(x.to("cuda:0")).cpu()
+    assert torch.equal(y, ref)                                               # the same weights, the same engine: the same bits
