@@ -11,6 +11,8 @@
 // Workgroup = 16 x 16 (or 16 x 32) outputs = 18 x 18 (18 x 34) input pixels (halo re-reads 1.27x / 1.19x, neighbours' — L2), 4 waves; T
 // is kept channel-major [28][336 / 624] so that phase-1 writes (16 pixels x 4 lane groups) and phase-2 reads (consecutive pixels) are
 // conflict-free.
+#include <cstdlib>
+
 #include "swin_kernels.h"
 
 namespace nunif {
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(256) cunet_head_kernel(CunetHeadArgs g) {
 }
 
 bool cunet_head_supported(const CunetHeadArgs &g) {
-    static const bool off = getenv("NUNIF_CUNET_HEAD") && atoi(getenv("NUNIF_CUNET_HEAD")) == 0;
+    const bool off = getenv("NUNIF_CUNET_HEAD") && atoi(getenv("NUNIF_CUNET_HEAD")) == 0;          // read per call (tests A/B it)
     return !off && g.w && g.a && g.out32 && g.B > 0 && g.Ho == g.Hi - 2 && g.Wo == g.Wi - 2 && g.Ho > 0 && g.Wo > 0 && g.B <= 65535 &&
            (g.Ho + 15) / 16 <= 65535;
 }
@@ -111,7 +113,7 @@ int launch_cunet_head(const CunetHeadArgs &g, hipStream_t s) {
     NUNIF_REQUIRE(cunet_head_supported(g), "cunet_head: unsupported shape");
     // 16 x 16 tiles: 37 KiB of LDS, four workgroups per CU; NUNIF_CUNET_HEAD_TW=32: 16 x 32 tiles (68 KiB, two per CU; halo 1.19x
     // instead of 1.27x)
-    static const int tw = getenv("NUNIF_CUNET_HEAD_TW") && atoi(getenv("NUNIF_CUNET_HEAD_TW")) == 32 ? 32 : 16;
+    const int tw = getenv("NUNIF_CUNET_HEAD_TW") && atoi(getenv("NUNIF_CUNET_HEAD_TW")) == 32 ? 32 : 16;
     const dim3 grid((g.Wo + tw - 1) / tw, (g.Ho + 15) / 16, g.B);
     // per output pixel: 2 * 576 * 3 flops; bytes: the 64-channel input once + 12 output bytes (+ 12 of the added map)
     ProfScope ps("cunet_head_kernel", s, 2.0 * 576 * 3 * g.B * (double)g.Ho * g.Wo,

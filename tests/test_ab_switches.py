@@ -1,0 +1,53 @@
+"""The A/B switches of the library: every ``NUNIF_*`` variable read once per process in ``nunif_amd/csrc`` selects between two forms of
+a kernel or of a launch sequence that were both kept for same-box measurements.  The forms that no other test toggles
+in-process are exercised here: ``tools/switch_probe.py`` runs the same small workloads through every engine in a subprocess, once with
+the defaults and once with every such switch on its OTHER value, and the outputs must agree (the forms differ in summation order or in
+where an fp16 rounding falls, never in what they compute)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import psnr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ALTERNATES = {
+    "NUNIF_PATCHUP": "0", "NUNIF_PATCHDOWN": "0",                   # swin PatchUp / PatchDown on gemm_kernel / gemm_res_kernel (round 4)
+    "NUNIF_STEM_ROWS": "2", "NUNIF_STEM_ROWS_CUNET": "3",           # rows per wave of the fused stems
+    "NUNIF_STITCH_TOGETHER": "0", "NUNIF_STITCH_FAST": "0",         # the stitcher's per-channel form, without the single-tile fast path
+    "NUNIF_SWIN_GELU32": "1",                                       # fp32-polynomial GELU in every swin tail (default: the 1x net only)
+    "NUNIF_CUNET_SE_FUSE": "0", "NUNIF_CUNET_SLICED": "0", "NUNIF_CUNET_UP": "0",
+    "NUNIF_CONV3_DMA_MIN": "1000000",                               # the LDS-staged conv instead of the LDS-DMA conv wherever both apply
+    "NUNIF_DA_OUTCONV_FIRST": "0", "NUNIF_DA_RCU1_BRANCH": "0",     # the reference's op order in the DPT head, RCU1 inside the head
+    "NUNIF_LI_CONV_SLICES": "0",
+    "NUNIF_PROF_TAGS": "1",                                         # profiler class names only
+}
+SECOND = {"NUNIF_STITCH_VEC8": "1", "NUNIF_STITCH_BS": "128"}       # (the 8-pixel stitcher form and another block size)
+
+
+def _run(path, env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), path], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    return torch.load(path, weights_only=True)
+
+
+@pytest.mark.gpu
+def test_every_process_level_switch_computes_the_same_thing(hiplib, tmp_path):
+    base = _run(str(tmp_path / "base.pt"), {})
+    alt = _run(str(tmp_path / "alt.pt"), ALTERNATES)
+    alt2 = _run(str(tmp_path / "alt2.pt"), SECOND)
+    assert set(base) == set(alt) == set(alt2)
+    for k in base:
+        a, b, c = base[k], alt[k], alt2[k]
+        span = float(a.max() - a.min())
+        assert torch.isfinite(b).all() and span > 1e-3, k
+        # image-valued outputs in [0, 1] / depth maps on their own range: >= 50 dB like every engine-vs-oracle test
+        assert psnr(a / span, b / span) >= 50.0, (k, psnr(a / span, b / span))
+        # the stitcher forms are bit-exact replays of the same fp32 recurrence; nothing else changes under SECOND
+        assert torch.equal(a, c), (k, float((a - c).abs().max()))
