@@ -170,17 +170,18 @@ def test_dma_staged_conv_is_bit_identical_to_the_register_staged_one(hiplib, mon
         d = m(x).clone()
         monkeypatch.setenv("NUNIF_CUNET_DOWN_GEMM", "1")
         assert psnr(b, d) >= 57.0, psnr(b, d)
-        # the 64 -> 3 image heads in tap-scatter form (cunet_head.hip) against the conv form: the same 576 fp32 products per output,
-        # channels summed first (~1e-6 on unet1's head, whose output then runs through unet2's fp16 layers: measured 3e-4 at worst);
-        # its two tile shapes compute every output in the same order
+        # the 64 -> 3 image heads in tap-scatter form (cunet_head.hip) against the conv form, everything else as it is now (K halves on):
+        # the same 576 fp32 products per output, channels summed first — ~1e-6 on unet1's head, whose output then runs through unet2's
+        # fp16 layers; its two tile shapes compute every output in the same order
+        b2 = m(x).clone()
         monkeypatch.setenv("NUNIF_CUNET_HEAD", "0")
         e = m(x).clone()
         monkeypatch.setenv("NUNIF_CUNET_HEAD", "1")
-        assert psnr(b, e) >= 70.0 and float((b - e).abs().max()) < 2e-3, (psnr(b, e), float((b - e).abs().max()))
+        assert psnr(b2, e) >= 59.0 and float((b2 - e).abs().max()) < 2e-3, (psnr(b2, e), float((b2 - e).abs().max()))   # (psnr() saturates at 60 dB)
         monkeypatch.setenv("NUNIF_CUNET_HEAD_TW", "32")
         f32 = m(x).clone()
         monkeypatch.delenv("NUNIF_CUNET_HEAD_TW")
-        assert torch.equal(b, f32)
+        assert torch.equal(b2, f32), float((b2 - f32).abs().max())
     net = HipDepthAnythingV2(ODA.random_state_dict(601), "cuda:0")
     xd = torch.stack([synth_image(90 + i, 3, 392, 686) for i in range(4)]).to("cuda:0") * 2 - 1
     monkeypatch.setenv("NUNIF_CONV3_DMA", "0")
