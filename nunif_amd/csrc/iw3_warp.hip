@@ -17,6 +17,8 @@
 // HBM traffic: read rgb + depth once, write each eye once (40 B / pixel for both eyes).
 // This file is compiled with -ffp-contract=off: the arithmetic below mirrors the reference's separately rounded
 // fp32 operations so that indices, masks and pixels are bit-identical for identical inputs.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace nunif {
@@ -55,16 +57,28 @@ constexpr int kMaxTries = 100;
 // 1080p frames = 4 % of HBM; 238 us with 1024).  Staging the source row in LDS instead was measured SLOWER (314 us):
 // 101 KiB of LDS per row halves the resident workgroups.
 constexpr int kWarpThreads = 1024;
+constexpr int kPairIters = 2;          // element pairs per thread in the window passes: rows up to 4 096 pixels (wider: the per-element form)
 
-__global__ void __launch_bounds__(1024) forward_warp_kernel(FwdWarpArgs a) {
+// Round 5: the kernel is INSTRUCTION-bound, not barrier- or latency-bound — a persistent form that prefetches the next row's depth
+// values and warms L2 with its colour lines measured 89.0 vs 85.7 us, the 64-wide window in 2 passes of 8 reads (four barriers
+// fewer per eye) 93.2, both 111 (profiles/r05ae_fw_forms.txt): every form with more instructions is slower.  DIET removes some:
+// the ceil weight of every source is kept in LDS by the splat (over the idx2 row, which is dead until shift_fill), so that the combine
+// reads two floats instead of evaluating bilinear_target twice more per destination; the window passes read a clamped index (min /
+// max are idempotent: a repeated element of the window changes nothing) instead of branching around the row's end.
+// (<= 64 VGPRs and <= 80 SGPRs keep two rows = 8 waves per SIMD resident.  The compiler reports "Occupancy: 8" up to 96 SGPRs, the
+//  hardware does not deliver it: the same code at 86 SGPRs measured 103-109 us against 70, profiles/r05ag_fw_pairs.txt; round 4 saw
+//  the same at 102)
+template <bool DIET>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) forward_warp_kernel(FwdWarpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = a.W, pad = a.pad, Wp = W + 2 * pad;
     unsigned long long *kf = reinterpret_cast<unsigned long long *>(smem);   // [Wp] floor winners
     unsigned long long *kc = kf + Wp;                                        // [Wp] ceil winners
     float *img = reinterpret_cast<float *>(kc + Wp);                         // [3][W]
     float *idx = img + 3 * W;                                                // [W] warped x index
-    float *idx2 = idx + W;                                                   // [W] after shift_fill
-    float *dl = idx2 + W;                                                    // [W] the depth row (read once, both eyes)
+    float *dl = idx + W;                                                     // [W] the depth row (read once, both eyes)
+    float *idx2 = dl + W;                                                    // [Wp] after shift_fill ([W] used); before it: the sources' ceil weights
+    float *cws = idx2;                                                       // [Wp] ceil weight of source column xs (DIET)
     const int row = blockIdx.x;                  // b*H + y
     const int b = row / a.H, y = row - b * a.H;
     const float *drow = a.depth + (long)row * W;
@@ -86,6 +100,7 @@ __global__ void __launch_bounds__(1024) forward_warp_kernel(FwdWarpArgs a) {
             const unsigned long long key = ((unsigned long long)order_key(d) << 32) | (unsigned int)(xs + 1);
             atomicMax(&kf[fl], key);
             atomicMax(&kc[ce], key);
+            if constexpr (DIET) cws[xs] = cw;
         }
         __syncthreads();
         // ---- combine the two winners of every destination inside the un-padded region -----------------------------------
@@ -96,16 +111,24 @@ __global__ void __launch_bounds__(1024) forward_warp_kernel(FwdWarpArgs a) {
             float fwt = 0.f, cwt = 0.f, fv[4] = {-1.f, -1.f, -1.f, -1.f}, cv[4] = {-1.f, -1.f, -1.f, -1.f};
             if (sf >= 0) {
                 const int sx = min(max(sf - pad, 0), W - 1);
-                int fl, ce; float fw, cw;
-                bilinear_target(dl[sx], sgn, a.shift_size, a.shift_conv, sf, Wp, fl, ce, fw, cw);
-                fwt = fw;
+                if constexpr (DIET) {
+                    fwt = 1.0f - cws[sf];                               // bilinear_target: fw = 1.0f - cw
+                } else {
+                    int fl, ce; float fw, cw;
+                    bilinear_target(dl[sx], sgn, a.shift_size, a.shift_conv, sf, Wp, fl, ce, fw, cw);
+                    fwt = fw;
+                }
                 fv[0] = crow[sx]; fv[1] = crow[cplane + sx]; fv[2] = crow[2 * cplane + sx]; fv[3] = (float)sf;
             }
             if (sc >= 0) {
                 const int sx = min(max(sc - pad, 0), W - 1);
-                int fl, ce; float fw, cw;
-                bilinear_target(dl[sx], sgn, a.shift_size, a.shift_conv, sc, Wp, fl, ce, fw, cw);
-                cwt = cw;
+                if constexpr (DIET) {
+                    cwt = cws[sc];
+                } else {
+                    int fl, ce; float fw, cw;
+                    bilinear_target(dl[sx], sgn, a.shift_size, a.shift_conv, sc, Wp, fl, ce, fw, cw);
+                    cwt = cw;
+                }
                 cv[0] = crow[sx]; cv[1] = crow[cplane + sx]; cv[2] = crow[2 * cplane + sx]; cv[3] = (float)sc;
             }
             const float wsum = fwt + cwt;
@@ -138,17 +161,81 @@ __global__ void __launch_bounds__(1024) forward_warp_kernel(FwdWarpArgs a) {
         // per pixel was 100 LDS reads per pixel per eye and ~85 % of this kernel; min / max are exact in any order, so
         // the window is covered by two overlapping power-of-two windows built by doubling (a sparse table's top row):
         // w64[j] = op over 64 elements from j, result = op(w64[j], w64[j +- (kMaxTries + 1 - 64)]) — 6 passes of 2 reads.
-        {
-            static_assert(kMaxTries + 1 > 64 && kMaxTries + 1 <= 128, "window = 64 + remainder");
-            constexpr int kRem = kMaxTries + 1 - 64;
+        static_assert(kMaxTries + 1 > 64 && kMaxTries + 1 <= 128, "window = 64 + remainder");
+        constexpr int kRem = kMaxTries + 1 - 64;
+        if (DIET && W >= 128 && (W & 1) == 0 && W <= 2 * kPairIters * kWarpThreads) {
+            // PAIRS (round 5).  A thread owns the adjacent elements (j0, j0 + 1), j0 = 2 t (+ 2 048 for rows beyond 2 048 pixels), through
+            // all passes: its own values stay in registers, the partner pair is ONE 8-byte LDS read (j0 + st is even from the second
+            // pass on) and the result one 8-byte write — ~5 instructions per pass and pair where the element-per-thread form spends ~10
+            // per element.  The level arrays carry a 40-element apron on the side the window looks at, filled once: beyond the row's
+            // end every level equals idx2[W - 1] (left eye; idx2[0] before the start for the right eye), which lies inside every window
+            // that reaches that far.
+            constexpr int kApron = 40;                                    // >= 32 + 1 and >= kRem + 1
+            float *t0 = reinterpret_cast<float *>(kf) + kApron, *t1 = reinterpret_cast<float *>(kc) + kApron;   // the keys are dead until the next eye
+            if (tid < kApron) {
+                const float e = eye == 0 ? idx2[W - 1] : idx2[0];
+                const int q = eye == 0 ? W + tid : -1 - tid;
+                t0[q] = e;
+                t1[q] = e;
+            }
+            float a0[kPairIters], a1[kPairIters], o0[kPairIters], o1[kPairIters];
+#pragma unroll
+            for (int it = 0; it < kPairIters; ++it) {
+                const int j0 = 2 * tid + it * 2 * kWarpThreads;
+                a0[it] = a1[it] = o0[it] = o1[it] = 0.f;
+                if (j0 < W) {
+                    const float2 own = *reinterpret_cast<const float2 *>(idx2 + j0);
+                    o0[it] = own.x; o1[it] = own.y;
+                    if (eye == 0) { a0[it] = fminf(own.x, own.y); a1[it] = fminf(own.y, idx2[min(j0 + 2, W - 1)]); }
+                    else { a1[it] = fmaxf(own.y, own.x); a0[it] = fmaxf(own.x, idx2[max(j0 - 1, 0)]); }
+                    *reinterpret_cast<float2 *>(t0 + j0) = make_float2(a0[it], a1[it]);
+                }
+            }
+            __syncthreads();
+            const float *src = t0;
+            float *dst = t1;
+            for (int st = 2; st <= 32; st <<= 1) {
+#pragma unroll
+                for (int it = 0; it < kPairIters; ++it) {
+                    const int j0 = 2 * tid + it * 2 * kWarpThreads;
+                    if (j0 < W) {
+                        const float2 n = *reinterpret_cast<const float2 *>(src + (eye == 0 ? j0 + st : j0 - st));
+                        if (eye == 0) { a0[it] = fminf(a0[it], n.x); a1[it] = fminf(a1[it], n.y); }
+                        else { a0[it] = fmaxf(a0[it], n.x); a1[it] = fmaxf(a1[it], n.y); }
+                        *reinterpret_cast<float2 *>(dst + j0) = make_float2(a0[it], a1[it]);
+                    }
+                }
+                __syncthreads();
+                float *nd = const_cast<float *>(src);
+                src = dst;
+                dst = nd;
+            }
+#pragma unroll
+            for (int it = 0; it < kPairIters; ++it) {
+                const int j0 = 2 * tid + it * 2 * kWarpThreads;
+                if (j0 < W) {
+                    float m0, m1;
+                    if (eye == 0) { m0 = fminf(a0[it], src[j0 + kRem]); m1 = fminf(a1[it], src[j0 + 1 + kRem]); }
+                    else { m0 = fmaxf(a0[it], src[j0 - kRem]); m1 = fmaxf(a1[it], src[j0 + 1 - kRem]); }
+                    if (m0 != o0[it]) { img[j0] = -2.f; img[W + j0] = -2.f; img[2 * W + j0] = -2.f; }
+                    if (m1 != o1[it]) { img[j0 + 1] = -2.f; img[W + j0 + 1] = -2.f; img[2 * W + j0 + 1] = -2.f; }
+                }
+            }
+        } else {
             float *t0 = reinterpret_cast<float *>(kf), *t1 = t0 + W;      // the z-test keys are dead until the next eye
             const float *src = idx2;
             float *dst = t0;
             for (int st = 1; st <= 32; st <<= 1) {
                 for (int j = tid; j < W; j += kWarpThreads) {
                     float v = src[j];
-                    if (eye == 0) { if (j + st < W) v = fminf(v, src[j + st]); }
-                    else { if (j - st >= 0) v = fmaxf(v, src[j - st]); }
+                    if constexpr (DIET) {
+                        // beyond the row's end the clamped index repeats an element of this window: min / max do not change
+                        if (eye == 0) v = fminf(v, src[min(j + st, W - 1)]);
+                        else v = fmaxf(v, src[max(j - st, 0)]);
+                    } else {
+                        if (eye == 0) { if (j + st < W) v = fminf(v, src[j + st]); }
+                        else { if (j - st >= 0) v = fmaxf(v, src[j - st]); }
+                    }
                     dst[j] = v;
                 }
                 __syncthreads();
@@ -158,8 +245,13 @@ __global__ void __launch_bounds__(1024) forward_warp_kernel(FwdWarpArgs a) {
             for (int j = tid; j < W; j += kWarpThreads) {
                 const float v0 = idx2[j];
                 float m = src[j];
-                if (eye == 0) { if (j + kRem < W) m = fminf(m, src[j + kRem]); }
-                else { if (j - kRem >= 0) m = fmaxf(m, src[j - kRem]); }
+                if constexpr (DIET) {
+                    if (eye == 0) m = fminf(m, src[min(j + kRem, W - 1)]);
+                    else m = fmaxf(m, src[max(j - kRem, 0)]);
+                } else {
+                    if (eye == 0) { if (j + kRem < W) m = fminf(m, src[j + kRem]); }
+                    else { if (j - kRem >= 0) m = fmaxf(m, src[j - kRem]); }
+                }
                 if (m != v0) { img[j] = -2.f; img[W + j] = -2.f; img[2 * W + j] = -2.f; }
             }
         }
@@ -292,19 +384,24 @@ extern "C" int nunif_hip_forward_warp(const float *c, const float *depth, float 
     a.shift_size = (float)shift_size;
     a.shift_conv = (float)(shift_size * p->convergence);
     const long Wp = (long)p->W + 2 * pad;
-    const size_t smem = (size_t)Wp * 16 + (size_t)p->W * 6 * sizeof(float);
+    const size_t smem = (size_t)Wp * 16 + (size_t)p->W * 5 * sizeof(float) + (size_t)Wp * sizeof(float);
     NUNIF_REQUIRE(smem <= 160 * 1024, "forward_warp: row of %d (+2*%d pad) does not fit LDS", p->W, pad);
     hipStream_t s = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)forward_warp_kernel,
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)forward_warp_kernel<true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)forward_warp_kernel<false>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const double px = (double)p->B * p->H * p->W;
     const int eyes = (a.out[0] ? 1 : 0) + (a.out[1] ? 1 : 0);
     ProfScope ps("forward_warp", s, 0.0, px * (16.0 + 12.0 * eyes));
-    forward_warp_kernel<<<p->B * p->H, kWarpThreads, smem, s>>>(a);
+    // NUNIF_FW_DIET=0: round 4's instruction stream (A/B runs; the results are the same bits)
+    static const bool diet = !(getenv("NUNIF_FW_DIET") && atoi(getenv("NUNIF_FW_DIET")) == 0);
+    if (diet) forward_warp_kernel<true><<<p->B * p->H, kWarpThreads, smem, s>>>(a);
+    else forward_warp_kernel<false><<<p->B * p->H, kWarpThreads, smem, s>>>(a);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }

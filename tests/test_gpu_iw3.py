@@ -44,7 +44,11 @@ CASES = [(2, 64, 96, "edges", 2.0, 0.5, True, "both", True), (1, 80, 120, "edges
          (1, 80, 120, "smooth_edges", 5.0, 0.3, False, "both", True), (1, 60, 100, "ramp", 4.0, 0.0, True, "both", True),
          (1, 60, 100, "const", 4.0, 1.0, True, "both", True), (1, 64, 96, "edges", 3.0, 0.5, True, "right", True),
          (1, 64, 96, "edges", 3.0, 0.5, False, "left", True), (1, 40, 400, "edges", 40.0, 0.5, True, "both", True),
-         (1, 3, 7, "edges", 30.0, 0.5, True, "both", True)]
+         (1, 3, 7, "edges", 30.0, 0.5, True, "both", True),
+         # the pair-wise window passes of round 5: the smallest even row that takes them, an odd row (per-element form), a row beyond
+         # 2 048 pixels (second pair per thread) and a 4K row (one row per CU)
+         (1, 4, 128, "edges", 8.0, 0.5, True, "both", True), (1, 4, 131, "edges", 8.0, 0.5, True, "both", True),
+         (1, 3, 2200, "edges", 2.0, 0.5, True, "both", True), (1, 2, 3840, "smooth_edges", 1.0, 0.5, True, "both", True)]
 
 
 @pytest.mark.parametrize("b,h,w,kind,div,conv,fill,view,wb", CASES)

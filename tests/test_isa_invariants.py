@@ -61,9 +61,12 @@ def test_no_spills_no_scratch_in_the_dispatched_kernels(kernels):
 
 
 def test_forward_warp_keeps_two_rows_per_cu(kernels):
-    # 1024 threads x 2 workgroups per CU = 8 waves per SIMD: <= 64 VGPRs, and <= 80 SGPRs (above 96 the hardware admits 6 waves per
-    # SIMD whatever the occupancy API says: measured 129 vs 87 us, profiles/r04_fw_trace.txt)
-    for name, (body, sg, vg, sp) in _pick(kernels, "forward_warp_kernel"):
+    # 1024 threads x 2 workgroups per CU = 8 waves per SIMD: <= 64 VGPRs, and <= 80 SGPRs (beyond that the hardware keeps fewer waves
+    # resident whatever the compiler's "Occupancy: 8" says: 129 vs 87 us at 102 SGPRs in round 4, profiles/r04_fw_trace.txt; 103-109 vs
+    # 70 us at 86 in round 5, profiles/r05ag_fw_pairs.txt) — both instantiations (the diet form and round 4's, kept for A/B runs)
+    hits = _pick(kernels, "forward_warp_kernel")
+    assert len(hits) == 2
+    for name, (body, sg, vg, sp) in hits:
         assert vg <= 64 and sg <= 80, (name, vg, sg)
 
 
