@@ -57,7 +57,8 @@ constexpr int kMaxTries = 100;
 // 1080p frames = 4 % of HBM; 238 us with 1024).  Staging the source row in LDS instead was measured SLOWER (314 us):
 // 101 KiB of LDS per row halves the resident workgroups.
 constexpr int kWarpThreads = 1024;
-constexpr int kPairIters = 2;          // element pairs per thread in the window passes: rows up to 4 096 pixels (wider: the per-element form)
+// (element pairs per thread in the window passes = the template parameter PI: 1 for rows up to 2 048 pixels, 2 up to 4 096; wider
+//  rows take the per-element form)
 
 // Round 5: the kernel is INSTRUCTION-bound, not barrier- or latency-bound — a persistent form that prefetches the next row's depth
 // values and warms L2 with its colour lines measured 89.0 vs 85.7 us, the 64-wide window in 2 passes of 8 reads (four barriers
@@ -68,8 +69,9 @@ constexpr int kPairIters = 2;          // element pairs per thread in the window
 // (<= 64 VGPRs and <= 80 SGPRs keep two rows = 8 waves per SIMD resident.  The compiler reports "Occupancy: 8" up to 96 SGPRs, the
 //  hardware does not deliver it: the same code at 86 SGPRs measured 103-109 us against 70, profiles/r05ag_fw_pairs.txt; round 4 saw
 //  the same at 102)
-template <bool DIET>
+template <bool DIET, int PI>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) forward_warp_kernel(FwdWarpArgs a) {
+    constexpr int kPairIters = PI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = a.W, pad = a.pad, Wp = W + 2 * pad;
     unsigned long long *kf = reinterpret_cast<unsigned long long *>(smem);   // [Wp] floor winners
@@ -389,9 +391,11 @@ extern "C" int nunif_hip_forward_warp(const float *c, const float *depth, float 
     hipStream_t s = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)forward_warp_kernel<true>,
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)forward_warp_kernel<true, 1>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)forward_warp_kernel<false>,
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)forward_warp_kernel<true, 2>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)forward_warp_kernel<false, 1>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -400,8 +404,9 @@ extern "C" int nunif_hip_forward_warp(const float *c, const float *depth, float 
     ProfScope ps("forward_warp", s, 0.0, px * (16.0 + 12.0 * eyes));
     // NUNIF_FW_DIET=0: round 4's instruction stream (A/B runs; the results are the same bits)
     static const bool diet = !(getenv("NUNIF_FW_DIET") && atoi(getenv("NUNIF_FW_DIET")) == 0);
-    if (diet) forward_warp_kernel<true><<<p->B * p->H, kWarpThreads, smem, s>>>(a);
-    else forward_warp_kernel<false><<<p->B * p->H, kWarpThreads, smem, s>>>(a);
+    if (diet && p->W <= 2 * kWarpThreads) forward_warp_kernel<true, 1><<<p->B * p->H, kWarpThreads, smem, s>>>(a);
+    else if (diet) forward_warp_kernel<true, 2><<<p->B * p->H, kWarpThreads, smem, s>>>(a);
+    else forward_warp_kernel<false, 1><<<p->B * p->H, kWarpThreads, smem, s>>>(a);
     NUNIF_LAUNCH_CHECK();
     return NUNIF_HIP_OK;
 }

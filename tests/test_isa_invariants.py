@@ -65,7 +65,7 @@ def test_forward_warp_keeps_two_rows_per_cu(kernels):
     # resident whatever the compiler's "Occupancy: 8" says: 129 vs 87 us at 102 SGPRs in round 4, profiles/r04_fw_trace.txt; 103-109 vs
     # 70 us at 86 in round 5, profiles/r05ag_fw_pairs.txt) — both instantiations (the diet form and round 4's, kept for A/B runs)
     hits = _pick(kernels, "forward_warp_kernel")
-    assert len(hits) == 2
+    assert len(hits) == 3                   # <DIET, 1>, <DIET, 2> (rows beyond 2 048 pixels), round 4's form
     for name, (body, sg, vg, sp) in hits:
         assert vg <= 64 and sg <= 80, (name, vg, sg)
 
