@@ -23,6 +23,7 @@ ALTERNATES = {
     "NUNIF_CONV3_DMA_MIN": "1000000",                               # the LDS-staged conv instead of the LDS-DMA conv wherever both apply
     "NUNIF_DA_OUTCONV_FIRST": "0", "NUNIF_DA_RCU1_BRANCH": "0",     # the reference's op order in the DPT head, RCU1 inside the head
     "NUNIF_LI_CONV_SLICES": "0",
+    "NUNIF_FW_DIET": "0",                                           # round 4's instruction stream of the forward warp (the same bits)
     "NUNIF_PROF_TAGS": "1",                                         # profiler class names only
 }
 SECOND = {"NUNIF_STITCH_VEC8": "1", "NUNIF_STITCH_BS": "128"}       # (the 8-pixel stitcher form and another block size)
@@ -49,5 +50,7 @@ def test_every_process_level_switch_computes_the_same_thing(hiplib, tmp_path):
         assert torch.isfinite(b).all() and span > 1e-3, k
         # image-valued outputs in [0, 1] / depth maps on their own range: >= 50 dB like every engine-vs-oracle test
         assert psnr(a / span, b / span) >= 50.0, (k, psnr(a / span, b / span))
+        if k == "forward_fill":
+            assert torch.equal(a, b)                                      # the warp is bit-exact in both forms
         # the stitcher forms are bit-exact replays of the same fp32 recurrence; nothing else changes under SECOND
         assert torch.equal(a, c), (k, float((a - c).abs().max()))

@@ -1,7 +1,6 @@
 #!/bin/bash
-# call 47: the final HEAD: full GPU suite
+# call 48: the switch probe with the forward warp in it
 cd /root/repo
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/r05fin4_gpu_suite.log
-echo "suite rc=$?" >> gpurun_out/r05fin4_gpu_suite.log
-tail -3 gpurun_out/r05fin4_gpu_suite.log
+timeout 300 python -m pytest tests/test_ab_switches.py -m gpu -x -q 2>&1 | tail -12 > gpurun_out/r05fin5_switch_test.log
+cat gpurun_out/r05fin5_switch_test.log | tail -6

@@ -3,7 +3,7 @@
 (``NUNIF_*`` read once per process in ``nunif_amd/csrc``) are exercised by running this under two environments and comparing the
 files (tests/test_ab_switches.py).  Workloads: swin_unet 2x and 1x tiled renders (stem, PatchUp / PatchDown, tails, stitcher),
 cunet and upcunet tile batches (stem, down / up kernels, sliced bottom convs, SE fusion, image heads), the Depth-Anything ViT-S
-(out_conv order, RCU1 branch), light_inpaint_v1 (conv slices)."""
+(out_conv order, RCU1 branch), light_inpaint_v1 (conv slices), the forward warp (its two instruction streams)."""
 import os
 import sys
 
@@ -44,6 +44,10 @@ li = li.to(dev)
 mask = torch.zeros(2, 1, 256, 256, device=dev, dtype=torch.bool)
 mask[:, :, 60:200, 90:120] = True
 out["light_inpaint_v1"] = li.infer(tiles, mask).float().cpu()
+from nunif_amd.iw3.forward_warp import apply_divergence_forward_warp  # noqa: E402
+d = S.synth_depth(5, 2, 256, 256, "smooth_edges").to(dev)
+le, ri = apply_divergence_forward_warp(tiles, d, 4.0, 0.5, method="forward_fill", synthetic_view="both")
+out["forward_fill"] = torch.cat([le, ri], dim=1).float().cpu()
 torch.cuda.synchronize()
 torch.save(out, sys.argv[1])
 print("OK", {k: tuple(v.shape) for k, v in out.items()})
