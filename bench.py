@@ -480,6 +480,30 @@ def cunet_sharded_leg(dist, world, rank, dev, barrier, frames_per_rank=16):
             "value": round(FRAME_H * FRAME_W * frames_per_rank * world / dt / 1e6, 1)}
 
 
+def config5_replicas_leg(dist, world, rank, dev, barrier, record_fn=None):
+    """BASELINE configs[4] at N GPUs.  The stream is sequential — the depth net attends to its previous 31 frames, the inpaint net
+    works on a 12-frame queue — and the reference runs it on one GPU (``multi_gpu_supported`` False,
+    iw3/video_depth_anything_streaming_model.py:129-131): REPLICAS ONLY: every rank runs a stream of its own (another
+    video or scene segment), nothing is exchanged.  ``value`` = N streams' input MPix/s at the SLOWEST rank's time per frame."""
+    import torch
+    barrier()
+    rec = (record_fn or config5_record)(dev)
+    barrier()
+    t = torch.tensor([float(rec["ms_per_frame"])], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    slowest = float(t.item())
+    table = [None] * world
+    dist.all_gather_object(table, {"rank": rank, "ms_per_frame": rec["ms_per_frame"], "frames_in": rec["frames_in"]})
+    if rank != 0:
+        return None
+    h5, w5 = rec["frame"]
+    out = {k: rec[k] for k in ("config", "depth_net", "frame", "unit", "target") if k in rec}
+    out.update({"world": world, "scaling": "replicas (one independent stream per rank, no data-path collective)", "per_rank": table,
+                "ms_per_frame_per_gpu": round(slowest, 2), "fps": round(world * 1e3 / slowest, 1),
+                "value": round(h5 * w5 * world / slowest / 1e3, 1)})
+    return out
+
+
 def scale4x_record(dev):
     import torch
     from nunif_amd.nunif.utils.render import tiled_render
@@ -918,6 +942,10 @@ def main():
                 r_cu = cunet_sharded_leg(dist, world, rank, dev, barrier)
                 if rank == 0:
                     result["cunet"] = r_cu
+            if not args.no_config5:
+                r_c5 = config5_replicas_leg(dist, world, rank, dev, barrier)
+                if rank == 0:
+                    result["config5"] = r_c5
             done.set()
             if rank == 0:
                 if delivered[0] != n_g:

@@ -284,3 +284,37 @@ def test_bench_iw3_leg_at_two_ranks_prints_a_record(tmp_path):
     rec = torch.load(path)
     assert rec["world"] == 2 and rec["frames"] == 16 and rec["frames_delivered"] == 16 and rec["value"] > 0
     assert "stereo_frames_sharded" in rec["config"] and rec["unit"] == "input MPix/s"
+
+
+def _config5_leg_worker(rank, world, port, path):
+    import importlib.util
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    here = os.path.dirname(os.path.abspath(__file__))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(here), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def fake_record(dev):           # what config5_record returns, rank 1 the slower stream
+        ms = 20.0 + 5.0 * rank
+        return {"config": "fake config 5", "depth_net": "vda_streaming_vits", "frame": [2160, 3840], "frames_in": 24, "frames_out": 24,
+                "ms_per_frame": ms, "fps": round(1e3 / ms, 1), "value": 1.0, "unit": "input MPix/s", "target": "t"}
+
+    rec = bench.config5_replicas_leg(dist, world, rank, torch.device("cpu"), dist.barrier, record_fn=fake_record)
+    if rank == 0:
+        torch.save(rec, path)
+    else:
+        assert rec is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_config5_leg_runs_replicas_and_prices_them_at_the_slowest_rank(tmp_path):
+    """``bench.py --gpus N``: config 5 does not shard (temporal depth net, 12-frame inpaint queue; the reference runs it on one GPU) —
+    N independent streams, ``value`` at the slowest rank's time per frame."""
+    path = str(tmp_path / "rec.pt")
+    mp.spawn(_config5_leg_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    rec = torch.load(path)
+    assert rec["world"] == 2 and rec["ms_per_frame_per_gpu"] == 25.0 and rec["fps"] == 80.0
+    assert rec["value"] == round(2160 * 3840 * 2 / 25.0 / 1e3, 1) and rec["scaling"].startswith("replicas")
+    assert [r["rank"] for r in rec["per_rank"]] == [0, 1] and rec["depth_net"] == "vda_streaming_vits"

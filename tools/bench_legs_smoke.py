@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-rank smoke test of bench.py's N > 1 legs on a real GPU: a single-process `nccl` group (world size 1) through
-``iw3_sharded_leg`` and ``cunet_sharded_leg`` with the HIP engine — the code paths the driver's 8-GPU run takes, minus the peers.
+``iw3_sharded_leg``, ``cunet_sharded_leg`` and ``config5_replicas_leg`` with the HIP engine — the code paths the driver's 8-GPU run takes, minus the peers.
     python tools/bench_legs_smoke.py"""
 import json
 import os
@@ -30,6 +30,7 @@ def barrier():
 
 out = {"iw3": bench.iw3_sharded_leg(dist, 1, 0, dev, barrier, frames_per_rank=int(os.environ.get('LEG_FRAMES', '24'))),
        "cunet": bench.cunet_sharded_leg(dist, 1, 0, dev, barrier, frames_per_rank=4),
+       "config5": bench.config5_replicas_leg(dist, 1, 0, dev, barrier),
        "multi_gpu": bench.collect_multi_gpu(dist, 1, 0, 0, dev)}
 print(json.dumps(out))
 dist.destroy_process_group()
