@@ -189,3 +189,22 @@ def test_dma_staged_conv_is_bit_identical_to_the_register_staged_one(hiplib, mon
     monkeypatch.setenv("NUNIF_CONV3_DMA", "1")
     b = net(xd).clone()
     assert torch.isfinite(b).all() and torch.equal(a, b), float((a - b).abs().max())
+
+
+def test_tap_scatter_form_of_the_image_head_is_the_valid_3x3_conv():
+    """``cunet_head_kernel`` (nunif_amd/csrc/cunet_head.hip) in torch: contract the 64 channels first — T[p][3 tap + c] =
+    sum_ci W[c][ci][tap] x[p][ci], one 64 -> 27 Linear per INPUT pixel — then out[y][x][c] = bias[c] + sum_tap T[(y + dy, x + dx)][3 tap + c].
+    The same 576 products per output as Conv2d(64, 3, 3) VALID (waifu2x/models/cunet.py:62,120), summed in another order."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 21, 19, generator=g)
+    w = torch.randn(3, 64, 3, 3, generator=g) * 0.1
+    b = torch.randn(3, generator=g)
+    ref = torch.nn.functional.conv2d(x, w, b)
+    w27 = w.permute(2, 3, 0, 1).reshape(27, 64)                       # row n = 3 tap + c, tap = 3 dy + dx
+    t = torch.einsum("nk,bkhw->bnhw", w27, x)                         # [B, 27, H, W]
+    out = torch.zeros_like(ref)
+    for tap in range(9):
+        dy, dx = divmod(tap, 3)
+        out += t[:, 3 * tap:3 * tap + 3, dy:dy + ref.shape[2], dx:dx + ref.shape[3]]
+    out += b.view(1, 3, 1, 1)
+    assert float((out - ref).abs().max()) < 1e-4
