@@ -24,6 +24,14 @@ namespace nunif {
 
 #define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
+// LDS operands requested one step ahead (round 6): 1 = weight fragments, 2 = qkv biases, 4 = score bias rows
+#ifndef NUNIF_QKV_PF
+#define NUNIF_QKV_PF 3
+#endif
+#ifndef NUNIF_QKV_PF192
+#define NUNIF_QKV_PF192 0
+#endif
+
 // the "real key" column 36 of the bias table carries 1000: padded keys end up 1000 (log2 units) below every real one
 constexpr float kRegionR = 100.0f;     // added where query and key share a shift region
 
@@ -181,6 +189,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     decode(wb, wy, wx, special);
     if (w0 < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
 
+    f16x8 wnx = wl[lane];                  // first weight fragment of the next head (see the head loop)
 #pragma unroll 1
     for (int wi = w0; wi < a.n_windows; wi += wstride) {
         // shift regions of this window (only the last window row / column straddles two regions)
@@ -209,25 +218,48 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
             const int head = pass * HPP + hl;
             const f16x8 *wh = wl + (hl * FPH) * 64 + lane;
             // ---- q, k (channels x tokens) and v (tokens x channels: operands swapped) of this head ----------------
+            // Round 6: every LDS operand is requested one step before the MFMAs that consume it (weight fragment f + 1 and the
+            // next part's bias behind the MFMAs of fragment f; the first fragment of the NEXT head — carried in wnx across the
+            // head and the window loop — behind the last): the round-5 form issued each ds_read directly in front of its
+            // s_waitcnt lgkmcnt(0), 18 exposed LDS round trips per head and wave (31 % of the wave cycles in s_waitcnt,
+            // profiles/r05b_sq.txt SQ_WAIT_ANY).
+            constexpr int PF = C == 96 ? NUNIF_QKV_PF : NUNIF_QKV_PF192;
             f16x4 qt4[NTH][3], kt4[NTH][3], vt4[NTH][3];
+            f16x8 wq2[2];
+            wq2[0] = (PF & 1) ? wnx : wh[0];
+            f32x4 bnx = *reinterpret_cast<const f32x4 *>(bl + head * HD + 4 * grp);
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
 #pragma unroll
                 for (int nt = 0; nt < NTH; ++nt) {
                     const int ch0 = part * C + head * HD + nt * 16;
+                    const int fidx = (part * NTH + nt) * KS;
                     f32x4 acc[3];
-                    if (part == 2) {
-                        const float bv = bl[ch0 + r16];
-#pragma unroll
-                        for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){bv, bv, bv, bv};
-                    } else {
-                        const f32x4 bb = *reinterpret_cast<const f32x4 *>(bl + ch0 + 4 * grp);
-#pragma unroll
-                        for (int mt = 0; mt < 3; ++mt) acc[mt] = bb;
+                    if constexpr (!(PF & 2)) {
+                        if (part == 2) { const float bv = bl[ch0 + r16]; bnx = (f32x4){bv, bv, bv, bv}; }
+                        else bnx = *reinterpret_cast<const f32x4 *>(bl + ch0 + 4 * grp);
                     }
 #pragma unroll
+                    for (int mt = 0; mt < 3; ++mt) acc[mt] = bnx;
+                    // bias of the next output tile: parts 0 / 1 four channels per lane group, part 2 (operands swapped) one per column
+                    if constexpr ((PF & 2) != 0) {
+                        const int nf = part * NTH + nt + 1;
+                        if (nf < 3 * NTH) {
+                            const int np = nf / NTH, nn = nf % NTH;
+                            const int nch0 = np * C + head * HD + nn * 16;
+                            if (np == 2) { const float bv = bl[nch0 + r16]; bnx = (f32x4){bv, bv, bv, bv}; }
+                            else bnx = *reinterpret_cast<const f32x4 *>(bl + nch0 + 4 * grp);
+                        }
+                    }
+                    (void)ch0;
+#pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
-                        const f16x8 w = wh[((part * NTH + nt) * KS + ks) * 64];
+                        const int f = fidx + ks;
+                        // the fragment after the head's last one is the next head's first (the next window's first after the last head)
+                        if constexpr ((PF & 1) != 0)
+                            wq2[(f + 1) & 1] = (f + 1 < FPH) ? wh[(f + 1) * 64] : (hl + 1 < HPP ? wh[FPH * 64] : wl[lane]);
+                        else wq2[f & 1] = wh[f * 64];
+                        const f16x8 w = wq2[f & 1];
 #pragma unroll
                         for (int mt = 0; mt < 3; ++mt)
                             acc[mt] = part == 2 ? MFMA_16x16x32(xf[mt][ks], w, acc[mt]) : MFMA_16x16x32(w, xf[mt][ks], acc[mt]);
@@ -239,16 +271,27 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     }
                 }
             }
+            if constexpr ((PF & 1) != 0) wnx = wq2[FPH & 1];
+            f32x4 sb[3];                                   // score accumulators' initial values (bias rows) of the coming query tile
+            if constexpr ((PF & 4) != 0) {
+                const float *brow = bt32 + (hl * 36 + tokc[0]) * kBiasStride + 4 * grp;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) sb[kt] = *reinterpret_cast<const f32x4 *>(brow + 16 * kt);
+            }
 
             // ---- attention of this head: 3 q tiles x 3 key tiles ---------------------------------------------------
 #pragma unroll
             for (int qt = 0; qt < 3; ++qt) {
                 f32x4 s[3];
                 {
-                    const float *brow = bt32 + (hl * 36 + tokc[qt]) * kBiasStride + 4 * grp;
+                    if constexpr (!(PF & 4)) {
+                        const float *brow = bt32 + (hl * 36 + tokc[qt]) * kBiasStride + 4 * grp;
+#pragma unroll
+                        for (int kt = 0; kt < 3; ++kt) sb[kt] = *reinterpret_cast<const f32x4 *>(brow + 16 * kt);
+                    }
 #pragma unroll
                     for (int kt = 0; kt < 3; ++kt) {
-                        f32x4 acc = *reinterpret_cast<const f32x4 *>(brow + 16 * kt);
+                        f32x4 acc = sb[kt];
                         if constexpr (HD == 16) {
                             acc = MFMA_16x16x32(cat8r(kt4[0][kt], rkr[kt]), cat8r(qt4[0][qt], rqr[qt]), acc);
                         } else {
@@ -256,6 +299,11 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                             if (special) acc = MFMA_16x16x32(cat8r(rkr[kt], zero4), cat8r(rqr[qt], zero4), acc);
                         }
                         s[kt] = acc;
+                    }
+                    if ((PF & 4) && qt + 1 < 3) {           // the next query tile's bias rows travel behind this tile's softmax
+                        const float *brow = bt32 + (hl * 36 + tokc[qt + 1]) * kBiasStride + 4 * grp;
+#pragma unroll
+                        for (int kt = 0; kt < 3; ++kt) sb[kt] = *reinterpret_cast<const f32x4 *>(brow + 16 * kt);
                     }
                 }
                 // 9 real keys per lane: tiles 0 and 1 whole, register 0 of tile 2 (key 32 + grp); registers 1-3 of tile 2 are padding

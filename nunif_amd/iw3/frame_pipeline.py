@@ -512,7 +512,13 @@ class ShardedStereoStream:
         self.arrived, self.emit_next = {}, 0
         self._pending = []                 # rounds whose (min, max) table is still on its way to the host (ROCm devices)
         self._pinned, self._pin_i = [], 0
-        self._lag = int(os.environ.get("NUNIF_SHARD_LAG", "1"))      # rounds between queueing a depth batch and replaying it (0: A/B runs)
+        # rounds between queueing a depth batch and replaying it (0: A/B runs).  lag + 1 tables are in flight and lag + 2 pinned
+        # buffers rotate, so the value is bounded: anything outside [0, 4] (or not a number) is the default
+        try:
+            lag = int(os.environ.get("NUNIF_SHARD_LAG", "1"))
+        except ValueError:
+            lag = 1
+        self._lag = lag if 0 <= lag <= 4 else 1
 
     # -- the replayed recurrence ---------------------------------------------------------------------------------------------
     def _assign(self, results):
@@ -585,9 +591,12 @@ class ShardedStereoStream:
             # depth network it has just queued — it replays round r - 1 (long finished on the device) and queues those frames' stereo
             # stage while the device runs round r.  (Consumed in the same call, every round cost a host synchronisation with the GPU
             # idle during the ~100 launches of the next forward: 0.69-0.82 instead of ~0.55 ms per 1080p frame on one GPU.)
-            if not self._pinned or self._pinned[0].shape != table.shape:      # three pinned tables, reused in turn (two are in flight at most)
-                self._pinned = [torch.empty(table.shape, dtype=table.dtype, pin_memory=True) for _ in range(3)]
-            host = self._pinned[self._pin_i % 3]
+            n_pin = self._lag + 2                                             # lag + 1 in flight at most, one being filled
+            if len(self._pinned) != n_pin or self._pinned[0].shape != table.shape:
+                while self._pending:                                         # a shape change (the last, short round) first drains
+                    self._consume(self._pending.pop(0))
+                self._pinned = [torch.empty(table.shape, dtype=table.dtype, pin_memory=True) for _ in range(n_pin)]
+            host = self._pinned[self._pin_i % n_pin]
             self._pin_i += 1
             host.copy_(table, non_blocking=True)
             ev = torch.cuda.Event()
@@ -621,6 +630,8 @@ class ShardedStereoStream:
         if not fresh:
             return []
         if self.world == 1:
+            for i in fresh:
+                del self.owner[i], self.pts[i]
             return [self.out_local.pop(i) for i in fresh]          # the recurrence releases frames in stream order
         per = [[i for i in fresh if self.owner[i] == r] for r in range(self.world)]
         for i in fresh:
@@ -637,14 +648,18 @@ class ShardedStereoStream:
         block = torch.zeros((maxc, *shape), dtype=dtype, device=self._dev())
         for k, i in enumerate(mine):
             block[k] = self.out_local.pop(i)
+        # Frames travel as BYTES: 10 / 12 / 16-bit pix_fmts make int16 frames (``use_16bit``, _ops.py to_frame) and neither the
+        # nccl nor the gloo process group moves Short tensors ("Unsupported data type")
+        wire = block.view(torch.uint8)
         if self.rank != self.dst:
-            dist.gather(block, None, dst=self.dst, group=self.group)
+            dist.gather(wire, None, dst=self.dst, group=self.group)
             return []
-        parts = [torch.empty_like(block) for _ in range(self.world)]
-        dist.gather(block, parts, dst=self.dst, group=self.group)
+        parts = [torch.empty_like(wire) for _ in range(self.world)]
+        dist.gather(wire, parts, dst=self.dst, group=self.group)
         for r in range(self.world):
+            got = parts[r].view(dtype)
             for k, i in enumerate(per[r]):
-                self.arrived[i] = parts[r][k]
+                self.arrived[i] = got[k]
         out = []
         while self.emit_next in self.arrived:
             out.append(self.arrived.pop(self.emit_next))

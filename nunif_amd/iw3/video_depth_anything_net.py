@@ -52,7 +52,10 @@ class HipVideoDepthAnythingStreaming(HipDepthAnythingV2):
     def infer_video_depth_batch(self, frames, use_amp=True):
         """frames: [B, 3, h, w], B CONSECUTIVE frames of the stream -> [B, h, w]: what B calls of ``infer_video_depth_one`` return, in one
         pass of the engine (encoder, convs and Linears over the B frames at once; only the temporal attention steps frame by frame).
-        Not part of the hub object's interface — ``VideoDepthAnythingStreamingModel.infer`` takes it when the network offers it."""
+        Not part of the hub object's interface — ``VideoDepthAnythingStreamingModel.infer`` takes it when the network offers it.
+        A batch must NOT span a scene cut: ``reset_state()`` takes effect between calls only (the reference resets between frames,
+        ``iw3/video_depth_anything_streaming_model.py:74-75``), so callers split their batches at cuts — the per-frame route the
+        reference takes for this model (``bind_single_frame_callback``, ``iw3/utils.py:1115``) hands over one frame per call."""
         if frames.dim() != 4:
             raise ValueError(f"infer_video_depth_batch takes BCHW frames, got {tuple(frames.shape)}")
         self.frame_id += frames.shape[0]

@@ -18,6 +18,7 @@ with the hub model's streaming interface
 State is per instance and sequential: shard by scene segment or file across ranks, never by frame.
 """
 import os
+import warnings
 
 import torch
 
@@ -62,6 +63,9 @@ class PerFrameStreamingBackbone:
         return self
 
 
+_WARNED_UNPINNED = False
+
+
 class VideoDepthAnythingStreamingModel(BaseDepthModel):
     def __init__(self, model_type, backbone=None, depth_aa=None, model_dir=None):
         super().__init__(model_type)
@@ -89,6 +93,18 @@ class VideoDepthAnythingStreamingModel(BaseDepthModel):
                     raise FileNotFoundError(f"{p} not found (no downloads here: copy the published checkpoint there, or pass "
                                             "state_dict= / backbone=<object with infer_video_depth_one / reset_state>)")
                 state_dict = torch.load(p, map_location="cpu", weights_only=True)
+                # A REAL checkpoint in the engine's restatement of the streaming network: its cache policy and sliding position
+                # encoding were restated from the published architecture and never compared with the hub implementation the reference
+                # runs (oracle/video_depth_anything_net.py: PARITY UNPINNED) — say so, once per process.
+                global _WARNED_UNPINNED
+                if not _WARNED_UNPINNED and os.environ.get("NUNIF_VDA_ACCEPT_UNPINNED", "0") != "1":
+                    _WARNED_UNPINNED = True
+                    warnings.warn(
+                        f"{os.path.basename(p)}: loading a published Video-Depth-Anything checkpoint into nunif_amd's own streaming "
+                        "network, whose temporal cache policy has NOT been verified against the reference's hub model (parity "
+                        "unpinned, DESIGN.md 4.22).  Depth may differ from the reference's.  Pass backbone=<the hub model> to run "
+                        "the reference network behind this wrapper, or set NUNIF_VDA_ACCEPT_UNPINNED=1 to silence this.",
+                        RuntimeWarning, stacklevel=2)
             model = HipVideoDepthAnythingStreaming(state_dict, device, metric_depth=self.metric_depth)
             if self.depth_aa is None:
                 from .stereo_model_factory import default_model_dir

@@ -25,10 +25,15 @@ gather and leave through ITS encoder; the other ranks' ``process_video`` sees an
 removed.  Decoding N times is the price of not touching the reference's loop (a 1080p software decode runs at several hundred
 frames per second per process; the GPUs' share of a frame is ~0.5 ms).
 
-What it still refuses, with the reason: a ``.yml`` export config with several GPUs, and — from inside ``ShardedFrameCallbackPool``
-— a video whose depth or side model carries temporal state (VideoDepthAnything, the video inpaint queue): those shard by scene
-segment, which is not built.  A waifu2x video with several GPUs is refused too (its frames are independent, but its CLI route does
-not pass through the two names above).  A single image runs on the first GPU of the list.
+The ranks decide TOGETHER what happens to the file (``install_video_guards``): rank 0 evaluates the reference's early exits
+(``--resume`` / ``--skip-error`` / an existing output without ``--yes``, ``iw3/utils.py:1000-1011``) against the real ``--output``
+and broadcasts the verdict; scene detection and its cache run on rank 0 and ``segment_pts`` is broadcast.  Option sets that take
+the reference's PER-FRAME routes (``--low-vram``, ``--debug-depth``, ``--keyframe``, VideoDepthAnything, the inpaint side
+models: temporal state, sharded by scene segment — not built) run on the first GPU of the list only, the other ranks leave.
+
+What it refuses, with the reason: a ``.yml`` export config or ``--export`` of one video with several GPUs, and a waifu2x video
+with several GPUs (its frames are independent, but its CLI route does not pass through the two names above).  A single image
+runs on the first GPU of the list.
 
 The reference checkout must be importable (``PYTHONPATH=/path/to/nunif``): this is a launcher FOR it, it carries no CLI of its own.
 """
@@ -205,6 +210,90 @@ def install_frame_sharding(rank, world):
     vu.FrameCallbackPool = sharded_pool
 
 
+_SINGLE_FRAME_DEPTH = {"VideoDepthAnything", "VideoDepthAnythingStreaming"}
+_INPAINT_METHODS = {"forward_inpaint", "mlbw_l2_inpaint"}
+
+
+def video_decision(iu, vu, input_filename, output_path, args, depth_model):
+    """What ``iw3.utils.process_video_full`` (iw3/utils.py:974-1170) will do with this file, decided ONCE (on rank 0, with the real
+    ``--output``) so that N ranks act alike: ``"skip"`` = one of its early exits fires (``--resume`` with the output present,
+    ``--skip-error`` with an error file, an existing output without ``--yes`` — the reference would prompt on stdin, which N ranks
+    under torchrun cannot answer); ``"rank0"`` = the reference takes a per-frame route that does not pass through the two names the
+    launcher rebinds (``bind_single_frame_callback`` / ``bind_vda_frame_callback``, iw3/utils.py:1098-1135: ``--low-vram``,
+    ``--debug-depth``, a depth or side model with temporal state; also ``--keyframe``), so one rank runs it and the others leave;
+    ``"go"`` = the frame-sharded batch route."""
+    import os.path as path
+    output_parent_dir = path.basename(output_path)
+    input_parent_dir = path.basename(path.dirname(input_filename))
+    if iu.is_output_dir(output_path) or (output_parent_dir != "" and output_parent_dir == input_parent_dir):
+        output_filename = path.join(output_path, iu.make_output_filename(path.basename(input_filename), args, video=True))
+    else:
+        output_filename = output_path
+    if (getattr(args, "resume", False) and path.exists(output_filename)) or \
+            (getattr(args, "skip_error", False) and path.exists(vu.make_error_file_path(output_filename))):
+        return "skip"
+    if not getattr(args, "yes", False) and path.exists(output_filename):
+        sys.stderr.write(f"nunif_amd.launch: '{output_filename}' already exists; pass --yes to overwrite it (no prompt under "
+                         "one process per GPU).  Skipped.\n")
+        return "skip"
+    name = depth_model.get_name() if hasattr(depth_model, "get_name") else ""
+    if (getattr(args, "keyframe", False) or getattr(args, "low_vram", False) or getattr(args, "debug_depth", False)
+            or name in _SINGLE_FRAME_DEPTH or getattr(args, "method", None) in _INPAINT_METHODS
+            or getattr(depth_model, "has_temporal_state", False)):
+        sys.stderr.write("nunif_amd.launch: this option set takes the reference's per-frame route (temporal state or --low-vram / "
+                         "--debug-depth / --keyframe), which shards by scene segment — not built.  Running on the first GPU only.\n")
+        return "rank0"
+    return "go"
+
+
+def install_video_guards(rank, world, real_output, iu=None, vu=None, bcast=None):
+    """One video on N ranks: every rank must take the SAME way through ``iw3.utils.process_video`` (the early exits of
+    ``process_video_full`` fired on rank 0 only — ranks > 0 have a scratch ``--output`` — and rank 0 then sat in a barrier against
+    the others' all-gather).  Rank 0 decides (``video_decision``), the decision is broadcast, and scene detection + its cache
+    (iw3/utils.py:1015-1036) run on rank 0 only with ``segment_pts`` broadcast.  Returns the state dict (``mode`` = last decision)."""
+    import importlib
+    iu = iu or importlib.import_module("iw3.utils")
+    vu = vu or importlib.import_module("nunif.utils.video")
+    if bcast is None:
+        import torch.distributed as dist
+
+        def bcast(obj):
+            box = [obj]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+    state = {"mode": None}
+    orig_process_video = iu.process_video
+
+    def process_video(input_filename, output_path, args, depth_model, side_model):
+        mode = video_decision(iu, vu, input_filename, real_output, args, depth_model) if rank == 0 else None
+        mode = state["mode"] = bcast(mode)
+        if mode == "skip" or (mode == "rank0" and rank > 0):
+            return None
+        return orig_process_video(input_filename, output_path, args, depth_model, side_model)
+
+    iu.process_video = process_video
+
+    def on_rank0(fn):
+        def wrapper(*a, **kw):
+            if state["mode"] != "go":                     # rank 0 alone is in here: nobody to talk to
+                return fn(*a, **kw)
+            return bcast(fn(*a, **kw) if rank == 0 else None)
+        return wrapper
+
+    if hasattr(iu, "try_load_scene_cache"):
+        iu.try_load_scene_cache = on_rank0(iu.try_load_scene_cache)
+    if hasattr(iu, "SBD") and hasattr(iu.SBD, "detect_boundary"):
+        iu.SBD.detect_boundary = on_rank0(iu.SBD.detect_boundary)
+    if hasattr(iu, "save_scene_cache"):
+        orig_save = iu.save_scene_cache
+
+        def save_scene_cache(*a, **kw):
+            return orig_save(*a, **kw) if rank == 0 else None
+
+        iu.save_scene_cache = save_scene_cache
+    return state
+
+
 def run_in_process(tool, argv, gpu, rank=0, world=1):
     """install() + the reference's ``<tool>.cli.main()`` with ``--gpu <gpu>`` and, for world > 1, this rank's share of the files."""
     import tempfile
@@ -219,6 +308,7 @@ def run_in_process(tool, argv, gpu, rank=0, world=1):
     if not engine_install.is_installed():
         engine_install.install(strict=False)
     scratch = []
+    guard = None
     if world > 1:
         if kind == "dir":
             install_listing_shards(rank, world, src)
@@ -237,6 +327,7 @@ def run_in_process(tool, argv, gpu, rank=0, world=1):
                     torch.cuda.set_device(gpu)
                 dist.init_process_group(backend)
             install_frame_sharding(rank, world)
+            guard = install_video_guards(rank, world, option_value(argv, "--output", "-o"))
             if rank > 0:
                 # this rank's encoder sees an empty stream: its file goes to a scratch directory
                 tmp = tempfile.mkdtemp(prefix=f"nunif_amd_rank{rank}_")
@@ -258,7 +349,9 @@ def run_in_process(tool, argv, gpu, rank=0, world=1):
         if world > 1 and kind == "video":
             import torch.distributed as dist
             if dist.is_initialized():
-                dist.barrier()
+                # "rank0": the other ranks left at once and rank 0 may run for hours — a barrier would only meet the watchdog
+                if guard is None or guard["mode"] != "rank0":
+                    dist.barrier()
                 dist.destroy_process_group()
     return 0
 
@@ -281,6 +374,11 @@ def main(argv=None):
     if len(gpus) <= 1:
         return run_in_process(tool, rest, gpus[0] if gpus else None)
     kind = classify_input(option_value(rest, "--input", "-i"))
+    exporting = any(a in ("--export", "--export-disparity") for a in rest)
+    if kind == "video" and tool == "iw3" and exporting:
+        sys.stderr.write("nunif_amd.launch: --export of ONE video with several GPUs: the export route (iw3/utils.py export_video) "
+                         "does not pass through the frame scheduler the launcher shards.  Run it with one GPU.\n")
+        return 2
     if kind in ("config", "other", "none") or (kind == "video" and tool != "iw3"):
         sys.stderr.write(
             f"nunif_amd.launch: --gpu {' '.join(map(str, gpus))} with a single {kind} input for {tool}.  One process per GPU "

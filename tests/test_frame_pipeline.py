@@ -206,6 +206,50 @@ def test_sharded_single_process(name):
     assert torch.equal(torch.stack(out), torch.from_numpy(g[name + "_frames"]))
 
 
+def _stereo_fn_16bit(args):
+    """Finished frames as the engine's ``to_frame(use_16bit=True)`` makes them for 10 / 12 / 16-bit pix_fmts: HWC ``int16`` holding
+    the uint16 bit patterns (nunif_amd/iw3/_ops.py; reference ``VU.to_frame`` nunif/utils/video.py:236-245)."""
+    base = _stereo_fn(args)
+
+    def fn(xs, ds, reset_pts):
+        return [(f.permute(1, 2, 0) * 65535.0).round().to(torch.int32).to(torch.uint16).view(torch.int16) for f in base(xs, ds, reset_pts)]
+    return fn
+
+
+def _worker_16bit(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, bs, cuts, ema, _ = FRAME_POOL_CASES["ema"]
+    frames = frame_pool_frames(n)
+    mine = {i for b in range(rank, (n + bs - 1) // bs, world) for i in range(b * bs, min(n, (b + 1) * bs))}
+    frames = [f if i in mine else None for i, f in enumerate(frames)]
+    with torch.inference_mode():
+        out = stereo_frames_sharded(frames, list(range(n)), set(cuts), _model(ema), _stereo_fn_16bit(_args(bs)), bs, dst=0)
+    if rank == 0:
+        torch.save(torch.stack(out), path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_two_ranks_move_16bit_frames(tmp_path):
+    """``iw3 --gpu 0 1 --pix-fmt yuv420p10le``: the finished frames are int16 and neither gloo nor nccl gathers Short tensors — they
+    travel as bytes.  Two ranks == one process, bit for bit, dtype kept."""
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_worker_16bit, args=(2, _free_port(), path), nprocs=2, join=True)
+    n, bs, cuts, ema, _ = FRAME_POOL_CASES["ema"]
+    ref = stereo_frames_sharded(frame_pool_frames(n), list(range(n)), set(cuts), _model(ema), _stereo_fn_16bit(_args(bs)), bs)
+    got = torch.load(path)
+    assert got.dtype == torch.int16 and torch.equal(got, torch.stack(ref))
+
+
+def test_shard_lag_is_bounded(monkeypatch):
+    from nunif_amd.iw3.frame_pipeline import ShardedStereoStream
+    for raw, want in (("0", 0), ("2", 2), ("4", 4), ("7", 1), ("-3", 1), ("x", 1)):
+        monkeypatch.setenv("NUNIF_SHARD_LAG", raw)
+        assert ShardedStereoStream(_model(None), lambda *a: [], 2, set())._lag == want
+
+
 def _worker_idle(rank, world, port, path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -95,3 +95,37 @@ def test_one_video_is_frame_sharded_over_two_ranks(tmp_path, case):
     assert rec["frames_encoded"] == golden.shape[0] and sum(rec["calls"]) == golden.shape[0]
     assert torch.equal(torch.load(out / "frames.pt"), torch.from_numpy(golden))
     assert not (out / "rank1.json").exists()             # rank 1 encoded nothing and its scratch output is gone
+
+
+def _trace(tmp_path, rank):
+    return json.load(open(tmp_path / f"trace{rank}.json"))
+
+
+def test_ranks_take_the_same_exit_through_process_video(tmp_path, monkeypatch):
+    """with one video on N ranks the early exits of ``process_video_full`` (iw3/utils.py:1000-1011) fired on rank 0
+    only — ranks > 0 write to a scratch ``--output`` — and rank 0 then waited in a barrier against the others' collectives.  The
+    decision is now rank 0's, broadcast: (a) a fresh output runs sharded, through the reference's own ``process_video``; (b) the
+    same line again without ``--yes`` and (c) with ``--resume`` leaves on BOTH ranks (no prompt, no hang: the 300 s timeout of
+    ``_run`` is the assertion); (d) ``--low-vram`` = the per-frame route runs on rank 0 alone."""
+    import numpy as np
+    import torch
+    monkeypatch.setenv("NUNIF_AMD_FAKE_CLI_TRACE", str(tmp_path))
+    (tmp_path / "out").mkdir()
+    out = tmp_path / "out" / "movie_sbs.mp4"            # a FILE name, as the early exits test it; the stand-in's frames go beside it
+    base = ["iw3", "-i", "movie.mp4", "-o", str(out), "--gpu", "0", "1", "--case", "ema", "--via-process-video"]
+    _run(base + ["--yes"], tmp_path, cli="fake_cli.iw3_cli")
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "frame_pool.npz"))["ema_frames"]
+    assert torch.equal(torch.load(str(out) + ".frames/frames.pt"), torch.from_numpy(golden)) and out.is_file()
+    assert _trace(tmp_path, 0)["ran"] == [str(out)] and len(_trace(tmp_path, 1)["ran"]) == 1
+    for extra in ([], ["--resume"]):
+        r = _run(base + extra, tmp_path, cli="fake_cli.iw3_cli")
+        assert _trace(tmp_path, 0)["ran"] == [] and _trace(tmp_path, 1)["ran"] == []
+        if not extra:
+            assert "pass --yes" in r.stderr
+    r = _run(base + ["--yes", "--low-vram"], tmp_path, cli="fake_cli.iw3_cli")
+    assert _trace(tmp_path, 0)["ran"] == [str(out)] and _trace(tmp_path, 1)["ran"] == []
+    assert "first GPU only" in r.stderr
+
+
+def test_export_of_one_video_with_several_gpus_is_refused():
+    assert L.main(["iw3", "-i", "movie.mp4", "-o", "out", "--gpu", "0", "1", "--export"]) == 2

@@ -253,7 +253,10 @@ def test_streaming_model_loads_the_network_from_a_checkpoint_file(vda_net, tmp_p
     sd, net = vda_net
     (tmp_path / "checkpoints").mkdir()
     torch.save(sd, tmp_path / "checkpoints" / "video_depth_anything_vits.pth")
-    model = VideoDepthAnythingStreamingModel("VDA_Stream_S", model_dir=str(tmp_path)).load(gpu=0, resolution=126)
+    import nunif_amd.iw3.video_depth_anything_streaming_model as SM
+    SM._WARNED_UNPINNED = False
+    with pytest.warns(RuntimeWarning, match="parity unpinned"):             # a real checkpoint in the unpinned network is announced
+        model = VideoDepthAnythingStreamingModel("VDA_Stream_S", model_dir=str(tmp_path)).load(gpu=0, resolution=126)
     assert isinstance(model.model, HipVideoDepthAnythingStreaming) and model.model.prep_lower_bound == 126
     g = torch.Generator().manual_seed(21)
     x = F.avg_pool2d(torch.rand(2, 3, 90, 160, generator=g), 3, stride=1, padding=1)
