@@ -448,24 +448,31 @@ def iw3_sharded_leg(dist, world, rank, dev, barrier, frames_per_rank=48, batch=4
             "value": round(H * W * n / dt / 1e6, 1)}
 
 
-def cunet_sharded_leg(dist, world, rank, dev, barrier, frames_per_rank=16):
+def cunet_sharded_leg(dist, world, rank, dev, barrier, frames_per_rank=16, render_fn=None, frame=None):
     """north_star's second generator at N GPUs: every rank renders its own 1080p frames with waifu2x cunet (tile 256, whole frame in
-    one minibatch), no collective inside the timed region; ``value`` = all ranks' input MPix/s over the MAX of the ranks' times."""
+    one minibatch), no collective inside the timed region; ``value`` = all ranks' input MPix/s over the MAX of the ranks' times.
+    ``render_fn`` / ``frame``: stand-ins of the CPU launcher rehearsal (``dry_standins``)."""
     import torch
-    from nunif_amd.nunif.models import create_model
-    from nunif_amd.nunif.utils.render import tiled_render
-    import nunif_amd.waifu2x.models.cunet  # noqa: F401
-    from nunif_amd.synthetic import cunet_state_dict
-    m = create_model("waifu2x.cunet").eval()
-    m.load_state_dict(cunet_state_dict(201))
-    m = m.to(dev)
-    frame = synth_frame(32 + rank, FRAME_H, FRAME_W).to(dev)
+    m = None
+    if render_fn is None:
+        from nunif_amd.nunif.models import create_model
+        from nunif_amd.nunif.utils.render import tiled_render
+        import nunif_amd.waifu2x.models.cunet  # noqa: F401
+        from nunif_amd.synthetic import cunet_state_dict
+        m = create_model("waifu2x.cunet").eval()
+        m.load_state_dict(cunet_state_dict(201))
+        m = m.to(dev)
+
+        def render_fn(f):
+            return tiled_render(f, m, tile_size=TILE, batch_size=66)
+    if frame is None:
+        frame = synth_frame(32 + rank, FRAME_H, FRAME_W).to(dev)
     for _ in range(3):
-        tiled_render(frame, m, tile_size=TILE, batch_size=66)
+        render_fn(frame)
     barrier()
     t0 = time.perf_counter()
     for _ in range(frames_per_rank):
-        tiled_render(frame, m, tile_size=TILE, batch_size=66)
+        render_fn(frame)
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -683,6 +690,42 @@ def config5_record(dev):
     return rec
 
 
+def dry_standins():
+    """``NUNIF_BENCH_BACKEND=gloo``: the LAUNCHER rehearsal — ``python bench.py --gpus N`` end to end on N CPU
+    ranks: ``relaunch_as_ranks`` -> ``torch.distributed.run`` -> rendezvous on 127.0.0.1 -> the timed loop with its barrier and
+    MAX over ranks -> the delivery leg -> the iw3 / cunet / config-5 legs -> ONE line on rank 0 -> process group down, with torch-CPU
+    stand-ins for every device function (the HIP engine refuses CPU tensors).  Nothing in the line is a measurement: ``data`` says
+    "dry".  What it proves is the control flow the first real N > 1 run takes (tests/test_bench_launcher.py)."""
+    import torch
+    from nunif_amd.iw3.base_depth_model import BaseDepthModel
+
+    class DryDepth(BaseDepthModel):
+        def load_model(self, model_type, resolution=None, device=None, **kw):
+            return None
+
+        def is_metric(self):
+            return False
+
+        def infer(self, x, **kw):
+            x = x if x.ndim == 4 else x[None]
+            return x.mean(dim=1) * 0.5 + x[:, 0] * 0.25
+
+    def stereo_fn(xs, ds, reset_pts):
+        sbs = torch.cat([xs, xs.flip(-1)], dim=3) * ds[:, None].repeat(1, 1, 1, 2).clamp(0, 1)
+        return [(sbs[i].clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0) for i in range(xs.shape[0])]
+
+    def render(frame):
+        return torch.nn.functional.interpolate(frame[None], scale_factor=2, mode="nearest")[0].clamp(0, 1)
+
+    def config5(dev):
+        rank = int(os.environ.get("RANK", "0"))
+        ms = 20.0 + rank
+        return {"config": "dry stand-in", "depth_net": "dry", "frame": [2160, 3840], "frames_in": 4, "frames_out": 4,
+                "ms_per_frame": ms, "fps": round(1e3 / ms, 1), "value": 1.0, "unit": "input MPix/s", "target": "dry"}
+
+    return {"depth": DryDepth("dry"), "stereo_fn": stereo_fn, "render": render, "config5": config5, "frame_hw": (48, 80)}
+
+
 def collect_multi_gpu(dist, world, rank, local_rank, dev):
     """Self-evidence for the driver's N > 1 runs: how many ranks took part in a collective and which physical devices they hold
     (one distinct PCI bus id per rank, or the run was not N GPUs).  ``dev`` may be a CPU device in the gloo unit test."""
@@ -713,39 +756,65 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus})")
+    # NUNIF_BENCH_BACKEND=gloo: the CPU launcher rehearsal (dry_standins).  NUNIF_BENCH_FORCE_DIST=1: take the N > 1 path with
+    # whatever world size there is — ``python bench.py --gpus 1`` then runs every collective of the driver's N-rank run on a
+    # one-rank nccl group, and its ``value`` must agree with the plain line (tools/bench_n1_check.sh)
+    dry = os.environ.get("NUNIF_BENCH_BACKEND", "") == "gloo"
+    multi = world > 1 or os.environ.get("NUNIF_BENCH_FORCE_DIST", "0") == "1"
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
-    multi_gpu = collect_multi_gpu(dist, world, rank, local_rank, dev) if world > 1 else None
-
-    from nunif_amd import _hip
-    from nunif_amd.nunif.utils.render import tiled_render
-    from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x
-    from nunif_amd.synthetic import swin_unet_state_dict    # seeded random-init weights (no checkpoints offline)
-    from nunif_amd.parallel import ConcurrentRenderer, render_sharded
-
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531")
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device("cpu") if dry else torch.device(f"cuda:{local_rank}")
+    if not dry:
+        torch.cuda.set_device(dev)
+    multi_gpu = collect_multi_gpu(dist, world, rank, local_rank, dev) if multi else None
     torch.set_grad_enabled(False)
-    sd = swin_unet_state_dict(102, 2)
     n_streams = max(1, args.streams)
+    fh, fw = FRAME_H, FRAME_W
+    stand = None
+    if dry:
+        stand = dry_standins()
+        fh, fw = stand["frame_hw"]
+        n_streams = 1
+        frames = [synth_frame(1234 + rank * 16 + i, fh, fw) for i in range(4)]
 
-    def make_model():
-        mm = SwinUNet2x().eval()
-        mm.load_state_dict(sd)
-        return mm
+        def render(m, frame):
+            return stand["render"](frame)
 
-    pool = ConcurrentRenderer(make_model, n_streams, dev)       # n_streams engine replicas, one HIP stream each
-    model = pool.models[0]
-    # a few distinct frames per rank, resident in HBM before the timed region
-    frames = [synth_frame(1234 + rank * 16 + i, FRAME_H, FRAME_W).to(dev) for i in range(4)]
+        model = pool = None
+        _hip = tiled_render = None
 
-    def render(m, frame):
-        return tiled_render(frame, m, tile_size=TILE, batch_size=args.batch_size)
+    if not dry:
+        from nunif_amd import _hip
+        from nunif_amd.nunif.utils.render import tiled_render
+        from nunif_amd.waifu2x.models.swin_unet import SwinUNet2x
+        from nunif_amd.synthetic import swin_unet_state_dict    # seeded random-init weights (no checkpoints offline)
+        from nunif_amd.parallel import ConcurrentRenderer
+
+        sd = swin_unet_state_dict(102, 2)
+
+        def make_model():
+            mm = SwinUNet2x().eval()
+            mm.load_state_dict(sd)
+            return mm
+
+        pool = ConcurrentRenderer(make_model, n_streams, dev)       # n_streams engine replicas, one HIP stream each
+        model = pool.models[0]
+        # a few distinct frames per rank, resident in HBM before the timed region
+        frames = [synth_frame(1234 + rank * 16 + i, FRAME_H, FRAME_W).to(dev) for i in range(4)]
+
+        def render(m, frame):
+            return tiled_render(frame, m, tile_size=TILE, batch_size=args.batch_size)
+    from nunif_amd.parallel import render_sharded
 
     def step(i):
         if n_streams == 1:
@@ -753,11 +822,15 @@ def main():
         # one frame per stream, no cross-stream dependence; results are left on their streams (the barrier syncs them)
         return [pool.submit(render, frames[(i * n_streams + k) % len(frames)]) for k in range(n_streams)]
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+    def dev_sync():
+        if not dry:
             torch.cuda.synchronize(dev)
+
+    def barrier():
+        dev_sync()
+        if multi:
+            dist.barrier()
+            dev_sync()
 
     for i in range(args.warmup):
         step(i)
@@ -767,14 +840,14 @@ def main():
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- the same K frames on ONE stream (reported next to `value`; the per-kernel roofline below is measured this way) ----
     single = None
-    if n_streams > 1 and rank == 0:
+    if n_streams > 1 and rank == 0 and not dry:
         n1 = min(args.steps, 100)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -787,7 +860,7 @@ def main():
 
     # ---- per-kernel timing with HIP events on the launch stream (library hooks), outside the timed region ----------
     roofline, classes = None, []
-    if rank == 0:
+    if rank == 0 and not dry:
         _hip.profile_read(reset=True)
         _hip.profile_enable(True)
         n_prof = max(1, min(5, args.steps))
@@ -810,15 +883,16 @@ def main():
             for r in sorted(recs, key=lambda r: -r["total_ms"])[:4]]
 
     if rank == 0:
-        mpix_in = FRAME_H * FRAME_W / 1e6
+        mpix_in = fh * fw / 1e6
         value = mpix_in * args.steps * n_streams * world / elapsed
         result = {
             "metric": "input MPix/s, waifu2x swin_unet 2x tiled render (tile 256) of 1080p frames",
             "value": round(value, 2), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic" if not dry else "dry: CPU stand-ins on gloo ranks (launcher rehearsal, nothing here is a measurement)",
             "config": {"workload": "waifu2x swin_unet 2x (art scale2x geometry), tile_size=256, 1080p frame, "
-                                   "random-init weights", "frame": [FRAME_H, FRAME_W], "tile_size": TILE,
+                                   "random-init weights", "frame": [fh, fw], "tile_size": TILE,
                        "tile_batch": args.batch_size, "tiles_per_frame": 45, "frames_per_step_per_gpu": n_streams,
                        "concurrent_streams": n_streams, "timed_region_s": round(elapsed, 3),
                        "parallelism": f"frame-sharded x{world}"},
@@ -833,7 +907,7 @@ def main():
                 result.setdefault("errors", []).append("ranks / devices do not add up to --gpus")
         if single is not None:
             result["single_stream"] = single        # one frame at a time on one stream, same build, same run
-        if not args.no_host_frames and world == 1:
+        if not args.no_host_frames and not multi:
             # host uint8 frame -> pinned ring -> H2D -> to_tensor -> render -> quantise -> D2H -> host uint8 frame
             from nunif_amd.frame_ring import FrameRing
             host = [(f.clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy() for f in frames]
@@ -869,15 +943,15 @@ def main():
                 result[key] = {"error": repr(e)}
                 result.setdefault("errors", []).append(f"sub-record {key} raised")
 
-        if not args.no_4k and world == 1:
+        if not args.no_4k and not multi:
             sub_record("scale4x_4k", lambda: scale4x_record(dev))
-        if not args.no_cunet and world == 1:
+        if not args.no_cunet and not multi:
             sub_record("cunet", lambda: cunet_record(dev, with_cpu=not args.no_cpu_baseline))
-        if not args.no_iw3 and world == 1:
+        if not args.no_iw3 and not multi:
             sub_record("iw3", lambda: iw3_record(dev, with_cpu=not args.no_cpu_baseline))
-        if not args.no_config5 and world == 1:
+        if not args.no_config5 and not multi:
             sub_record("config5", lambda: config5_record(dev))
-        if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
+        if not args.no_cpu_baseline and not multi:      # contract: CPU baseline on rank 0 at N = 1 only
             base, crop, ref, ref_whole = cpu_baseline(sd, frames[0].cpu())
             got = tiled_render(crop.to(dev), model, tile_size=TILE, batch_size=args.batch_size).cpu()
             mse = torch.mean((got.double() - ref.double()) ** 2).item()
@@ -897,7 +971,7 @@ def main():
                     "frame": [FRAME_H, FRAME_W], "tile_batch": args.batch_size, "concurrent_streams": n_streams,
                     "max_abs_diff": round(float((outs[0] - ref_whole).abs().max()), 6),
                     "against": "oracle tiled_render of the same whole frame on the host cores (the cpu_baseline pass, output kept)"}
-    if world > 1:
+    if multi:
         import threading
         done = threading.Event()
 
@@ -933,28 +1007,33 @@ def main():
             # BASELINE's other metrics at N GPUs (each leg is entered by every rank; a rank that fails raises into the handler
             # below, the others then wait in a collective and the watchdog ends them — the headline line is out either way)
             if not args.no_iw3:
-                r_iw3 = iw3_sharded_leg(dist, world, rank, dev, barrier)
+                r_iw3 = (iw3_sharded_leg(dist, world, rank, dev, barrier) if not dry else
+                         iw3_sharded_leg(dist, world, rank, dev, barrier, frames_per_rank=8, batch=2, depth_model=stand["depth"],
+                                         stereo_fn=stand["stereo_fn"], frame_hw=(fh, fw), make_frame=lambda i: frames[i % 4]))
                 if rank == 0:
                     result["iw3"] = r_iw3
                     if r_iw3["frames_delivered"] != r_iw3["frames"]:
                         result.setdefault("errors", []).append("iw3 leg: frames lost on the way to rank 0")
             if not args.no_cunet:
-                r_cu = cunet_sharded_leg(dist, world, rank, dev, barrier)
+                r_cu = (cunet_sharded_leg(dist, world, rank, dev, barrier) if not dry else
+                        cunet_sharded_leg(dist, world, rank, dev, barrier, frames_per_rank=2, render_fn=stand["render"], frame=frames[0]))
                 if rank == 0:
                     result["cunet"] = r_cu
             if not args.no_config5:
-                r_c5 = config5_replicas_leg(dist, world, rank, dev, barrier)
+                r_c5 = config5_replicas_leg(dist, world, rank, dev, barrier, record_fn=stand["config5"] if dry else None)
                 if rank == 0:
                     result["config5"] = r_c5
             done.set()
             if rank == 0:
                 if delivered[0] != n_g:
                     result.setdefault("errors", []).append(f"delivery leg: {delivered[0]} of {n_g} frames arrived on rank 0")
+                # next to `value` in the line's top-level keys: the rate with every finished frame DELIVERED to rank 0
+                result["gathered_value"] = round(fh * fw / 1e6 * n_g / dtg, 2)
                 result["gathered"] = {
-                    "value": round(FRAME_H * FRAME_W / 1e6 * n_g / dtg, 2), "unit": "MPix/s", "frames": n_g,
+                    "value": round(fh * fw / 1e6 * n_g / dtg, 2), "unit": "MPix/s", "frames": n_g,
                     "frames_delivered": delivered[0],
                     "ms_per_frame_per_gpu": round(1e3 * dtg / (n_g / world), 3),
-                    "bytes_delivered_per_frame": 2 * FRAME_H * 2 * FRAME_W * 3,
+                    "bytes_delivered_per_frame": 2 * fh * 2 * fw * 3,
                     "path": "render (one frame at a time per rank) -> HIP quantise to HWC uint8 -> batch_isend_irecv "
                             "to rank 0, overlapped with the next render (nunif_amd.parallel.render_sharded)"}
 
@@ -969,7 +1048,7 @@ def main():
                 os._exit(emit(result))
             threading.Event().wait()            # the watchdog ends this rank with exit code 0
     rc = emit(result) if rank == 0 else 0
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rc:

@@ -17,6 +17,7 @@
 //   * the next window's x is requested at the end of a window's trip (four waves per SIMD hide the rest).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "swin_kernels.h"
 
@@ -26,10 +27,18 @@ namespace nunif {
 
 // LDS operands requested one step ahead (round 6): 1 = weight fragments, 2 = qkv biases, 4 = score bias rows
 #ifndef NUNIF_QKV_PF
-#define NUNIF_QKV_PF 3
+#define NUNIF_QKV_PF 1
 #endif
 #ifndef NUNIF_QKV_PF192
 #define NUNIF_QKV_PF192 0
+#endif
+// Round 6, the instruction diet continued (every VALU instruction is >= 4 issue cycles of a SIMD that is VALU-port bound,
+// profiles/r02_ubench_mix.txt): 1 = window-major stores as `SGPR base + 32-bit lane constant` (no 64-bit address arithmetic per
+// tile), 2 = `o * inv` and its fp16 convert in one v_fma_mixlo / mixhi_f16 per value (one rounding instead of two), 4 = the lone
+// probability of key tile 2 converted and zero-padded by ONE v_cvt_pk_f16_f32 (hipcc: v_cvt_f16_f32 + v_pack_b32_f16), 8 = the
+// head loop unrolled (LDS addresses of every head become instruction immediates: 12 address adds per head less)
+#ifndef NUNIF_QKV_DIET
+#define NUNIF_QKV_DIET 15
 #endif
 
 // the "real key" column 36 of the bias table carries 1000: padded keys end up 1000 (log2 units) below every real one
@@ -47,6 +56,27 @@ struct QkvAttnRArgs {
 
 __device__ __forceinline__ f16x8 cat8r(f16x4 lo, f16x4 hi) {
     return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// o * inv -> fp16, the product rounded ONCE: (f16) fma(o, inv, 0) is v_fma_mixlo / mixhi_f16 (fp32 fma, converted on the way out) —
+// one instruction per value instead of v_mul_f32 + half a v_cvt_pk_f16_f32.  (Written as C so that hipcc counts the wait states
+// between the MFMA that produces `o` and this read: as inline asm it does not, and the first version read half-written accumulators.)
+__device__ __forceinline__ f16x4 mul4_to_f16(const f32x4 &o, float inv) {
+    if constexpr ((NUNIF_QKV_DIET & 2) != 0) {
+        return (f16x4){(f16)__builtin_fmaf(o[0], inv, 0.0f), (f16)__builtin_fmaf(o[1], inv, 0.0f), (f16)__builtin_fmaf(o[2], inv, 0.0f),
+                       (f16)__builtin_fmaf(o[3], inv, 0.0f)};
+    } else {
+        return (f16x4){(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
+    }
+}
+// {(f16) e, 0, 0, 0}: with a zero hipcc cannot see through (`zf`, an SGPR) the pair is ONE v_cvt_pk_f16_f32 instead of v_cvt_f16_f32 +
+// v_pack_b32_f16
+__device__ __forceinline__ f16x4 lone_to_f16x4(float e, float zf) {
+    if constexpr ((NUNIF_QKV_DIET & 4) != 0) {
+        return (f16x4){(f16)e, (f16)zf, (f16)0.f, (f16)0.f};
+    } else {
+        return (f16x4){(f16)e, (f16)0.f, (f16)0.f, (f16)0.f};
+    }
 }
 
 constexpr int kBiasStride = 52;        // fp32 row stride of the CBIAS table: 16 lanes x 16 B land in 16 distinct bank quads
@@ -98,6 +128,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     const int grp = lane >> 4;
     const int nwx = a.W / 6, nwy = a.H / 6;
     const f16x4 zero4 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    float zf = 0.f;
+    asm("" : "+s"(zf));                     // a zero the compiler cannot fold (lone_to_f16x4)
 
     for (int i = tid; i < 3 * C; i += NTHR) bl[i] = a.bqkv[i];
     const f16x8 ones8 = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
@@ -112,6 +144,9 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
         ixc[mt] = tokc[mt] - 6 * iyc[mt];
         xoff[mt] = (unsigned)(((iyc[mt] * a.W + ixc[mt]) * C + 8 * grp) * 2);
     }
+    unsigned wm_off[3];                     // window-major store offset of (token, channels 4 grp ..) inside a head's 36 x HD block
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) wm_off[mt] = (unsigned)((tokc[mt] * HD + 4 * grp) * 2);
     const bool store2 = (r16 & 3) == 0;                                              // tile 2: columns 0, 4, 8, 12 are real
     // store offset of a lane relative to its load offset (non-WM): channel run of the 16-byte epilogue instead of 8 grp
     const int st_delta = (NTH == 2 ? pair_run_channel(grp) : 4 * grp) * 2 - 16 * grp;
@@ -192,9 +227,20 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     f16x8 wnx = wl[lane];                  // first weight fragment of the next head (see the head loop)
 #pragma unroll 1
     for (int wi = w0; wi < a.n_windows; wi += wstride) {
+        const int wq = (wb * nwy + wy) * nwx + wx;                         // index of this window in the window-major att map
+        char *ab = reinterpret_cast<char *>(a.att) + (WM ? (long)wq * (HEADS * 36 * HD * 2) : (long)wb * img_bytes);
+        // window-major map: a wave-uniform byte offset (the launcher keeps the map below 4 GB) + a lane constant per tile
+        const unsigned wm_base = (unsigned)__builtin_amdgcn_readfirstlane(wq * (HEADS * 36 * HD * 2));
+
+        // C = 96: the six heads unrolled (every LDS address an immediate); C = 192 does not fit that way (143 spilled registers).
+        // DIET & 16 (head_dim 16): the windows that need no shift-region term — all but the last row / column of a shifted map — take
+        // a path of their own (SP = false) with K = 16 score MFMAs; the others the K = 32 form with the region one-hots, rolled.
+        constexpr bool kSplit = (NUNIF_QKV_DIET & 16) && HD == 16;
+        auto run_heads = [&](auto sp_tag) {
+        constexpr bool SP = decltype(sp_tag)::value;
         // shift regions of this window (only the last window row / column straddles two regions)
         f16x4 rkr[3], rqr[3];
-        if (special) {
+        if (special && (SP || !kSplit)) {
             const bool last_y = wy == nwy - 1, last_x = wx == nwx - 1;
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) {
@@ -210,10 +256,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) { rkr[mt] = rk0; rqr[mt] = rq0; }
         }
-        const int wq = (wb * nwy + wy) * nwx + wx;                         // index of this window in the window-major att map
-        char *ab = reinterpret_cast<char *>(a.att) + (WM ? (long)wq * (HEADS * 36 * HD * 2) : (long)wb * img_bytes);
-
-#pragma unroll 1
+        constexpr int kHeadUnroll = ((NUNIF_QKV_DIET & 8) && C == 96 && !(kSplit && SP)) ? HPP : 1;
+#pragma unroll kHeadUnroll
         for (int hl = 0; hl < HPP; ++hl) {
             const int head = pass * HPP + hl;
             const f16x8 *wh = wl + (hl * FPH) * 64 + lane;
@@ -293,7 +337,14 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     for (int kt = 0; kt < 3; ++kt) {
                         f32x4 acc = sb[kt];
                         if constexpr (HD == 16) {
-                            acc = MFMA_16x16x32(cat8r(kt4[0][kt], rkr[kt]), cat8r(qt4[0][qt], rqr[qt]), acc);
+                            if constexpr (kSplit && !SP) {
+                                // K = 16 is the whole head: v_mfma_f32_16x16x16_f16 takes q and k as they leave the converts (no
+                                // 4-register operands to assemble, ~10 v_mov per head); the shift-region term is a constant over
+                                // every row of these windows
+                                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(kt4[0][kt], qt4[0][qt], acc, 0, 0, 0);
+                            } else {
+                                acc = MFMA_16x16x32(cat8r(kt4[0][kt], rkr[kt]), cat8r(qt4[0][qt], rqr[qt]), acc);
+                            }
                         } else {
                             acc = MFMA_16x16x32(cat8r(kt4[0][kt], kt4[1][kt]), cat8r(qt4[0][qt], qt4[1][qt]), acc);
                             if (special) acc = MFMA_16x16x32(cat8r(rkr[kt], zero4), cat8r(rqr[qt], zero4), acc);
@@ -317,7 +368,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     const float p2 = __builtin_amdgcn_exp2f(s[kt][2] - mx), p3 = __builtin_amdgcn_exp2f(s[kt][3] - mx);
                     pf[kt] = (f16x4){(f16)p0, (f16)p1, (f16)p2, (f16)p3};
                 }
-                pf[2] = (f16x4){(f16)__builtin_amdgcn_exp2f(s[2][0] - mx), (f16)0.f, (f16)0.f, (f16)0.f};
+                pf[2] = lone_to_f16x4(__builtin_amdgcn_exp2f(s[2][0] - mx), zf);
                 // ONE fragment [p0 + p1 | p2] serves the denominator (ones x it = the sum of the fp16 probabilities the PV
                 // product actually uses) AND the key-tile-2 part of PV (V of tile 2 sits in the HIGH k-slots of vz, zeros below)
                 const f16x8 psum = cat8r(pf[0] + pf[1], pf[2]);
@@ -332,7 +383,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                 for (int dt = 0; dt < NTH; ++dt) {
                     f32x4 o = MFMA_16x16x32(cat8r(vt4[dt][0], vt4[dt][1]), cat8r(pf[0], pf[1]), z4);
                     o = MFMA_16x16x32(cat8r(zero4, vt4[dt][2]), psum, o);
-                    ov[dt] = (f16x4){(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
+                    ov[dt] = mul4_to_f16(o, inv);
                 }
                 if constexpr (NTH == 2) {
                     const f16x8 run = pair_to_run(ov[0], ov[1]);
@@ -342,11 +393,30 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     // of this store cover ONE contiguous 512-byte run (16 tokens x 32 B) instead of sixteen 8-byte pieces 192 B
                     // apart (1.48x write amplification in the r02 counters).  Pairing with the neighbouring head's tile (held
                     // across one trip of the head loop) was measured slower (504 vs 457 us): plain 8-byte stores
-                    if (store) *reinterpret_cast<f16x4 *>(ab + ((head * 36 + tokc[qt]) * HD + 4 * grp) * 2) = ov[0];
+                    if constexpr ((NUNIF_QKV_DIET & 1) != 0) {
+                        // the base is pinned in an SGPR pair (an opaque asm: hipcc otherwise re-associates the sum into 64-bit
+                        // per-lane arithmetic) so that the store is `global_store_dwordx2 v_off, v_data, s[base]`
+                        unsigned long hb = reinterpret_cast<unsigned long>(a.att) + (wm_base + (unsigned)(head * (36 * HD * 2)));
+                        asm("" : "+s"(hb));
+                        typedef __attribute__((address_space(1))) char gchar;        // (an integer -> pointer cast would be a FLAT store)
+                        typedef __attribute__((address_space(1))) f16x4 gf16x4;
+                        unsigned lo = wm_off[qt];
+                        asm("" : "+v"(lo));         // keeps the zero-extension next to the add (hoisted, it becomes a 64-bit VGPR pair)
+                        if (store) *reinterpret_cast<gf16x4 *>(reinterpret_cast<gchar *>(hb) + lo) = ov[0];
+                    } else {
+                        if (store) *reinterpret_cast<f16x4 *>(ab + ((head * 36 + tokc[qt]) * HD + 4 * grp) * 2) = ov[0];
+                    }
                 } else {
                     if (store) *reinterpret_cast<f16x4 *>(ab + (vo[qt] + (unsigned)st_delta) + head * (HD * 2)) = ov[0];
                 }
             }
+            if constexpr (kHeadUnroll > 1) __builtin_amdgcn_sched_barrier(0);   // unrolled heads stay apart: nothing of head h + 1 is scheduled into head h
+        }
+        };
+        if constexpr (kSplit) {
+            if (special) run_heads(std::true_type{}); else run_heads(std::false_type{});
+        } else {
+            run_heads(std::true_type{});
         }
 
         advance();
