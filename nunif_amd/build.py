@@ -25,7 +25,7 @@ NO_SLP = ["-fno-slp-vectorize"]
 EXTRA_FLAGS = {"stitch.hip": ["-ffp-contract=off"], "iw3_warp.hip": ["-ffp-contract=off"],
                "iw3_depth.hip": ["-ffp-contract=off"], "image_ops.hip": ["-ffp-contract=off"], "swin_block_tail.hip": NO_SLP, "swin_block_tail_ws.hip": NO_SLP, "swin_qkv_attn_r.hip": NO_SLP + ["-fno-honor-nans"], "swin_block96.hip": NO_SLP + ["-fno-honor-nans"],
                "swin_kernels.hip": NO_SLP, "swin_patchup.hip": NO_SLP, "swin_patchdown.hip": NO_SLP, "cunet_up.hip": NO_SLP, "cunet_head.hip": NO_SLP,
-               "cunet_kernels.hip": NO_SLP, "rowflow.hip": NO_SLP, "depth_aa.hip": NO_SLP, "depth_anything.hip": NO_SLP, "depth_temporal.hip": NO_SLP, "conv3_lds.hip": NO_SLP}
+               "cunet_kernels.hip": NO_SLP, "rowflow.hip": NO_SLP, "depth_aa.hip": NO_SLP, "depth_anything.hip": NO_SLP + ["-fno-honor-nans"], "depth_temporal.hip": NO_SLP, "conv3_lds.hip": NO_SLP}
 
 
 def sources():

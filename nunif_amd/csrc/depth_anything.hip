@@ -27,6 +27,7 @@
 //   da_upsample_kernel    bilinear, align_corners=True, NHWC
 //   im2col / assemble / final 1x1 + ReLU
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -220,28 +221,40 @@ __global__ void __launch_bounds__(WAVES * 64) da_attn_kernel(const f16 *__restri
         for (int dt = 0; dt < 4; ++dt) o[dt] = MFMA_16x16x32(vf[dt], pf, o[dt]);
     };
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    // one half of the unrolled loop: computes `step` from `slot`; st_old holds step + 2 (fetched one half earlier), st_new takes step + 3
-    auto half_step = [&](int step, int slot, f16x8 &st_new, const f16x8 &st_old) {
+    // one third of the unrolled loop: computes `step` from `slot`; st_old holds step + 2 (fetched one trip earlier), st_new takes step + 3.
+    // Round 6: the SLOT is a compile-time constant (the loop is unrolled by 6 = lcm(3 slots, 2 register sets)): with a run-time slot
+    // hipcc rebuilt the LDS address of each of the 8 fragment reads per step (13 v_lshl_add_u32 + 4 v_add_u32 + 3 v_lshl_or_b32 of the
+    // step's ~83 VALU instructions in a kernel that is 3 : 1 VALU-bound); now every read is `base VGPR + immediate`.
+    auto third_step = [&](int step, auto slot_c, f16x8 &st_new, const f16x8 &st_old) {
+        constexpr int slot = decltype(slot_c)::value;
         st_new = stage(step + 3);                 // unconditional (keys are clamped): a conditional load makes hipcc wait vmcnt(0)
-        if (has_q && step < steps) compute(step, slot);
-        // slot (slot + 2) % 3; unconditional as well (behind the last steps it rewrites a slot nobody reads again): a skipped
-        // publish is a path without its vmcnt wait, and hipcc then drains vmcnt(0) at the loop header
+        if (has_q) compute(step, slot);
+        // slot (slot + 2) % 3; unconditional as well (behind the last steps it rewrites a slot nobody reads again)
         publish(slot >= 1 ? slot - 1 : 2, st_old);
         lds_barrier();
     };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
     f16x8 sa, sb;
     publish(0, stage(0));
     if (steps > 1) publish(1, stage(1));
     sb = stage(2);
     lds_barrier();
-    int slot = 0;
+    // `steps` is uniform over the workgroup, so every wave leaves at the same barrier count; leaving abandons the loads in flight
 #pragma unroll 1
-    for (int step = 0; step < steps; step += 2) {
-        half_step(step, slot, sa, sb);
-        slot = slot == 2 ? 0 : slot + 1;
-        half_step(step + 1, slot, sb, sa);        // always (it only skips its MFMAs behind the last step): a path around it would
-                                                  // reach the loop header with sa's load in flight, i.e. another vmcnt(0)
-        slot = slot == 2 ? 0 : slot + 1;
+    for (int step = 0; step < steps; step += 6) {
+        third_step(step, S0{}, sa, sb);
+        if (step + 1 >= steps) break;
+        third_step(step + 1, S1{}, sb, sa);
+        if (step + 2 >= steps) break;
+        third_step(step + 2, S2{}, sa, sb);
+        if (step + 3 >= steps) break;
+        third_step(step + 3, S0{}, sb, sa);
+        if (step + 4 >= steps) break;
+        third_step(step + 4, S1{}, sa, sb);
+        if (step + 5 >= steps) break;
+        third_step(step + 5, S2{}, sb, sa);
     }
     float l = l_run;
     l += __shfl_xor(l, 16);                      // all lanes take part (the exchange partners share r16, not the branch below)
