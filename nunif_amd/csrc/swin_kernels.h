@@ -187,9 +187,18 @@ int launch_proj_mlp_ws(const f16 *att, f16 *x, const f16 *wws, const float *bp, 
 // ---- fused qkv Linear + (shifted) 6x6 window attention, one window per wave, qkv weights resident in LDS, no barrier in the
 // window loop (swin_qkv_attn_r.hip); C = 96 (6 heads of 16) or 192 (6 heads of 32).  x: [B,H,W,C] -> att: [B,H,W,C]
 // (pre-projection attention output at the un-rolled positions); wres: per head Wq | Wk | Wv fragments, q pre-scaled;
-// btab32: fp32 [heads][36][52] C-operand table
+// btab32: fp32 C-operand table of the score MFMAs, log2(e) * bias, key columns in win_token order, padded keys -1000:
+// kQkvBiasFragMajor = 1 (round 6): [heads][query tile 3][key tile 3][64 lanes][4] — the C fragment of lane (r16, grp) for (qt, kt) is one
+// lane-linear 16-byte read like the weight fragments (no bank conflicts: the [36][52] row form cost 24 conflict cycles per head and
+// window, SQ_LDS_BANK_CONFLICT 10.37 M per launch in profiles/r04b_sq.txt .. r06b_sq.txt, and a per-lane row address per tile);
+// 0: [heads][36][52] rows
 // window_major = 1 (C = 96): att is written as [window][head][36][16] — every store instruction covers one contiguous
 // 512-byte run; launch_proj_mlp's WinMap reads it back in the same order
+#ifndef NUNIF_QKV_BTAB_FRAG
+#define NUNIF_QKV_BTAB_FRAG 0
+#endif
+constexpr int kQkvBiasFragMajor = NUNIF_QKV_BTAB_FRAG;
+constexpr int kQkvBiasFloatsPerHead = kQkvBiasFragMajor ? 9 * 64 * 4 : 36 * 52;
 int launch_qkv_attn_r(const f16 *x, f16 *att, const f16 *wres, const float *bqkv, const float *btab32,
                       int B, int H, int W, int C, int heads, int shift, hipStream_t s, int rev = 0, int window_major = 0);
 

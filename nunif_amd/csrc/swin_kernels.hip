@@ -126,6 +126,29 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
             const int OC = g.n_real / s2;
             float *o = reinterpret_cast<float *>(g.out);
             const long OH = g.OH ? g.OH : (long)g.Ho * s, OW = g.OW ? g.OW : (long)g.Wo * s;
+            if ((s == 4 || s == 8) && g.oshift == 0 && (OW & 3) == 0) {
+                // Round 6 (the 4x nets' head: 560 us per launch at 2.0 TB/s, 7 % of a 4K frame, profiles/r06k_kernel_stats_4k.csv):
+                // with s = 4 a lane's four columns n0 .. n0 + 3 are the four sub-pixels j of ONE output row (c = n0 / 16,
+                // i = n0 / 4 % 4) — one 16-byte store, 256 contiguous bytes per lane group, and no division by a run-time s
+                // (the general form below issued 8 integer divisions and 16 four-byte stores per output tile).
+                // (s = 8, the 8x net: the four columns are sub-pixels j0 .. j0 + 3, j0 = n0 % 8, of row i = n0 / 8 % 8 of c = n0 / 64)
+                const int ls = s == 4 ? 2 : 3;
+                const int c = n0 >> (2 * ls), i = (n0 >> ls) & (s - 1), j0 = n0 & (s - 1);
+                if (n0 < g.n_real) {
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+                        if (!valid[f]) continue;
+                        float4 v = {acc[f][0] + bv.x, acc[f][1] + bv.y, acc[f][2] + bv.z, acc[f][3] + bv.w};
+                        if (!g.no_clamp) {
+                            v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
+                            v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
+                        }
+                        const long oy = (long)ty[f] * s + i, ox = (long)tx[f] * s + j0;
+                        if (oy < OH && ox + 3 < OW) *reinterpret_cast<float4 *>(o + (((long)tb[f] * OC + c) * OH + oy) * OW + ox) = v;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
                 if (!valid[f]) continue;

@@ -38,7 +38,7 @@ namespace nunif {
 // probability of key tile 2 converted and zero-padded by ONE v_cvt_pk_f16_f32 (hipcc: v_cvt_f16_f32 + v_pack_b32_f16), 8 = the
 // head loop unrolled (LDS addresses of every head become instruction immediates: 12 address adds per head less)
 #ifndef NUNIF_QKV_DIET
-#define NUNIF_QKV_DIET 15
+#define NUNIF_QKV_DIET 47
 #endif
 
 // the "real key" column 36 of the bias table carries 1000: padded keys end up 1000 (log2 units) below every real one
@@ -119,7 +119,10 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
     f16x8 *wl = reinterpret_cast<f16x8 *>(smem_r);                                   // [HPP*FPH][64]
     float *bt32 = reinterpret_cast<float *>(wl + HPP * FPH * 64);                    // [HPP][36][52]
-    float *bl = bt32 + HPP * 36 * kBiasStride;                                       // [3C]
+    // qkv biases: kQkvBiasFragMajor: the accumulators' initial values as FRAGMENTS [HPP][3 NTH][64 lanes] f32x4 (q / k tiles: four
+    // channels per lane group, v tiles — operands swapped — the column's channel in all four registers): one lane-linear read like
+    // every other LDS operand of this kernel, whose single address register is lane * 16; otherwise [3C] floats
+    float *bl = bt32 + HPP * kQkvBiasFloatsPerHead;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -131,7 +134,9 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     float zf = 0.f;
     asm("" : "+s"(zf));                     // a zero the compiler cannot fold (lone_to_f16x4)
 
-    for (int i = tid; i < 3 * C; i += NTHR) bl[i] = a.bqkv[i];
+    if constexpr (!kQkvBiasFragMajor) {
+        for (int i = tid; i < 3 * C; i += NTHR) bl[i] = a.bqkv[i];
+    }
     const f16x8 ones8 = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
 
     // ---- per-lane constants of the launch: the window token of column r16 of tile mt, its pixel offset ----------------------
@@ -170,8 +175,18 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     {
         const f16x8 *src = reinterpret_cast<const f16x8 *>(a.wres) + (long)pass * HPP * FPH * 64;
         for (int i = tid; i < HPP * FPH * 64; i += NTHR) wl[i] = src[i];
-        const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.btab32 + (long)pass * HPP * 36 * kBiasStride);
-        for (int i = tid; i < HPP * 36 * kBiasStride / 4; i += NTHR) reinterpret_cast<f32x4 *>(bt32)[i] = bsrc[i];
+        if constexpr (kQkvBiasFragMajor) {
+            for (int i = tid; i < HPP * 3 * NTH * 64; i += NTHR) {
+                const int ln = i & 63, t = i >> 6, hl = t / (3 * NTH), pn = t - hl * (3 * NTH), part = pn / NTH, nt = pn - part * NTH;
+                const int ch0 = part * C + (pass * HPP + hl) * HD + nt * 16;
+                f32x4 v;
+                if (part == 2) { const float bv = a.bqkv[ch0 + (ln & 15)]; v = (f32x4){bv, bv, bv, bv}; }
+                else v = *reinterpret_cast<const f32x4 *>(a.bqkv + ch0 + 4 * (ln >> 4));
+                reinterpret_cast<f32x4 *>(bl)[i] = v;
+            }
+        }
+        const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.btab32 + (long)pass * HPP * kQkvBiasFloatsPerHead);
+        for (int i = tid; i < HPP * kQkvBiasFloatsPerHead / 4; i += NTHR) reinterpret_cast<f32x4 *>(bt32)[i] = bsrc[i];
     }
     __syncthreads();
 
@@ -187,15 +202,29 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
         if (special) {
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) {
-                int yy = y0 + iyc[mt], xx = x0 + ixc[mt];
+                // (token coordinates recomputed here, in the rare path, instead of six more per-lane constants live across the window loop)
+                const int tk = win_token(mt, r16), iy = tk / 6, ix = tk - 6 * iy;
+                int yy = y0 + iy, xx = x0 + ix;
                 if (yy >= a.H) yy -= a.H;
                 if (xx >= a.W) xx -= a.W;
                 vo[mt] = (unsigned)(((yy * a.W + xx) * C + 8 * grp) * 2);
             }
         } else {
             const unsigned org = (unsigned)((y0 * a.W + x0) * C * 2);
+            if constexpr ((NUNIF_QKV_DIET & 32) != 0) {
+                // the lane's offsets rebuilt from the lane id (an opaque copy: hoisted out of the window loop they are three more
+                // registers carried — and spilled — across it): ~15 VALU per window
+                int rl = r16;
+                asm("" : "+v"(rl));
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt) vo[mt] = org + xoff[mt];
+                for (int mt = 0; mt < 3; ++mt) {
+                    const int tk = win_token(mt, rl), iy = (tk * 43) >> 8, ix = tk - 6 * iy;        // tk / 6 for tk < 36
+                    vo[mt] = org + (unsigned)(((iy * a.W + ix) * C + 8 * grp) * 2);
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) vo[mt] = org + xoff[mt];
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) {
@@ -217,6 +246,23 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
         cb += db;
     };
 
+    // initial accumulator of output tile (part, nt) of local head hl (global head `head`)
+    auto qkv_bias = [&](int hl, int head, int part, int nt) -> f32x4 {
+        if constexpr (kQkvBiasFragMajor) {
+            return reinterpret_cast<const f32x4 *>(bl)[(hl * 3 * NTH + part * NTH + nt) * 64 + lane];
+        } else {
+            const int ch0 = part * C + head * HD + nt * 16;
+            if (part == 2) { const float bv = bl[ch0 + r16]; return (f32x4){bv, bv, bv, bv}; }
+            return *reinterpret_cast<const f32x4 *>(bl + ch0 + 4 * grp);
+        }
+    };
+    // C operand of the score tile (query tile qt, key tile kt) of local head hl
+    auto bias_frag = [&](int hl, int qt, int kt) -> f32x4 {
+        if constexpr (kQkvBiasFragMajor)
+            return reinterpret_cast<const f32x4 *>(bt32)[((hl * 3 + qt) * 3 + kt) * 64 + lane];
+        else
+            return *reinterpret_cast<const f32x4 *>(bt32 + (hl * 36 + tokc[qt]) * kBiasStride + 4 * grp + 16 * kt);
+    };
     f16x8 xf[3][KS];
     unsigned vo[3];
     int wb, wy, wx;
@@ -236,6 +282,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
         // DIET & 16 (head_dim 16): the windows that need no shift-region term — all but the last row / column of a shifted map — take
         // a path of their own (SP = false) with K = 16 score MFMAs; the others the K = 32 form with the region one-hots, rolled.
         constexpr bool kSplit = (NUNIF_QKV_DIET & 16) && HD == 16;
+        constexpr bool kEarlyX = (NUNIF_QKV_DIET & 32) && (NUNIF_QKV_DIET & 8) && C == 96 && WM && !kSplit;
         auto run_heads = [&](auto sp_tag) {
         constexpr bool SP = decltype(sp_tag)::value;
         // shift regions of this window (only the last window row / column straddles two regions)
@@ -244,7 +291,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
             const bool last_y = wy == nwy - 1, last_x = wx == nwx - 1;
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) {
-                const int reg = ((last_y && iyc[mt] >= 3) ? 2 : 0) + ((last_x && ixc[mt] >= 3) ? 1 : 0);
+                const int tk = win_token(mt, r16), iy = tk / 6, ix = tk - 6 * iy;
+                const int reg = ((last_y && iy >= 3) ? 2 : 0) + ((last_x && ix >= 3) ? 1 : 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool on = grp == 2 && reg == j;                  // cols 40..43 live in lane group 2
@@ -271,7 +319,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
             f16x4 qt4[NTH][3], kt4[NTH][3], vt4[NTH][3];
             f16x8 wq2[2];
             wq2[0] = (PF & 1) ? wnx : wh[0];
-            f32x4 bnx = *reinterpret_cast<const f32x4 *>(bl + head * HD + 4 * grp);
+            f32x4 bnx = qkv_bias(hl, head, 0, 0);
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
 #pragma unroll
@@ -279,20 +327,14 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     const int ch0 = part * C + head * HD + nt * 16;
                     const int fidx = (part * NTH + nt) * KS;
                     f32x4 acc[3];
-                    if constexpr (!(PF & 2)) {
-                        if (part == 2) { const float bv = bl[ch0 + r16]; bnx = (f32x4){bv, bv, bv, bv}; }
-                        else bnx = *reinterpret_cast<const f32x4 *>(bl + ch0 + 4 * grp);
-                    }
+                    if constexpr (!(PF & 2)) bnx = qkv_bias(hl, head, part, nt);
 #pragma unroll
                     for (int mt = 0; mt < 3; ++mt) acc[mt] = bnx;
                     // bias of the next output tile: parts 0 / 1 four channels per lane group, part 2 (operands swapped) one per column
                     if constexpr ((PF & 2) != 0) {
                         const int nf = part * NTH + nt + 1;
                         if (nf < 3 * NTH) {
-                            const int np = nf / NTH, nn = nf % NTH;
-                            const int nch0 = np * C + head * HD + nn * 16;
-                            if (np == 2) { const float bv = bl[nch0 + r16]; bnx = (f32x4){bv, bv, bv, bv}; }
-                            else bnx = *reinterpret_cast<const f32x4 *>(bl + nch0 + 4 * grp);
+                            bnx = qkv_bias(hl, head, nf / NTH, nf % NTH);
                         }
                     }
                     (void)ch0;
@@ -316,11 +358,20 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                 }
             }
             if constexpr ((PF & 1) != 0) wnx = wq2[FPH & 1];
+            if constexpr (kEarlyX) {
+                // DIET & 32: x is dead once the LAST head's q / k / v exist — the next window's x is requested here, one softmax phase
+                // (~1 000 issue cycles x 4 waves) ahead of the top of the next trip, where it used to be requested AND awaited.
+                // (Needs the unrolled head loop: `hl` is a constant here.  The window-major stores do not read vo.)
+                if (hl == HPP - 1) {
+                    advance();
+                    decode(wb, wy, wx, special);
+                    if (wi + wstride < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
+                }
+            }
             f32x4 sb[3];                                   // score accumulators' initial values (bias rows) of the coming query tile
             if constexpr ((PF & 4) != 0) {
-                const float *brow = bt32 + (hl * 36 + tokc[0]) * kBiasStride + 4 * grp;
 #pragma unroll
-                for (int kt = 0; kt < 3; ++kt) sb[kt] = *reinterpret_cast<const f32x4 *>(brow + 16 * kt);
+                for (int kt = 0; kt < 3; ++kt) sb[kt] = bias_frag(hl, 0, kt);
             }
 
             // ---- attention of this head: 3 q tiles x 3 key tiles ---------------------------------------------------
@@ -329,9 +380,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                 f32x4 s[3];
                 {
                     if constexpr (!(PF & 4)) {
-                        const float *brow = bt32 + (hl * 36 + tokc[qt]) * kBiasStride + 4 * grp;
 #pragma unroll
-                        for (int kt = 0; kt < 3; ++kt) sb[kt] = *reinterpret_cast<const f32x4 *>(brow + 16 * kt);
+                        for (int kt = 0; kt < 3; ++kt) sb[kt] = bias_frag(hl, qt, kt);
                     }
 #pragma unroll
                     for (int kt = 0; kt < 3; ++kt) {
@@ -352,9 +402,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                         s[kt] = acc;
                     }
                     if ((PF & 4) && qt + 1 < 3) {           // the next query tile's bias rows travel behind this tile's softmax
-                        const float *brow = bt32 + (hl * 36 + tokc[qt + 1]) * kBiasStride + 4 * grp;
 #pragma unroll
-                        for (int kt = 0; kt < 3; ++kt) sb[kt] = *reinterpret_cast<const f32x4 *>(brow + 16 * kt);
+                        for (int kt = 0; kt < 3; ++kt) sb[kt] = bias_frag(hl, qt + 1, kt);
                     }
                 }
                 // 9 real keys per lane: tiles 0 and 1 whole, register 0 of tile 2 (key 32 + grp); registers 1-3 of tile 2 are padding
@@ -419,9 +468,11 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
             run_heads(std::true_type{});
         }
 
-        advance();
-        decode(wb, wy, wx, special);
-        if (wi + wstride < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
+        if constexpr (!kEarlyX) {
+            advance();
+            decode(wb, wy, wx, special);
+            if (wi + wstride < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
+        }
     }
 }
 
@@ -429,7 +480,8 @@ int qkv_attn_r_frags(int C) { return 3 * (C / 16) * (C / 32); }
 
 template <int C, int HD, int HPP, int WAVES = 8, bool WM = false>
 static int launch_r(const QkvAttnRArgs &a, int grid, hipStream_t s) {
-    constexpr size_t smem = (size_t)HPP * 3 * (HD / 16) * (C / 32) * 1024 + HPP * 36 * kBiasStride * 4 + 3 * C * 4;
+    constexpr size_t smem = (size_t)HPP * 3 * (HD / 16) * (C / 32) * 1024 + HPP * kQkvBiasFloatsPerHead * 4 +
+                            (kQkvBiasFragMajor ? (size_t)HPP * 3 * (HD / 16) * 1024 : (size_t)3 * C * 4);
     static bool configured = false;
     if (!configured) {
         NUNIF_HIP_CHECK(hipFuncSetAttribute((const void *)qkv_attn_r_kernel<C, HD, HPP, WAVES, WM>,

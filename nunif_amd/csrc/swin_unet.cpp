@@ -335,6 +335,21 @@ int make_stage(nunif_swin_unet *h, const TensorMap &m, const std::string &key, i
                     btab32[((size_t)hh * 36 + q) * 52 + k] =
                         key >= 0 ? bias[((size_t)hh * 36 + q) * 48 + key] * 1.4426950408889634f : -1000.0f;
                 }
+        if (kQkvBiasFragMajor) {
+            // fragment-major: lane (r16, grp) of the score tile (qt, kt) holds rows 4 grp .. + 3 (keys) of column r16 (query win_token(qt, r16))
+            std::vector<float> frag((size_t)heads * kQkvBiasFloatsPerHead, 0.0f);
+            for (int hh = 0; hh < heads; ++hh)
+                for (int qt = 0; qt < 3; ++qt)
+                    for (int kt = 0; kt < 3; ++kt)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int r16 = lane & 15, grp = lane >> 4;
+                            const int q = qt < 2 ? 16 * qt + r16 : ((r16 & 3) == 0 ? 32 + (r16 >> 2) : 35);      // win_token
+                            for (int j = 0; j < 4; ++j)
+                                frag[((((size_t)hh * 3 + qt) * 3 + kt) * 64 + lane) * 4 + j] =
+                                    btab32[((size_t)hh * 36 + q) * 52 + 16 * kt + 4 * grp + j];
+                        }
+            btab32.swap(frag);
+        }
         if ((rc = upload(h, btab32, &bl.attn_btab32))) return rc;
     }
     return NUNIF_HIP_OK;

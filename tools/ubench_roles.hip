@@ -167,6 +167,65 @@ void run_bare(const char *name) {
     printf("   [cycles per MFMA per SIMD]\n");
 }
 
+
+// Generic two-role mix (16x16x32 only): wave >= 4 issues MH MFMAs + VH packed-fp16 VALU per trip, wave < 4 MP MFMAs + VP fp32 VALU, the
+// VALU spread evenly behind the MFMAs.  What would BALANCING the two roles of a SIMD buy (the GELU split between H and P)?
+template <int MH, int VH, int MP, int VP, bool BAR>
+__global__ void __launch_bounds__(512) kmix2(float *out, long long *cyc, float seed) {
+    const int wave = threadIdx.x >> 6;
+    const bool role_h = wave >= 4;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = seed + i + threadIdx.x;
+    f32x4 acc4[3];
+    for (int i = 0; i < 3; ++i) acc4[i] = (f32x4){seed, seed, seed, seed};
+    f16x8 fa, fb;
+    for (int i = 0; i < 8; ++i) { fa[i] = (f16)(seed * 0.01f + i * 0.001f); fb[i] = (f16)(seed * 0.01f - i * 0.001f); }
+    const float m = seed * 0.999f, c = seed * 0.0001f;
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int it = 0; it < TRIPS; ++it) {
+        int r = 0;
+        if (role_h) {
+#pragma unroll
+            for (int i = 0; i < MH; ++i) {
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc4[i % 3]) : "v"(fa), "v"(fb));
+                constexpr int lo = VH / MH, extra = VH % MH;
+                if (i < extra) fill_pk<lo + 1>(a, m, c, r); else fill_pk<lo>(a, m, c, r);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MP; ++i) {
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc4[i % 3]) : "v"(fa), "v"(fb));
+                constexpr int lo = VP / MP, extra = VP % MP;
+                if (i < extra) fill_pk<lo + 1>(a, m, c, r); else fill_pk<lo>(a, m, c, r);
+            }
+        }
+        if constexpr (BAR) asm volatile("s_barrier" ::: "memory");
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i];
+    for (int i = 0; i < 3; ++i) s += acc4[i][0] + acc4[i][1] + acc4[i][2] + acc4[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[wave] = t1 - t0;
+}
+
+template <int MH, int VH, int MP, int VP, bool BAR>
+void run_mix2() {
+    kmix2<MH, VH, MP, VP, BAR><<<1, 512>>>(g_out, g_cyc, 1.0f);
+    kmix2<MH, VH, MP, VP, BAR><<<1, 512>>>(g_out, g_cyc, 1.0f);
+    hipDeviceSynchronize();
+    std::vector<long long> h(8);
+    hipMemcpy(h.data(), g_cyc, 8 * 8, hipMemcpyDeviceToHost);
+    long long hp = 0, hh = 0;
+    for (int i = 0; i < 4; ++i) { hp = h[i] > hp ? h[i] : hp; hh = h[i + 4] > hh ? h[i + 4] : hh; }
+    printf("mix2  H %3d MFMA + %3d VALU | P %3d MFMA + %3d VALU  barrier=%d : P wave %7.1f  H wave %7.1f  cycles per 32 tokens\n", MH, VH, MP, VP,
+           (int)BAR, (double)hp / TRIPS, (double)hh / TRIPS);
+}
+
 int main() {
     hipMalloc(&g_out, 1024 * 4);
     hipMalloc(&g_cyc, 16 * 8);
@@ -179,5 +238,11 @@ int main() {
     run_roles<1, false, 3>();
     run_roles<0, true, 3>();
     run_roles<1, true, 3>();
+    run_mix2<72, 540, 108, 200, true>();      // today's roles
+    run_mix2<72, 370, 108, 370, true>();      // the GELU split evenly between the two waves of a SIMD
+    run_mix2<90, 370, 90, 370, true>();       // MFMAs balanced too
+    run_mix2<72, 270, 108, 470, true>();      // over-corrected (the P wave carries the surplus)
+    run_mix2<72, 540, 108, 200, false>();
+    run_mix2<72, 370, 108, 370, false>();
     return 0;
 }
