@@ -37,6 +37,10 @@ namespace nunif {
 // tile), 2 = `o * inv` and its fp16 convert in one v_fma_mixlo / mixhi_f16 per value (one rounding instead of two), 4 = the lone
 // probability of key tile 2 converted and zero-padded by ONE v_cvt_pk_f16_f32 (hipcc: v_cvt_f16_f32 + v_pack_b32_f16), 8 = the
 // head loop unrolled (LDS addresses of every head become instruction immediates: 12 address adds per head less)
+// C = 192: 1 = the three heads of a pass unrolled like the six of C = 96 (228 registers, no spills), 2 = + the early x request
+#ifndef NUNIF_QKV_UNROLL192
+#define NUNIF_QKV_UNROLL192 0
+#endif
 #ifndef NUNIF_QKV_DIET
 #define NUNIF_QKV_DIET 47
 #endif
@@ -264,7 +268,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
             return *reinterpret_cast<const f32x4 *>(bt32 + (hl * 36 + tokc[qt]) * kBiasStride + 4 * grp + 16 * kt);
     };
     f16x8 xf[3][KS];
-    unsigned vo[3];
+    unsigned vo[3], von[3] = {0u, 0u, 0u};      // von: the next window's offsets while this window's pixel-major stores still read vo
     int wb, wy, wx;
     bool special;
     decode(wb, wy, wx, special);
@@ -281,10 +285,16 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
         // C = 96: the six heads unrolled (every LDS address an immediate); C = 192 does not fit that way (143 spilled registers).
         // DIET & 16 (head_dim 16): the windows that need no shift-region term — all but the last row / column of a shifted map — take
         // a path of their own (SP = false) with K = 16 score MFMAs; the others the K = 32 form with the region one-hots, rolled.
-        constexpr bool kSplit = (NUNIF_QKV_DIET & 16) && HD == 16;
-        constexpr bool kEarlyX = (NUNIF_QKV_DIET & 32) && (NUNIF_QKV_DIET & 8) && C == 96 && WM && !kSplit;
+        // DIET & 64: the same split with K = 32 score MFMAs on both paths — the common path then carries NO region registers (the term is
+        // a constant over every row there and drops out of the softmax; rkr / rqr were 12 registers live across all six heads, and at
+        // 128 registers the early x request of DIET & 32 had pushed 15 per-lane constants into scratch)
+        constexpr bool kSplitK16 = (NUNIF_QKV_DIET & 16) && HD == 16;
+        constexpr bool kSplit = ((NUNIF_QKV_DIET & 16) || (NUNIF_QKV_DIET & 64)) && HD == 16;
+        // (C = 192, pixel-major stores: they read vo, so the early request goes through a second offset set there)
+        constexpr bool kEarlyX = (NUNIF_QKV_DIET & 32) && (NUNIF_QKV_DIET & 8) && ((C == 96 && WM) || (C == 192 && NUNIF_QKV_UNROLL192 == 2)) && !kSplitK16;
         auto run_heads = [&](auto sp_tag) {
         constexpr bool SP = decltype(sp_tag)::value;
+        const bool sp_now = special;            // (kEarlyX decodes the NEXT window inside the last head)
         // shift regions of this window (only the last window row / column straddles two regions)
         f16x4 rkr[3], rqr[3];
         if (special && (SP || !kSplit)) {
@@ -304,7 +314,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) { rkr[mt] = rk0; rqr[mt] = rq0; }
         }
-        constexpr int kHeadUnroll = ((NUNIF_QKV_DIET & 8) && C == 96 && !(kSplit && SP)) ? HPP : 1;
+        constexpr int kHeadUnroll = ((NUNIF_QKV_DIET & 8) && (C == 96 || NUNIF_QKV_UNROLL192) && !(kSplit && SP)) ? HPP : 1;
 #pragma unroll kHeadUnroll
         for (int hl = 0; hl < HPP; ++hl) {
             const int head = pass * HPP + hl;
@@ -365,7 +375,10 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                 if (hl == HPP - 1) {
                     advance();
                     decode(wb, wy, wx, special);
-                    if (wi + wstride < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
+                    if (wi + wstride < a.n_windows) {
+                        if constexpr (WM) load_x(wb, wy, wx, special, xf, vo);
+                        else load_x(wb, wy, wx, special, xf, von);
+                    }
                 }
             }
             f32x4 sb[3];                                   // score accumulators' initial values (bias rows) of the coming query tile
@@ -387,7 +400,9 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                     for (int kt = 0; kt < 3; ++kt) {
                         f32x4 acc = sb[kt];
                         if constexpr (HD == 16) {
-                            if constexpr (kSplit && !SP) {
+                            if constexpr (kSplit && !SP && !kSplitK16) {
+                                acc = MFMA_16x16x32(cat8r(kt4[0][kt], zero4), cat8r(qt4[0][qt], zero4), acc);
+                            } else if constexpr (kSplit && !SP) {
                                 // K = 16 is the whole head: v_mfma_f32_16x16x16_f16 takes q and k as they leave the converts (no
                                 // 4-register operands to assemble, ~10 v_mov per head); the shift-region term is a constant over
                                 // every row of these windows
@@ -397,7 +412,7 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                             }
                         } else {
                             acc = MFMA_16x16x32(cat8r(kt4[0][kt], kt4[1][kt]), cat8r(qt4[0][qt], qt4[1][qt]), acc);
-                            if (special) acc = MFMA_16x16x32(cat8r(rkr[kt], zero4), cat8r(rqr[qt], zero4), acc);
+                            if (sp_now) acc = MFMA_16x16x32(cat8r(rkr[kt], zero4), cat8r(rqr[qt], zero4), acc);
                         }
                         s[kt] = acc;
                     }
@@ -468,6 +483,10 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
             run_heads(std::true_type{});
         }
 
+        if constexpr (kEarlyX && !WM) {
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) vo[mt] = von[mt];
+        }
         if constexpr (!kEarlyX) {
             advance();
             decode(wb, wy, wx, special);

@@ -54,10 +54,42 @@ def _pick(kernels, *needles):
     return hits
 
 
+def _is_level1_attention_wm(name):
+    return "qkv_attn_r_kernel" in name and "ILi96ELi16ELi6ELi16ELb1E" in name
+
+
 def test_no_spills_no_scratch_in_the_dispatched_kernels(kernels):
     for name, (body, sg, vg, sp) in kernels.items():
-        assert sp == 0 and "scratch_" not in body, (name, sp)
         assert vg <= 256, (name, vg)
+        if _is_level1_attention_wm(name):
+            continue                                        # its own test below
+        if "qkv_attn_r_kernel" in name and "ILi96ELi16E" in name:
+            # the pixel-major instance (launches beyond 2^31 att bytes, the debug taps): a handful of per-lane constants in scratch
+            assert sp <= 16, (name, sp)
+            continue
+        assert sp == 0 and "scratch_" not in body, (name, sp)
+
+
+def test_level1_attention_keeps_scratch_out_of_its_head_loop(kernels):
+    """Round 6: with the next window's x requested inside the last head (DIET & 32) the window-major level-1 attention runs at exactly
+    128 registers and hipcc parks some per-lane constants in scratch — in the launch prologue and on the path of the windows of the last
+    row / column (5 % of the windows).  That measured FASTER than the spill-free form (338.5 -> 333.4 us, profiles/r06h_attn_early_x_ab.txt);
+    what must not happen is a scratch access in the common path of the window loop: the six unrolled heads (the code between the
+    `sched_barrier` markers that separate them, and the first head in front of the first marker up to the loop header) are scratch-free,
+    and so is the stretch that issues the early x loads on the common path."""
+    (name, (body, sg, vg, sp)), = [kv for kv in kernels.items() if _is_level1_attention_wm(kv[0])]
+    lines = body.splitlines()
+    marks = [i for i, ln in enumerate(lines) if "sched_barrier" in ln]
+    assert len(marks) == 6, len(marks)                       # six unrolled heads, one marker behind each
+    loop_head = max(i for i, ln in enumerate(lines) if "Loop Header" in ln or "Inner Loop" in ln)       # the window loop is the last loop
+    # (hipcc rotates the loop: the stretch behind the LAST marker is the last head's softmax with the early x request in it)
+    hot = lines[loop_head:marks[-1]]
+    assert sum(1 for i in marks if i > loop_head) >= 5
+    assert not any("scratch_" in ln for ln in hot), [ln for ln in hot if "scratch_" in ln][:3]
+    # behind the last marker: reloads on the rare branch only, never a spill STORE inside the window loop
+    tail = lines[marks[-1]:]
+    assert not any("scratch_store" in ln for ln in lines[loop_head:]), "a spill store inside the window loop"
+    assert sum("scratch_load" in ln for ln in tail) <= 12 and sp <= 16, (sp, sum("scratch_load" in ln for ln in tail))
 
 
 def test_forward_warp_keeps_two_rows_per_cu(kernels):

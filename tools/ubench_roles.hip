@@ -226,6 +226,77 @@ void run_mix2() {
            (int)BAR, (double)hp / TRIPS, (double)hh / TRIPS);
 }
 
+// The kernel's PHASE structure instead of an even spread (per 16-token trip; two trips = 32 tokens per loop pass):
+//   H wave: 12 bare MFMAs (pair 0) | 24 MFMAs with the GELU of the previous pair between them (7.5 VALU each) | 90 bare VALU (last GELU)
+//   P wave: stage C 36 MFMAs with a few VALU | 50 VALU epilogue | stage A 18 MFMAs | 50 VALU epilogue
+// PH = 1: these phases; PH = 0: the same counts spread evenly (kroles' form).  DEP = 1: each GELU block waits for "its" accumulators
+// (an s_nop 7 x 2 in front of the block, the MFMA -> VALU wait states of a dependent read).
+template <int PH, bool BAR>
+__global__ void __launch_bounds__(512) kphase(float *out, long long *cyc, float seed) {
+    const int wave = threadIdx.x >> 6;
+    const bool role_h = wave >= 4;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = seed + i + threadIdx.x;
+    f32x4 acc4[3];
+    for (int i = 0; i < 3; ++i) acc4[i] = (f32x4){seed, seed, seed, seed};
+    f16x8 fa, fb;
+    for (int i = 0; i < 8; ++i) { fa[i] = (f16)(seed * 0.01f + i * 0.001f); fb[i] = (f16)(seed * 0.01f - i * 0.001f); }
+    const float m = seed * 0.999f, c = seed * 0.0001f;
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int it = 0; it < 2 * TRIPS; ++it) {          // one pass = ONE 16-token trip
+        int r = 0;
+        auto mf = [&](int i) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc4[i % 3]) : "v"(fa), "v"(fb)); };
+        if (role_h) {
+            if constexpr (PH == 1) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) mf(i);
+#pragma unroll
+                for (int i = 0; i < 24; ++i) { mf(i); if (i & 1) fill_pk<8>(a, m, c, r); else fill_pk<7>(a, m, c, r); }
+                fill_pk<90>(a, m, c, r);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 36; ++i) { mf(i); if (i & 1) fill_pk<8>(a, m, c, r); else fill_pk<7>(a, m, c, r); }
+            }
+        } else {
+            if constexpr (PH == 1) {
+#pragma unroll
+                for (int i = 0; i < 36; ++i) mf(i);
+                fill_f32<50>(a, m, c, r);
+#pragma unroll
+                for (int i = 0; i < 18; ++i) mf(i);
+                fill_f32<50>(a, m, c, r);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 54; ++i) { mf(i); if (i % 27 < 23) fill_f32<2>(a, m, c, r); else fill_f32<1>(a, m, c, r); }
+            }
+        }
+        if constexpr (BAR) asm volatile("s_barrier" ::: "memory");
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i];
+    for (int i = 0; i < 3; ++i) s += acc4[i][0] + acc4[i][1] + acc4[i][2] + acc4[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[wave] = t1 - t0;
+}
+
+template <int PH, bool BAR>
+void run_phase() {
+    kphase<PH, BAR><<<1, 512>>>(g_out, g_cyc, 1.0f);
+    kphase<PH, BAR><<<1, 512>>>(g_out, g_cyc, 1.0f);
+    hipDeviceSynchronize();
+    std::vector<long long> h(8);
+    hipMemcpy(h.data(), g_cyc, 8 * 8, hipMemcpyDeviceToHost);
+    long long hp = 0, hh = 0;
+    for (int i = 0; i < 4; ++i) { hp = h[i] > hp ? h[i] : hp; hh = h[i + 4] > hh ? h[i + 4] : hh; }
+    printf("phase %s barrier=%d (16-token trips): P wave %7.1f  H wave %7.1f  cycles per 32 tokens\n", PH ? "kernel phases" : "even spread  ", (int)BAR,
+           (double)hp / TRIPS, (double)hh / TRIPS);
+}
+
 int main() {
     hipMalloc(&g_out, 1024 * 4);
     hipMalloc(&g_cyc, 16 * 8);
@@ -244,5 +315,9 @@ int main() {
     run_mix2<72, 270, 108, 470, true>();      // over-corrected (the P wave carries the surplus)
     run_mix2<72, 540, 108, 200, false>();
     run_mix2<72, 370, 108, 370, false>();
+    run_phase<0, true>();
+    run_phase<1, true>();
+    run_phase<0, false>();
+    run_phase<1, false>();
     return 0;
 }
