@@ -355,6 +355,24 @@ __global__ void __launch_bounds__(512) gemm_res_kernel(GemmArgs g) {
             const int OC = g.n_real / s2;
             float *o = reinterpret_cast<float *>(g.out);
             const long OH = g.OH ? g.OH : (long)g.Ho * s, OW = g.OW ? g.OW : (long)g.Wo * s;
+            if ((s == 4 || s == 8) && g.oshift == 0 && (OW & 3) == 0) {          // as in gemm_kernel: one 16-byte store per lane and tile
+                const int ls = s == 4 ? 2 : 3;
+                const int c = n0 >> (2 * ls), i = (n0 >> ls) & (s - 1), j0 = n0 & (s - 1);
+                if (n0 < g.n_real) {
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+                        if (!valid[f]) continue;
+                        float4 v = {acc[f][0] + bv.x, acc[f][1] + bv.y, acc[f][2] + bv.z, acc[f][3] + bv.w};
+                        if (!g.no_clamp) {
+                            v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
+                            v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
+                        }
+                        const long oy = (long)ty[f] * s + i, ox = (long)tx[f] * s + j0;
+                        if (oy < OH && ox + 3 < OW) *reinterpret_cast<float4 *>(o + (((long)tb[f] * OC + c) * OH + oy) * OW + ox) = v;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
                 if (!valid[f]) continue;
@@ -456,7 +474,9 @@ static int launch_gemm_t(const GemmArgs &g, hipStream_t s, const char *ring_sym,
     // ... and for the plain K = 192 Linears over millions of tokens (the inpaint net's proj_out at 4K, config 5: 3.4 M tokens x
     // (384 B in + 192 B out)): the ring form is one 256-token tile per workgroup and all prologue, 1 040 us = 1.9 TB/s; resident
     // 543 us = 3.2 TB/s.  K = 96 measured equal (stays on the ring).
-    const bool big_plain = MF == 4 && KS == 6 && g.mode == 0 && M >= gemm_big_m();
+    // (round 6: and the image head of the 4x / 8x nets, mode 2 — NUNIF_GEMM_RES_IMAGE=0 keeps it on the ring for A/B runs)
+    static const bool res_image = !(getenv("NUNIF_GEMM_RES_IMAGE") && atoi(getenv("NUNIF_GEMM_RES_IMAGE")) == 0);
+    const bool big_plain = MF == 4 && KS == 6 && (g.mode == 0 || (g.mode == 2 && res_image)) && M >= gemm_big_m();
     const bool res = fits && !ring_only && (MF == 2 || big_plain) && g.res_W == 0 && !g.in_scale;     // (the cropped residual and the input scale exist in the ring form only)
     // profiler classes are named after the kernel symbol so that they line up with rocprofv3's kernel stats
     // (NUNIF_PROF_TAGS=1 names the class after the call site instead: separates e.g. the two gemm_kernel<6,4> users)
