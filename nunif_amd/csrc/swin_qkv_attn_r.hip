@@ -271,12 +271,29 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
     unsigned vo[3], von[3] = {0u, 0u, 0u};      // von: the next window's offsets while this window's pixel-major stores still read vo
     int wb, wy, wx;
     bool special;
-    decode(wb, wy, wx, special);
-    if (w0 < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
-
     f16x8 wnx = wl[lane];                  // first weight fragment of the next head (see the head loop)
+    // DIET & 128 (C = 96, window-major): TWO passes over the wave's windows — first the windows that need no shift-region term (all but
+    // the last row / column of a shifted map) through the unrolled heads with no region registers and the early x request, then the
+    // others through the rolled form.  One loop over both kinds made hipcc allocate for their union: 15 per-lane constants in
+    // scratch, reloaded per window (+7.4 % FETCH_SIZE, profiles/r06n_attn_fetch_by_variant.txt).  MODE 0: one pass over all windows.
+    constexpr bool kTwoLoops = (NUNIF_QKV_DIET & 128) && C == 96 && WM && HD == 16;
+    const int cx0 = cx, cy0 = cy, cb0 = cb;
+    auto run_windows = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;            // 0: every window, 1: the plain ones, 2: the ones with two shift regions
+    int wi = w0;
+    cx = cx0; cy = cy0; cb = cb0;
+    decode(wb, wy, wx, special);
+    // step(): on to the next window of this pass
+    auto skip = [&]() {
+        if constexpr (MODE != 0) {
+            while (wi < a.n_windows && special != (MODE == 2)) { advance(); wi += wstride; decode(wb, wy, wx, special); }
+        }
+    };
+    auto step = [&]() { advance(); wi += wstride; decode(wb, wy, wx, special); skip(); };
+    skip();
+    if (wi < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
 #pragma unroll 1
-    for (int wi = w0; wi < a.n_windows; wi += wstride) {
+    while (wi < a.n_windows) {
         const int wq = (wb * nwy + wy) * nwx + wx;                         // index of this window in the window-major att map
         char *ab = reinterpret_cast<char *>(a.att) + (WM ? (long)wq * (HEADS * 36 * HD * 2) : (long)wb * img_bytes);
         // window-major map: a wave-uniform byte offset (the launcher keeps the map below 4 GB) + a lane constant per tile
@@ -289,9 +306,9 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
         // a constant over every row there and drops out of the softmax; rkr / rqr were 12 registers live across all six heads, and at
         // 128 registers the early x request of DIET & 32 had pushed 15 per-lane constants into scratch)
         constexpr bool kSplitK16 = (NUNIF_QKV_DIET & 16) && HD == 16;
-        constexpr bool kSplit = ((NUNIF_QKV_DIET & 16) || (NUNIF_QKV_DIET & 64)) && HD == 16;
+        constexpr bool kSplit = (((NUNIF_QKV_DIET & 16) || (NUNIF_QKV_DIET & 64)) && HD == 16) || MODE != 0;
         // (C = 192, pixel-major stores: they read vo, so the early request goes through a second offset set there)
-        constexpr bool kEarlyX = (NUNIF_QKV_DIET & 32) && (NUNIF_QKV_DIET & 8) && ((C == 96 && WM) || (C == 192 && NUNIF_QKV_UNROLL192 == 2)) && !kSplitK16;
+        constexpr bool kEarlyX = (NUNIF_QKV_DIET & 32) && (NUNIF_QKV_DIET & 8) && ((C == 96 && WM) || (C == 192 && NUNIF_QKV_UNROLL192 == 2)) && !kSplitK16 && MODE != 2;
         auto run_heads = [&](auto sp_tag) {
         constexpr bool SP = decltype(sp_tag)::value;
         const bool sp_now = special;            // (kEarlyX decodes the NEXT window inside the last head)
@@ -373,9 +390,8 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
                 // (~1 000 issue cycles x 4 waves) ahead of the top of the next trip, where it used to be requested AND awaited.
                 // (Needs the unrolled head loop: `hl` is a constant here.  The window-major stores do not read vo.)
                 if (hl == HPP - 1) {
-                    advance();
-                    decode(wb, wy, wx, special);
-                    if (wi + wstride < a.n_windows) {
+                    step();
+                    if (wi < a.n_windows) {
                         if constexpr (WM) load_x(wb, wy, wx, special, xf, vo);
                         else load_x(wb, wy, wx, special, xf, von);
                     }
@@ -477,7 +493,11 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
             if constexpr (kHeadUnroll > 1) __builtin_amdgcn_sched_barrier(0);   // unrolled heads stay apart: nothing of head h + 1 is scheduled into head h
         }
         };
-        if constexpr (kSplit) {
+        if constexpr (MODE == 1) {
+            run_heads(std::false_type{});
+        } else if constexpr (MODE == 2) {
+            run_heads(std::true_type{});
+        } else if constexpr (kSplit) {
             if (special) run_heads(std::true_type{}); else run_heads(std::false_type{});
         } else {
             run_heads(std::true_type{});
@@ -488,10 +508,16 @@ qkv_attn_r_kernel(QkvAttnRArgs a) {
             for (int mt = 0; mt < 3; ++mt) vo[mt] = von[mt];
         }
         if constexpr (!kEarlyX) {
-            advance();
-            decode(wb, wy, wx, special);
-            if (wi + wstride < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
+            step();
+            if (wi < a.n_windows) load_x(wb, wy, wx, special, xf, vo);
         }
+    }
+    };
+    if constexpr (kTwoLoops) {
+        run_windows(std::integral_constant<int, 1>{});
+        if (a.shift > 0) run_windows(std::integral_constant<int, 2>{});
+    } else {
+        run_windows(std::integral_constant<int, 0>{});
     }
 }
 
