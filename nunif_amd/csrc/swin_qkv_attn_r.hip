@@ -32,12 +32,21 @@ namespace nunif {
 #ifndef NUNIF_QKV_PF192
 #define NUNIF_QKV_PF192 0
 #endif
-// Round 6, the instruction diet continued (every VALU instruction is >= 4 issue cycles of a SIMD that is VALU-port bound,
-// profiles/r02_ubench_mix.txt): 1 = window-major stores as `SGPR base + 32-bit lane constant` (no 64-bit address arithmetic per
-// tile), 2 = `o * inv` and its fp16 convert in one v_fma_mixlo / mixhi_f16 per value (one rounding instead of two), 4 = the lone
-// probability of key tile 2 converted and zero-padded by ONE v_cvt_pk_f16_f32 (hipcc: v_cvt_f16_f32 + v_pack_b32_f16), 8 = the
-// head loop unrolled (LDS addresses of every head become instruction immediates: 12 address adds per head less)
-// C = 192: 1 = the three heads of a pass unrolled like the six of C = 96 (228 registers, no spills), 2 = + the early x request
+// Round 6: compile-time switches of this kernel, each measured as a same-box A/B of build variants (tools/build_variant.py,
+// tools/ab_multi.sh; DESIGN.md 6.000000, profiles/r06*_attn_*).  NUNIF_QKV_DIET is a bit mask; the default is what measured fastest.
+//   ON   1  window-major stores as `SGPR base + 32-bit lane constant` (no 64-bit address arithmetic per tile)
+//   ON   2  `o * inv` and its fp16 convert as one v_fma_mixlo / mixhi_f16 per value (one rounding instead of two)
+//   ON   4  (the lone probability of key tile 2 built from an opaque zero: hipcc still emits v_cvt_f16_f32 + v_pack_b32_f16 — no effect)
+//   ON   8  C = 96: the six heads unrolled behind sched_barrier(0): every LDS address an immediate (13 address adds per head gone)
+//   ON  32  C = 96 window-major: the next window's x requested when the last head's q / k / v exist          338.5 -> 333.4 us
+//   off 16  K = 16 score MFMAs (v_mfma_f32_16x16x16_f16) on a path of their own for the windows without shift regions   344.9 vs 342.1
+//   off 64  that split with K = 32 MFMAs on both paths (no region registers on the common path)                  24 spilled registers
+//   off 128 two passes over a wave's windows (plain, then the last row / column): no scratch, 353.0 vs 341.7 (a tail of 0-3 windows)
+//   off NUNIF_QKV_BTAB_FRAG (swin_kernels.h): bias tables / qkv biases as lane-linear fragments: no bank conflicts, 353.3 vs 342.7
+//   off NUNIF_QKV_UNROLL192 1 / 2: C = 192 heads unrolled / + early x: 137.5 / 140.7 vs 138.6
+// With 1 + 2 + 8 + 32 the window-major C = 96 instance sits at exactly 128 registers and hipcc parks ~15 per-lane constants of the
+// last-row / last-column path in scratch (prologue + that path; +7.4 % FETCH_SIZE); tests/test_isa_invariants.py pins that no scratch
+// access sits inside the unrolled heads.
 #ifndef NUNIF_QKV_UNROLL192
 #define NUNIF_QKV_UNROLL192 0
 #endif
