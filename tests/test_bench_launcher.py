@@ -50,3 +50,14 @@ def test_leg_switches_and_world_size_mismatch():
     # launched by hand with the wrong world size: refused before any collective
     r, lines = _bench(["--gpus", "2", "--steps", "1"], extra_env={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
     assert r.returncode != 0 and not lines and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_four_ranks_deliver_every_frame():
+    """The driver's scaling run goes 1 / 2 / 4 / 8: the same line at four ranks (odd frame counts per rank, three peers sending to
+    rank 0 per round)."""
+    r, lines = _bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--no-cunet", "--no-config5"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["ok"] and rec["n_gpus"] == 4 and rec["multi_gpu"]["ranks_seen"] == 4 and rec["multi_gpu"]["distinct_pci_bus_ids"] == 4
+    assert rec["gathered"]["frames_delivered"] == rec["gathered"]["frames"] == 16
+    assert rec["iw3"]["world"] == 4 and rec["iw3"]["frames_delivered"] == rec["iw3"]["frames"] == 32
