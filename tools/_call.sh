@@ -1,11 +1,13 @@
+# the very last HEAD of round 6: GPU suite + the default bench line + smoke
 cd /root/repo
-AB_TESTS="tests/test_gpu_swin.py tests/test_gpu_waifu2x_api.py tests/test_gpu_swin_v2.py tests/test_hot_regime.py" bash tools/ab_multi.sh r06o 2 cur t175 t175p3 2>&1 | tail -20
-REPO=$PWD; OUT=$REPO/gpurun_out
-cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --batch-size 45 --no-cpu-baseline --no-host-frames --no-iw3 --no-4k --no-cunet --no-config5 --streams 1 --steps 2 --warmup 1"
-for v in t175; do
-  d=/tmp/pf_$v; rm -rf $d
-  NUNIF_HIP_LIB=$REPO/nunif_amd/libnunif_hip_$v.so rocprofv3 --pmc FETCH_SIZE --output-format csv -d $d -o pmc -- $BENCH > /dev/null 2>&1
-  f=$(find $d -name '*counter_collection.csv' | head -1)
-  echo "== $v"; python $REPO/tools/aggregate_pmc.py "$f" FETCH_SIZE | grep "qkv_attn_r_kernel<96" | cut -c1-150
-done | tee -a $OUT/r06n_attn_fetch_by_variant.txt
+OUT=gpurun_out; mkdir -p $OUT
+timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/r06fin2_gpu_suite.log 2>&1; echo "suite rc=$? $(tail -1 $OUT/r06fin2_gpu_suite.log)"
+python bench.py > $OUT/r06fin2_bench_line.json 2> $OUT/r06fin2_bench.err
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/r06fin2_smoke.log 2>&1; tail -1 $OUT/r06fin2_smoke.log
+python - <<'PY'
+import json
+r=json.loads([l for l in open('gpurun_out/r06fin2_bench_line.json') if l.startswith('{')][-1])
+print('value',r['value'],'single',r['single_stream']['value'],'psnr',r.get('psnr_whole_frame_db'),'roofline',r['roofline']['frac'],r['roofline']['avg_launch_us'])
+print([ (k['kernel'],k['avg_us']) for k in r['kernel_classes'][:4]])
+print('4k',r['scale4x_4k']['ms_per_frame'],'cunet',r['cunet']['frame_1080p']['value'],'ff',r['iw3']['forward_fill']['fps'],'vits',r['iw3']['depth_infer_fps']['vits'],'c5',r['config5']['ms_per_frame'],'ok',r['ok'])
+PY
